@@ -1,0 +1,144 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE's own numpy code.
+
+Runs ONLY in the build container (needs /root/reference).  Nothing here, and
+no reference source, travels to the GPU box: the outputs are plain data
+(inputs + expected outputs) committed under tests/golden/.
+
+Recipe: casadi and pyDOE are not installable, so
+empty stub modules are injected before `import gp_mpc`; the pure-numpy parts
+of the hot path then run unmodified:
+  optimize.calc_cov_matrix   (a1)      optimize.calc_NLL_numpy (a3,a4,a5,a7)
+  GP.covSEard (a1 two-input) GP.covar  (a14, via object.__new__)
+  optimize.train_gp_numpy    (a8,a6; zero mean, get_mean_function patched to
+                              its 'zero' definition gp_functions.py:44-47)
+plus the two saved models examples/models/gp_{tank,car}_example.json, the only
+known-answer artefacts the reference ships (written by gp_class.py:693-726).
+
+Usage:  python oracle/make_golden.py
+"""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+
+REF = '/root/reference'
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tests', 'golden')
+
+
+def import_reference():
+    ca = types.ModuleType('casadi')
+    ca.tools = types.ModuleType('casadi.tools')
+    sys.modules.update({'casadi': ca, 'casadi.tools': ca.tools,
+                        'pyDOE': types.ModuleType('pyDOE')})
+    import matplotlib
+    matplotlib.use('Agg')
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, REF)
+    import gp_mpc  # noqa: F401
+    from gp_mpc import optimize, GP
+    ca.MX = lambda x: x
+    optimize.get_mean_function = \
+        lambda h, Xt, func='zero': (lambda A: np.zeros(A.shape[1]))
+    return optimize, GP
+
+
+def ref_gp(GP, X, hyper, chol):
+    d = X.shape[1]
+    g = object.__new__(GP)
+    g._GP__Ny, g._GP__X, g._GP__chol = hyper.shape[0], X, chol
+    g._GP__hyper_length_scales = hyper[:, :d]
+    g._GP__hyper_signal_variance = hyper[:, d] ** 2
+    return g
+
+
+def pack_lower(A):
+    """[Ny,N,N] -> [Ny, N(N+1)/2] row-major lower triangle."""
+    il = np.tril_indices(A.shape[-1])
+    return np.stack([a[il] for a in A])
+
+
+def from_model(optimize, GP, name, n_test, seed):
+    d = json.load(open(f'{REF}/examples/models/gp_{name}_example.json'))
+    X = np.array(d['X'])
+    Y = np.array(d['Y'])
+    H = np.array(d['hyper']['hyper'])
+    chol = np.array(d['hyper']['chol'])
+    alpha = np.array(d['hyper']['alpha'])
+    invK = np.array(d['hyper']['invK'])
+    N, D = X.shape
+    Ny = Y.shape[1]
+    assert np.all(np.triu(chol[0], 1) == 0.0)
+    rng = np.random.default_rng(seed)
+    Z = X[rng.integers(0, N, n_test)] + 0.25 * rng.standard_normal((n_test, D)) * X.std(0)
+    g = ref_gp(GP, X, H, chol)
+    covar = g.covar(Z.copy())[:Ny]                       # reference a14
+    K = np.stack([optimize.calc_cov_matrix(X, H[a, :D], H[a, D] ** 2)   # reference a1
+                  for a in range(Ny)])
+    ks = np.stack([g.covSEard(X.copy(), Z.copy(), H[a, :D], H[a, D] ** 2)  # reference a1 (2-input)
+                   for a in range(Ny)])
+    nll = np.array([float(optimize.calc_NLL_numpy(H[a], X, Y[:, a]))     # reference a7
+                    for a in range(Ny)])
+    out = dict(X=X, Y=Y, hyper=H, alpha=alpha,
+               chol_packed=pack_lower(chol), invK_packed=pack_lower(invK),
+               length_scale=np.array(d['hyper']['length_scale']),
+               signal_var=np.array(d['hyper']['signal_var']),
+               noise_var=np.array(d['hyper']['noise_var']),
+               hyper_mean=np.array(d['hyper']['mean']),
+               normalize=np.array(bool(d['normalize'])),
+               Z=Z, ref_covar_diag=np.stack([np.diag(c) for c in covar]),
+               ref_covar=covar, ref_K_packed=pack_lower(K), ref_ks=ks, ref_nll=nll)
+    if d.get('normalize'):
+        for k, v in d['meta'].items():
+            out['meta_' + k] = np.array(v)
+        for k in ('xlb', 'xub', 'ulb', 'uub'):
+            out[k] = np.array(d[k])
+    np.savez_compressed(os.path.join(OUT, f'{name}_model.npz'), **out)
+    print(name, 'N', N, 'D', D, 'Ny', Ny, 'nll', nll)
+
+
+def synthetic(optimize, GP):
+    """Small seeded problem run through the reference's numpy training path."""
+    rng = np.random.default_rng(20180101)
+    N, d, Ny = 40, 2, 2
+    X = rng.uniform(-2, 2, (N, d))
+    Y = np.stack([np.sin(X[:, 0]) * np.cos(0.5 * X[:, 1]),
+                  0.3 * X[:, 0] ** 2 - X[:, 1]], axis=1) + 1e-3 * rng.standard_normal((N, Ny))
+    opt = optimize.train_gp_numpy(X, Y, multistart=1, optimizer_opts={'disp': False})  # reference a8
+    H = opt['hyper']
+    nll = np.array([float(optimize.calc_NLL_numpy(H[a], X, Y[:, a])) for a in range(Ny)])
+    # NLL on a grid of hyper rows (a7) incl. one that needs the jitter branch
+    probes = np.array([[1.0, 1.0, 1.0, 1e-2], [0.5, 2.0, 0.7, 1e-3],
+                       [3.0, 3.0, 2.0, 1e-5], [50.0, 50.0, 1.0, 1e-10]])
+    import io
+    import contextlib
+    probe_nll = np.zeros((len(probes), Ny))
+    probe_jit = np.zeros((len(probes), Ny), dtype=np.int32)
+    for i, h in enumerate(probes):
+        for a in range(Ny):
+            buf = io.StringIO()
+            with contextlib.redirect_stdout(buf):
+                probe_nll[i, a] = float(optimize.calc_NLL_numpy(h, X, Y[:, a]))
+            probe_jit[i, a] = int('jitter' in buf.getvalue())
+    Z = rng.uniform(-2, 2, (16, d))
+    g = ref_gp(GP, X, H, opt['chol'])
+    covar = g.covar(Z.copy())[:Ny]
+    np.savez_compressed(os.path.join(OUT, 'train_small.npz'), X=X, Y=Y, hyper=H,
+                        chol=opt['chol'], alpha=opt['alpha'], invK=opt['invK'],
+                        nll=nll, probes=probes, probe_nll=probe_nll, probe_jitter=probe_jit,
+                        Z=Z, ref_covar=covar)
+    print('train_small hyper', H, 'nll', nll, 'jitter flags', probe_jit.tolist())
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    optimize, GP = import_reference()
+    from_model(optimize, GP, 'tank', 24, 1)
+    from_model(optimize, GP, 'car', 24, 2)
+    synthetic(optimize, GP)
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,55 @@
+"""pytest configuration: `gpu` marker, import paths, golden-fixture helpers."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+for p in (ROOT, os.path.join(ROOT, 'oracle')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu via gpurun)')
+
+
+def unpack_lower(P, N, symmetric=False):
+    """[Ny, N(N+1)/2] packed row-major lower triangle -> [Ny, N, N]."""
+    il = np.tril_indices(N)
+    out = np.zeros((P.shape[0], N, N))
+    for a in range(P.shape[0]):
+        out[a][il] = P[a]
+        if symmetric:
+            out[a] = out[a] + np.tril(out[a], -1).T
+    return out
+
+
+def load_model(name):
+    g = dict(np.load(os.path.join(GOLDEN, f'{name}_model.npz')))
+    N = g['X'].shape[0]
+    g['chol'] = unpack_lower(g['chol_packed'], N)
+    g['invK'] = unpack_lower(g['invK_packed'], N, symmetric=True)
+    g['ref_K'] = unpack_lower(g['ref_K_packed'], N, symmetric=True)
+    g['normalize'] = bool(g['normalize'])
+    if g['normalize']:
+        g['meta'] = {k[5:]: v for k, v in g.items() if k.startswith('meta_')}
+    return g
+
+
+@pytest.fixture(scope='session')
+def tank():
+    return load_model('tank')
+
+
+@pytest.fixture(scope='session')
+def car():
+    return load_model('car')
+
+
+@pytest.fixture(scope='session')
+def train_small():
+    return dict(np.load(os.path.join(GOLDEN, 'train_small.npz')))

@@ -1,0 +1,210 @@
+"""CPU tier: pin the oracle (oracle/gp_oracle.py) to the reference.
+
+Golden vectors in tests/golden/ were produced by oracle/make_golden.py, which
+RUNS the reference's numpy code (calc_cov_matrix, calc_NLL_numpy, GP.covar,
+GP.covSEard, train_gp_numpy) and reads its two saved models.  Functions that
+only exist as CasADi graphs in the reference (a9-a12) are pinned through
+identities."""
+import numpy as np
+import pytest
+
+import gp_oracle as go
+
+
+def relF(A, B):
+    return np.linalg.norm(A - B) / np.linalg.norm(B)
+
+
+@pytest.mark.parametrize('name', ['tank', 'car'])
+def test_kernel_matrix_matches_reference(name, request):
+    g = request.getfixturevalue(name)
+    d = g['X'].shape[1]
+    for a in range(g['hyper'].shape[0]):
+        K = go.cov_se_ard(g['X'], g['X'], g['hyper'][a, :d], g['hyper'][a, d] ** 2)
+        assert np.max(np.abs(K - g['ref_K'][a])) <= 1e-15 * g['hyper'][a, d] ** 2   # a1, same op order
+        ks = go.cov_se_ard(g['X'], g['Z'], g['hyper'][a, :d], g['hyper'][a, d] ** 2)
+        assert np.max(np.abs(ks - g['ref_ks'][a])) <= 1e-15 * g['hyper'][a, d] ** 2
+        # a2 direct-difference form agrees with the expanded form to rounding
+        kd = go.cov_se_ard_direct(g['X'], g['Z'], g['hyper'][a, :d], g['hyper'][a, d] ** 2)
+        assert np.max(np.abs(kd - ks)) <= 1e-11 * g['hyper'][a, d] ** 2
+
+
+@pytest.mark.parametrize('name,tol_alpha', [('tank', 1e-6), ('car', 1e-4)])
+def test_refit_matches_saved_model(name, tol_alpha, request):
+    """Stored chol/alpha/invK (written by gp_class.py:693-726) are re-derived
+    from stored X, hyper.  L: 1e-10 rel-F.  alpha/invK are cond-limited
+    (cond(K) up to 7e10) -> residual test."""
+    g = request.getfixturevalue(name)
+    f = go.fit(g['X'], g['Y'], g['hyper'])
+    for a in range(g['hyper'].shape[0]):
+        assert relF(f['chol'][a], g['chol'][a]) <= 1e-10
+        assert np.all(np.triu(f['chol'][a], 1) == 0.0)
+        assert relF(f['alpha'][a], g['alpha'][a]) <= tol_alpha
+        d = g['X'].shape[1]
+        K = go.gram(g['X'], g['hyper'][a, :d], g['hyper'][a, d] ** 2, g['hyper'][a, d + 1] ** 2)
+        res = np.linalg.norm(K @ f['alpha'][a] - g['Y'][:, a]) / (np.linalg.norm(K) * np.linalg.norm(f['alpha'][a]))
+        assert res <= 1e-14
+    assert np.all(f['info'] == 0)
+    # derived hyper fields, incl. the off-by-one `mean` slice gp_class.py:139-142
+    d = g['X'].shape[1]
+    assert np.allclose(g['length_scale'], g['hyper'][:, :d], rtol=0, atol=0)
+    assert np.allclose(g['signal_var'], g['hyper'][:, d] ** 2, rtol=1e-15)
+    assert np.allclose(g['noise_var'], g['hyper'][:, d + 1] ** 2, rtol=1e-15)
+    assert np.allclose(g['hyper_mean'], g['hyper'][:, d + 1:], rtol=0, atol=0)
+
+
+@pytest.mark.parametrize('name', ['tank', 'car'])
+def test_nll_matches_reference(name, request):
+    g = request.getfixturevalue(name)
+    N = g['X'].shape[0]
+    for a in range(g['hyper'].shape[0]):
+        v = go.nll(g['hyper'][a], g['X'], g['Y'][:, a])
+        assert abs(v - g['ref_nll'][a]) / (abs(g['ref_nll'][a]) + N) <= 1e-12
+
+
+@pytest.mark.parametrize('name', ['tank', 'car'])
+def test_variance_matches_reference_covar(name, request):
+    """a14 `GP.covar` is the only numeric variance code in the reference."""
+    g = request.getfixturevalue(name)
+    gp = go.OracleGP(g['X'], g['Y'], g['hyper'], g['chol'], g['alpha'], g['invK'])
+    cv = gp.covar(g['Z'])[:gp.Ny]
+    d = gp.Nx
+    for a in range(gp.Ny):
+        sf2 = g['hyper'][a, d] ** 2
+        assert np.max(np.abs(cv[a] - g['ref_covar'][a])) <= 1e-12 * sf2
+    # a9 restatement (direct-form ks, triangular solve) == diag(covar)
+    mean, var, _ = go.mean_var_jac(g['Z'], g['X'], g['hyper'], g['alpha'], g['chol'])
+    for a in range(gp.Ny):
+        sf2 = g['hyper'][a, d] ** 2
+        assert np.max(np.abs(var[:, a] - g['ref_covar_diag'][a])) <= 1e-10 * sf2
+        ks = go.cov_se_ard(g['X'], g['Z'], g['hyper'][a, :d], sf2)
+        ref_mean = ks.T @ g['alpha'][a]
+        scale = np.abs(ks).T @ np.abs(g['alpha'][a])
+        assert np.max(np.abs(mean[:, a] - ref_mean) / scale) <= 1e-10
+
+
+def test_jitter_rule(train_small):
+    t = train_small
+    for i, h in enumerate(t['probes']):
+        for a in range(t['Y'].shape[1]):
+            d = t['X'].shape[1]
+            K = go.gram(t['X'], h[:d], h[d] ** 2, h[d + 1] ** 2)
+            _, info = go.chol_jitter(K)
+            assert info == t['probe_jitter'][i, a]
+            v = go.nll(h, t['X'], t['Y'][:, a])
+            assert abs(v - t['probe_nll'][i, a]) <= 1e-9 * (abs(t['probe_nll'][i, a]) + 40)
+
+
+def test_train_reproduces_reference_optimum(train_small):
+    """a8: same SLSQP call as optimize.py:466-467 on the restated NLL."""
+    t = train_small
+    opt = go.train(t['X'], t['Y'], multistart=1)
+    assert np.allclose(opt['hyper'], t['hyper'], rtol=1e-5, atol=1e-9)
+    for a in range(2):
+        assert relF(opt['chol'][a], t['chol'][a]) <= 1e-4
+    f = go.fit(t['X'], t['Y'], t['hyper'])
+    for a in range(2):
+        assert relF(f['chol'][a], t['chol'][a]) <= 1e-10
+        assert relF(f['invK'][a], t['invK'][a]) <= 1e-5
+        assert abs(go.nll(t['hyper'][a], t['X'], t['Y'][:, a]) - t['nll'][a]) <= 1e-9
+
+
+def test_nll_gradient_vs_finite_differences(tank):
+    g = tank
+    X, y = g['X'], g['Y'][:, 1]
+    h = np.array([12.0, 25.0, 14.0, 18.0, 22.0, 27.0, 2.1, 0.05])
+    v, grad = go.nll_grad(h, X, y)
+    assert abs(v - go.nll(h, X, y)) <= 1e-9 * (abs(v) + 60)
+    for i in range(len(h)):
+        e = np.zeros_like(h)
+        e[i] = 1e-5 * max(1.0, abs(h[i]))
+        fd = (go.nll(h + e, X, y) - go.nll(h - e, X, y)) / (2 * e[i])
+        assert abs(fd - grad[i]) <= 1e-5 * (abs(grad[i]) + 1e-3), (i, fd, grad[i])
+
+
+def test_mean_jacobian_vs_finite_differences(tank):
+    g = tank
+    z = g['Z'][:3]
+    _, _, J = go.mean_var_jac(z, g['X'], g['hyper'], g['alpha'], g['chol'])
+    eps = 1e-6
+    for dd in range(z.shape[1]):
+        e = np.zeros(z.shape[1])
+        e[dd] = eps
+        mp, _, _ = go.mean_var_jac(z + e, g['X'], g['hyper'], g['alpha'], g['chol'], False)
+        mm, _, _ = go.mean_var_jac(z - e, g['X'], g['hyper'], g['alpha'], g['chol'], False)
+        assert np.allclose((mp - mm) / (2 * eps), J[:, :, dd], rtol=1e-4, atol=1e-5)
+
+
+def _well_conditioned(seed=3, N=50, d=3, Ny=2):
+    p = go.synthetic_problem(N, d, Ny, 4, seed=seed, sn=0.1)
+    p['hyper'][:, :d] = [[1.2, 0.9, 1.5], [0.8, 1.4, 1.1]]
+    f = go.fit(p['X'], p['Y'], p['hyper'])
+    return p, f
+
+
+def test_exact_moment_identities():
+    """a11 pins: beta==alpha; EM(Sigma->0) == ME; Monte-Carlo
+    moments of the ME predictor under z~N(mu,Sigma) match EM."""
+    p, f = _well_conditioned()
+    X, Y, H = p['X'], p['Y'], p['hyper']
+    d = X.shape[1]
+    mu = np.array([0.3, -0.2, 0.5])
+    for a in range(2):
+        assert np.allclose(f['invK'][a] @ Y[:, a], f['alpha'][a], rtol=1e-9, atol=1e-11)
+    m0, c0 = go.exact_moment(f['invK'], X, Y, H, mu, np.eye(d) * 1e-12)
+    mean, var, _ = go.mean_var_jac(mu, X, H, f['alpha'], f['chol'], False)
+    assert np.allclose(m0, mean[0], rtol=1e-8)
+    assert np.allclose(np.diag(c0), var[0], rtol=1e-5, atol=1e-9)
+    A = np.array([[0.3, 0.0, 0.0], [0.1, 0.2, 0.0], [-0.05, 0.1, 0.25]])
+    Sigma = A @ A.T
+    m, c = go.exact_moment(f['invK'], X, Y, H, mu, Sigma)
+    rng = np.random.default_rng(0)
+    zs = mu + rng.standard_normal((40000, d)) @ A.T
+    ms, vs, _ = go.mean_var_jac(zs, X, H, f['alpha'], f['chol'], False)
+    mc_mean = ms.mean(0)
+    mc_cov = np.cov(ms.T) + np.diag(vs.mean(0))
+    assert np.allclose(m, mc_mean, atol=4 * ms.std(0).max() / np.sqrt(len(zs)) + 1e-3)
+    assert np.allclose(c, mc_cov, atol=0.02 * np.abs(mc_cov).max() + 1e-3)
+    assert np.allclose(c, c.T, rtol=0, atol=0)
+    # TA is a first-order approximation of the same thing
+    _, var1, J = go.mean_var_jac(mu, X, H, f['alpha'], f['chol'])
+    ta = go.ta_cov(var1, J, (Sigma * 1e-4)[None])[0]
+    _, em = go.exact_moment(f['invK'], X, Y, H, mu, Sigma * 1e-4)
+    assert np.allclose(ta, em, rtol=5e-2, atol=1e-7)
+
+
+def test_legacy_methods_agree_with_me_on_well_conditioned_data():
+    p, f = _well_conditioned()
+    X, Y, H = p['X'], p['Y'], p['hyper']
+    z = np.array([0.1, 0.4, -0.3])
+    mean, var, _ = go.mean_var_jac(z, X, H, f['alpha'], f['chol'], False)
+    m1, c1 = go.old_me(f['invK'], X, Y, H, z)
+    assert np.allclose(m1, mean[0], rtol=1e-9)
+    assert np.allclose(np.diag(c1), var[0], rtol=1e-7, atol=1e-10)
+    m2, c2 = go.old_ta(f['invK'], X, Y, H, z, np.zeros((3, 3)))
+    assert np.allclose(m2, mean[0], rtol=1e-9)
+    assert np.allclose(np.diag(c2), var[0], rtol=1e-7, atol=1e-10)
+
+
+def test_predict_standardisation_and_rollout(tank):
+    g = tank
+    gp = go.OracleGP(g['X'], g['Y'], g['hyper'], g['chol'], g['alpha'], g['invK'],
+                     normalize=True, meta=g['meta'], gp_method='ME')
+    x = g['meta']['meanX'] + 0.1 * g['meta']['stdX']
+    u = g['meta']['meanU'] - 0.2 * g['meta']['stdU']
+    mean, cov = gp.predict(x, u, np.eye(6) * 1e-6)
+    assert mean.shape == (4, 1) and cov.shape == (4, 4)
+    zs = np.concatenate([(x - g['meta']['meanX']) / g['meta']['stdX'],
+                         (u - g['meta']['meanU']) / g['meta']['stdU']])
+    m, v, _ = go.mean_var_jac(zs, g['X'], g['hyper'], g['alpha'], g['chol'], False)
+    assert np.allclose(mean[:, 0], m[0] * g['meta']['stdY'] + g['meta']['meanY'])
+    assert np.allclose(np.diag(cov), v[0])        # covariance stays standardised (gp_class.py:262)
+    with pytest.raises(NameError):
+        gp.set_method('XX')
+    U = np.tile(u, (5, 1))
+    mr, vr = gp.rollout(x, U, methods=('EM', 'TA', 'ME'))
+    assert mr.shape == (3, 6, 4) and np.all(np.isfinite(mr)) and np.all(np.isfinite(vr))
+    # first step: the three methods agree closely because the input covariance is tiny
+    assert np.allclose(mr[0, 1], mr[2, 1], rtol=1e-3, atol=1e-3)
+    A, Bm = gp.discrete_linearize(x, u, np.eye(6) * 1e-6)
+    assert A.shape == (4, 4) and Bm.shape == (4, 2)
