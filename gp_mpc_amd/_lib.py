@@ -1,0 +1,285 @@
+"""ctypes binding of the C ABI in include/gpmpc.h (libgpmpc_hip.so).
+
+The product path has exactly one backend: the hipcc-built gfx950 library that lives in-tree at
+gp_mpc_amd/csrc/libgpmpc_hip.so.  `get_lib()` raises if it is missing or cannot be loaded -- there
+is no CPU fallback.  (`GpmpcLib(path)` takes an explicit path only so that the CPU test tier can
+hand in the HIP-emulator build of the same sources, tests/emu/.)
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+LIB_PATH = os.path.join(CSRC, 'libgpmpc_hip.so')
+HEADER = os.path.abspath(os.path.join(HERE, '..', 'include', 'gpmpc.h'))
+
+OK, EINVAL, EHIP, ENOTFIT, ENOTPD, ENOMEM = 0, -1, -2, -3, -4, -5
+METHODS = {'ME': 0, 'TA': 1, 'EM': 2, 'old_ME': 3, 'old_TA': 4}
+PTR_HOST, PTR_DEVICE = 0, 1
+PHASES = ['gram', 'factor', 'solve', 'invK', 'crosscov', 'vargemm', 'finish', 'em', 'nll']
+
+_dp = ctypes.POINTER(ctypes.c_double)
+_ip = ctypes.POINTER(ctypes.c_int)
+_vp = ctypes.c_void_p
+
+# name -> (restype, argtypes); must list every symbol gpmpc.h declares (tests/test_abi.py checks)
+SIGNATURES = {
+    'gpmpc_abi_version': (ctypes.c_int, []),
+    'gpmpc_last_error': (ctypes.c_char_p, []),
+    'gpmpc_device_count': (ctypes.c_int, [_ip]),
+    'gpmpc_device_name': (ctypes.c_int, [ctypes.c_int, ctypes.c_char_p, ctypes.c_int]),
+    'gpmpc_mfma_selftest': (ctypes.c_int, [ctypes.c_int, _ip, _dp]),
+    'gpmpc_create': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, _vp,
+                                    ctypes.POINTER(_vp)]),
+    'gpmpc_destroy': (ctypes.c_int, [_vp]),
+    'gpmpc_get_size': (ctypes.c_int, [_vp, _ip, _ip, _ip]),
+    'gpmpc_set_pointer_mode': (ctypes.c_int, [_vp, ctypes.c_int]),
+    'gpmpc_set_stream': (ctypes.c_int, [_vp, _vp]),
+    'gpmpc_synchronize': (ctypes.c_int, [_vp]),
+    'gpmpc_profile_enable': (ctypes.c_int, [_vp, ctypes.c_int]),
+    'gpmpc_profile_read': (ctypes.c_int, [_vp, ctypes.c_int, _dp, ctypes.POINTER(ctypes.c_long), ctypes.c_int]),
+    'gpmpc_fit': (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp]),
+    'gpmpc_get_factors': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    'gpmpc_set_factors': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    'gpmpc_predict_mean_var': (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp]),
+    'gpmpc_mean_jac': (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp]),
+    'gpmpc_predict': (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, _vp]),
+    'gpmpc_covar': (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp]),
+    'gpmpc_nll': (ctypes.c_int, [_vp, ctypes.c_int, _vp, _dp, _vp, _ip]),
+    'gpmpc_cholesky': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _vp, _vp, _ip]),
+    'gpmpc_dgemm': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                   ctypes.c_int, ctypes.c_double, _vp, ctypes.c_int, _vp, ctypes.c_int,
+                                   ctypes.c_double, _vp, ctypes.c_int]),
+}
+
+
+class GpmpcError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f'gpmpc error {code}: {msg}')
+        self.code = code
+
+
+class NotPositiveDefinite(GpmpcError, np.linalg.LinAlgError):
+    """K not SPD even after the one-shot jitter (the reference lets LinAlgError propagate,
+    optimize.py:349-350)."""
+
+
+def _ptr(a):
+    """host ndarray (C-contiguous fp64) or raw device address (int) -> void*"""
+    if a is None:
+        return None
+    if isinstance(a, (int, np.integer)):
+        return ctypes.c_void_p(int(a))
+    assert a.dtype == np.float64 and a.flags['C_CONTIGUOUS'], 'need C-contiguous float64'
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class GpmpcLib:
+    """Loaded C-ABI library with typed entry points."""
+
+    def __init__(self, path):
+        self.path = path
+        self.dll = ctypes.CDLL(path)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(self.dll, name)  # AttributeError if the library lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+
+    def check(self, rc):
+        if rc == OK:
+            return
+        msg = (self.dll.gpmpc_last_error() or b'').decode('utf-8', 'replace')
+        if rc == ENOTPD:
+            raise NotPositiveDefinite(rc, msg)
+        raise GpmpcError(rc, msg)
+
+    # -- library / device
+    def device_count(self):
+        n = ctypes.c_int(0)
+        self.check(self.dll.gpmpc_device_count(ctypes.byref(n)))
+        return n.value
+
+    def device_name(self, device=0):
+        buf = ctypes.create_string_buffer(256)
+        self.check(self.dll.gpmpc_device_name(device, buf, 256))
+        return buf.value.decode()
+
+    def mfma_selftest(self, device=0):
+        layout = ctypes.c_int(-1)
+        tf = ctypes.c_double(0.0)
+        self.check(self.dll.gpmpc_mfma_selftest(device, ctypes.byref(layout), ctypes.byref(tf)))
+        return layout.value, tf.value
+
+    # -- low-level dense ops
+    def cholesky(self, A, device=0, want_inverse=False):
+        A = _f64(A).copy()
+        n = A.shape[0]
+        inv = np.zeros_like(A) if want_inverse else None
+        info = ctypes.c_int(0)
+        self.check(self.dll.gpmpc_cholesky(device, n, _ptr(A), _ptr(inv), ctypes.byref(info)))
+        return (A, inv, info.value) if want_inverse else (A, info.value)
+
+    def dgemm(self, A, B, C=None, alpha=1.0, beta=0.0, transa=False, transb=False, device=0):
+        A, B = _f64(A), _f64(B)
+        M = A.shape[1] if transa else A.shape[0]
+        K = A.shape[0] if transa else A.shape[1]
+        N = B.shape[0] if transb else B.shape[1]
+        C = np.zeros((M, N)) if C is None else _f64(C).copy()
+        self.check(self.dll.gpmpc_dgemm(device, int(transa), int(transb), M, N, K, alpha, _ptr(A), A.shape[1],
+                                        _ptr(B), B.shape[1], beta, _ptr(C), N))
+        return C
+
+
+class Handle:
+    """One GP model on one GPU (gpmpc_gp*).  Thin, typed wrapper; numpy in / numpy out in host
+    pointer mode, raw device addresses (e.g. torch.Tensor.data_ptr()) in device mode."""
+
+    def __init__(self, lib: GpmpcLib, X, Y, device=0):
+        self.lib = lib
+        X, Y = _f64(X), _f64(Y)
+        self.N, self.d = X.shape
+        self.Ny = Y.shape[1]
+        assert Y.shape[0] == self.N
+        h = ctypes.c_void_p()
+        lib.check(lib.dll.gpmpc_create(device, self.N, self.d, self.Ny, _ptr(X), _ptr(Y), ctypes.byref(h)))
+        self.h = h
+        self.device_mode = False
+
+    def close(self):
+        if getattr(self, 'h', None):
+            self.lib.dll.gpmpc_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_pointer_mode(self, device: bool):
+        self.lib.check(self.lib.dll.gpmpc_set_pointer_mode(self.h, PTR_DEVICE if device else PTR_HOST))
+        self.device_mode = device
+
+    def set_stream(self, stream_ptr):
+        self.lib.check(self.lib.dll.gpmpc_set_stream(self.h, ctypes.c_void_p(stream_ptr or 0)))
+
+    def synchronize(self):
+        self.lib.check(self.lib.dll.gpmpc_synchronize(self.h))
+
+    def profile_enable(self, on=True):
+        self.lib.check(self.lib.dll.gpmpc_profile_enable(self.h, int(on)))
+
+    def profile_read(self, reset=True):
+        out = {}
+        for i, name in enumerate(PHASES):
+            ms, n = ctypes.c_double(0), ctypes.c_long(0)
+            self.lib.check(self.lib.dll.gpmpc_profile_read(self.h, i, ctypes.byref(ms), ctypes.byref(n), int(reset)))
+            out[name] = (ms.value, n.value)
+        return out
+
+    def fit(self, hyper, want_invK=False):
+        hyper = _f64(hyper).reshape(self.Ny, self.d + 2)
+        info = np.zeros(self.Ny, dtype=np.int32)
+        rc = self.lib.dll.gpmpc_fit(self.h, _ptr(hyper), int(want_invK), info.ctypes.data_as(ctypes.c_void_p))
+        self.info = info
+        self.lib.check(rc)
+        return info
+
+    def get_factors(self, chol=True, alpha=True, invK=False):
+        N, Ny = self.N, self.Ny
+        hyper = np.zeros((Ny, self.d + 2))
+        L = np.zeros((Ny, N, N)) if chol else None
+        al = np.zeros((Ny, N)) if alpha else None
+        iK = np.zeros((Ny, N, N)) if invK else None
+        self.lib.check(self.lib.dll.gpmpc_get_factors(self.h, _ptr(hyper), _ptr(L), _ptr(al), _ptr(iK)))
+        return dict(hyper=hyper, chol=L, alpha=al, invK=iK)
+
+    def set_factors(self, hyper, chol, alpha=None, invK=None):
+        hyper = _f64(hyper).reshape(self.Ny, self.d + 2)
+        chol = _f64(chol).reshape(self.Ny, self.N, self.N)
+        alpha = None if alpha is None else _f64(alpha).reshape(self.Ny, self.N)
+        invK = None if invK is None else _f64(invK).reshape(self.Ny, self.N, self.N)
+        self.lib.check(self.lib.dll.gpmpc_set_factors(self.h, _ptr(hyper), _ptr(chol), _ptr(alpha), _ptr(invK)))
+
+    # -- predict family (host mode: numpy in/out)
+    def predict_mean_var(self, Z):
+        Z = _f64(Z).reshape(-1, self.d)
+        B = Z.shape[0]
+        mean, var = np.zeros((B, self.Ny)), np.zeros((B, self.Ny))
+        self.lib.check(self.lib.dll.gpmpc_predict_mean_var(self.h, B, _ptr(Z), _ptr(mean), _ptr(var)))
+        return mean, var
+
+    def mean_jac(self, Z):
+        Z = _f64(Z).reshape(-1, self.d)
+        B = Z.shape[0]
+        mean, J = np.zeros((B, self.Ny)), np.zeros((B, self.Ny, self.d))
+        self.lib.check(self.lib.dll.gpmpc_mean_jac(self.h, B, _ptr(Z), _ptr(mean), _ptr(J)))
+        return mean, J
+
+    def predict(self, method, Z, Sigma=None):
+        code = METHODS[method] if isinstance(method, str) else int(method)
+        Z = _f64(Z).reshape(-1, self.d)
+        B = Z.shape[0]
+        if Sigma is not None:
+            Sigma = _f64(Sigma).reshape(B, self.d, self.d)
+        mean, cov = np.zeros((B, self.Ny)), np.zeros((B, self.Ny, self.Ny))
+        self.lib.check(self.lib.dll.gpmpc_predict(self.h, code, B, _ptr(Z), _ptr(Sigma), _ptr(mean), _ptr(cov)))
+        return mean, cov
+
+    def covar(self, Xnew):
+        Xnew = _f64(Xnew).reshape(-1, self.d)
+        n = Xnew.shape[0]
+        out = np.zeros((self.Ny, n, n))
+        self.lib.check(self.lib.dll.gpmpc_covar(self.h, n, _ptr(Xnew), _ptr(out)))
+        return out
+
+    def nll(self, a, hyper_row, want_grad=False):
+        hyper_row = _f64(hyper_row).reshape(self.d + 2)
+        val = ctypes.c_double(0.0)
+        grad = np.zeros(self.d + 2) if want_grad else None
+        jit = ctypes.c_int(0)
+        self.lib.check(self.lib.dll.gpmpc_nll(self.h, int(a), _ptr(hyper_row), ctypes.byref(val), _ptr(grad),
+                                              ctypes.byref(jit)))
+        self.last_jitter = jit.value
+        return (val.value, grad) if want_grad else val.value
+
+    # -- raw device-pointer entry points (device pointer mode)
+    def predict_mean_var_dev(self, B, z_ptr, mean_ptr, var_ptr):
+        self.lib.check(self.lib.dll.gpmpc_predict_mean_var(self.h, B, _ptr(z_ptr), _ptr(mean_ptr), _ptr(var_ptr)))
+
+    def predict_dev(self, method, B, z_ptr, sigma_ptr, mean_ptr, cov_ptr):
+        code = METHODS[method] if isinstance(method, str) else int(method)
+        self.lib.check(self.lib.dll.gpmpc_predict(self.h, code, B, _ptr(z_ptr), _ptr(sigma_ptr), _ptr(mean_ptr),
+                                                  _ptr(cov_ptr)))
+
+
+# ------------------------------------------------------------------------------------------------
+_LIB = None
+
+
+def build(verbose=False):
+    """Compile the HIP sources for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    cmd = ['make', '-C', CSRC] + ([] if verbose else ['-s'])
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+def get_lib() -> GpmpcLib:
+    """The product library.  Fails loudly: no library, no GPU path, no fallback."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f'{LIB_PATH} is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                f'or `make -C {CSRC}` (needs hipcc); gp_mpc_amd has no CPU fallback')
+        _LIB = GpmpcLib(LIB_PATH)
+    return _LIB

@@ -1,0 +1,355 @@
+// SE-ARD kernel-matrix kernels and the small per-point assembly / reduction kernels of the GP
+// hot path.  Layouts: XT[d][Np] (inputs transposed so that a wave reads 64 consecutive training
+// points per dimension), Y/alpha/w [Ny][Np], K/L/invL [Ny][Np][Np] row-major, KsT[Ny][Bp][Np]
+// (one contiguous k_a(X, z_j) vector per test point = the K-contiguous B operand of the variance
+// GEMM).  Np = N rounded up to 64; padded rows/columns of K are the identity, padded entries of
+// every vector are exact zeros, so padded quantities never contribute.
+#pragma once
+#include "mfma_f64.hpp"
+
+namespace gpmpc {
+
+constexpr int DMAX = 16;  // max GP input dimension d = Nx + Nu
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+
+// a1 + a3: K_a = sf^2 exp(-1/2 dist) + (sn^2 [+ jitter]) I on the lower triangle, with dist
+// accumulated EXACTLY as the reference's numeric K build does (calc_cov_matrix optimize.py:314-318 /
+// GP.covSEard gp_class.py:346-349): per input dimension the expanded form
+//     dist = ((x_i^2 + x_j^2) - 2 (x_i x_j)) / ell^2 + dist
+// in that operation order and without FMA contraction, so K matches numpy's K to the last bit of
+// exp().  (On the reference's saved models, cond(K) up to 7e10, the choice of form moves chol(K) by
+// 1e-10 relative -- the parity bar -- so the K build follows the form the fixtures were made with;
+// the predict-side ks uses the direct-difference form that build_gp evaluates.)
+// grid (Np/64, Np/64, batch), 256 threads; tiles above the diagonal exit at once.  HBM-write bound:
+// 4 N (N+1) bytes per output.
+__global__ void __launch_bounds__(256) gram_kernel(const double* __restrict__ XT, const double* __restrict__ hyper,
+                                                   const double* __restrict__ jitter, double* __restrict__ K,
+                                                   int N, int Np, int d) {
+#pragma clang fp contract(off)
+    const int tn = blockIdx.x, tm = blockIdx.y, a = blockIdx.z;
+    if (tn > tm) return;
+    __shared__ double Xr[DMAX][64], Xc[DMAX][64], Qr[DMAX][64], Qc[DMAX][64], e2[DMAX];
+    const int tid = threadIdx.x, m0 = tm * 64, n0 = tn * 64;
+    for (int idx = tid; idx < 64 * d; idx += 256) {
+        const int dd = idx >> 6, i = idx & 63;
+        const double xr = XT[(long)dd * Np + m0 + i], xc = XT[(long)dd * Np + n0 + i];
+        Xr[dd][i] = xr;
+        Xc[dd][i] = xc;
+        Qr[dd][i] = xr * xr;
+        Qc[dd][i] = xc * xc;
+    }
+    const double* hy = hyper + (long)a * (d + 2);
+    if (tid < d) e2[tid] = hy[tid] * hy[tid];
+    const double sf2 = hy[d] * hy[d], sn2 = hy[d + 1] * hy[d + 1], jit = jitter[a];
+    __syncthreads();
+    double* __restrict__ Ka = K + (long)a * Np * Np;
+#pragma unroll 4
+    for (int s = 0; s < 16; ++s) {
+        const int idx = tid + 256 * s, r = idx >> 6, c = idx & 63;
+        const int i = m0 + r, j = n0 + c;
+        double v;
+        if (i >= N || j >= N) {
+            v = (i == j) ? 1.0 : 0.0;
+        } else if (j > i) {
+            v = 0.0;
+        } else {
+            double dist = 0.0;
+            for (int dd = 0; dd < d; ++dd) {
+                const double t = (Qr[dd][r] + Qc[dd][c]) - 2.0 * (Xr[dd][r] * Xc[dd][c]);
+                dist = t / e2[dd] + dist;
+            }
+            v = sf2 * exp(-0.5 * dist);
+            if (i == j) v = (v + sn2) + jit;
+        }
+        Ka[(long)i * Np + j] = v;
+    }
+}
+
+// a9 (first half): ks_a(X, z_j) for JT test points per workgroup, written as KsT[a][j][:], fused
+// with mean_a(z_j) = ks^T alpha_a (gp_functions.py:114-120,135).  grid (Bp/JT, Ny), 256 threads.
+// D (the GP input dimension) is a template parameter so that a training point's coordinates live in
+// registers and the distance loop is fully unrolled; the JT test points are wave-uniform LDS reads.
+template <int D, int JT>
+__global__ void __launch_bounds__(256) crosscov_kernel(const double* __restrict__ XT, const double* __restrict__ hyper,
+                                                       const double* __restrict__ alpha, const double* __restrict__ Z,
+                                                       double* __restrict__ KsT, double* __restrict__ meanT,
+                                                       int N, int Np, int B, int Bp) {
+    const int j0 = blockIdx.x * JT, a = blockIdx.y, tid = threadIdx.x;
+    __shared__ double Zs[JT][D], w[D], red[4][JT];
+    const double* hy = hyper + (long)a * (D + 2);
+    if (tid < JT * D) {
+        const int jj = tid / D, dd = tid % D;
+        Zs[jj][dd] = (j0 + jj < B) ? Z[(long)(j0 + jj) * D + dd] : 0.0;
+    }
+    if (tid < D) w[tid] = 1.0 / (hy[tid] * hy[tid]);
+    const double sf2 = hy[D] * hy[D];
+    __syncthreads();
+    double macc[JT];
+#pragma unroll
+    for (int jj = 0; jj < JT; ++jj) macc[jj] = 0.0;
+    const double* __restrict__ al = alpha + (long)a * Np;
+    double* __restrict__ out = KsT + ((long)a * Bp + j0) * Np;
+    for (int i = tid; i < Np; i += 256) {
+        double x[D];
+#pragma unroll
+        for (int dd = 0; dd < D; ++dd) x[dd] = XT[(long)dd * Np + i];
+        const double ai = al[i];
+        const bool live = i < N;
+#pragma unroll
+        for (int jj = 0; jj < JT; ++jj) {
+            double dist = 0.0;
+#pragma unroll
+            for (int dd = 0; dd < D; ++dd) {
+                const double df = x[dd] - Zs[jj][dd];
+                dist += df * df * w[dd];
+            }
+            const double ks = (live && j0 + jj < B) ? sf2 * exp(-0.5 * dist) : 0.0;
+            out[(long)jj * Np + i] = ks;
+            macc[jj] += ks * ai;
+        }
+    }
+#pragma unroll
+    for (int jj = 0; jj < JT; ++jj) {
+        const double s = wave_sum(macc[jj]);
+        if ((tid & 63) == 0) red[tid >> 6][jj] = s;
+    }
+    __syncthreads();
+    if (tid < JT) meanT[(long)a * Bp + j0 + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+}
+
+constexpr int CROSSCOV_JT = 8;
+
+template <int D>
+inline void launch_crosscov_d(hipStream_t st, const double* XT, const double* hyper, const double* alpha,
+                              const double* Z, double* KsT, double* meanT, int N, int Np, int B, int Bp, int Ny) {
+    hipLaunchKernelGGL((crosscov_kernel<D, CROSSCOV_JT>), dim3(Bp / CROSSCOV_JT, Ny), dim3(256), 0, st, XT, hyper, alpha,
+                       Z, KsT, meanT, N, Np, B, Bp);
+}
+
+inline void launch_crosscov(hipStream_t st, int d, const double* XT, const double* hyper, const double* alpha,
+                            const double* Z, double* KsT, double* meanT, int N, int Np, int B, int Bp, int Ny) {
+#define GPMPC_CC(DD) case DD: launch_crosscov_d<DD>(st, XT, hyper, alpha, Z, KsT, meanT, N, Np, B, Bp, Ny); break;
+    switch (d) {
+        GPMPC_CC(1) GPMPC_CC(2) GPMPC_CC(3) GPMPC_CC(4) GPMPC_CC(5) GPMPC_CC(6) GPMPC_CC(7) GPMPC_CC(8)
+        GPMPC_CC(9) GPMPC_CC(10) GPMPC_CC(11) GPMPC_CC(12) GPMPC_CC(13) GPMPC_CC(14) GPMPC_CC(15) GPMPC_CC(16)
+        default: break;
+    }
+#undef GPMPC_CC
+}
+
+// a9 (second half): var_a(z_j) = sf_a^2 - sum over row tiles of the column sums of squares
+// written by the variance GEMM (gp_functions.py:125-126,136: kss = sf^2, no noise), and the
+// transposition of mean to the caller's [B][Ny] layout.  One thread per test point.
+__global__ void __launch_bounds__(256) var_finish_kernel(const double* __restrict__ part, const double* __restrict__ meanT,
+                                                         const double* __restrict__ hyper, double* __restrict__ mean,
+                                                         double* __restrict__ var, int B, int Bp, int Ny, int d,
+                                                         int tilesM) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    for (int a = 0; a < Ny; ++a) {
+        const double sf = hyper[(long)a * (d + 2) + d];
+        double s = 0.0;
+        for (int t = 0; t < tilesM; ++t) s += part[((long)a * tilesM + t) * Bp + b];
+        if (var) var[(long)b * Ny + a] = sf * sf - s;
+        if (mean) mean[(long)b * Ny + a] = meanT[(long)a * Bp + b];
+    }
+}
+
+// Analytic mean Jacobian J[b][a][dd] = sum_i alpha_i ks_i (X_i,dd - z_dd) / ell_dd^2 (what CasADi's
+// AD yields for mean_jac_z, gp_functions.py:146-147).  grid (B, Ny), 256 threads; reads the ks
+// vector the cross-covariance kernel left in KsT.
+__global__ void __launch_bounds__(256) mean_jac_kernel(const double* __restrict__ XT, const double* __restrict__ hyper,
+                                                       const double* __restrict__ alpha, const double* __restrict__ Z,
+                                                       const double* __restrict__ KsT, double* __restrict__ J,
+                                                       int N, int Np, int d, int Bp, int Ny) {
+    const int b = blockIdx.x, a = blockIdx.y, tid = threadIdx.x;
+    __shared__ double red[4][DMAX];
+    const double* hy = hyper + (long)a * (d + 2);
+    const double* __restrict__ ks = KsT + ((long)a * Bp + b) * Np;
+    const double* __restrict__ al = alpha + (long)a * Np;
+    double z[DMAX], acc[DMAX];
+#pragma unroll
+    for (int dd = 0; dd < DMAX; ++dd) {
+        z[dd] = (dd < d) ? Z[(long)b * d + dd] : 0.0;
+        acc[dd] = 0.0;
+    }
+    for (int i = tid; i < N; i += 256) {
+        const double c = ks[i] * al[i];
+#pragma unroll
+        for (int dd = 0; dd < DMAX; ++dd)
+            if (dd < d) acc[dd] += c * (XT[(long)dd * Np + i] - z[dd]);
+    }
+#pragma unroll
+    for (int dd = 0; dd < DMAX; ++dd) {
+        const double s = wave_sum(acc[dd]);
+        if ((tid & 63) == 0) red[tid >> 6][dd] = s;
+    }
+    __syncthreads();
+    if (tid < d) {
+        const double s = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+        J[((long)b * Ny + a) * d + tid] = s / (hy[tid] * hy[tid]);
+    }
+}
+
+// a10 build_TA_cov gp_functions.py:152-173: cov[b] = diag(var[b]) + J[b] Sigma[b] J[b]^T
+// (Sigma == nullptr -> the 'ME' covariance diag(var), gp_functions.py:143).  One thread per entry.
+__global__ void __launch_bounds__(256) cov_assemble_kernel(const double* __restrict__ var, const double* __restrict__ J,
+                                                           const double* __restrict__ Sigma, double* __restrict__ cov,
+                                                           int B, int Ny, int d) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long)B * Ny * Ny) return;
+    const int c = (int)(e % Ny), a = (int)((e / Ny) % Ny);
+    const long b = e / ((long)Ny * Ny);
+    double v = (a == c) ? var[b * Ny + a] : 0.0;
+    if (Sigma) {
+        const double* Ja = J + (b * Ny + a) * d;
+        const double* Jc = J + (b * Ny + c) * d;
+        const double* S = Sigma + b * d * d;
+        for (int p = 0; p < d; ++p) {
+            double t = 0.0;
+            for (int q = 0; q < d; ++q) t += S[p * d + q] * Jc[q];
+            v += Ja[p] * t;
+        }
+    }
+    cov[e] = v;
+}
+
+// a7 tail: nll[a] = 1/2 w^T w + sum_i log|L_ii| with w = L^-1 y (= 1/2 y^T alpha + 1/2 logdet K,
+// optimize.py:352-355).  grid (batch), 256 threads, fixed-order reduction (deterministic).
+__global__ void __launch_bounds__(256) nll_reduce_kernel(const double* __restrict__ L, const double* __restrict__ w,
+                                                         double* __restrict__ nll, int N, int Np) {
+    const int a = blockIdx.x, tid = threadIdx.x;
+    __shared__ double red[4];
+    const double* La = L + (long)a * Np * Np;
+    const double* wa = w + (long)a * Np;
+    double s = 0.0;
+    for (int i = tid; i < N; i += 256) s += 0.5 * wa[i] * wa[i] + log(fabs(La[(long)i * Np + i]));
+    s = wave_sum(s);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) nll[a] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// Analytic NLL gradient, Rasmussen & Williams eq. 5.9 (no reference function; optimize.py:371-375):
+//   g_theta = 1/2 sum_ij W_ij dK_ij/dtheta,  W = K^-1 - alpha alpha^T,
+//   dK/d ell_dd = Kse_ij (x_id - x_jd)^2 / ell_dd^3,  dK/d sf = 2 Kse / sf,  dK/d sn = 2 sn I.
+// One pass over the lower triangle of K^-1 with Kse recomputed on the fly (HBM-read bound:
+// 4 N^2 bytes); per-tile partial sums are written out and reduced in a fixed order.
+// grid (Np/64, Np/64), 256 threads; partial[tile][d+2].
+__global__ void __launch_bounds__(256) nll_grad_kernel(const double* __restrict__ XT, const double* __restrict__ hyper,
+                                                       const double* __restrict__ invK, const double* __restrict__ alpha,
+                                                       double* __restrict__ partial, int N, int Np, int d) {
+    const int tn = blockIdx.x, tm = blockIdx.y, tid = threadIdx.x;
+    const int tiles = Np / 64;
+    double* out = partial + ((long)tm * tiles + tn) * (DMAX + 2);
+    if (tn > tm) return;
+    __shared__ double Xr[DMAX][64], Xc[DMAX][64], w[DMAX], ar[64], ac[64], red[4][DMAX + 2];
+    const int m0 = tm * 64, n0 = tn * 64;
+    for (int idx = tid; idx < 64 * d; idx += 256) {
+        const int dd = idx >> 6, i = idx & 63;
+        Xr[dd][i] = XT[(long)dd * Np + m0 + i];
+        Xc[dd][i] = XT[(long)dd * Np + n0 + i];
+    }
+    if (tid < 64) { ar[tid] = alpha[m0 + tid]; ac[tid] = alpha[n0 + tid]; }
+    if (tid < DMAX) w[tid] = (tid < d) ? 1.0 / (hyper[tid] * hyper[tid]) : 0.0;
+    const double sf2 = hyper[d] * hyper[d];
+    __syncthreads();
+    double g[DMAX], gsf = 0.0, gtr = 0.0;
+#pragma unroll
+    for (int dd = 0; dd < DMAX; ++dd) g[dd] = 0.0;
+    for (int s = 0; s < 16; ++s) {
+        const int idx = tid + 256 * s, r = idx >> 6, c = idx & 63;
+        const int i = m0 + r, j = n0 + c;
+        if (i < N && j <= i) {
+            const double Wij = invK[(long)i * Np + j] - ar[r] * ac[c];
+            const double mult = (j < i) ? 2.0 : 1.0;  // symmetric counterpart
+            double dist = 0.0, df2[DMAX];
+#pragma unroll
+            for (int dd = 0; dd < DMAX; ++dd) {
+                const double df = (dd < d) ? Xr[dd][r] - Xc[dd][c] : 0.0;
+                df2[dd] = df * df;
+                dist += df2[dd] * w[dd];
+            }
+            const double wk = mult * Wij * sf2 * exp(-0.5 * dist);
+#pragma unroll
+            for (int dd = 0; dd < DMAX; ++dd) g[dd] += wk * df2[dd];
+            gsf += wk;
+            if (i == j) gtr += Wij;
+        }
+    }
+#pragma unroll
+    for (int dd = 0; dd < DMAX; ++dd) {
+        const double s = wave_sum(g[dd]);
+        if ((tid & 63) == 0) red[tid >> 6][dd] = s;
+    }
+    gsf = wave_sum(gsf);
+    gtr = wave_sum(gtr);
+    if ((tid & 63) == 0) { red[tid >> 6][DMAX] = gsf; red[tid >> 6][DMAX + 1] = gtr; }
+    __syncthreads();
+    if (tid < DMAX + 2) out[tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+}
+
+// fixed-order final reduction of the gradient partials -> grad[d+2]
+__global__ void __launch_bounds__(64) nll_grad_finish_kernel(const double* __restrict__ partial,
+                                                             const double* __restrict__ hyper,
+                                                             double* __restrict__ grad, int Np, int d) {
+    const int tid = threadIdx.x, tiles = Np / 64;
+    if (tid >= d + 2) return;
+    const int col = tid < d ? tid : (tid == d ? DMAX : DMAX + 1);
+    double s = 0.0;
+    for (int tm = 0; tm < tiles; ++tm)
+        for (int tn = 0; tn <= tm; ++tn) s += partial[((long)tm * tiles + tn) * (DMAX + 2) + col];
+    double g;
+    if (tid < d) g = 0.5 * s / (hyper[tid] * hyper[tid] * hyper[tid]);
+    else if (tid == d) g = 0.5 * s * 2.0 / hyper[d];
+    else g = 0.5 * s * 2.0 * hyper[d + 1];
+    grad[tid] = g;
+}
+
+// mirror the strictly-lower triangle into the upper one (K^-1 is exported as a full symmetric
+// matrix, gp_class.py:698).  grid (Np/64, Np/64, batch); 64 x 64 tiles through LDS.
+__global__ void __launch_bounds__(256) symmetrize_kernel(double* __restrict__ A, int Np) {
+    const int tn = blockIdx.x, tm = blockIdx.y;
+    if (tn > tm) return;
+    __shared__ double tile[64][65];
+    double* Aa = A + (long)blockIdx.z * Np * Np;
+    const int tid = threadIdx.x, m0 = tm * 64, n0 = tn * 64;
+    for (int idx = tid; idx < 4096; idx += 256) {
+        const int r = idx >> 6, c = idx & 63;
+        tile[r][c] = Aa[(long)(m0 + r) * Np + n0 + c];
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 4096; idx += 256) {
+        const int r = idx >> 6, c = idx & 63;  // writes element (n0 + r, m0 + c) = tile[c][r]
+        if (tm != tn || c > r) Aa[(long)(n0 + r) * Np + m0 + c] = tile[c][r];
+    }
+}
+
+// f64 MFMA fragment-layout probe + rate micro-benchmark (gpmpc_mfma_selftest).
+__global__ void __launch_bounds__(64) mfma_probe_kernel(const double* __restrict__ A, const double* __restrict__ B,
+                                                        double* __restrict__ D) {
+    const int l = threadIdx.x;
+    d4 c = d4{0.0, 0.0, 0.0, 0.0};
+    c = mfma16(A[(l & 15) * 4 + (l >> 4)], B[(l >> 4) * 16 + (l & 15)], c);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) D[l * 4 + r] = c[r];
+}
+
+__global__ void __launch_bounds__(256) mfma_rate_kernel(double* __restrict__ out, int iters) {
+    const double a = 1.0 + 1e-9 * threadIdx.x, b = 1.0 - 1e-9 * threadIdx.x;
+    d4 c0 = d4{0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
+    for (int i = 0; i < iters; ++i) {
+        c0 = mfma16(a, b, c0);
+        c1 = mfma16(a, b, c1);
+        c2 = mfma16(a, b, c2);
+        c3 = mfma16(a, b, c3);
+    }
+    out[(long)blockIdx.x * 256 + threadIdx.x] = c0[0] + c1[1] + c2[2] + c3[3];
+}
+
+}  // namespace gpmpc

@@ -1,0 +1,933 @@
+// C ABI of libgpmpc_hip.so (include/gpmpc.h): host-side orchestration of the HIP kernels.
+// One translation unit: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC gpmpc_api.hip
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/gpmpc.h"
+#include "em_kernels.hpp"
+#include "gemm_f64.hpp"
+#include "gp_kernels.hpp"
+#include "leaf64.hpp"
+
+using namespace gpmpc;
+
+// ------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+static int fail(int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                                  \
+    do {                                                                                              \
+        hipError_t e_ = (expr);                                                                       \
+        if (e_ != hipSuccess)                                                                         \
+            return fail(GPMPC_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__,   \
+                        __LINE__);                                                                    \
+    } while (0)
+#define CHK(expr)                 \
+    do {                          \
+        int rc_ = (expr);         \
+        if (rc_ != GPMPC_OK) return rc_; \
+    } while (0)
+
+static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// ------------------------------------------------------------------------------------------------
+// device bring-up + fp64 MFMA self-test
+// ------------------------------------------------------------------------------------------------
+static int g_crow_mode[64];
+static bool g_dev_ready[64];
+
+static int mfma_selftest(int device, int* layout_out, double* tflops_out) {
+    HIPCHK(hipSetDevice(device));
+    double hA[64], hB[64], hD[256];
+    for (int i = 0; i < 16; ++i)
+        for (int k = 0; k < 4; ++k) hA[i * 4 + k] = 1.0 + i * 0.25 - k * 0.5 + 0.03125 * i * k;
+    for (int k = 0; k < 4; ++k)
+        for (int j = 0; j < 16; ++j) hB[k * 16 + j] = -2.0 + 0.5 * j + 0.125 * k * k - 0.0625 * j * k;
+    double *dA, *dB, *dD;
+    HIPCHK(hipMalloc(&dA, sizeof(hA)));
+    HIPCHK(hipMalloc(&dB, sizeof(hB)));
+    HIPCHK(hipMalloc(&dD, sizeof(hD)));
+    HIPCHK(hipMemcpy(dA, hA, sizeof(hA), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dB, hB, sizeof(hB), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(mfma_probe_kernel, dim3(1), dim3(64), 0, 0, dA, dB, dD);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(hD, dD, sizeof(hD), hipMemcpyDeviceToHost));
+    int layout = -1;
+    for (int mode = 0; mode < 2 && layout < 0; ++mode) {
+        bool ok = true;
+        for (int l = 0; l < 64 && ok; ++l)
+            for (int r = 0; r < 4 && ok; ++r) {
+                const int row = mode == 0 ? (l >> 4) + 4 * r : 4 * (l >> 4) + r, col = l & 15;
+                double s = 0.0;
+                for (int k = 0; k < 4; ++k) s += hA[row * 4 + k] * hB[k * 16 + col];
+                if (std::fabs(s - hD[l * 4 + r]) > 1e-12 * (1.0 + std::fabs(s))) ok = false;
+            }
+        if (ok) layout = mode;
+    }
+    if (layout_out) *layout_out = layout;
+    if (tflops_out) {
+        *tflops_out = 0.0;
+#ifndef GPMPC_EMULATED
+        hipDeviceProp_t prop;
+        HIPCHK(hipGetDeviceProperties(&prop, device));
+        const int blocks = prop.multiProcessorCount * 2, iters = 4096;
+        double* dOut;
+        HIPCHK(hipMalloc(&dOut, (size_t)blocks * 256 * sizeof(double)));
+        hipEvent_t e0, e1;
+        HIPCHK(hipEventCreate(&e0));
+        HIPCHK(hipEventCreate(&e1));
+        hipLaunchKernelGGL(mfma_rate_kernel, dim3(blocks), dim3(256), 0, 0, dOut, 64);
+        HIPCHK(hipEventRecord(e0, 0));
+        hipLaunchKernelGGL(mfma_rate_kernel, dim3(blocks), dim3(256), 0, 0, dOut, iters);
+        HIPCHK(hipEventRecord(e1, 0));
+        HIPCHK(hipEventSynchronize(e1));
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+        const double flops = (double)blocks * 4 /*waves*/ * iters * 4.0 * 2.0 * 16 * 16 * 4;
+        *tflops_out = flops / (ms * 1e-3) * 1e-12;
+        hipEventDestroy(e0);
+        hipEventDestroy(e1);
+        hipFree(dOut);
+#endif
+    }
+    hipFree(dA);
+    hipFree(dB);
+    hipFree(dD);
+    if (layout < 0)
+        return fail(GPMPC_EHIP, "v_mfma_f64_16x16x4_f64 returned a fragment layout this library does not know");
+    return GPMPC_OK;
+}
+
+static int ensure_device(int device) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(GPMPC_EHIP, "no HIP device visible (libgpmpc_hip needs an MI355X / gfx950 GPU)");
+    if (device < 0 || device >= n || device >= 64) return fail(GPMPC_EINVAL, "device %d out of range (count %d)", device, n);
+    HIPCHK(hipSetDevice(device));
+    if (!g_dev_ready[device]) {
+#ifndef GPMPC_EMULATED
+        hipDeviceProp_t prop;
+        HIPCHK(hipGetDeviceProperties(&prop, device));
+        if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+            return fail(GPMPC_EHIP, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+#endif
+        int layout = -1;
+        CHK(mfma_selftest(device, &layout, nullptr));
+        g_crow_mode[device] = layout;
+        g_dev_ready[device] = true;
+    }
+    return GPMPC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// factorisation workspace: K (destroyed), L, L^-1, scratch, w, alpha for `batch` matrices
+// ------------------------------------------------------------------------------------------------
+struct Workspace {
+    int batch = 0, Np = 0, d = 0;
+    double *K = nullptr, *L = nullptr, *Inv = nullptr, *InvK = nullptr, *W = nullptr;
+    double *w = nullptr, *alpha = nullptr, *hyper = nullptr, *jitter = nullptr, *nll = nullptr;
+    int* info = nullptr;
+    long mat() const { return (long)Np * Np; }
+};
+
+static int ws_alloc(Workspace& ws, int batch, int Np, int d) {
+    ws.batch = batch;
+    ws.Np = Np;
+    ws.d = d;
+    const size_t mb = (size_t)batch * Np * Np * sizeof(double);
+    HIPCHK(hipMalloc(&ws.K, mb));
+    HIPCHK(hipMalloc(&ws.L, mb));
+    HIPCHK(hipMalloc(&ws.Inv, mb));
+    const long hw = Np / 2 + 64;
+    HIPCHK(hipMalloc(&ws.W, (size_t)batch * hw * hw * sizeof(double)));
+    HIPCHK(hipMalloc(&ws.w, (size_t)batch * Np * sizeof(double)));
+    HIPCHK(hipMalloc(&ws.alpha, (size_t)batch * Np * sizeof(double)));
+    HIPCHK(hipMalloc(&ws.hyper, (size_t)batch * (d + 2) * sizeof(double)));
+    HIPCHK(hipMalloc(&ws.jitter, (size_t)batch * sizeof(double)));
+    HIPCHK(hipMalloc(&ws.nll, (size_t)batch * sizeof(double)));
+    HIPCHK(hipMalloc(&ws.info, (size_t)batch * sizeof(int)));
+    HIPCHK(hipMemset(ws.K, 0, mb));
+    HIPCHK(hipMemset(ws.L, 0, mb));
+    HIPCHK(hipMemset(ws.Inv, 0, mb));
+    HIPCHK(hipMemset(ws.alpha, 0, (size_t)batch * Np * sizeof(double)));
+    HIPCHK(hipMemset(ws.w, 0, (size_t)batch * Np * sizeof(double)));
+    return GPMPC_OK;
+}
+
+static void ws_free(Workspace& ws) {
+    hipFree(ws.K); hipFree(ws.L); hipFree(ws.Inv); hipFree(ws.InvK); hipFree(ws.W);
+    hipFree(ws.w); hipFree(ws.alpha); hipFree(ws.hyper); hipFree(ws.jitter); hipFree(ws.nll); hipFree(ws.info);
+    ws = Workspace();
+}
+
+static int ws_need_invK(Workspace& ws) {
+    if (!ws.InvK) HIPCHK(hipMalloc(&ws.InvK, (size_t)ws.batch * ws.mat() * sizeof(double)));
+    return GPMPC_OK;
+}
+
+struct Ctx {
+    hipStream_t stream;
+    int crow_mode;
+};
+
+static GemmP gemm_base(const Ctx& cx) {
+    GemmP p;
+    std::memset(&p, 0, sizeof(p));
+    p.alpha = 1.0;
+    p.crow_mode = cx.crow_mode;
+    return p;
+}
+
+// Recursive blocked Cholesky fused with the triangular inverse (both end up as fp64 MFMA GEMMs):
+//   [L11 0; L21 L22]:  L11,inv11 <- rec(A11);  L21 = A21 inv11^T;  A22 -= L21 L21^T;
+//                      L22,inv22 <- rec(A22);  inv21 = -inv22 (L21 inv11).
+// K is consumed (trailing updates are applied in place), L and Inv are written; all [batch][Np x Np].
+static void factor_rec(const Ctx& cx, Workspace& ws, int off, int n, bool do_chol) {
+    const long ld = ws.Np, sM = ws.mat();
+    if (n <= 64) {
+        hipLaunchKernelGGL(leaf64_kernel, dim3(1, 1, ws.batch), dim3(256), 0, cx.stream,
+                           do_chol ? (const double*)ws.K : (const double*)ws.L, ws.L, ws.Inv, ld, sM, off,
+                           do_chol ? 1 : 0, ws.info, cx.crow_mode);
+        return;
+    }
+    const int h1 = (n / 64 / 2) * 64, h2 = n - h1;
+    const long o11 = (long)off * ld + off, o21 = (long)(off + h1) * ld + off, o22 = (long)(off + h1) * ld + off + h1;
+    factor_rec(cx, ws, off, h1, do_chol);
+    if (do_chol) {
+        GemmP p = gemm_base(cx);  // L21 = A21 inv11^T
+        p.A = ws.K + o21; p.lda = ld; p.sA = sM; p.a_mc = 0;
+        p.B = ws.Inv + o11; p.ldb = ld; p.sB = sM; p.b_nc = 0; p.kflags = KB_LE_N;
+        p.C = ws.L + o21; p.ldc = ld; p.sC = sM;
+        p.M = h2; p.N = h1; p.K = h1;
+        launch_gemm(p, ws.batch, cx.stream);
+        GemmP q = gemm_base(cx);  // A22 -= L21 L21^T (lower)
+        q.A = ws.L + o21; q.lda = ld; q.sA = sM; q.a_mc = 0;
+        q.B = ws.L + o21; q.ldb = ld; q.sB = sM; q.b_nc = 0;
+        q.C = ws.K + o22; q.ldc = ld; q.sC = sM;
+        q.M = h2; q.N = h2; q.K = h1; q.alpha = -1.0; q.beta = 1.0; q.lower = 1;
+        launch_gemm(q, ws.batch, cx.stream);
+    }
+    factor_rec(cx, ws, off + h1, h2, do_chol);
+    const long hw = ws.Np / 2 + 64;
+    GemmP t = gemm_base(cx);  // W = L21 inv11
+    t.A = ws.L + o21; t.lda = ld; t.sA = sM; t.a_mc = 0;
+    t.B = ws.Inv + o11; t.ldb = ld; t.sB = sM; t.b_nc = 1; t.kflags = KB_GE_N;
+    t.C = ws.W; t.ldc = h1; t.sC = hw * hw;
+    t.M = h2; t.N = h1; t.K = h1;
+    launch_gemm(t, ws.batch, cx.stream);
+    GemmP u = gemm_base(cx);  // inv21 = -inv22 W
+    u.A = ws.Inv + o22; u.lda = ld; u.sA = sM; u.a_mc = 0; u.kflags = KA_LE_M;
+    u.B = ws.W; u.ldb = h1; u.sB = hw * hw; u.b_nc = 1;
+    u.C = ws.Inv + o21; u.ldc = ld; u.sC = sM;
+    u.M = h2; u.N = h1; u.K = h2; u.alpha = -1.0;
+    launch_gemm(u, ws.batch, cx.stream);
+}
+
+// w = L^-1 y (N = 1 product with the explicit inverse), alpha = L^-T w.  y: [batch] vectors with
+// stride sy.
+static void solve_alpha(const Ctx& cx, Workspace& ws, const double* y, long sy) {
+    const long ld = ws.Np, sM = ws.mat();
+    GemmP p = gemm_base(cx);
+    p.A = ws.Inv; p.lda = ld; p.sA = sM; p.a_mc = 0; p.kflags = KA_LE_M;
+    p.B = y; p.ldb = ld; p.sB = sy; p.b_nc = 0;
+    p.C = ws.w; p.ldc = 1; p.sC = ld;
+    p.M = ws.Np; p.N = 1; p.K = ws.Np;
+    launch_gemm(p, ws.batch, cx.stream);
+    GemmP q = gemm_base(cx);
+    q.A = ws.Inv; q.lda = ld; q.sA = sM; q.a_mc = 1; q.kflags = KA_GE_M;
+    q.B = ws.w; q.ldb = ld; q.sB = ld; q.b_nc = 0;
+    q.C = ws.alpha; q.ldc = 1; q.sC = ld;
+    q.M = ws.Np; q.N = 1; q.K = ws.Np;
+    launch_gemm(q, ws.batch, cx.stream);
+}
+
+// K^-1 = L^-T L^-1 (lower triangle by MFMA, then mirrored)
+static int compute_invK(const Ctx& cx, Workspace& ws) {
+    CHK(ws_need_invK(ws));
+    const long ld = ws.Np, sM = ws.mat();
+    GemmP p = gemm_base(cx);
+    p.A = ws.Inv; p.lda = ld; p.sA = sM; p.a_mc = 1;
+    p.B = ws.Inv; p.ldb = ld; p.sB = sM; p.b_nc = 1;
+    p.kflags = KA_GE_M | KB_GE_N;
+    p.C = ws.InvK; p.ldc = ld; p.sC = sM;
+    p.M = ws.Np; p.N = ws.Np; p.K = ws.Np; p.lower = 1;
+    launch_gemm(p, ws.batch, cx.stream);
+    hipLaunchKernelGGL(symmetrize_kernel, dim3(ws.Np / 64, ws.Np / 64, ws.batch), dim3(256), 0, cx.stream, ws.InvK,
+                       ws.Np);
+    return GPMPC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// model handle
+// ------------------------------------------------------------------------------------------------
+struct Prof {
+    bool on = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[GPMPC_PH_COUNT];
+    std::vector<hipEvent_t> pool;
+    double total[GPMPC_PH_COUNT] = {0};
+    long count[GPMPC_PH_COUNT] = {0};
+};
+
+struct gpmpc_gp {
+    int device = 0, N = 0, Np = 0, d = 0, Ny = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    int ptr_mode = GPMPC_PTR_HOST;
+    int crow_mode = 0;
+    bool fitted = false, have_invK = false;
+    double *XT = nullptr, *Y = nullptr;  // [d][Np], [Ny][Np]
+    Workspace ws;                        // model factors, batch = Ny
+    Workspace tws;                       // training workspace, batch = 1 (lazy)
+    double* gradPartial = nullptr;
+    double* gradOut = nullptr;
+    std::vector<double> hyper;           // host copy [Ny][d+2]
+    // predict scratch
+    int Bcap = 0;
+    double *Z = nullptr, *Sigma = nullptr, *KsT = nullptr, *part = nullptr, *meanT = nullptr;
+    double *mean = nullptr, *var = nullptr, *J = nullptr, *cov = nullptr;
+    double* em = nullptr;  // exact-moment scratch
+    long emBytes = 0;
+    Prof prof;
+    Ctx cx() const { return Ctx{stream, crow_mode}; }
+};
+
+struct PhaseTimer {
+    gpmpc_gp* h;
+    int phase;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    PhaseTimer(gpmpc_gp* h_, int ph) : h(h_), phase(ph) {
+        if (!h->prof.on) return;
+        auto get = [&]() {
+            hipEvent_t e;
+            if (!h->prof.pool.empty()) { e = h->prof.pool.back(); h->prof.pool.pop_back(); }
+            else hipEventCreate(&e);
+            return e;
+        };
+        e0 = get();
+        e1 = get();
+        hipEventRecord(e0, h->stream);
+    }
+    ~PhaseTimer() {
+        if (!e0) return;
+        hipEventRecord(e1, h->stream);
+        h->prof.ev[phase].push_back({e0, e1});
+    }
+};
+
+static int prof_collect(gpmpc_gp* h) {
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (int ph = 0; ph < GPMPC_PH_COUNT; ++ph) {
+        for (auto& pr : h->prof.ev[ph]) {
+            float ms = 0.f;
+            hipEventElapsedTime(&ms, pr.first, pr.second);
+            h->prof.total[ph] += ms;
+            h->prof.count[ph] += 1;
+            h->prof.pool.push_back(pr.first);
+            h->prof.pool.push_back(pr.second);
+        }
+        h->prof.ev[ph].clear();
+    }
+    return GPMPC_OK;
+}
+
+extern "C" {
+
+int gpmpc_abi_version(void) { return GPMPC_ABI_VERSION; }
+const char* gpmpc_last_error(void) { return g_err.c_str(); }
+
+int gpmpc_device_count(int* count) {
+    if (!count) return fail(GPMPC_EINVAL, "count is NULL");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+    *count = n;
+    return GPMPC_OK;
+}
+
+int gpmpc_device_name(int device, char* buf, int buflen) {
+    if (!buf || buflen <= 0) return fail(GPMPC_EINVAL, "bad buffer");
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    snprintf(buf, buflen, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    return GPMPC_OK;
+}
+
+int gpmpc_mfma_selftest(int device, int* layout_out, double* tflops_out) {
+    CHK(ensure_device(device));
+    return mfma_selftest(device, layout_out, tflops_out);
+}
+
+int gpmpc_create(int device, int N, int d, int Ny, const double* X, const double* Y, gpmpc_gp** out) {
+    if (!out) return fail(GPMPC_EINVAL, "out is NULL");
+    *out = nullptr;
+    if (N <= 0 || d <= 0 || Ny <= 0 || !X || !Y) return fail(GPMPC_EINVAL, "bad N/d/Ny or NULL data");
+    if (d > DMAX) return fail(GPMPC_EINVAL, "input dimension d=%d exceeds the built-in maximum %d", d, DMAX);
+    CHK(ensure_device(device));
+    gpmpc_gp* h = new gpmpc_gp();
+    h->device = device; h->N = N; h->d = d; h->Ny = Ny; h->Np = round_up(N, 64);
+    h->crow_mode = g_crow_mode[device];
+    HIPCHK(hipStreamCreate(&h->own_stream));
+    h->stream = h->own_stream;
+    const int Np = h->Np;
+    std::vector<double> xt((size_t)d * Np, 0.0), yt((size_t)Ny * Np, 0.0);
+    for (int i = 0; i < N; ++i) {
+        for (int k = 0; k < d; ++k) xt[(size_t)k * Np + i] = X[(size_t)i * d + k];
+        for (int a = 0; a < Ny; ++a) yt[(size_t)a * Np + i] = Y[(size_t)i * Ny + a];
+    }
+    HIPCHK(hipMalloc(&h->XT, xt.size() * sizeof(double)));
+    HIPCHK(hipMalloc(&h->Y, yt.size() * sizeof(double)));
+    HIPCHK(hipMemcpy(h->XT, xt.data(), xt.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->Y, yt.data(), yt.size() * sizeof(double), hipMemcpyHostToDevice));
+    int rc = ws_alloc(h->ws, Ny, Np, d);
+    if (rc != GPMPC_OK) { gpmpc_destroy(h); return rc; }
+    h->hyper.assign((size_t)Ny * (d + 2), 0.0);
+    *out = h;
+    return GPMPC_OK;
+}
+
+int gpmpc_destroy(gpmpc_gp* h) {
+    if (!h) return GPMPC_OK;
+    hipSetDevice(h->device);
+    if (h->stream) hipStreamSynchronize(h->stream);
+    ws_free(h->ws);
+    ws_free(h->tws);
+    hipFree(h->XT); hipFree(h->Y); hipFree(h->gradPartial); hipFree(h->gradOut);
+    hipFree(h->Z); hipFree(h->Sigma); hipFree(h->KsT); hipFree(h->part); hipFree(h->meanT);
+    hipFree(h->mean); hipFree(h->var); hipFree(h->J); hipFree(h->cov); hipFree(h->em);
+    for (int ph = 0; ph < GPMPC_PH_COUNT; ++ph)
+        for (auto& pr : h->prof.ev[ph]) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+    for (auto e : h->prof.pool) hipEventDestroy(e);
+    if (h->own_stream) hipStreamDestroy(h->own_stream);
+    delete h;
+    return GPMPC_OK;
+}
+
+int gpmpc_get_size(const gpmpc_gp* h, int* N, int* d, int* Ny) {
+    if (!h) return fail(GPMPC_EINVAL, "NULL handle");
+    if (N) *N = h->N;
+    if (d) *d = h->d;
+    if (Ny) *Ny = h->Ny;
+    return GPMPC_OK;
+}
+
+int gpmpc_set_pointer_mode(gpmpc_gp* h, int mode) {
+    if (!h || (mode != GPMPC_PTR_HOST && mode != GPMPC_PTR_DEVICE)) return fail(GPMPC_EINVAL, "bad pointer mode");
+    h->ptr_mode = mode;
+    return GPMPC_OK;
+}
+
+int gpmpc_set_stream(gpmpc_gp* h, void* s) {
+    if (!h) return fail(GPMPC_EINVAL, "NULL handle");
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->stream = s ? (hipStream_t)s : h->own_stream;
+    return GPMPC_OK;
+}
+
+int gpmpc_synchronize(gpmpc_gp* h) {
+    if (!h) return fail(GPMPC_EINVAL, "NULL handle");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return GPMPC_OK;
+}
+
+int gpmpc_profile_enable(gpmpc_gp* h, int enable) {
+    if (!h) return fail(GPMPC_EINVAL, "NULL handle");
+    h->prof.on = enable != 0;
+    return GPMPC_OK;
+}
+
+int gpmpc_profile_read(gpmpc_gp* h, int phase, double* total_ms, long* launches, int reset) {
+    if (!h || phase < 0 || phase >= GPMPC_PH_COUNT) return fail(GPMPC_EINVAL, "bad phase");
+    CHK(prof_collect(h));
+    if (total_ms) *total_ms = h->prof.total[phase];
+    if (launches) *launches = h->prof.count[phase];
+    if (reset) { h->prof.total[phase] = 0.0; h->prof.count[phase] = 0; }
+    return GPMPC_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// fit
+// ------------------------------------------------------------------------------------------------
+// gram + factor on a workspace whose hyper/jitter buffers are already on the device.
+static void gram_and_factor(gpmpc_gp* h, Workspace& ws) {
+    const Ctx cx = h->cx();
+    {
+        PhaseTimer t(h, GPMPC_PH_GRAM);
+        hipLaunchKernelGGL(gram_kernel, dim3(ws.Np / 64, ws.Np / 64, ws.batch), dim3(256), 0, cx.stream, h->XT,
+                           ws.hyper, ws.jitter, ws.K, h->N, ws.Np, h->d);
+    }
+    {
+        PhaseTimer t(h, GPMPC_PH_FACTOR);
+        hipMemsetAsync(ws.info, 0, ws.batch * sizeof(int), cx.stream);
+        factor_rec(cx, ws, 0, ws.Np, true);
+    }
+}
+
+// Runs gram+Cholesky with the reference's one-shot jitter rule (optimize.py:345-350).
+// info_out[b]: 0 ok, 1 jitter applied, <0: -(first bad pivot) after jitter.
+static int factor_with_jitter(gpmpc_gp* h, Workspace& ws, const double* hyper_host, int* info_out) {
+    const int nb = ws.batch;
+    std::vector<double> jit(nb, 0.0);
+    std::vector<int> info(nb, 0), res(nb, 0);
+    HIPCHK(hipMemcpyAsync(ws.hyper, hyper_host, (size_t)nb * (h->d + 2) * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        HIPCHK(hipMemcpyAsync(ws.jitter, jit.data(), nb * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        gram_and_factor(h, ws);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(info.data(), ws.info, nb * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        bool any = false;
+        for (int b = 0; b < nb; ++b)
+            if (info[b] != 0) {
+                any = true;
+                if (attempt == 0) { jit[b] = 1e-8; res[b] = 1; }
+                else res[b] = -info[b];
+            }
+        if (!any) break;
+    }
+    int rc = GPMPC_OK;
+    for (int b = 0; b < nb; ++b) {
+        if (info_out) info_out[b] = res[b];
+        if (res[b] < 0) rc = GPMPC_ENOTPD;
+    }
+    if (rc != GPMPC_OK) return fail(rc, "K is not positive definite even after adding 1e-8*I");
+    return GPMPC_OK;
+}
+
+extern "C" int gpmpc_fit(gpmpc_gp* h, const double* hyper, int want_invK, int* info) {
+    if (!h || !hyper) return fail(GPMPC_EINVAL, "NULL handle/hyper");
+    HIPCHK(hipSetDevice(h->device));
+    for (int a = 0; a < h->Ny; ++a)
+        for (int k = 0; k < h->d + 2; ++k) {
+            const double v = hyper[(size_t)a * (h->d + 2) + k];
+            if (!(v == v) || (k < h->d && v == 0.0) || (k == h->d && v == 0.0))
+                return fail(GPMPC_EINVAL, "hyper[%d][%d] = %g is not a usable SE-ARD parameter", a, k, v);
+        }
+    h->fitted = false;
+    h->have_invK = false;
+    CHK(factor_with_jitter(h, h->ws, hyper, info));
+    {
+        PhaseTimer t(h, GPMPC_PH_SOLVE);
+        solve_alpha(h->cx(), h->ws, h->Y, h->Np);
+    }
+    if (want_invK) {
+        PhaseTimer t(h, GPMPC_PH_INVK);
+        CHK(compute_invK(h->cx(), h->ws));
+        h->have_invK = true;
+    }
+    HIPCHK(hipGetLastError());
+    h->hyper.assign(hyper, hyper + (size_t)h->Ny * (h->d + 2));
+    h->fitted = true;
+    return GPMPC_OK;
+}
+
+// copy [Ny][Np x Np] device matrices to/from the caller's dense [Ny][N x N]
+static int export_mats(gpmpc_gp* h, const double* dsrc, double* dst) {
+    const int N = h->N, Np = h->Np;
+    std::vector<double> tmp((size_t)Np * Np);
+    for (int a = 0; a < h->Ny; ++a) {
+        HIPCHK(hipMemcpy(tmp.data(), dsrc + (size_t)a * Np * Np, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
+        for (int i = 0; i < N; ++i)
+            std::memcpy(dst + ((size_t)a * N + i) * N, tmp.data() + (size_t)i * Np, N * sizeof(double));
+    }
+    return GPMPC_OK;
+}
+
+static int import_mats(gpmpc_gp* h, const double* src, double* ddst, bool identity_pad) {
+    const int N = h->N, Np = h->Np;
+    std::vector<double> tmp((size_t)Np * Np);
+    for (int a = 0; a < h->Ny; ++a) {
+        std::fill(tmp.begin(), tmp.end(), 0.0);
+        for (int i = 0; i < N; ++i)
+            std::memcpy(tmp.data() + (size_t)i * Np, src + ((size_t)a * N + i) * N, N * sizeof(double));
+        if (identity_pad)
+            for (int i = N; i < Np; ++i) tmp[(size_t)i * Np + i] = 1.0;
+        HIPCHK(hipMemcpy(ddst + (size_t)a * Np * Np, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    return GPMPC_OK;
+}
+
+extern "C" int gpmpc_get_factors(gpmpc_gp* h, double* hyper, double* chol, double* alpha, double* invK) {
+    if (!h) return fail(GPMPC_EINVAL, "NULL handle");
+    if (!h->fitted) return fail(GPMPC_ENOTFIT, "model has no factors (call gpmpc_fit or gpmpc_set_factors)");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (hyper) std::memcpy(hyper, h->hyper.data(), h->hyper.size() * sizeof(double));
+    if (chol) CHK(export_mats(h, h->ws.L, chol));
+    if (alpha) {
+        std::vector<double> tmp((size_t)h->Ny * h->Np);
+        HIPCHK(hipMemcpy(tmp.data(), h->ws.alpha, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
+        for (int a = 0; a < h->Ny; ++a) std::memcpy(alpha + (size_t)a * h->N, tmp.data() + (size_t)a * h->Np, h->N * sizeof(double));
+    }
+    if (invK) {
+        if (!h->have_invK) {
+            CHK(compute_invK(h->cx(), h->ws));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            h->have_invK = true;
+        }
+        CHK(export_mats(h, h->ws.InvK, invK));
+    }
+    return GPMPC_OK;
+}
+
+extern "C" int gpmpc_set_factors(gpmpc_gp* h, const double* hyper, const double* chol, const double* alpha,
+                                 const double* invK) {
+    if (!h || !hyper || !chol) return fail(GPMPC_EINVAL, "hyper and chol are required");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->fitted = false;
+    h->have_invK = false;
+    h->hyper.assign(hyper, hyper + (size_t)h->Ny * (h->d + 2));
+    HIPCHK(hipMemcpy(h->ws.hyper, hyper, h->hyper.size() * sizeof(double), hipMemcpyHostToDevice));
+    CHK(import_mats(h, chol, h->ws.L, true));
+    factor_rec(h->cx(), h->ws, 0, h->Np, false);  // L^-1 from the stored L
+    if (alpha) {
+        std::vector<double> tmp((size_t)h->Ny * h->Np, 0.0);
+        for (int a = 0; a < h->Ny; ++a) std::memcpy(tmp.data() + (size_t)a * h->Np, alpha + (size_t)a * h->N, h->N * sizeof(double));
+        HIPCHK(hipMemcpy(h->ws.alpha, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice));
+    } else {
+        solve_alpha(h->cx(), h->ws, h->Y, h->Np);
+    }
+    if (invK) {
+        CHK(ws_need_invK(h->ws));
+        CHK(import_mats(h, invK, h->ws.InvK, true));
+        h->have_invK = true;
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->fitted = true;
+    return GPMPC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// predict
+// ------------------------------------------------------------------------------------------------
+static int chunk_size(const gpmpc_gp* h) {
+    const double budget = 2.0e9;  // bytes of KsT scratch
+    long c = (long)(budget / (8.0 * h->Np * h->Ny));
+    c = c / 64 * 64;
+    if (c < 64) c = 64;
+    if (c > 32768) c = 32768;
+    return (int)c;
+}
+
+static int ensure_scratch(gpmpc_gp* h, int B) {
+    const int need = round_up(B < chunk_size(h) ? B : chunk_size(h), 64);
+    if (need <= h->Bcap) return GPMPC_OK;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    hipFree(h->Z); hipFree(h->Sigma); hipFree(h->KsT); hipFree(h->part); hipFree(h->meanT);
+    hipFree(h->mean); hipFree(h->var); hipFree(h->J); hipFree(h->cov);
+    h->Z = h->Sigma = h->KsT = h->part = h->meanT = h->mean = h->var = h->J = h->cov = nullptr;
+    h->Bcap = 0;
+    const size_t d = h->d, Ny = h->Ny, Np = h->Np, Bc = need;
+    HIPCHK(hipMalloc(&h->Z, Bc * d * sizeof(double)));
+    HIPCHK(hipMalloc(&h->Sigma, Bc * d * d * sizeof(double)));
+    HIPCHK(hipMalloc(&h->KsT, Ny * Bc * Np * sizeof(double)));
+    HIPCHK(hipMalloc(&h->part, Ny * (Np / 64) * Bc * sizeof(double)));
+    HIPCHK(hipMalloc(&h->meanT, Ny * Bc * sizeof(double)));
+    HIPCHK(hipMalloc(&h->mean, Bc * Ny * sizeof(double)));
+    HIPCHK(hipMalloc(&h->var, Bc * Ny * sizeof(double)));
+    HIPCHK(hipMalloc(&h->J, Bc * Ny * d * sizeof(double)));
+    HIPCHK(hipMalloc(&h->cov, Bc * Ny * Ny * sizeof(double)));
+    h->Bcap = need;
+    return GPMPC_OK;
+}
+
+// One chunk (B <= Bcap) with device pointers: mean/var (either may be NULL), optional J.
+static int predict_chunk(gpmpc_gp* h, int B, const double* dZ, double* dMean, double* dVar, double* dJ) {
+    const Ctx cx = h->cx();
+    const int Bp = round_up(B, 64), Np = h->Np, Ny = h->Ny;
+    {
+        PhaseTimer t(h, GPMPC_PH_CROSSCOV);
+        launch_crosscov(cx.stream, h->d, h->XT, h->ws.hyper, h->ws.alpha, dZ, h->KsT, h->meanT, h->N, Np, B, Bp, Ny);
+    }
+    int tilesM = 0;
+    if (dVar) {
+        PhaseTimer t(h, GPMPC_PH_VARGEMM);
+        GemmP p = gemm_base(cx);  // V = L^-1 Ks, reduced to column sums of squares in the epilogue
+        p.A = h->ws.Inv; p.lda = Np; p.sA = (long)Np * Np; p.a_mc = 0; p.kflags = KA_LE_M;
+        p.B = h->KsT; p.ldb = Np; p.sB = (long)Bp * Np; p.b_nc = 0;
+        p.M = Np; p.N = Bp; p.K = Np;
+        p.epi = EPI_COLSUMSQ; p.part = h->part; p.ldpart = Bp;
+        const long t128 = (long)((Np + 127) / 128) * ((Bp + 127) / 128) * Ny;
+        const int tile = t128 >= 192 ? 128 : 64;
+        tilesM = (Np + tile - 1) / tile;
+        p.sPart = (long)tilesM * Bp;
+        launch_gemm(p, Ny, cx.stream, tile);
+    }
+    {
+        PhaseTimer t(h, GPMPC_PH_FINISH);
+        hipLaunchKernelGGL(var_finish_kernel, dim3((B + 255) / 256), dim3(256), 0, cx.stream, h->part, h->meanT,
+                           h->ws.hyper, dMean, dVar, B, Bp, Ny, h->d, tilesM);
+        if (dJ)
+            hipLaunchKernelGGL(mean_jac_kernel, dim3(B, Ny), dim3(256), 0, cx.stream, h->XT, h->ws.hyper,
+                               h->ws.alpha, dZ, h->KsT, dJ, h->N, Np, h->d, Bp, Ny);
+    }
+    HIPCHK(hipGetLastError());
+    return GPMPC_OK;
+}
+
+#include "predict_em.inl"
+
+// Generic driver: handles host/device pointer modes and chunking.  Outputs any of mean[B][Ny],
+// var[B][Ny], J[B][Ny][d], cov[B][Ny][Ny] (cov per `method`).
+static int predict_driver(gpmpc_gp* h, int method, int B, const double* Z, const double* Sigma, double* mean,
+                          double* var, double* J, double* cov) {
+    if (!h) return fail(GPMPC_EINVAL, "NULL handle");
+    if (!h->fitted) return fail(GPMPC_ENOTFIT, "model has no factors (call gpmpc_fit or gpmpc_set_factors)");
+    if (B <= 0 || !Z) return fail(GPMPC_EINVAL, "bad B or NULL Z");
+    const bool need_sigma = (method == GPMPC_TA || method == GPMPC_EM || method == GPMPC_OLD_TA);
+    if (cov && need_sigma && !Sigma) return fail(GPMPC_EINVAL, "this method needs the input covariance Sigma");
+    HIPCHK(hipSetDevice(h->device));
+    CHK(ensure_scratch(h, B));
+    const int d = h->d, Ny = h->Ny;
+    const bool host = h->ptr_mode == GPMPC_PTR_HOST;
+    const bool moments = cov && (method == GPMPC_EM || method == GPMPC_OLD_ME || method == GPMPC_OLD_TA);
+    if (moments && !h->have_invK) {
+        PhaseTimer t(h, GPMPC_PH_INVK);
+        CHK(compute_invK(h->cx(), h->ws));
+        h->have_invK = true;
+    }
+    for (int b0 = 0; b0 < B; b0 += h->Bcap) {
+        const int nb = (B - b0 < h->Bcap) ? B - b0 : h->Bcap;
+        const double* dZ = Z + (size_t)b0 * d;
+        const double* dS = Sigma ? Sigma + (size_t)b0 * d * d : nullptr;
+        if (host) {
+            HIPCHK(hipMemcpyAsync(h->Z, dZ, (size_t)nb * d * sizeof(double), hipMemcpyHostToDevice, h->stream));
+            dZ = h->Z;
+            if (dS && cov && need_sigma) {
+                HIPCHK(hipMemcpyAsync(h->Sigma, dS, (size_t)nb * d * d * sizeof(double), hipMemcpyHostToDevice, h->stream));
+                dS = h->Sigma;
+            }
+        }
+        double* oMean = mean ? (host ? h->mean : mean + (size_t)b0 * Ny) : nullptr;
+        double* oVar = var ? (host ? h->var : var + (size_t)b0 * Ny) : nullptr;
+        double* oJ = J ? (host ? h->J : J + (size_t)b0 * Ny * d) : nullptr;
+        double* oCov = cov ? (host ? h->cov : cov + (size_t)b0 * Ny * Ny) : nullptr;
+        if (moments) {
+            CHK(predict_moments_chunk(h, method, nb, dZ, dS, oMean ? oMean : h->mean, oCov));
+        } else {
+            const bool ta = cov && method == GPMPC_TA;
+            double* jbuf = oJ ? oJ : (ta ? h->J : nullptr);
+            double* vbuf = oVar ? oVar : (cov ? h->var : nullptr);
+            CHK(predict_chunk(h, nb, dZ, oMean, vbuf, jbuf));
+            if (cov) {
+                PhaseTimer t(h, GPMPC_PH_FINISH);
+                const long ne = (long)nb * Ny * Ny;
+                hipLaunchKernelGGL(cov_assemble_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, h->stream,
+                                   vbuf, jbuf, ta ? dS : (const double*)nullptr, oCov, nb, Ny, d);
+            }
+        }
+        if (host) {
+            if (mean) HIPCHK(hipMemcpyAsync(mean + (size_t)b0 * Ny, h->mean, (size_t)nb * Ny * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+            if (var) HIPCHK(hipMemcpyAsync(var + (size_t)b0 * Ny, h->var, (size_t)nb * Ny * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+            if (J) HIPCHK(hipMemcpyAsync(J + (size_t)b0 * Ny * d, h->J, (size_t)nb * Ny * d * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+            if (cov) HIPCHK(hipMemcpyAsync(cov + (size_t)b0 * Ny * Ny, h->cov, (size_t)nb * Ny * Ny * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+        }
+    }
+    HIPCHK(hipGetLastError());
+    return GPMPC_OK;
+}
+
+extern "C" int gpmpc_predict_mean_var(gpmpc_gp* h, int B, const double* Z, double* mean, double* var) {
+    if (!mean && !var) return fail(GPMPC_EINVAL, "both outputs NULL");
+    return predict_driver(h, GPMPC_ME, B, Z, nullptr, mean, var, nullptr, nullptr);
+}
+
+extern "C" int gpmpc_mean_jac(gpmpc_gp* h, int B, const double* Z, double* mean, double* J) {
+    if (!J) return fail(GPMPC_EINVAL, "J is NULL");
+    return predict_driver(h, GPMPC_ME, B, Z, nullptr, mean, nullptr, J, nullptr);
+}
+
+extern "C" int gpmpc_predict(gpmpc_gp* h, int method, int B, const double* Z, const double* Sigma, double* mean,
+                             double* cov) {
+    if (method < GPMPC_ME || method > GPMPC_OLD_TA) return fail(GPMPC_EINVAL, "No GP method with code %d", method);
+    if (!mean || !cov) return fail(GPMPC_EINVAL, "mean/cov NULL");
+    return predict_driver(h, method, B, Z, Sigma, mean, nullptr, nullptr, cov);
+}
+
+// ------------------------------------------------------------------------------------------------
+// a14 GP.covar: covar[a] = sf^2 - V^T V, V = L^-1 ks(X, Xnew)   (gp_class.py:353-381)
+// ------------------------------------------------------------------------------------------------
+extern "C" int gpmpc_covar(gpmpc_gp* h, int n, const double* Xnew, double* covar) {
+    if (!h || n <= 0 || !Xnew || !covar) return fail(GPMPC_EINVAL, "bad arguments");
+    if (!h->fitted) return fail(GPMPC_ENOTFIT, "model has no factors");
+    if (n > chunk_size(h)) return fail(GPMPC_EINVAL, "covar: n=%d exceeds the single-chunk limit %d", n, chunk_size(h));
+    HIPCHK(hipSetDevice(h->device));
+    CHK(ensure_scratch(h, n));
+    const Ctx cx = h->cx();
+    const int Np = h->Np, Ny = h->Ny, d = h->d, Bp = round_up(n, 64);
+    const bool host = h->ptr_mode == GPMPC_PTR_HOST;
+    const double* dZ = Xnew;
+    if (host) {
+        HIPCHK(hipMemcpyAsync(h->Z, Xnew, (size_t)n * d * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        dZ = h->Z;
+    }
+    launch_crosscov(cx.stream, d, h->XT, h->ws.hyper, h->ws.alpha, dZ, h->KsT, h->meanT, h->N, Np, n, Bp, Ny);
+    double *VT = nullptr, *C = nullptr;
+    HIPCHK(hipMalloc(&VT, (size_t)Ny * Bp * Np * sizeof(double)));
+    HIPCHK(hipMalloc(&C, (size_t)Ny * Bp * Bp * sizeof(double)));
+    GemmP p = gemm_base(cx);  // VT[j][i] = sum_k KsT[j][k] invL[i][k]
+    p.A = h->KsT; p.lda = Np; p.sA = (long)Bp * Np; p.a_mc = 0;
+    p.B = h->ws.Inv; p.ldb = Np; p.sB = (long)Np * Np; p.b_nc = 0; p.kflags = KB_LE_N;
+    p.C = VT; p.ldc = Np; p.sC = (long)Bp * Np;
+    p.M = Bp; p.N = Np; p.K = Np;
+    launch_gemm(p, Ny, cx.stream);
+    GemmP q = gemm_base(cx);  // C = -VT VT^T
+    q.A = VT; q.lda = Np; q.sA = (long)Bp * Np; q.a_mc = 0;
+    q.B = VT; q.ldb = Np; q.sB = (long)Bp * Np; q.b_nc = 0;
+    q.C = C; q.ldc = Bp; q.sC = (long)Bp * Bp;
+    q.M = Bp; q.N = Bp; q.K = Np; q.alpha = -1.0;
+    launch_gemm(q, Ny, cx.stream);
+    std::vector<double> tmp((size_t)Ny * Bp * Bp);
+    HIPCHK(hipMemcpyAsync(tmp.data(), C, tmp.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    hipFree(VT);
+    hipFree(C);
+    std::vector<double> out((size_t)Ny * n * n);
+    for (int a = 0; a < Ny; ++a) {
+        const double sf = h->hyper[(size_t)a * (d + 2) + d];
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j) out[((size_t)a * n + i) * n + j] = sf * sf + tmp[((size_t)a * Bp + i) * Bp + j];
+    }
+    if (host) std::memcpy(covar, out.data(), out.size() * sizeof(double));
+    else HIPCHK(hipMemcpy(covar, out.data(), out.size() * sizeof(double), hipMemcpyHostToDevice));
+    return GPMPC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// a7 NLL (+ analytic gradient) on the separate single-output training workspace
+// ------------------------------------------------------------------------------------------------
+extern "C" int gpmpc_nll(gpmpc_gp* h, int a, const double* hyper_row, double* nll, double* grad, int* jitter_out) {
+    if (!h || !hyper_row || !nll || a < 0 || a >= h->Ny) return fail(GPMPC_EINVAL, "bad arguments");
+    HIPCHK(hipSetDevice(h->device));
+    const int d = h->d, Np = h->Np;
+    for (int k = 0; k < d + 1; ++k)
+        if (!(hyper_row[k] == hyper_row[k]) || hyper_row[k] == 0.0)
+            return fail(GPMPC_EINVAL, "hyper_row[%d] = %g is not a usable SE-ARD parameter", k, hyper_row[k]);
+    if (!h->tws.K) {
+        CHK(ws_alloc(h->tws, 1, Np, d));
+        HIPCHK(hipMalloc(&h->gradPartial, (size_t)(Np / 64) * (Np / 64) * (DMAX + 2) * sizeof(double)));
+        HIPCHK(hipMalloc(&h->gradOut, (DMAX + 2) * sizeof(double)));
+    }
+    Workspace& ws = h->tws;
+    int info = 0;
+    CHK(factor_with_jitter(h, ws, hyper_row, &info));
+    if (jitter_out) *jitter_out = info;
+    const Ctx cx = h->cx();
+    {
+        PhaseTimer t(h, GPMPC_PH_SOLVE);
+        solve_alpha(cx, ws, h->Y + (size_t)a * Np, Np);
+    }
+    {
+        PhaseTimer t(h, GPMPC_PH_NLL);
+        hipLaunchKernelGGL(nll_reduce_kernel, dim3(1), dim3(256), 0, cx.stream, ws.L, ws.w, ws.nll, h->N, Np);
+    }
+    if (grad) {
+        {
+            PhaseTimer t(h, GPMPC_PH_INVK);
+            CHK(ws_need_invK(ws));
+            GemmP p = gemm_base(cx);  // lower triangle of K^-1 = L^-T L^-1 is all the gradient pass reads
+            p.A = ws.Inv; p.lda = Np; p.sA = ws.mat(); p.a_mc = 1;
+            p.B = ws.Inv; p.ldb = Np; p.sB = ws.mat(); p.b_nc = 1;
+            p.kflags = KA_GE_M | KB_GE_N;
+            p.C = ws.InvK; p.ldc = Np; p.sC = ws.mat();
+            p.M = Np; p.N = Np; p.K = Np; p.lower = 1;
+            launch_gemm(p, 1, cx.stream);
+        }
+        PhaseTimer t(h, GPMPC_PH_NLL);
+        hipLaunchKernelGGL(nll_grad_kernel, dim3(Np / 64, Np / 64), dim3(256), 0, cx.stream, h->XT, ws.hyper, ws.InvK,
+                           ws.alpha, h->gradPartial, h->N, Np, d);
+        hipLaunchKernelGGL(nll_grad_finish_kernel, dim3(1), dim3(64), 0, cx.stream, h->gradPartial, ws.hyper,
+                           h->gradOut, Np, d);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(nll, ws.nll, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (grad) HIPCHK(hipMemcpyAsync(grad, h->gradOut, (d + 2) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return GPMPC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// low-level dense ops for the parity tests
+// ------------------------------------------------------------------------------------------------
+extern "C" int gpmpc_cholesky(int device, int n, double* A, double* Ainv, int* info) {
+    if (n <= 0 || !A || !info) return fail(GPMPC_EINVAL, "bad arguments");
+    CHK(ensure_device(device));
+    const int Np = round_up(n, 64);
+    Workspace ws;
+    CHK(ws_alloc(ws, 1, Np, 1));
+    std::vector<double> tmp((size_t)Np * Np, 0.0);
+    for (int i = 0; i < n; ++i) std::memcpy(tmp.data() + (size_t)i * Np, A + (size_t)i * n, n * sizeof(double));
+    for (int i = n; i < Np; ++i) tmp[(size_t)i * Np + i] = 1.0;
+    HIPCHK(hipMemcpy(ws.K, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice));
+    Ctx cx{nullptr, g_crow_mode[device]};
+    HIPCHK(hipMemset(ws.info, 0, sizeof(int)));
+    factor_rec(cx, ws, 0, Np, true);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(info, ws.info, sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(tmp.data(), ws.L, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; ++i) std::memcpy(A + (size_t)i * n, tmp.data() + (size_t)i * Np, n * sizeof(double));
+    if (Ainv) {
+        HIPCHK(hipMemcpy(tmp.data(), ws.Inv, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
+        for (int i = 0; i < n; ++i) std::memcpy(Ainv + (size_t)i * n, tmp.data() + (size_t)i * Np, n * sizeof(double));
+    }
+    ws_free(ws);
+    return GPMPC_OK;
+}
+
+extern "C" int gpmpc_dgemm(int device, int transa, int transb, int M, int N, int K, double alpha, const double* A,
+                           int lda, const double* B, int ldb, double beta, double* C, int ldc) {
+    if (M <= 0 || N <= 0 || K <= 0 || !A || !B || !C) return fail(GPMPC_EINVAL, "bad arguments");
+    CHK(ensure_device(device));
+    // repack into padded device buffers: K padded to 16, leading dimensions even
+    const int Kp = round_up(K, 16), Mp = round_up(M, 2), Nq = round_up(N, 2);
+    const int rowsA = transa ? Kp : M, colsA = transa ? Mp : Kp;
+    const int rowsB = transb ? N : Kp, colsB = transb ? Kp : Nq;
+    std::vector<double> a((size_t)rowsA * colsA, 0.0), b((size_t)rowsB * colsB, 0.0);
+    for (int i = 0; i < (transa ? K : M); ++i)
+        std::memcpy(a.data() + (size_t)i * colsA, A + (size_t)i * lda, (transa ? M : K) * sizeof(double));
+    for (int i = 0; i < (transb ? N : K); ++i)
+        std::memcpy(b.data() + (size_t)i * colsB, B + (size_t)i * ldb, (transb ? K : N) * sizeof(double));
+    double *dA, *dB, *dC;
+    HIPCHK(hipMalloc(&dA, a.size() * sizeof(double)));
+    HIPCHK(hipMalloc(&dB, b.size() * sizeof(double)));
+    HIPCHK(hipMalloc(&dC, (size_t)M * N * sizeof(double)));
+    HIPCHK(hipMemcpy(dA, a.data(), a.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dB, b.data(), b.size() * sizeof(double), hipMemcpyHostToDevice));
+    std::vector<double> c((size_t)M * N);
+    for (int i = 0; i < M; ++i) std::memcpy(c.data() + (size_t)i * N, C + (size_t)i * ldc, N * sizeof(double));
+    HIPCHK(hipMemcpy(dC, c.data(), c.size() * sizeof(double), hipMemcpyHostToDevice));
+    Ctx cx{nullptr, g_crow_mode[device]};
+    GemmP p = gemm_base(cx);
+    p.A = dA; p.lda = colsA; p.a_mc = transa ? 1 : 0;
+    p.B = dB; p.ldb = colsB; p.b_nc = transb ? 0 : 1;
+    p.C = dC; p.ldc = N;
+    p.M = M; p.N = N; p.K = Kp; p.alpha = alpha; p.beta = beta;
+    launch_gemm(p, 1, cx.stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(c.data(), dC, c.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (int i = 0; i < M; ++i) std::memcpy(C + (size_t)i * ldc, c.data() + (size_t)i * N, N * sizeof(double));
+    hipFree(dA); hipFree(dB); hipFree(dC);
+    return GPMPC_OK;
+}

@@ -1,0 +1,173 @@
+// Leaf of the recursive Cholesky / triangular-inverse: one workgroup factors a 64 x 64 diagonal
+// block held in LDS and inverts the factor (a4 + a6 on a diagonal block; np.linalg.cholesky
+// optimize.py:346, invL optimize.py:489).
+//
+// Inside the block the same right-looking scheme runs at 16-column granularity: a 16 x 16
+// diagonal sub-block is factored and inverted by ONE wave with a row per lane in registers and
+// SGPR broadcasts (v_readlane) -- no LDS round trips, no barriers on the sequential chain -- and
+// the sub-panel solve, the rank-16 update and the assembly of the 64 x 64 inverse are
+// v_mfma_f64_16x16x4_f64 products on LDS-resident operands.
+#pragma once
+#include "mfma_f64.hpp"
+
+namespace gpmpc {
+
+constexpr int LS = 65;  // padded LDS row stride (doubles)
+
+// acc += Aop(16 x K) * Bop(K x 16); Aop(i,k) = Sa[(ar+i)*LS + ac + k];
+// Bop(k,j) = BT ? Sb[(br+j)*LS + bc + k] : Sb[(br+k)*LS + bc + j]
+template <bool BT>
+__device__ __forceinline__ d4 lds_mm16(const double* Sa, int ar, int ac, const double* Sb, int br, int bc,
+                                       int K, int lane, d4 acc) {
+    const int fr = lane & 15, fk = lane >> 4;
+    for (int k0 = 0; k0 < K; k0 += 4) {
+        const double a = Sa[(ar + fr) * LS + ac + k0 + fk];
+        const double b = BT ? Sb[(br + fr) * LS + bc + k0 + fk] : Sb[(br + k0 + fk) * LS + bc + fr];
+        acc = mfma16(a, b, acc);
+    }
+    return acc;
+}
+
+__device__ __forceinline__ void lds_put16(double* S, int r0, int c0, d4 v, double scale, int lane, int mode) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) S[(r0 + crow(lane, r, mode)) * LS + c0 + (lane & 15)] = scale * v[r];
+}
+
+__device__ __forceinline__ void lds_sub16(double* S, int r0, int c0, d4 v, int lane, int mode) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) S[(r0 + crow(lane, r, mode)) * LS + c0 + (lane & 15)] -= v[r];
+}
+
+// One wave: Cholesky of the 16 x 16 block at (o,o) of S (if FACTOR) and its inverse into T.
+// Lane r (< 16) owns row r in registers; lanes >= 16 shadow rows r & 15 so that every lane
+// executes the same broadcasts.  Returns the first non-positive pivot column (0-based, local) or -1.
+template <bool FACTOR>
+__device__ __forceinline__ int potrf16_inv16(double* S, double* T, int o, int lane) {
+    const int r = lane & 15;
+    double a[16], rinv[16], x[16];
+    int bad = -1;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) a[c] = (c <= r) ? S[(o + r) * LS + o + c] : 0.0;
+    if (FACTOR) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const double ajj = bcast(a[j], j);
+            if (!(ajj > 0.0) && bad < 0) bad = j;  // also catches NaN; wave-uniform
+            const double ri = rsqrt(ajj);
+            rinv[j] = ri;
+            const double lj = (r == j) ? ajj * ri : a[j] * ri;
+            a[j] = lj;
+#pragma unroll
+            for (int k = j + 1; k < 16; ++k) a[k] -= lj * bcast(lj, k);
+        }
+        if (lane < 16) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) S[(o + r) * LS + o + c] = (c <= r) ? a[c] : 0.0;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) rinv[j] = 1.0 / bcast(a[j], j);
+    }
+    // column r of the inverse by forward substitution; l_ik comes from lane i's register a[k]
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        double s = (i == r) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < i; ++k) s -= bcast(a[k], i) * x[k];
+        x[i] = s * rinv[i];
+    }
+    if (lane < 16) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) T[(o + i) * LS + o + r] = x[i];
+    }
+    return bad;
+}
+
+// grid (1, 1, batch), 256 threads.  Ain: source of the diagonal block (the running K for a
+// factorisation, L itself for inverse-only); L / Inv: destinations.  All are [batch][ld x ld]
+// row-major, `off` is the block's first row/column.
+__global__ void __launch_bounds__(256) leaf64_kernel(const double* Ain, double* L, double* Inv, long ld,
+                                                     long sBatch, int off, int do_chol, int* info,
+                                                     int crow_mode) {
+    __shared__ double S[64 * LS];
+    __shared__ double T[64 * LS];
+    __shared__ double U[64 * LS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long base = (long)blockIdx.z * sBatch + (long)off * ld + off;
+    const double* __restrict__ src = Ain + base;
+    for (int idx = tid; idx < 4096; idx += 256) {
+        const int rr = idx >> 6, cc = idx & 63;
+        S[rr * LS + cc] = (cc <= rr) ? src[(long)rr * ld + cc] : 0.0;
+        T[rr * LS + cc] = 0.0;
+    }
+    __syncthreads();
+
+    if (do_chol) {
+        int bad = -1;
+        for (int t = 0; t < 4; ++t) {
+            const int o = 16 * t;
+            if (wave == 0) {
+                const int b = potrf16_inv16<true>(S, T, o, lane);
+                if (b >= 0 && bad < 0) bad = o + b;
+            }
+            __syncthreads();
+            // sub-panel: L_it = A_it inv(L_tt)^T, one 16 x 16 tile per wave
+            d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+            const int ti = t + 1 + wave;
+            if (ti <= 3) acc = lds_mm16<true>(S, 16 * ti, o, T, o, o, 16, lane, acc);
+            __syncthreads();
+            if (ti <= 3) lds_put16(S, 16 * ti, o, acc, 1.0, lane, crow_mode);
+            __syncthreads();
+            // rank-16 update of the remaining lower tiles: A_ij -= L_it L_jt^T, t < j <= i <= 3
+            int cnt = 0;
+            for (int i = t + 1; i <= 3; ++i)
+                for (int j = t + 1; j <= i; ++j, ++cnt)
+                    if ((cnt & 3) == wave) {
+                        d4 pacc = d4{0.0, 0.0, 0.0, 0.0};
+                        pacc = lds_mm16<true>(S, 16 * i, o, S, 16 * j, o, 16, lane, pacc);
+                        lds_sub16(S, 16 * i, 16 * j, pacc, lane, crow_mode);
+                    }
+            __syncthreads();
+        }
+        if (wave == 0 && lane == 0 && bad >= 0) atomicCAS(&info[blockIdx.z], 0, off + bad + 1);
+    } else {
+        potrf16_inv16<false>(S, T, 16 * wave, lane);
+        __syncthreads();
+    }
+
+    // assemble the 64 x 64 inverse from the four 16 x 16 diagonal inverses:
+    // inv21 = -inv22 (L21 inv11), first for the two 32-blocks, then for the 64-block
+    {
+        const int c1 = 32 * wave, r2 = c1 + 16;
+        d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+        if (wave < 2) acc = lds_mm16<false>(S, r2, c1, T, c1, c1, 16, lane, acc);
+        if (wave < 2) lds_put16(U, r2, c1, acc, 1.0, lane, crow_mode);
+        __syncthreads();
+        acc = d4{0.0, 0.0, 0.0, 0.0};
+        if (wave < 2) acc = lds_mm16<false>(T, r2, r2, U, r2, c1, 16, lane, acc);
+        if (wave < 2) lds_put16(T, r2, c1, acc, -1.0, lane, crow_mode);
+        __syncthreads();
+    }
+    {
+        const int pi = wave >> 1, pj = wave & 1;
+        d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+        acc = lds_mm16<false>(S, 32 + 16 * pi, 0, T, 0, 16 * pj, 32, lane, acc);
+        lds_put16(U, 32 + 16 * pi, 16 * pj, acc, 1.0, lane, crow_mode);
+        __syncthreads();
+        acc = d4{0.0, 0.0, 0.0, 0.0};
+        acc = lds_mm16<false>(T, 32 + 16 * pi, 32, U, 32, 16 * pj, 32, lane, acc);
+        __syncthreads();
+        lds_put16(T, 32 + 16 * pi, 16 * pj, acc, -1.0, lane, crow_mode);
+        __syncthreads();
+    }
+
+    double* __restrict__ dl = L + base;
+    double* __restrict__ di = Inv + base;
+    for (int idx = tid; idx < 4096; idx += 256) {
+        const int rr = idx >> 6, cc = idx & 63;
+        if (do_chol) dl[(long)rr * ld + cc] = (cc <= rr) ? S[rr * LS + cc] : 0.0;
+        di[(long)rr * ld + cc] = (cc <= rr) ? T[rr * LS + cc] : 0.0;
+    }
+}
+
+}  // namespace gpmpc

@@ -1,0 +1,136 @@
+/* gpmpc.h -- C ABI of libgpmpc_hip.so: the MI355X (gfx950) GP-regression inner loop of GP-MPC.
+ *
+ * The reference (helgeanl/GP-MPC) is pure Python and has no FFI layer; its de-facto operator API
+ * for this path is the `GP` object as `mpc_class.MPC` uses it.  Each entry
+ * point below names the reference code it replaces (file:line into /root/reference/gp_mpc/).
+ * `INTEGRATION.md` shows the ctypes stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain C symbols, no exceptions cross the boundary; every function returns an int status
+ *     (GPMPC_OK = 0, < 0 error; text via gpmpc_last_error()).
+ *   - all arrays are C-contiguous IEEE fp64 (numpy default), row-major; the caller owns every
+ *     buffer.  By default array arguments are HOST pointers (copied in/out on the handle's
+ *     stream); gpmpc_set_pointer_mode(h, GPMPC_PTR_DEVICE) makes the bulk arguments of the
+ *     predict family device pointers (inputs already resident in HBM, no PCIe in the call).
+ *   - hyper[a] = [ell_1 .. ell_d, sf, sn], sf and sn are STANDARD DEVIATIONS
+ *     (gp_functions.py:129-130, optimize.py:338-340).  Z rows are z = [x, u] in the GP's own
+ *     (standardised) input units; standardisation stays in the Python host class like
+ *     gp_class.py:253-261.
+ *   - one handle = one GP model = one HIP stream.  Calls on different handles are thread-safe,
+ *     calls on one handle are serialised by the caller.
+ */
+#ifndef GPMPC_H
+#define GPMPC_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPMPC_ABI_VERSION 1
+
+/* status codes */
+#define GPMPC_OK 0
+#define GPMPC_EINVAL (-1)  /* bad argument */
+#define GPMPC_EHIP (-2)    /* HIP runtime error / no usable gfx950 device */
+#define GPMPC_ENOTFIT (-3) /* model has no factors yet (call gpmpc_fit / gpmpc_set_factors) */
+#define GPMPC_ENOTPD (-4)  /* K not positive definite even after the one-shot 1e-8 jitter */
+#define GPMPC_ENOMEM (-5)
+
+/* uncertainty-propagation methods: the strings of GP.set_method, gp_class.py:193-242 */
+#define GPMPC_ME 0     /* 'ME'     gp_class.py:212-215: [mean(z), diag(var(z))]            */
+#define GPMPC_TA 1     /* 'TA'     gp_class.py:216-219: diag(var) + J Sigma J^T            */
+#define GPMPC_EM 2     /* 'EM'     gp_class.py:220-224: gp_exact_moment                    */
+#define GPMPC_OLD_ME 3 /* 'old_ME' gp_class.py:225-229: gp()                               */
+#define GPMPC_OLD_TA 4 /* 'old_TA' gp_class.py:230-235: gp_taylor_approx(diag=True)        */
+
+#define GPMPC_PTR_HOST 0
+#define GPMPC_PTR_DEVICE 1
+
+/* profiling phases for gpmpc_profile_read */
+#define GPMPC_PH_GRAM 0       /* SE-ARD K build                              */
+#define GPMPC_PH_FACTOR 1     /* Cholesky + triangular inverse recursion     */
+#define GPMPC_PH_SOLVE 2      /* w = L^-1 y, alpha = L^-T w                  */
+#define GPMPC_PH_INVK 3       /* K^-1 = L^-T L^-1                            */
+#define GPMPC_PH_CROSSCOV 4   /* ks(X, Z) + mean                             */
+#define GPMPC_PH_VARGEMM 5    /* V = L^-1 Ks, column sums of squares (MFMA)  */
+#define GPMPC_PH_FINISH 6     /* var / Jacobian / TA covariance assembly     */
+#define GPMPC_PH_EM 7         /* exact-moment N x N pair tiles               */
+#define GPMPC_PH_NLL 8        /* NLL reductions + gradient pass              */
+#define GPMPC_PH_COUNT 9
+
+typedef struct gpmpc_gp gpmpc_gp; /* opaque model handle */
+
+/* ---- library / device -------------------------------------------------------------------- */
+int gpmpc_abi_version(void);
+const char* gpmpc_last_error(void); /* thread-local text of the last failing call */
+int gpmpc_device_count(int* count);
+int gpmpc_device_name(int device, char* buf, int buflen);
+/* fp64 MFMA self-test: verifies the v_mfma_f64_16x16x4_f64 fragment layout the kernels assume
+ * (layout_out: 0 = row=(lane>>4)+4r documented for gfx950, 1 = row=4(lane>>4)+r) and measures the
+ * issue-bound rate of the instruction (TFLOP/s over the whole chip; the fp64 roofline "peak"). */
+int gpmpc_mfma_selftest(int device, int* layout_out, double* tflops_out);
+
+/* ---- model life cycle -------------------------------------------------------------------- */
+/* Copies X[N x d] and Y[N x Ny] to the device (the GP owns its data, gp_class.py:29-35). */
+int gpmpc_create(int device, int N, int d, int Ny, const double* X, const double* Y, gpmpc_gp** out);
+int gpmpc_destroy(gpmpc_gp* h);
+/* (N, d, Ny); GP.get_size gp_class.py:266-274 derives (N, Ny, Nu = d - Ny) from these. */
+int gpmpc_get_size(const gpmpc_gp* h, int* N, int* d, int* Ny);
+int gpmpc_set_pointer_mode(gpmpc_gp* h, int mode);
+int gpmpc_set_stream(gpmpc_gp* h, void* hip_stream); /* NULL restores the handle's own stream */
+int gpmpc_synchronize(gpmpc_gp* h);
+int gpmpc_profile_enable(gpmpc_gp* h, int enable);   /* HIP-event brackets per phase on the handle's stream */
+int gpmpc_profile_read(gpmpc_gp* h, int phase, double* total_ms, long* launches, int reset);
+
+/* ---- fit: a1,a3-a6 ----------------------------------------------------------------------- */
+/* K_a = k_a(X,X) + sn_a^2 I (optimize.py:303-319,343-344), L = chol(K) with the one-shot jitter
+ * rule (optimize.py:345-350, :483-488; gp_class.py:524-529): info[a] = 0 ok, 1 = 1e-8*I was added
+ * once, and the call returns GPMPC_ENOTPD (info[a] = -(first bad pivot index, 1-based)) if that
+ * also fails.  alpha = K^-1 y (optimize.py:494), and if want_invK: K^-1 (optimize.py:489-490).
+ * hyper is [Ny x (d+2)]; info may be NULL. */
+int gpmpc_fit(gpmpc_gp* h, const double* hyper, int want_invK, int* info);
+/* Export in the reference's save_model layout (gp_class.py:693-704): hyper[Ny x (d+2)],
+ * chol[Ny x N x N] (lower, zeros above), alpha[Ny x N], invK[Ny x N x N]; any pointer may be NULL. */
+int gpmpc_get_factors(gpmpc_gp* h, double* hyper, double* chol, double* alpha, double* invK);
+/* Import a saved model (GP.load_model -> ctor branch gp_class.py:58-66): chol and hyper are
+ * required; alpha == NULL recomputes it from Y; invK == NULL computes it lazily when a method
+ * needs it.  L^-1 (the predict operand) is rebuilt on the device. */
+int gpmpc_set_factors(gpmpc_gp* h, const double* hyper, const double* chol, const double* alpha,
+                      const double* invK);
+
+/* ---- predict: a9-a13 --------------------------------------------------------------------- */
+/* mean[B x Ny], var[B x Ny]: build_gp's mean/var functions, gp_functions.py:114-136
+ * (mean = ks^T alpha, var = sf^2 - ||L^-1 ks||^2, no noise term). */
+int gpmpc_predict_mean_var(gpmpc_gp* h, int B, const double* Z, double* mean, double* var);
+/* mean[B x Ny] and J[B x Ny x d] = d mean / d z: mean_jac_z gp_functions.py:146-147 (CasADi AD
+ * there, analytic here); the operand of GP.discrete_linearize / jacobian gp_class.py:647-672. */
+int gpmpc_mean_jac(gpmpc_gp* h, int B, const double* Z, double* mean, double* J);
+/* GP.__predict (gp_class.py:212-235) batched over B input distributions:
+ * Z[B x d], Sigma[B x d x d] (ignored for ME/old_ME, may be NULL) -> mean[B x Ny],
+ * cov[B x Ny x Ny] in standardised units (gp_class.py:262 leaves cov unscaled). */
+int gpmpc_predict(gpmpc_gp* h, int method, int B, const double* Z, const double* Sigma,
+                  double* mean, double* cov);
+/* a14 GP.covar gp_class.py:353-381: covar[Ny x n x n] = sf^2 - V^T V for n new inputs. */
+int gpmpc_covar(gpmpc_gp* h, int n, const double* Xnew, double* covar);
+
+/* ---- training objective: a7 (+ gradient) ------------------------------------------------- */
+/* NLL of output `a` at hyper_row[d+2] (calc_NLL_numpy optimize.py:322-356: 0.5 y^T alpha +
+ * sum log|L_ii|, jitter rule included); grad[d+2] (may be NULL) is dNLL/dhyper, Rasmussen &
+ * Williams eq. 5.9 -- the reference has no analytic gradient (optimize.py:371-375).
+ * jitter_out (may be NULL) reports whether the jitter branch was taken. */
+int gpmpc_nll(gpmpc_gp* h, int a, const double* hyper_row, double* nll, double* grad, int* jitter_out);
+
+/* ---- low-level dense ops (host pointers), used by the parity tests ------------------------ */
+/* In-place lower Cholesky of the n x n row-major SPD matrix A (np.linalg.cholesky,
+ * optimize.py:346).  *info = 0 ok, k > 0: leading minor k is not positive definite (LAPACK dpotrf
+ * convention).  Ainv (may be NULL) receives L^-1. */
+int gpmpc_cholesky(int device, int n, double* A, double* Ainv, int* info);
+/* C = alpha * op(A) op(B) + beta * C on the fp64 MFMA GEMM core (row-major, ld = row length).
+ * transa/transb as in BLAS ('N' = 0 / 'T' = 1). */
+int gpmpc_dgemm(int device, int transa, int transb, int M, int N, int K, double alpha,
+                const double* A, int lda, const double* B, int ldb, double beta, double* C, int ldc);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPMPC_H */

@@ -1,0 +1,52 @@
+"""CPU tier: run the UNMODIFIED HIP kernel sources under the emulator (tests/emu) and check them
+against the oracle at small sizes.  This is test infrastructure for catching kernel-logic bugs
+without a GPU; the product never loads this library (gp_mpc_amd/_lib.py::get_lib)."""
+import os
+import subprocess
+
+import pytest
+
+import parity_cases as pc
+from gp_mpc_amd._lib import GpmpcLib
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope='module')
+def emu():
+    subprocess.check_call([os.path.join(HERE, 'emu', 'build_emu.sh')], stdout=subprocess.DEVNULL)
+    return GpmpcLib(os.path.join(HERE, 'emu', '_build', 'libgpmpc_emu.so'))
+
+
+def test_emu_mfma_layout(emu):
+    layout, _ = emu.mfma_selftest(0)
+    assert layout == 0
+
+
+def test_emu_dgemm(emu):
+    pc.check_dgemm(emu)
+
+
+def test_emu_cholesky(emu):
+    pc.check_cholesky(emu)
+
+
+def test_emu_tank_model(emu, tank):
+    pc.check_model_fixture(emu, tank, tolL=1e-10, tol_nll=1e-10)
+
+
+def test_emu_car_model(emu, car):
+    pc.check_model_fixture(emu, car, tolL=5e-10, tol_nll=1e-7)
+
+
+def test_emu_synthetic(emu):
+    pc.check_synthetic(emu, N=200, d=6, Ny=2, B=40, sn=0.1, strict_rel=True)
+    pc.check_synthetic(emu, N=150, d=3, Ny=1, B=70, sn=1e-2, strict_rel=False)
+
+
+def test_emu_jitter_rule(emu, train_small):
+    pc.check_jitter_rule(emu, train_small)
+
+
+def test_emu_nll_gradient(emu, tank):
+    pc.check_nll_gradient(emu, tank)
