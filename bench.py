@@ -1,0 +1,167 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the GP hot path (BASELINE.json metric) on MI355X.
+
+Workload (config.workload "C2"): BASELINE.json configs[1] -- single-output SE-ARD GP, N=4096, d=6,
+fp64: one STEP = K build + Cholesky (+ L^-1, alpha) at fixed hyper-parameters + 10 000 mean+variance
+predictions, everything through the C ABI of libgpmpc_hip.so with X, Y, Z and the outputs resident
+in HBM (device pointer mode).  `value` = predictions/s over whole steps (fit included), summed over
+ranks.  With --gpus N every rank runs its own model / test batch on its own GPU (independent GP
+objects shard trivially, no data-path collective): weak scaling.
+
+Extra objects on the JSON line:
+  roofline     -- the dominant kernel (variance GEMM V = L^-1 Ks with fused column sums of squares):
+                  algorithmic flops per launch N(N+1) B / HIP-event time of that launch, vs the fp64
+                  MFMA peak (78.6 TFLOP/s spec; the measured issue-bound rate is reported beside it).
+  cpu_baseline -- the oracle's reference-formulation CPU path (numpy/LAPACK, same box, rank 0, N=1):
+                  one full fit + 1000 of the 10 000 predictions (prediction time scaled x10).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, 'oracle')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X datasheet, dense fp64 matrix (not in the local guides)
+
+
+def cpu_baseline(p, B):
+    """Oracle ("port") timed on the host cores: the reference formulation exactly --
+    expanded-form K (optimize.py:303-319), np.linalg.cholesky, LU np.linalg.solve for alpha and for
+    v = L^-1 ks (gp_class.py:377-380), var = sf^2 - v^T v."""
+    import numpy as np
+    import gp_oracle as go
+    X, Y, H, Z = p['X'], p['Y'], p['hyper'], p['Z']
+    d = X.shape[1]
+    nsub = min(1000, B)
+    t0 = time.perf_counter()
+    K = go.gram(X, H[0, :d], H[0, d] ** 2, H[0, d + 1] ** 2)
+    L, _ = go.chol_jitter(K)
+    alpha = go.alpha_from_chol(L, Y[:, 0])
+    t_fit = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    ks = go.cov_se_ard(X, Z[:nsub], H[0, :d], H[0, d] ** 2)
+    mean = ks.T @ alpha
+    v = np.linalg.solve(L, ks)
+    var = H[0, d] ** 2 - np.sum(v * v, axis=0)
+    t_pred = (time.perf_counter() - t0) * (B / nsub)
+    return dict(value=B / (t_fit + t_pred), unit='predictions/s', cores=os.cpu_count(), kind='port',
+                sample=f'1 full fit (N={X.shape[0]}) + {nsub} of {B} predictions, prediction time scaled x{B // nsub}; '
+                       f'fit {t_fit:.2f} s, predictions {t_pred:.2f} s (scaled); numpy {np.__version__}',
+                fit_s=t_fit, predict_s=t_pred), mean, var
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--N', type=int, default=4096)
+    ap.add_argument('--d', type=int, default=6)
+    ap.add_argument('--B', type=int, default=10000)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch                     # first: one HIP runtime in the process (torch's), shared by the library
+    import gp_oracle as go
+    from gp_mpc_amd._lib import Handle, get_lib
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU (torch.cuda.is_available() is False)')
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+
+    N, d, B = args.N, args.d, args.B
+    p = go.synthetic_problem(N, d, 1, B, seed=1234 + rank, sn=1e-2)
+    lib = get_lib()
+    layout, mfma_rate = lib.mfma_selftest(local_rank)
+    h = Handle(lib, p['X'], p['Y'], device=local_rank)
+    dev = torch.device('cuda', local_rank)
+    z = torch.from_numpy(p['Z']).to(dev)
+    mean = torch.empty((B, 1), dtype=torch.float64, device=dev)
+    var = torch.empty((B, 1), dtype=torch.float64, device=dev)
+    hyper = np.ascontiguousarray(p['hyper'])
+    h.set_pointer_mode(True)
+
+    def step():
+        h.fit(hyper)                                                    # K build + Cholesky + L^-1 + alpha
+        h.predict_mean_var_dev(B, z.data_ptr(), mean.data_ptr(), var.data_ptr())   # 10k mean+var
+
+    def sync():
+        h.synchronize()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    h.profile_enable(True)
+    h.profile_read(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    h.profile_enable(False)
+    prof = h.profile_read(reset=True)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # parity spot check of the very buffers that were timed (rank 0)
+    out = None
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * B * args.steps / elapsed
+        gemm_ms, gemm_n = prof['vargemm']
+        flops = float(N) * (N + 1) * B              # 2 * N(N+1)/2 MACs per prediction (triangular L^-1)
+        achieved = flops / (gemm_ms / max(gemm_n, 1) * 1e-3) * 1e-12 if gemm_ms > 0 else 0.0
+        fac_ms, fac_n = prof['factor']
+        out = {
+            'metric': 'GP predict (mean+var)/sec, N=4096 d=6 fp64', 'value': value, 'unit': 'predictions/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': 'C2: single-output SE-ARD GP, K build + Cholesky + 10k mean+var predictions per step',
+                       'N': N, 'd': d, 'Ny': 1, 'B': B, 'parallelism': f'independent GP per GPU x{world}'},
+            'roofline': {'kernel': 'gemm_f64_kernel<128,128> (variance GEMM + column sum of squares)',
+                         'bound': 'mfma', 'achieved': achieved, 'peak': FP64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': achieved / FP64_MFMA_PEAK_TFLOPS, 'traffic': None,
+                         'avg_launch_ms': gemm_ms / max(gemm_n, 1), 'launches': gemm_n,
+                         'peak_measured_issue_bound': mfma_rate},
+            'phases_ms_per_step': {k: v[0] / args.steps for k, v in prof.items() if v[1] > 0},
+            'cholesky_plus_inverse': {'ms': fac_ms / max(fac_n, 1),
+                                      'tflops': (2.0 * N ** 3 / 3.0) / (fac_ms / max(fac_n, 1) * 1e-3) * 1e-12 if fac_ms > 0 else 0.0,
+                                      'note': 'N^3/3 (potrf) + N^3/3 (trtri) flops over the fused recursion'},
+            'predict_only_per_s': B / ((prof['crosscov'][0] + prof['vargemm'][0] + prof['finish'][0]) / args.steps * 1e-3),
+            'device': lib.device_name(local_rank), 'mfma_layout': layout,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cb, cmean, cvar = cpu_baseline(p, B)
+            out['cpu_baseline'] = cb
+            gm, gv = mean.cpu().numpy()[:len(cmean), 0], var.cpu().numpy()[:len(cvar), 0]
+            out['parity_vs_cpu'] = {'mean_maxabs': float(np.abs(gm - cmean).max()),
+                                    'var_maxabs_over_sf2': float(np.abs(gv - cvar).max())}
+    h.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()

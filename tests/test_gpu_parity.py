@@ -1,0 +1,88 @@
+"""GPU tier (-m gpu): the parity tests proper.  Everything goes through the C ABI of the
+hipcc-built product library on a real MI355X and is compared with the oracle on identical inputs."""
+import time
+
+import numpy as np
+import pytest
+
+import gp_oracle as go
+import parity_cases as pc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def lib():
+    from gp_mpc_amd._lib import get_lib
+    lib = get_lib()                       # raises if libgpmpc_hip.so is missing: no fallback
+    assert lib.device_count() >= 1
+    return lib
+
+
+def test_mfma_selftest(lib):
+    layout, tflops = lib.mfma_selftest(0)
+    print(f'\n[mfma] device={lib.device_name(0)} f64 16x16x4 layout={layout} issue-bound rate={tflops:.1f} TFLOP/s')
+    assert layout in (0, 1)
+    assert tflops > 10.0
+
+
+def test_dgemm(lib):
+    pc.check_dgemm(lib, sizes=((70, 33, 50), (128, 128, 64), (200, 130, 96), (1000, 900, 512), (2048, 2048, 256)))
+
+
+def test_cholesky_small(lib):
+    pc.check_cholesky(lib, sizes=(64, 100, 192, 256, 1000))
+
+
+def test_cholesky_4096_matches_cpu(lib):
+    """north_star: 'Cholesky matching CPU to 1e-10 rel' at the C2 size."""
+    p = go.synthetic_problem(4096, 6, 1, 1, seed=1234)
+    K = go.gram(p['X'], p['hyper'][0, :6], 1.0, 1e-4)
+    L, Li, info = lib.cholesky(K, want_inverse=True)
+    Lr = np.linalg.cholesky(K)
+    assert info == 0
+    assert pc.relF(L, Lr) <= 1e-10
+    assert np.linalg.norm(L @ L.T - K) / np.linalg.norm(K) <= 1e-14
+    assert np.abs(Li @ Lr - np.eye(4096)).max() <= 1e-9
+
+
+def test_tank_model(lib, tank):
+    pc.check_model_fixture(lib, tank, tolL=1e-10, tol_nll=1e-10)
+
+
+def test_car_model(lib, car):
+    pc.check_model_fixture(lib, car, tolL=5e-10, tol_nll=1e-7)
+
+
+def test_synthetic_strict(lib):
+    pc.check_synthetic(lib, N=1024, d=6, Ny=2, B=300, sn=0.1, strict_rel=True)
+
+
+def test_synthetic_default_noise(lib):
+    pc.check_synthetic(lib, N=1500, d=8, Ny=3, B=1000, sn=1e-2, strict_rel=False)
+
+
+def test_jitter_rule(lib, train_small):
+    pc.check_jitter_rule(lib, train_small)
+
+
+def test_nll_gradient(lib, tank):
+    pc.check_nll_gradient(lib, tank)
+
+
+def test_c2_full_size_vs_oracle_and_properties(lib):
+    """BASELINE config C2 (N=4096, d=6, 10k predictions) against the oracle on the same inputs,
+    plus size-independent properties: batch invariance (bitwise), 0 <= var <= sf^2, chunking."""
+    from gp_mpc_amd._lib import Handle
+    t0 = time.time()
+    r = pc.check_synthetic(lib, N=4096, d=6, Ny=1, B=10000, sn=1e-2, strict_rel=False)
+    print(f'\n[C2] full-size oracle comparison took {time.time() - t0:.1f} s')
+    h = Handle(lib, r['X'], r['Y'])
+    h.fit(r['H'])
+    mean, var = r['mean'], r['var']
+    m2, v2 = h.predict_mean_var(r['Z'][:777])
+    assert np.array_equal(m2, mean[:777]) and np.array_equal(v2, var[:777])     # deterministic, batch-invariant
+    assert np.all(var > 0) and np.all(var <= 1.0 + 1e-12)
+    mt, vt = h.predict_mean_var(r['X'][:512])                                   # at training inputs
+    assert np.max(np.abs(mt[:, 0] - r['Y'][:512, 0])) < 0.2 and np.all(vt < 1e-3)
+    h.close()
