@@ -51,6 +51,8 @@ SIGNATURES = {
     'gpmpc_predict': (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, _vp]),
     'gpmpc_covar': (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp]),
     'gpmpc_nll': (ctypes.c_int, [_vp, ctypes.c_int, _vp, _dp, _vp, _ip]),
+    'gpmpc_kernel_matrix': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp,
+                                           ctypes.c_double, _vp]),
     'gpmpc_cholesky': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _vp, _vp, _ip]),
     'gpmpc_dgemm': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                    ctypes.c_int, ctypes.c_double, _vp, ctypes.c_int, _vp, ctypes.c_int,
@@ -127,6 +129,13 @@ class GpmpcLib:
         info = ctypes.c_int(0)
         self.check(self.dll.gpmpc_cholesky(device, n, _ptr(A), _ptr(inv), ctypes.byref(info)))
         return (A, inv, info.value) if want_inverse else (A, info.value)
+
+    def kernel_matrix(self, X, Z, ell, sf2, device=0):
+        X, Z, ell = _f64(X), _f64(Z), _f64(ell)
+        out = np.zeros((X.shape[0], Z.shape[0]))
+        self.check(self.dll.gpmpc_kernel_matrix(device, X.shape[0], Z.shape[0], X.shape[1], _ptr(X), _ptr(Z), _ptr(ell),
+                                                float(sf2), _ptr(out)))
+        return out
 
     def dgemm(self, A, B, C=None, alpha=1.0, beta=0.0, transa=False, transb=False, device=0):
         A, B = _f64(A), _f64(B)

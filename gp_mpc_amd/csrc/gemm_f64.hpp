@@ -10,7 +10,7 @@
 //   * w = invL y, alpha = invL^T w as N = 1 products                             (a5, optimize.py:353-354)
 //   * predictive variance  sum_i (invL Ks)_ij^2                                  (a9, gp_functions.py:122-126)
 //
-// Design (MI355X): 256 threads = 4 waves in a 2 x 2 grid, block tile BM x BN (128 or 64), BK = 16.
+// Design (MI355X): 256 threads = 4 waves in a 2 x 2 grid, block tile BM x BN (128, 64 or 32), K step BK.
 // Operand tiles are staged global -> registers -> LDS with a one-tile software pipeline (the global
 // loads of tile t+1 are in flight while tile t feeds the matrix pipe; one barrier per K step).  LDS
 // holds each operand in MFMA-fragment order [k/4][row][k%4], so the 64 lanes of a fragment read
@@ -47,12 +47,14 @@ struct GemmP {
     int crow_mode;
 };
 
-template <int BM, int BN>
+template <int BM, int BN, int BK>
 __global__ void __launch_bounds__(256, 2) gemm_f64_kernel(GemmP p) {
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
-    constexpr int LA = BM / 32, LB = BN / 32;  // double2 loads per thread per tile
-    __shared__ __attribute__((aligned(16))) double As[2][4][BM][4];
-    __shared__ __attribute__((aligned(16))) double Bs[2][4][BN][4];
+    constexpr int HK = BK / 2, QK = BK / 4;                    // double2 per tile row, MFMA k-groups
+    constexpr int LA = BM * HK / 256, LB = BN * HK / 256;       // double2 loads per thread per tile
+    static_assert(LA >= 1 && LB >= 1, "tile too small for 256 threads");
+    __shared__ __attribute__((aligned(16))) double As[2][QK][BM][4];
+    __shared__ __attribute__((aligned(16))) double Bs[2][QK][BN][4];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -68,9 +70,9 @@ __global__ void __launch_bounds__(256, 2) gemm_f64_kernel(GemmP p) {
     if (p.kflags & KA_GE_M) klo = max(klo, m0);
     if (p.kflags & KB_LE_N) khi = min(khi, n0 + BN);
     if (p.kflags & KB_GE_N) klo = max(klo, n0);
-    klo &= ~15;
-    khi = min(p.K, (khi + 15) & ~15);
-    const int nk = khi > klo ? (khi - klo) >> 4 : 0;
+    klo = klo / BK * BK;
+    khi = min(p.K, (khi + BK - 1) / BK * BK);
+    const int nk = khi > klo ? (khi - klo) / BK : 0;
 
     const double* __restrict__ A = p.A + (long)blockIdx.z * p.sA;
     const double* __restrict__ B = p.B + (long)blockIdx.z * p.sB;
@@ -88,7 +90,7 @@ __global__ void __launch_bounds__(256, 2) gemm_f64_kernel(GemmP p) {
         for (int r = 0; r < LA; ++r) {
             const int idx = tid + 256 * r;
             if (!p.a_mc) {
-                const int row = idx >> 3, k = (idx & 7) * 2;
+                const int row = idx / HK, k = (idx % HK) * 2;
                 ra[r] = (m0 + row < p.M)
                             ? *reinterpret_cast<const double2*>(A + (long)(m0 + row) * p.lda + k0 + k)
                             : double2{0.0, 0.0};
@@ -103,7 +105,7 @@ __global__ void __launch_bounds__(256, 2) gemm_f64_kernel(GemmP p) {
         for (int r = 0; r < LB; ++r) {
             const int idx = tid + 256 * r;
             if (!p.b_nc) {
-                const int row = idx >> 3, k = (idx & 7) * 2;
+                const int row = idx / HK, k = (idx % HK) * 2;
                 rb[r] = (n0 + row < p.N)
                             ? *reinterpret_cast<const double2*>(B + (long)(n0 + row) * p.ldb + k0 + k)
                             : double2{0.0, 0.0};
@@ -120,7 +122,7 @@ __global__ void __launch_bounds__(256, 2) gemm_f64_kernel(GemmP p) {
         for (int r = 0; r < LA; ++r) {
             const int idx = tid + 256 * r;
             if (!p.a_mc) {
-                const int row = idx >> 3, k = (idx & 7) * 2;
+                const int row = idx / HK, k = (idx % HK) * 2;
                 *reinterpret_cast<double2*>(&As[buf][k >> 2][row][k & 3]) = ra[r];
             } else {
                 const int k = idx / (BM / 2), m = (idx % (BM / 2)) * 2;
@@ -132,7 +134,7 @@ __global__ void __launch_bounds__(256, 2) gemm_f64_kernel(GemmP p) {
         for (int r = 0; r < LB; ++r) {
             const int idx = tid + 256 * r;
             if (!p.b_nc) {
-                const int row = idx >> 3, k = (idx & 7) * 2;
+                const int row = idx / HK, k = (idx % HK) * 2;
                 *reinterpret_cast<double2*>(&Bs[buf][k >> 2][row][k & 3]) = rb[r];
             } else {
                 const int k = idx / (BN / 2), n = (idx % (BN / 2)) * 2;
@@ -150,9 +152,9 @@ __global__ void __launch_bounds__(256, 2) gemm_f64_kernel(GemmP p) {
     int cur = 0;
     const int fr = lane & 15, fk = lane >> 4;
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) load_tiles(klo + (kt + 1) * 16);
+        if (kt + 1 < nk) load_tiles(klo + (kt + 1) * BK);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < QK; ++q) {
             double a[TM], b[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) a[i] = As[cur][q][wm * WM + i * 16 + fr][fk];
@@ -205,18 +207,35 @@ __global__ void __launch_bounds__(256, 2) gemm_f64_kernel(GemmP p) {
     }
 }
 
-// Host-side launcher.  Chooses the 128- or 64-wide tile so that small problems still put enough
-// workgroups on the 256 CUs.
-inline void launch_gemm(const GemmP& p, int batch, hipStream_t stream, int force_tile = 0) {
-    const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * batch;
-    const bool big = force_tile ? (force_tile == 128) : ((p.lower ? t128 / 2 : t128) >= 192);
-    if (big) {
-        dim3 grid((p.N + 127) / 128, (p.M + 127) / 128, batch);
-        hipLaunchKernelGGL((gemm_f64_kernel<128, 128>), grid, dim3(256), 0, stream, p);
+// Host-side launcher.  f64 MFMA on gfx950 is issue-latency limited per wave (one
+// v_mfma_f64_16x16x4_f64 per ~142 cycles from a single wave, ~47 TFLOP/s chip-wide only with >= 2 waves
+// per SIMD -- tools/ubench/mfma_f64_bench.hip), so the tile is chosen to put >= 2 workgroups of 4 waves
+// on every CU: 128^2 tiles for the large contractions, 64^2 below that, and 32^2 tiles with a 64-deep K
+// step for the small latency-bound products of the factorisation recursion.
+// Returns the tile edge used (the caller of EPI_COLSUMSQ sizes `part` with it).
+inline int gemm_pick_tile(const GemmP& p, int batch) {
+    auto blocks = [&](int t) {
+        const long b = (long)((p.M + t - 1) / t) * ((p.N + t - 1) / t) * batch;
+        return p.lower ? (b + 1) / 2 : b;
+    };
+    if (blocks(128) >= 512) return 128;
+    if (blocks(64) >= 512) return 64;
+    return 32;
+}
+
+inline int launch_gemm(const GemmP& p, int batch, hipStream_t stream, int force_tile = 0) {
+    const int tile = force_tile ? force_tile : gemm_pick_tile(p, batch);
+    dim3 grid((p.N + tile - 1) / tile, (p.M + tile - 1) / tile, batch);
+    if (tile == 128) {
+        hipLaunchKernelGGL((gemm_f64_kernel<128, 128, 16>), grid, dim3(256), 0, stream, p);
+    } else if (tile == 64) {
+        hipLaunchKernelGGL((gemm_f64_kernel<64, 64, 16>), grid, dim3(256), 0, stream, p);
+    } else if (p.K % 64 == 0) {
+        hipLaunchKernelGGL((gemm_f64_kernel<32, 32, 64>), grid, dim3(256), 0, stream, p);
     } else {
-        dim3 grid((p.N + 63) / 64, (p.M + 63) / 64, batch);
-        hipLaunchKernelGGL((gemm_f64_kernel<64, 64>), grid, dim3(256), 0, stream, p);
+        hipLaunchKernelGGL((gemm_f64_kernel<32, 32, 16>), grid, dim3(256), 0, stream, p);
     }
+    return tile;
 }
 
 }  // namespace gpmpc

@@ -70,6 +70,24 @@ __global__ void __launch_bounds__(256) gram_kernel(const double* __restrict__ XT
     }
 }
 
+// a1, two-input form: GP.covSEard gp_class.py:314-350 for arbitrary X[n1 x d], Z[n2 x d]; same
+// per-dimension expanded-form accumulation as gram_kernel.  One thread per entry.
+__global__ void __launch_bounds__(256) kernel_matrix_kernel(const double* __restrict__ X, const double* __restrict__ Z,
+                                                            const double* __restrict__ ell, double sf2,
+                                                            double* __restrict__ out, int n1, int n2, int d) {
+#pragma clang fp contract(off)
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long)n1 * n2) return;
+    const int i = (int)(e / n2), j = (int)(e % n2);
+    double dist = 0.0;
+    for (int dd = 0; dd < d; ++dd) {
+        const double x = X[(long)i * d + dd], z = Z[(long)j * d + dd];
+        const double t = (x * x + z * z) - 2.0 * (x * z);
+        dist = t / (ell[dd] * ell[dd]) + dist;
+    }
+    out[e] = sf2 * exp(-0.5 * dist);
+}
+
 // a9 (first half): ks_a(X, z_j) for JT test points per workgroup, written as KsT[a][j][:], fused
 // with mean_a(z_j) = ks^T alpha_a (gp_functions.py:114-120,135).  grid (Bp/JT, Ny), 256 threads.
 // D (the GP input dimension) is a template parameter so that a training point's coordinates live in
@@ -217,6 +235,47 @@ __global__ void __launch_bounds__(256) cov_assemble_kernel(const double* __restr
         }
     }
     cov[e] = v;
+}
+
+// Matrix-vector products with the explicit factors (a5: alpha = L^-T (L^-1 y), optimize.py:353-354,494;
+// beta = K^-1 y, gp_functions.py:383).  HBM-read bound: 4 N^2 bytes for a triangular operand.
+// out[i] = sum_{k < (lower ? i+1 : Np)} A[i][k] x[k]: one wave per row, lanes stride the row (512 B
+// coalesced reads), butterfly reduction.  grid (Np/4, batch), 256 threads.
+__global__ void __launch_bounds__(256) gemv_rows_kernel(const double* __restrict__ A, const double* __restrict__ x,
+                                                        double* __restrict__ out, int Np, long sA, long sx, long so,
+                                                        int lower) {
+    const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const double* __restrict__ row = A + (long)blockIdx.y * sA + (long)i * Np;
+    const double* __restrict__ xv = x + (long)blockIdx.y * sx;
+    const int kend = lower ? i + 1 : Np;
+    double s = 0.0;
+    for (int k = lane; k < kend; k += 64) s += row[k] * xv[k];
+    s = wave_sum(s);
+    if (lane == 0) out[(long)blockIdx.y * so + i] = s;
+}
+
+// out[k] = sum_{i >= k} A[i][k] x[i] (A lower triangular, i.e. A^T x): a workgroup owns 64 columns,
+// its 16 waves take rows i = k0 + v, k0 + v + 16, ... (each row read is one 512 B line), fixed-order
+// reduction over the waves.  grid (Np/64, batch), 1024 threads.
+__global__ void __launch_bounds__(1024) gemv_lowerT_kernel(const double* __restrict__ A, const double* __restrict__ x,
+                                                           double* __restrict__ out, int Np, long sA, long sx, long so) {
+    __shared__ double red[16][64];
+    const int lane = threadIdx.x & 63, v = threadIdx.x >> 6, k0 = blockIdx.x * 64, k = k0 + lane;
+    const double* __restrict__ Ab = A + (long)blockIdx.y * sA;
+    const double* __restrict__ xv = x + (long)blockIdx.y * sx;
+    double s = 0.0;
+    for (int i = k0 + v; i < Np; i += 16) {
+        const double a = (k <= i) ? Ab[(long)i * Np + k] : 0.0;
+        s += a * xv[i];
+    }
+    red[v][lane] = s;
+    __syncthreads();
+    if (v == 0) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += red[w][lane];
+        out[(long)blockIdx.y * so + k] = t;
+    }
 }
 
 // a7 tail: nll[a] = 1/2 w^T w + sum_i log|L_ii| with w = L^-1 y (= 1/2 y^T alpha + 1/2 logdet K,

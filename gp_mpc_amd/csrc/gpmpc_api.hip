@@ -240,22 +240,14 @@ static void factor_rec(const Ctx& cx, Workspace& ws, int off, int n, bool do_cho
     launch_gemm(u, ws.batch, cx.stream);
 }
 
-// w = L^-1 y (N = 1 product with the explicit inverse), alpha = L^-T w.  y: [batch] vectors with
-// stride sy.
+// w = L^-1 y and alpha = L^-T w as two HBM-bound matrix-vector products with the explicit inverse.
+// y: [batch] vectors with stride sy.
 static void solve_alpha(const Ctx& cx, Workspace& ws, const double* y, long sy) {
-    const long ld = ws.Np, sM = ws.mat();
-    GemmP p = gemm_base(cx);
-    p.A = ws.Inv; p.lda = ld; p.sA = sM; p.a_mc = 0; p.kflags = KA_LE_M;
-    p.B = y; p.ldb = ld; p.sB = sy; p.b_nc = 0;
-    p.C = ws.w; p.ldc = 1; p.sC = ld;
-    p.M = ws.Np; p.N = 1; p.K = ws.Np;
-    launch_gemm(p, ws.batch, cx.stream);
-    GemmP q = gemm_base(cx);
-    q.A = ws.Inv; q.lda = ld; q.sA = sM; q.a_mc = 1; q.kflags = KA_GE_M;
-    q.B = ws.w; q.ldb = ld; q.sB = ld; q.b_nc = 0;
-    q.C = ws.alpha; q.ldc = 1; q.sC = ld;
-    q.M = ws.Np; q.N = 1; q.K = ws.Np;
-    launch_gemm(q, ws.batch, cx.stream);
+    const int Np = ws.Np;
+    hipLaunchKernelGGL(gemv_rows_kernel, dim3(Np / 4, ws.batch), dim3(256), 0, cx.stream, ws.Inv, y, ws.w, Np, ws.mat(), sy,
+                       (long)Np, 1);
+    hipLaunchKernelGGL(gemv_lowerT_kernel, dim3(Np / 64, ws.batch), dim3(1024), 0, cx.stream, ws.Inv, ws.w, ws.alpha, Np,
+                       ws.mat(), (long)Np, (long)Np);
 }
 
 // K^-1 = L^-T L^-1 (lower triangle by MFMA, then mirrored)
@@ -301,8 +293,11 @@ struct gpmpc_gp {
     int Bcap = 0;
     double *Z = nullptr, *Sigma = nullptr, *KsT = nullptr, *part = nullptr, *meanT = nullptr;
     double *mean = nullptr, *var = nullptr, *J = nullptr, *cov = nullptr;
-    double* em = nullptr;  // exact-moment scratch
+    double* em = nullptr;  // exact-moment / legacy scratch
     long emBytes = 0;
+    double* beta = nullptr;  // K^-1 y, [Ny][Np]
+    double* UT = nullptr;    // legacy: K^-1 ks per test point
+    bool have_beta = false;
     Prof prof;
     Ctx cx() const { return Ctx{stream, crow_mode}; }
 };
@@ -409,6 +404,7 @@ int gpmpc_destroy(gpmpc_gp* h) {
     hipFree(h->XT); hipFree(h->Y); hipFree(h->gradPartial); hipFree(h->gradOut);
     hipFree(h->Z); hipFree(h->Sigma); hipFree(h->KsT); hipFree(h->part); hipFree(h->meanT);
     hipFree(h->mean); hipFree(h->var); hipFree(h->J); hipFree(h->cov); hipFree(h->em);
+    hipFree(h->beta); hipFree(h->UT);
     for (int ph = 0; ph < GPMPC_PH_COUNT; ++ph)
         for (auto& pr : h->prof.ev[ph]) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     for (auto e : h->prof.pool) hipEventDestroy(e);
@@ -522,6 +518,7 @@ extern "C" int gpmpc_fit(gpmpc_gp* h, const double* hyper, int want_invK, int* i
         }
     h->fitted = false;
     h->have_invK = false;
+    h->have_beta = false;
     CHK(factor_with_jitter(h, h->ws, hyper, info));
     {
         PhaseTimer t(h, GPMPC_PH_SOLVE);
@@ -594,6 +591,7 @@ extern "C" int gpmpc_set_factors(gpmpc_gp* h, const double* hyper, const double*
     HIPCHK(hipStreamSynchronize(h->stream));
     h->fitted = false;
     h->have_invK = false;
+    h->have_beta = false;
     h->hyper.assign(hyper, hyper + (size_t)h->Ny * (h->d + 2));
     HIPCHK(hipMemcpy(h->ws.hyper, hyper, h->hyper.size() * sizeof(double), hipMemcpyHostToDevice));
     CHK(import_mats(h, chol, h->ws.L, true));
@@ -633,14 +631,15 @@ static int ensure_scratch(gpmpc_gp* h, int B) {
     if (need <= h->Bcap) return GPMPC_OK;
     HIPCHK(hipStreamSynchronize(h->stream));
     hipFree(h->Z); hipFree(h->Sigma); hipFree(h->KsT); hipFree(h->part); hipFree(h->meanT);
-    hipFree(h->mean); hipFree(h->var); hipFree(h->J); hipFree(h->cov);
+    hipFree(h->mean); hipFree(h->var); hipFree(h->J); hipFree(h->cov); hipFree(h->UT);
+    h->UT = nullptr;
     h->Z = h->Sigma = h->KsT = h->part = h->meanT = h->mean = h->var = h->J = h->cov = nullptr;
     h->Bcap = 0;
     const size_t d = h->d, Ny = h->Ny, Np = h->Np, Bc = need;
     HIPCHK(hipMalloc(&h->Z, Bc * d * sizeof(double)));
     HIPCHK(hipMalloc(&h->Sigma, Bc * d * d * sizeof(double)));
     HIPCHK(hipMalloc(&h->KsT, Ny * Bc * Np * sizeof(double)));
-    HIPCHK(hipMalloc(&h->part, Ny * (Np / 64) * Bc * sizeof(double)));
+    HIPCHK(hipMalloc(&h->part, Ny * (Np / 32) * Bc * sizeof(double)));
     HIPCHK(hipMalloc(&h->meanT, Ny * Bc * sizeof(double)));
     HIPCHK(hipMalloc(&h->mean, Bc * Ny * sizeof(double)));
     HIPCHK(hipMalloc(&h->var, Bc * Ny * sizeof(double)));
@@ -666,8 +665,7 @@ static int predict_chunk(gpmpc_gp* h, int B, const double* dZ, double* dMean, do
         p.B = h->KsT; p.ldb = Np; p.sB = (long)Bp * Np; p.b_nc = 0;
         p.M = Np; p.N = Bp; p.K = Np;
         p.epi = EPI_COLSUMSQ; p.part = h->part; p.ldpart = Bp;
-        const long t128 = (long)((Np + 127) / 128) * ((Bp + 127) / 128) * Ny;
-        const int tile = t128 >= 192 ? 128 : 64;
+        const int tile = gemm_pick_tile(p, Ny);
         tilesM = (Np + tile - 1) / tile;
         p.sPart = (long)tilesM * Bp;
         launch_gemm(p, Ny, cx.stream, tile);
@@ -929,5 +927,25 @@ extern "C" int gpmpc_dgemm(int device, int transa, int transb, int M, int N, int
     HIPCHK(hipMemcpy(c.data(), dC, c.size() * sizeof(double), hipMemcpyDeviceToHost));
     for (int i = 0; i < M; ++i) std::memcpy(C + (size_t)i * ldc, c.data() + (size_t)i * N, N * sizeof(double));
     hipFree(dA); hipFree(dB); hipFree(dC);
+    return GPMPC_OK;
+}
+
+extern "C" int gpmpc_kernel_matrix(int device, int n1, int n2, int d, const double* X, const double* Z, const double* ell,
+                                   double sf2, double* out) {
+    if (n1 <= 0 || n2 <= 0 || d <= 0 || !X || !Z || !ell || !out) return fail(GPMPC_EINVAL, "bad arguments");
+    CHK(ensure_device(device));
+    double *dX, *dZ, *dE, *dO;
+    HIPCHK(hipMalloc(&dX, (size_t)n1 * d * sizeof(double)));
+    HIPCHK(hipMalloc(&dZ, (size_t)n2 * d * sizeof(double)));
+    HIPCHK(hipMalloc(&dE, (size_t)d * sizeof(double)));
+    HIPCHK(hipMalloc(&dO, (size_t)n1 * n2 * sizeof(double)));
+    HIPCHK(hipMemcpy(dX, X, (size_t)n1 * d * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dZ, Z, (size_t)n2 * d * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dE, ell, (size_t)d * sizeof(double), hipMemcpyHostToDevice));
+    const long ne = (long)n1 * n2;
+    hipLaunchKernelGGL(kernel_matrix_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, 0, dX, dZ, dE, sf2, dO, n1, n2, d);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(out, dO, (size_t)ne * sizeof(double), hipMemcpyDeviceToHost));
+    hipFree(dX); hipFree(dZ); hipFree(dE); hipFree(dO);
     return GPMPC_OK;
 }

@@ -1,5 +1,72 @@
+// Moment-based methods: 'EM' (a11) and the legacy 'old_ME' / 'old_TA' (a12).  Included by gpmpc_api.hip.
+
+// beta_a = K_a^-1 y_a (gp_functions.py:383; the reference multiplies the explicit inverse)
+static int ensure_beta(gpmpc_gp* h) {
+    if (h->have_beta) return GPMPC_OK;
+    if (!h->beta) HIPCHK(hipMalloc(&h->beta, (size_t)h->Ny * h->Np * sizeof(double)));
+    const Ctx cx = h->cx();
+    hipLaunchKernelGGL(gemv_rows_kernel, dim3(h->Np / 4, h->Ny), dim3(256), 0, cx.stream, h->ws.InvK, h->Y, h->beta, h->Np,
+                       h->ws.mat(), (long)h->Np, (long)h->Np, 0);
+    // padded rows of K^-1 are identity rows against a zero-padded y: beta stays 0 there
+    h->have_beta = true;
+    return GPMPC_OK;
+}
+
+static int ensure_em_scratch(gpmpc_gp* h, long bytes) {
+    if (bytes <= h->emBytes) return GPMPC_OK;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    hipFree(h->em);
+    h->em = nullptr;
+    h->emBytes = 0;
+    HIPCHK(hipMalloc(&h->em, (size_t)bytes));
+    h->emBytes = bytes;
+    return GPMPC_OK;
+}
+
 static int predict_moments_chunk(gpmpc_gp* h, int method, int B, const double* dZ, const double* dSigma,
                                  double* dMean, double* dCov) {
-    (void)h; (void)method; (void)B; (void)dZ; (void)dSigma; (void)dMean; (void)dCov;
-    return fail(GPMPC_EINVAL, "moment-based methods are not built yet");
+    const Ctx cx = h->cx();
+    const int Np = h->Np, Ny = h->Ny, d = h->d, N = h->N;
+    CHK(ensure_beta(h));
+    if (method == GPMPC_EM) {
+        PhaseTimer t(h, GPMPC_PH_EM);
+        const int P = Ny * (Ny + 1) / 2, tiles = Np / 64;
+        const long prepN = (long)B * (Ny + P) * (d * d + 1), partN = (long)B * P * tiles;
+        CHK(ensure_em_scratch(h, (prepN + partN) * (long)sizeof(double)));
+        double* prep = h->em;
+        double* partial = h->em + prepN;
+        const long items = (long)B * (Ny + P);
+        hipLaunchKernelGGL(em_prep_kernel, dim3((unsigned)((items + 63) / 64)), dim3(64), 0, cx.stream, h->ws.hyper, dSigma,
+                           prep, B, Ny, d);
+        hipLaunchKernelGGL(em_mean_kernel, dim3(Ny, B), dim3(256), 0, cx.stream, h->XT, dZ, h->beta, prep, dMean, N, Np, d,
+                           Ny);
+        launch_em_pair(cx.stream, d, dim3(tiles, P, B), h->XT, dZ, h->ws.hyper, h->beta, h->ws.InvK, prep, partial, N, Np,
+                       Ny);
+        hipLaunchKernelGGL(em_finish_kernel, dim3((unsigned)(((long)B * P + 63) / 64)), dim3(64), 0, cx.stream, partial, prep,
+                           h->ws.hyper, dMean, dCov, B, Ny, d, tiles);
+        HIPCHK(hipGetLastError());
+        return GPMPC_OK;
+    }
+    // legacy: u = K^-1 ks for the whole batch as one GEMM  UT[j][:] = KsT[j][:] K^-1
+    const int Bp = round_up(B, 64);
+    const size_t utBytes = (size_t)Ny * h->Bcap * Np * sizeof(double);
+    if (!h->UT) HIPCHK(hipMalloc(&h->UT, utBytes));
+    CHK(ensure_em_scratch(h, (long)B * Ny * 4 * (long)sizeof(double)));
+    {
+        PhaseTimer t(h, GPMPC_PH_CROSSCOV);
+        launch_crosscov(cx.stream, d, h->XT, h->ws.hyper, h->ws.alpha, dZ, h->KsT, h->meanT, N, Np, B, Bp, Ny);
+    }
+    PhaseTimer t(h, GPMPC_PH_EM);
+    GemmP p = gemm_base(cx);
+    p.A = h->KsT; p.lda = Np; p.sA = (long)Bp * Np; p.a_mc = 0;
+    p.B = h->ws.InvK; p.ldb = Np; p.sB = h->ws.mat(); p.b_nc = 1;
+    p.C = h->UT; p.ldc = Np; p.sC = (long)Bp * Np;
+    p.M = Bp; p.N = Np; p.K = Np;
+    launch_gemm(p, Ny, cx.stream);
+    hipLaunchKernelGGL(legacy_scalars_kernel, dim3(B, Ny), dim3(256), 0, cx.stream, h->XT, dZ, h->ws.hyper, h->Y, h->beta,
+                       h->KsT, h->UT, h->em, N, Np, d, Bp, Ny);
+    hipLaunchKernelGGL(legacy_finish_kernel, dim3((B + 63) / 64), dim3(64), 0, cx.stream, h->em, h->XT, dZ, h->ws.hyper,
+                       dSigma, dMean, dCov, B, Ny, d, method == GPMPC_OLD_TA ? 1 : 0);
+    HIPCHK(hipGetLastError());
+    return GPMPC_OK;
 }

@@ -1,0 +1,422 @@
+"""`GP`: host-side mirror of the reference's `gp_mpc.GP` class (gp_class.py:20-861) for the hot path.
+
+Same constructor, method names, argument meaning and error behaviour as the reference, so that a
+caller such as `mpc_class.MPC` (mpc_class.py:167,234,412-413,596) can use it unchanged; all GP
+arithmetic runs in the HIP kernels behind the C ABI (include/gpmpc.h) -- there is no CPU path.
+Differences that are deliberate are marked "DIFF".
+
+Standardisation stays on the host exactly as in the reference: `predict` standardises x and u,
+calls the (device) predictor in the GP's own units and un-standardises the MEAN only
+(gp_class.py:245-263); `discrete_linearize` returns Jacobians in standardised coordinates
+(gp_class.py:647-661).
+"""
+from __future__ import annotations
+
+import json
+
+import numpy as np
+
+from . import _lib
+from .train import train_gp
+
+METHODS = ('ME', 'TA', 'EM', 'old_ME', 'old_TA')
+
+
+class GP:
+    def __init__(self, X, Y, mean_func="zero", gp_method="TA",
+                 optimizer_opts=None, hyper=None, normalize=True, multistart=1,
+                 xlb=None, xub=None, ulb=None, uub=None, meta=None,
+                 optimize_nummeric=True, device=0, lib=None):
+        """Initialize and optimize GP model (gp_class.py:21-75).
+
+        Extra arguments: `device` (GPU ordinal) and `lib` (a loaded `GpmpcLib`; default: the
+        in-tree libgpmpc_hip.so, raising if it is missing)."""
+        self._lib = lib if lib is not None else _lib.get_lib()
+        self._device = device
+        X = np.array(X, dtype=np.float64).copy()
+        Y = np.array(Y, dtype=np.float64).copy()
+        self.__X = X
+        self.__Y = Y
+        self.__Ny = Y.shape[1]
+        self.__Nx = X.shape[1]
+        self.__N = X.shape[0]
+        self.__Nu = self.__Nx - self.__Ny
+        self.__gp_method = gp_method
+        self.__mean_func = mean_func
+        self.__normalize = normalize
+        self._h = None
+        self._check_mean_func(mean_func)
+
+        if meta is not None:
+            self.__meanY = np.array(meta['meanY'])
+            self.__stdY = np.array(meta['stdY'])
+            self.__meanZ = np.array(meta['meanZ'])
+            self.__stdZ = np.array(meta['stdZ'])
+            self.__meanX = np.array(meta['meanX'])
+            self.__stdX = np.array(meta['stdX'])
+            self.__meanU = np.array(meta['meanU'])
+            self.__stdU = np.array(meta['stdU'])
+        if xlb is not None:
+            self.__xlb, self.__xub = np.array(xlb), np.array(xub)
+            self.__ulb, self.__uub = np.array(ulb), np.array(uub)
+
+        if hyper is None:
+            self.optimize(X=X, Y=Y, opts=optimizer_opts, mean_func=mean_func,
+                          xlb=xlb, xub=xub, ulb=ulb, uub=uub,
+                          multistart=multistart, normalize=normalize,
+                          optimize_nummeric=optimize_nummeric)
+        else:
+            # load_model branch (gp_class.py:58-66): stored X is already standardised
+            self.__hyper = np.array(hyper['hyper'], dtype=np.float64)
+            self.__hyper_length_scales = self.__hyper[:, :self.__Nx]
+            self.__hyper_signal_variance = self.__hyper[:, self.__Nx] ** 2
+            self.__hyper_noise_variance = self.__hyper[:, self.__Nx + 1] ** 2
+            self.__hyper_mean = self.__hyper[:, (self.__Nx + 1):]
+            self._new_handle()
+            self._h.set_factors(self.__hyper, np.array(hyper['chol'], dtype=np.float64),
+                                None if hyper.get('alpha') is None else np.array(hyper['alpha'], dtype=np.float64),
+                                None if hyper.get('invK') is None else np.array(hyper['invK'], dtype=np.float64))
+        self.set_method(gp_method)
+
+    # ------------------------------------------------------------------ internals
+    @staticmethod
+    def _check_mean_func(mean_func):
+        if mean_func not in ('zero', 'const', 'linear', 'polynomial'):
+            raise NameError('No mean function called: ' + str(mean_func))      # gp_functions.py:67
+        if mean_func != 'zero':
+            # the reference's own default training path supports only the zero mean (optimize.py:377-379)
+            raise NotImplementedError("mean_func='%s': only the zero prior mean is on the HIP path" % mean_func)
+
+    def _new_handle(self):
+        if self._h is not None:
+            self._h.close()
+        self._h = _lib.Handle(self._lib, self.__X, self.__Y, device=self._device)
+
+    def _refit(self, want_invK=False):
+        self._new_handle()
+        self._h.fit(self.__hyper, want_invK=want_invK)
+
+    @property
+    def handle(self):
+        """The C-ABI handle (for batched / device-pointer use)."""
+        return self._h
+
+    # ------------------------------------------------------------------ training
+    def optimize(self, X=None, Y=None, opts=None, mean_func='zero',
+                 xlb=None, xub=None, ulb=None, uub=None,
+                 multistart=1, normalize=True, warm_start=False,
+                 optimize_nummeric=True, random_restarts=False, seed=1234, gradient='analytic'):
+        """Optimize hyper-parameters (gp_class.py:78-142).  DIFF: both of the reference's optimiser
+        back-ends (scipy SLSQP with finite differences / CasADi+IPOPT) are replaced by one driver
+        (`gp_mpc_amd.train.train_gp`) that evaluates the NLL and its analytic gradient on the GPU;
+        `optimize_nummeric` selects the reference's bound/initialisation convention of the
+        corresponding path (True: optimize.py:434-449, False: optimize.py:207-229)."""
+        self._check_mean_func(mean_func)
+        self.__mean_func = mean_func
+        self.__normalize = normalize
+
+        if normalize and X is not None:
+            self.__xlb = np.array(xlb)
+            self.__xub = np.array(xub)
+            self.__ulb = np.array(ulb)
+            self.__uub = np.array(uub)
+            self.__meanY = np.mean(Y, 0)
+            self.__stdY = np.std(Y, 0)
+            self.__meanZ = np.mean(X, 0)
+            self.__stdZ = np.std(X, 0)
+            self.__meanX = np.mean(X[:, :self.__Ny], 0)
+            self.__stdX = np.std(X[:, :self.__Ny], 0)
+            self.__meanU = np.mean(X[:, self.__Ny:], 0)
+            self.__stdU = np.std(X[:, self.__Ny:], 0)
+
+        if X is not None:
+            X = np.array(X, dtype=np.float64).copy()
+            self.__X = self.standardize(X, self.__meanZ, self.__stdZ) if normalize else X.copy()
+        if Y is not None:
+            Y = np.array(Y, dtype=np.float64).copy()
+            self.__Y = self.standardize(Y, self.__meanY, self.__stdY) if (normalize and X is not None) else Y.copy()
+        self.__N = self.__X.shape[0]
+
+        hyp_init = self.__hyper if warm_start else None
+        self._new_handle()
+        opt = train_gp(self._h, self.__X, self.__Y, multistart=multistart, hyper_init=hyp_init,
+                       optimizer_opts=opts, numpy_path_conventions=optimize_nummeric,
+                       random_restarts=random_restarts, seed=seed, gradient=gradient)
+        self.__hyper = opt['hyper']
+        self.__lam_x = opt['lam_x']
+        self.__hyper_length_scales = self.__hyper[:, :self.__Nx]
+        self.__hyper_signal_variance = self.__hyper[:, self.__Nx] ** 2
+        self.__hyper_noise_variance = self.__hyper[:, self.__Nx + 1] ** 2
+        self.__hyper_mean = self.__hyper[:, (self.__Nx + 1):]      # off-by-one slice kept (gp_class.py:142)
+        self.train_info = opt
+
+    # ------------------------------------------------------------------ validation
+    def validate(self, X_test, Y_test, verbose=True):
+        """gp_class.py:145-190: SMSE (divides by std, :166) and MNLP; all test rows in ONE batched
+        device call instead of the reference's per-row loop."""
+        Y_test = np.array(Y_test, dtype=np.float64).copy()
+        X_test = np.array(X_test, dtype=np.float64).copy()
+        if self.__normalize:
+            Y_test = self.standardize(Y_test, self.__meanY, self.__stdY)
+            X_test = self.standardize(X_test, self.__meanZ, self.__stdZ)
+        N, Ny = Y_test.shape
+        mean, var = self._h.predict_mean_var(X_test)
+        var = var + self.noise_variance()
+        loss = np.sum((Y_test - mean) ** 2, axis=0) / N
+        NLP = np.sum(0.5 * np.log(2 * np.pi * var) + (Y_test - mean) ** 2 / (2 * var), axis=0)
+        SMSE = loss / np.std(Y_test, 0)
+        MNLP = NLP / N
+        if verbose:
+            print('\n________________________________________')
+            print('# Validation of GP model ')
+            print('----------------------------------------')
+            print('* Num training samples: ' + str(self.__N))
+            print('* Num test samples: ' + str(N))
+            for name, arr in (('Mean squared error', loss), ('Standardized mean squared error', SMSE),
+                              ('Mean Negative log Probability', MNLP)):
+                print('----------------------------------------')
+                print('* %s:' % name)
+                for i in range(Ny):
+                    print('\t- State %d: %f' % (i + 1, arr[i]))
+            print('----------------------------------------\n')
+        self.__SMSE = np.max(SMSE)
+        return np.array(SMSE).flatten(), np.array(MNLP).flatten()
+
+    # ------------------------------------------------------------------ prediction
+    def set_method(self, gp_method='TA'):
+        """Select which GP function to use (gp_class.py:193-242).  DIFF: strings are compared with
+        `==` (the reference's `is` only works through CPython string interning)."""
+        if gp_method not in METHODS:
+            raise NameError('No GP method called: ' + str(gp_method))          # gp_class.py:237
+        self.__gp_method = gp_method
+
+    def predict(self, x, u, cov):
+        """Predict future state (gp_class.py:245-263): x (Ny), u (Nu), cov of z=[x,u] (Nx x Nx)
+        -> mean (Ny x 1), cov (Ny x Ny, standardised units)."""
+        x = np.asarray(x, dtype=np.float64).reshape(-1)
+        u = np.asarray(u, dtype=np.float64).reshape(-1)
+        if self.__normalize:
+            x = self.standardize(x, self.__meanX, self.__stdX)
+            u = self.standardize(u, self.__meanU, self.__stdU)
+        z = np.concatenate([x, u]).reshape(1, self.__Nx)
+        S = np.asarray(cov, dtype=np.float64).reshape(1, self.__Nx, self.__Nx)
+        mean, c = self._h.predict(self.__gp_method, z, S)
+        mean = mean[0]
+        if self.__normalize:
+            mean = self.inverse_mean(mean, self.__meanY, self.__stdY)
+        return mean.reshape(self.__Ny, 1), c[0]
+
+    def predict_batch(self, Z, Sigma=None, method=None, standardized=True):
+        """All B inputs in one device call (the pattern MPC's Nt shooting nodes want):
+        Z[B x Nx] (already standardised unless standardized=False), Sigma[B x Nx x Nx]
+        -> mean[B x Ny] (un-standardised like `predict`), cov[B x Ny x Ny]."""
+        Z = np.asarray(Z, dtype=np.float64).reshape(-1, self.__Nx)
+        if self.__normalize and not standardized:
+            Z = self.standardize(Z, self.__meanZ, self.__stdZ)
+        mean, c = self._h.predict(method or self.__gp_method, Z, Sigma)
+        if self.__normalize:
+            mean = self.inverse_mean(mean, self.__meanY, self.__stdY)
+        return mean, c
+
+    def get_size(self):
+        """(N, Ny, Nu) -- gp_class.py:266-274."""
+        return self.__N, self.__Ny, self.__Nu
+
+    def get_hyper_parameters(self):
+        """gp_class.py:277-290."""
+        return dict(length_scale=self.__hyper_length_scales, signal_var=self.__hyper_signal_variance,
+                    noise_var=self.__hyper_noise_variance, mean=self.__hyper_mean)
+
+    def print_hyper_parameters(self):
+        """gp_class.py:293-312."""
+        print('\n________________________________________')
+        print('# Hyper-parameters')
+        print('----------------------------------------')
+        print('* Num samples:', self.__N)
+        print('* Ny:', self.__Ny)
+        print('* Nu:', self.__Nu)
+        print('* Normalization:', self.__normalize)
+        for state in range(self.__Ny):
+            print('----------------------------------------')
+            print('* Lengthscale: ', state)
+            for i in range(self.__Ny + self.__Nu):
+                print(('-- l{a}: {l}').format(a=i, l=self.__hyper_length_scales[state, i]))
+            print('* Signal variance: ', state)
+            print('-- sf2:', self.__hyper_signal_variance[state])
+            print('* Noise variance: ', state)
+            print('-- sn2:', self.__hyper_noise_variance[state])
+        print('----------------------------------------')
+
+    def covSEard(self, X, Z, ell, sf2):
+        """GP squared exponential kernel k(X, Z) (gp_class.py:314-350), evaluated on the device."""
+        X = np.atleast_2d(np.asarray(X, dtype=np.float64))
+        Z = np.atleast_2d(np.asarray(Z, dtype=np.float64))
+        if X.shape[1] != Z.shape[1]:
+            raise ValueError('Input dimensions are not the same! D_x=' + str(X.shape[1])
+                             + ', D_z=' + str(Z.shape[1]))                      # gp_class.py:342-344
+        return self._lib.kernel_matrix(X, Z, np.asarray(ell, dtype=np.float64), float(sf2), device=self._device)
+
+    def covar(self, X_new):
+        """Posterior covariance between new inputs (gp_class.py:353-381): (D x n x n) array whose
+        first Ny slabs are filled, like the reference."""
+        X_new = np.atleast_2d(np.asarray(X_new, dtype=np.float64))
+        n, D = X_new.shape
+        out = np.zeros((D, n, n))
+        out[:self.__Ny] = self._h.covar(X_new)
+        return out
+
+    # ------------------------------------------------------------------ data updates
+    def update_data(self, X_new, Y_new, N_new=None):
+        """The reference documents its incremental update as not working (gp_class.py:384-471:
+        argmin for 'max variance' :421, norm instead of norm^2 :443); use `update_data_all`."""
+        raise NotImplementedError('update_data is broken in the reference (gp_class.py:384-471); '
+                                  'use update_data_all / replace_data_all')
+
+    def _set_data_and_refit(self, X, Y):
+        self.__X, self.__Y = X, Y
+        self.__N = X.shape[0]
+        self._refit()
+
+    def update_data_all(self, X_new, Y_new):
+        """Append all new observations and recompute chol/alpha/invK with the EXISTING
+        hyper-parameters (gp_class.py:474-550)."""
+        X_new = np.array(X_new, dtype=np.float64).copy()
+        Y_new = np.array(Y_new, dtype=np.float64).copy()
+        if self.__normalize:
+            Y_new = self.standardize(Y_new, self.__meanY, self.__stdY)
+            X_new = self.standardize(X_new, self.__meanZ, self.__stdZ)
+        self._set_data_and_refit(np.vstack([self.__X, X_new]), np.vstack([self.__Y, Y_new]))
+
+    def replace_data_all(self, X_new, Y_new):
+        """Replace the training data, keep the hyper-parameters (gp_class.py:553-626)."""
+        X_new = np.array(X_new, dtype=np.float64).copy()
+        Y_new = np.array(Y_new, dtype=np.float64).copy()
+        if self.__normalize:
+            Y_new = self.standardize(Y_new, self.__meanY, self.__stdY)
+            X_new = self.standardize(X_new, self.__meanZ, self.__stdZ)
+        self._set_data_and_refit(X_new, Y_new)
+
+    # ------------------------------------------------------------------ scaling helpers (gp_class.py:629-644)
+    def standardize(self, Y, mean, std):
+        return (Y - mean) / std
+
+    def normalize(self, u, lb, ub):
+        return (u - lb) / (ub - lb)
+
+    def inverse_mean(self, x, mean, std):
+        return (x * std) + mean
+
+    def inverse_variance(self, variance):
+        return variance * self.__stdY ** 2
+
+    # ------------------------------------------------------------------ linearisation
+    def discrete_linearize(self, x0, u0, cov0):
+        """x[k+1] = A x[k] + B u[k] around (x0, u0): Jacobians of the predicted mean w.r.t. the
+        standardised x and u (gp_class.py:647-661; for every method the mean of ME/TA/old_* is the
+        plain GP mean, whose analytic Jacobian the device evaluates).  DIFF: for 'EM' the reference
+        differentiates the exact-moment mean; here the GP-mean Jacobian is returned (identical for
+        cov0 -> 0, which is how mpc_class.py:596-625 calls it)."""
+        x0 = np.asarray(x0, dtype=np.float64).reshape(-1)
+        u0 = np.asarray(u0, dtype=np.float64).reshape(-1)
+        if self.__normalize:
+            x0 = self.standardize(x0, self.__meanX, self.__stdX)
+            u0 = self.standardize(u0, self.__meanU, self.__stdU)
+        _, J = self._h.mean_jac(np.concatenate([x0, u0]).reshape(1, self.__Nx))
+        return J[0][:, :self.__Ny].copy(), J[0][:, self.__Ny:].copy()
+
+    def jacobian(self, x0, u0, cov0):
+        """J = d mu / d x at raw (x0, u0), no standardisation (gp_class.py:664-672)."""
+        z = np.concatenate([np.asarray(x0, dtype=np.float64).reshape(-1),
+                            np.asarray(u0, dtype=np.float64).reshape(-1)]).reshape(1, self.__Nx)
+        _, J = self._h.mean_jac(z)
+        return J[0][:, :self.__Ny].copy()
+
+    def noise_variance(self):
+        return self.__hyper_noise_variance                                      # gp_class.py:675-678
+
+    def sparse(self, M):
+        """FITC stub, empty in the reference too (gp_class.py:682-689)."""
+        return None
+
+    # ------------------------------------------------------------------ persistence (gp_class.py:693-743)
+    def _to_dict(self):
+        f = self._h.get_factors(chol=True, alpha=True, invK=True)
+        gp_dict = {}
+        gp_dict['X'] = self.__X.tolist()
+        gp_dict['Y'] = self.__Y.tolist()
+        gp_dict['hyper'] = dict(
+            hyper=self.__hyper.tolist(), invK=f['invK'].tolist(), alpha=f['alpha'].tolist(),
+            chol=f['chol'].tolist(), length_scale=self.__hyper_length_scales.tolist(),
+            signal_var=self.__hyper_signal_variance.tolist(), noise_var=self.__hyper_noise_variance.tolist(),
+            mean=self.__hyper_mean.tolist())
+        gp_dict['mean_func'] = self.__mean_func
+        gp_dict['normalize'] = self.__normalize
+        if self.__normalize:
+            gp_dict['xlb'] = self.__xlb.tolist()
+            gp_dict['xub'] = self.__xub.tolist()
+            gp_dict['ulb'] = self.__ulb.tolist()
+            gp_dict['uub'] = self.__uub.tolist()
+            gp_dict['meta'] = dict(
+                meanY=self.__meanY.tolist(), stdY=self.__stdY.tolist(), meanZ=self.__meanZ.tolist(),
+                stdZ=self.__stdZ.tolist(), meanX=self.__meanX.tolist(), stdX=self.__stdX.tolist(),
+                meanU=self.__meanU.tolist(), stdU=self.__stdU.tolist())
+        return gp_dict
+
+    def save_model(self, filename):
+        """Save model to `filename`.json in the reference's format (gp_class.py:729-734)."""
+        with open(filename + ".json", "w") as outfile:
+            json.dump(self._to_dict(), outfile)
+
+    @classmethod
+    def load_model(cls, filename, **kwargs):
+        """Create a new model from `filename`.json (gp_class.py:737-743); files written by the
+        reference load unchanged.  kwargs: device=, lib=."""
+        with open(filename + ".json") as json_data:
+            input_dict = json.load(json_data)
+        input_dict.update(kwargs)
+        return cls(**input_dict)
+
+    # ------------------------------------------------------------------ rollout (numeric part of predict_compare)
+    def rollout(self, x0, u, methods=None, feedback=False):
+        """The numeric loop of `predict_compare` (gp_class.py:746-804) without simulator and
+        plots: for every method feed (mean_t, cov_t) back into `predict` for Nt = len(u) steps.
+        Returns mean[len(methods), Nt+1, Ny] and var[...] (variances un-standardised by stdY^2 and
+        clipped at 0 like :795-796,826-827)."""
+        if feedback:
+            raise NotImplementedError('feedback=True needs the LQR gain of mpc_class.lqr (out of scope)')
+        Nx, Ny = self.__Nx, self.__Ny
+        u = np.atleast_2d(np.asarray(u, dtype=np.float64))
+        Nt = u.shape[0]
+        initVar = self.__hyper[:, Nx + 1] ** 2
+        if methods is None:
+            methods = ['EM', 'TA', 'ME']
+        mean = np.zeros((len(methods), Nt + 1, Ny))
+        var = np.zeros((len(methods), Nt + 1, Ny))
+        covar = np.eye(Nx) * 1e-6                                               # gp_class.py:764
+        keep = self.__gp_method
+        for i, m in enumerate(methods):
+            self.set_method(m)
+            mean_t = np.asarray(x0, dtype=np.float64).reshape(Ny)
+            covar[:Ny, :Ny] = np.diag(initVar)                                  # gp_class.py:780
+            mean[i, 0, :] = mean_t
+            for t in range(1, Nt + 1):
+                mean_t, covar_x = self.predict(mean_t, u[t - 1, :], covar)
+                mean_t = np.array(mean_t).reshape(Ny)
+                mean[i, t, :] = mean_t
+                var[i, t, :] = np.diag(covar_x)
+                if self.__normalize:
+                    var[i, t, :] = self.inverse_variance(var[i, t, :])
+                covar[:Ny, :Ny] = covar_x
+        self.set_method(keep)
+        if np.any(var < 0):
+            var = var.clip(min=0)
+        return mean, var
+
+    def predict_compare(self, *args, **kwargs):
+        raise NotImplementedError('predict_compare is the plotting front-end of the rollout loop '
+                                  '(matplotlib UI, out of scope); use GP.rollout for its numeric part')
+
+    def close(self):
+        if self._h is not None:
+            self._h.close()
+            self._h = None

@@ -1,0 +1,148 @@
+"""Hyper-parameter training (a8): multistart minimisation of the negative log marginal likelihood,
+restarts sharded over the GPUs of a node.
+
+Reference: `train_gp_numpy` optimize.py:359-503 (scipy SLSQP, finite-difference gradients, the
+default path of `GP.optimize`) and `train_gp` optimize.py:100-294 (CasADi + IPOPT).  Here one host
+driver serves both: the objective `gpmpc_nll` (K build + Cholesky + solves + reductions) and its
+analytic gradient (Rasmussen & Williams eq. 5.9; the reference's docstring asks for exactly this,
+optimize.py:371-375) run on the GPU, scipy only iterates on d+2 numbers.
+
+Conventions kept from the reference
+  * numpy path: bounds ell in [-1 (sic, `1-2`), 200], sf in [1e-8, 1e2], sn in [1e-10, 1e-2]
+    (optimize.py:434-443); init ell = std(X), sf = std(y), sn = 1e-5 (:445-449); SLSQP,
+    maxiter 10000, tol 1e-12 (:420,467).
+  * IPOPT path bounds: ell in [1e-2, 1e2] (:210-211), same sf / sn.
+  * `multistart` restarts, keep arg-min NLL (:474); the reference starts every restart from the SAME
+    point (its LHS line is commented out, :218), `random_restarts=True` draws the build's own
+    seeded Latin-hypercube starts in log space instead.
+  * after arg-min the factors are recomputed at theta* (:476-494) -- `gpmpc_fit`.
+
+Restart shard: with torch.distributed initialised (one process per GPU, backend nccl
+= RCCL over xGMI, or gloo in the CPU tests) restart r runs on rank r mod world; one all_gather of
+(NLL, theta) per output -- (1 + d + 2) doubles per restart, latency-bound -- then every rank takes
+the same arg-min and refits locally, so all ranks end with identical models and nothing large
+crosses the fabric.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def bounds_numpy_path(Nx):
+    lb = np.empty(Nx + 2)
+    ub = np.empty(Nx + 2)
+    lb[:Nx] = 1 - 2            # optimize.py:437 (typo for 1e-2 kept: ell only enters squared)
+    ub[:Nx] = 2e2
+    lb[Nx], ub[Nx] = 1e-8, 1e2
+    lb[Nx + 1], ub[Nx + 1] = 10 ** -10, 10 ** -2
+    return lb, ub
+
+
+def bounds_ipopt_path(Nx):
+    lb, ub = bounds_numpy_path(Nx)
+    lb[:Nx], ub[:Nx] = 1e-2, 1e2   # optimize.py:210-211
+    return lb, ub
+
+
+def default_init(X, y):
+    Nx = X.shape[1]
+    h = np.zeros(Nx + 2)
+    h[:Nx] = np.std(X, 0)          # optimize.py:447
+    h[Nx] = np.std(y)              # :448
+    h[Nx + 1] = 1e-5               # :449
+    return h
+
+
+def lhs_starts(n, lb, ub, seed):
+    """Seeded Latin hypercube in log space inside [lb, ub] (lower bounds floored at 1e-2 for ell)."""
+    rng = np.random.default_rng(seed)
+    lo = np.log(np.maximum(lb, 1e-10))
+    hi = np.log(ub)
+    dim = len(lb)
+    u = (rng.permuted(np.tile(np.arange(n), (dim, 1)), axis=1).T + rng.random((n, dim))) / n
+    return np.exp(lo + (hi - lo) * u)
+
+
+def _dist():
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist
+    except Exception:
+        pass
+    return None
+
+
+def _all_gather_rows(dist, local, world, device=None):
+    """all_gather of a fixed-size float64 block per rank (RCCL on GPU boxes, gloo in CPU tests)."""
+    import torch
+    backend = dist.get_backend()
+    dev = torch.device('cuda', torch.cuda.current_device()) if backend == 'nccl' else torch.device('cpu')
+    t = torch.from_numpy(np.ascontiguousarray(local)).to(dev)
+    out = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(out, t)
+    return np.stack([o.cpu().numpy() for o in out])
+
+
+def train_gp(handle, X, Y, multistart=1, hyper_init=None, optimizer_opts=None,
+             numpy_path_conventions=True, random_restarts=False, seed=1234, gradient='analytic',
+             method='SLSQP'):
+    """Train all Ny outputs of the model behind `handle` (a `gp_mpc_amd._lib.Handle` holding X, Y)
+    and fit it at the optimum.  Returns the reference's `opt` dictionary keys plus diagnostics."""
+    from scipy.optimize import minimize
+
+    N, Nx = X.shape
+    Ny = Y.shape[1]
+    options = {'disp': False, 'maxiter': 10000}
+    if optimizer_opts is not None:
+        options.update(optimizer_opts)
+    lb, ub = bounds_numpy_path(Nx) if numpy_path_conventions else bounds_ipopt_path(Nx)
+    bounds = np.stack([lb, ub], axis=1)
+
+    dist = _dist()
+    rank = dist.get_rank() if dist else 0
+    world = dist.get_world_size() if dist else 1
+
+    hyp_opt = np.zeros((Ny, Nx + 2))
+    all_obj = np.zeros((Ny, multistart))
+    n_eval = 0
+    for a in range(Ny):
+        if random_restarts:
+            starts = lhs_starts(multistart, lb, ub, seed + a)
+            if hyper_init is not None:
+                starts[0] = hyper_init[a]
+        else:
+            h0 = default_init(X, Y[:, a]) if hyper_init is None else np.asarray(hyper_init[a], dtype=np.float64)
+            starts = np.tile(h0, (multistart, 1))            # optimize.py:462-466: identical restarts
+
+        def fun(h):
+            nonlocal n_eval
+            n_eval += 1
+            if gradient == 'analytic':
+                v, g = handle.nll(a, h, want_grad=True)
+                return v, g
+            return handle.nll(a, h)
+
+        local = np.full((multistart, Nx + 3), np.inf)
+        for r in range(multistart):
+            if r % world != rank:
+                continue
+            try:
+                res = minimize(fun, starts[r], jac=(gradient == 'analytic'), method=method,
+                               options=options, bounds=bounds, tol=1e-12)
+                local[r, 0] = res.fun
+                local[r, 1:] = res.x
+            except np.linalg.LinAlgError:
+                pass                                         # this start ran into a non-SPD K twice
+        if dist:
+            gathered = _all_gather_rows(dist, local, world)   # [world, multistart, Nx+3]
+            owner = np.arange(multistart) % world
+            local = gathered[owner, np.arange(multistart)]
+        if not np.isfinite(local[:, 0]).any():
+            raise np.linalg.LinAlgError('every restart failed for output %d' % a)
+        best = int(np.argmin(local[:, 0]))                    # optimize.py:474
+        hyp_opt[a] = local[best, 1:]
+        all_obj[a] = local[:, 0]
+
+    info = handle.fit(hyp_opt, want_invK=True)               # optimize.py:476-494 at theta*
+    return dict(hyper=hyp_opt, lam_x=0, obj=all_obj, info=info, n_eval=n_eval, rank=rank, world=world)

@@ -121,6 +121,10 @@ int gpmpc_covar(gpmpc_gp* h, int n, const double* Xnew, double* covar);
 int gpmpc_nll(gpmpc_gp* h, int a, const double* hyper_row, double* nll, double* grad, int* jitter_out);
 
 /* ---- low-level dense ops (host pointers), used by the parity tests ------------------------ */
+/* k(X, Z)[n1 x n2] = sf2 exp(-1/2 sum_d (x_d - z_d)^2 / ell_d^2) for X[n1 x d], Z[n2 x d]: GP.covSEard
+ * gp_class.py:314-350 (same expanded-form operation order, no FMA contraction). */
+int gpmpc_kernel_matrix(int device, int n1, int n2, int d, const double* X, const double* Z,
+                        const double* ell, double sf2, double* out);
 /* In-place lower Cholesky of the n x n row-major SPD matrix A (np.linalg.cholesky,
  * optimize.py:346).  *info = 0 ok, k > 0: leading minor k is not positive definite (LAPACK dpotrf
  * convention).  Ainv (may be NULL) receives L^-1. */

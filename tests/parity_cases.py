@@ -194,3 +194,181 @@ def check_nll_gradient(lib, g):
         fd = (go.nll(hp + e, X, Y[:, 1]) - go.nll(hp - e, X, Y[:, 1])) / (2 * e[i])
         assert abs(fd - grad[i]) <= 1e-4 * (abs(grad[i]) + 1e-3)
     h.close()
+
+
+def _em_scale(invK, X, Y, H, mu, Sigma):
+    """Cancellation scale of the exact-moment covariance: t * sum_ij |A_ij Q_ij| per pair
+    (gp_functions.py:408-414 sums terms of this size to a result orders of magnitude smaller)."""
+    logH = np.log(H)
+    Ny, (N, Nx) = len(invK), X.shape
+    v = X - mu.reshape(1, Nx)
+    beta = np.stack([invK[a] @ Y[:, a] for a in range(Ny)], axis=1)
+    log_k = np.stack([2 * logH[a, Nx] - 0.5 * np.sum((v / H[a, :Nx]) ** 2, axis=1) for a in range(Ny)], axis=1)
+    scale = np.zeros((Ny, Ny))
+    for a in range(Ny):
+        ii = v / H[a, :Nx] ** 2
+        for b in range(a + 1):
+            R = Sigma @ np.diag(1 / H[a, :Nx] ** 2 + 1 / H[b, :Nx] ** 2) + np.eye(Nx)
+            t = 1.0 / np.sqrt(abs(np.linalg.det(R)))
+            ij = v / H[b, :Nx] ** 2
+            Q = np.exp(log_k[:, a][:, None] + log_k[:, b][None, :] + go.maha(ii, -ij, np.linalg.solve(R, Sigma * 0.5)))
+            A = np.outer(beta[:, a], beta[:, b])
+            if a == b:
+                A = A - invK[a]
+            scale[a, b] = scale[b, a] = t * np.sum(np.abs(A * Q))
+    return scale
+
+
+def check_moment_methods(lib, g=None):
+    """a11 'EM' and a12 'old_ME'/'old_TA' against the oracle restatement (same K^-1 fed to both)."""
+    if g is None:
+        p = go.synthetic_problem(150, 4, 3, 6, seed=3, sn=0.1)
+        X, Y, H, Z, S = p['X'], p['Y'], p['hyper'], p['Z'], p['Sigma'] * 30
+        tol = 1e-10
+    else:
+        X, Y, H, Z = g['X'], g['Y'], g['hyper'], g['Z'][:6]
+        S = go.synthetic_problem(8, X.shape[1], 1, 6, seed=5)['Sigma'] * 10
+        tol = 1e-10
+    d = X.shape[1]
+    h = Handle(lib, X, Y)
+    h.fit(H, want_invK=True)
+    f = h.get_factors(invK=True)
+    m, c = h.predict('EM', Z, S)
+    m1, c1 = h.predict('old_ME', Z)
+    m2, c2 = h.predict('old_TA', Z, S)
+    sf2 = H[:, d] ** 2
+    for b in range(len(Z)):
+        om, oc = go.exact_moment(f['invK'], X, Y, H, Z[b], S[b])
+        sc = _em_scale(f['invK'], X, Y, H, Z[b], S[b])
+        msc = np.array([np.sum(np.abs(f['invK'][a] @ Y[:, a])) * sf2[a] for a in range(len(H))])
+        assert np.max(np.abs(m[b] - om) / msc) <= tol
+        assert np.max(np.abs(c[b] - oc) / (sc + sf2.max())) <= 10 * tol, (b, np.abs(c[b] - oc).max(), sc.max())
+        assert np.array_equal(c[b], c[b].T)
+        o1m, o1c = go.old_me(f['invK'], X, Y, H, Z[b])
+        kscale = np.array([np.sum(np.abs(f['invK'][a])) * sf2[a] ** 2 for a in range(len(H))])
+        assert np.max(np.abs(m1[b] - o1m) / msc) <= tol
+        assert np.max(np.abs(np.diag(c1[b]) - np.diag(o1c)) / kscale) <= tol
+        o2m, o2c = go.old_ta(f['invK'], X, Y, H, Z[b], S[b])
+        assert np.max(np.abs(m2[b] - o2m) / msc) <= tol
+        assert np.max(np.abs(c2[b] - o2c)) <= 1e-6 * max(np.abs(o2c).max(), kscale.max() * 1e-4)
+    h.close()
+
+
+def check_gp_class(lib, g, tmp_path):
+    """The Python `GP` surface (reference gp_class.py) against `OracleGP` on a saved reference model."""
+    from gp_mpc_amd.gp import GP
+    hyper = dict(hyper=g['hyper'], chol=g['chol'], alpha=g['alpha'], invK=g['invK'])
+    kw = dict(normalize=g['normalize'], lib=lib)
+    if g['normalize']:
+        kw.update(meta=g['meta'], xlb=g['xlb'], xub=g['xub'], ulb=g['ulb'], uub=g['uub'])
+    gp = GP(g['X'], g['Y'], hyper=hyper, gp_method='TA', **kw)
+    og = go.OracleGP(g['X'], g['Y'], g['hyper'], g['chol'], g['alpha'], g['invK'], normalize=g['normalize'],
+                     meta=g.get('meta'), gp_method='TA')
+    N, Ny, Nu = gp.get_size()
+    assert (N, Ny, Nu) == (og.N, og.Ny, og.Nu)
+    Nx = Ny + Nu
+    if g['normalize']:
+        x = g['meta']['meanX'] + 0.3 * g['meta']['stdX']
+        u = g['meta']['meanU'] - 0.2 * g['meta']['stdU']
+    else:
+        x, u = g['X'][3, :Ny] * 1.01, g['X'][3, Ny:] * 0.99
+    A = np.random.default_rng(0).standard_normal((Nx, Nx)) * 0.03
+    S = A @ A.T + 1e-6 * np.eye(Nx)
+    sf2 = g['hyper'][:, Nx] ** 2
+    for m in ('ME', 'TA', 'EM', 'old_ME', 'old_TA'):
+        gp.set_method(m)
+        og.set_method(m)
+        mean, cov = gp.predict(x, u, S)
+        om, oc = og.predict(x, u, S)
+        assert mean.shape == (Ny, 1) and cov.shape == (Ny, Ny)
+        rel = 1e-9 if m in ('ME', 'TA') else 2e-5      # moment methods: K^-1 cancellation (cond(K) 6e7)
+        assert np.max(np.abs(mean - om)) <= rel * max(1.0, np.abs(om).max()), (m, mean.ravel(), om.ravel())
+        assert np.max(np.abs(cov - oc)) <= rel * max(sf2.max(), np.abs(oc).max()), (m, np.abs(cov - oc).max())
+    try:
+        gp.set_method('XX')
+        assert False
+    except NameError:
+        pass
+    gp.set_method('TA')
+    og.set_method('TA')
+    Ad, Bd = gp.discrete_linearize(x, u, S)
+    oA, oB = og.discrete_linearize(x, u, S)
+    assert np.allclose(Ad, oA, rtol=1e-8, atol=1e-10 * np.abs(oA).max()) and np.allclose(Bd, oB, rtol=1e-8, atol=1e-10 * np.abs(oB).max())
+    assert np.array_equal(gp.noise_variance(), g['hyper'][:, Nx + 1] ** 2)
+    hp = gp.get_hyper_parameters()
+    assert np.array_equal(hp['length_scale'], g['hyper'][:, :Nx]) and np.array_equal(hp['mean'], g['hyper'][:, Nx + 1:])
+    # rollout = numeric loop of predict_compare
+    U = np.tile(u, (4, 1))
+    mr, vr = gp.rollout(x, U, methods=['TA', 'ME'])
+    omr, ovr = og.rollout(x, U, methods=('TA', 'ME'))
+    assert np.allclose(mr, omr, rtol=1e-7, atol=1e-9) and np.allclose(vr, np.clip(ovr, 0, None), rtol=1e-5, atol=1e-9 * sf2.max())
+    # validate on the training inputs themselves
+    Xraw = g['X'] * g['meta']['stdZ'] + g['meta']['meanZ'] if g['normalize'] else g['X']
+    Yraw = g['Y'] * g['meta']['stdY'] + g['meta']['meanY'] if g['normalize'] else g['Y']
+    smse, mnlp = gp.validate(Xraw[:20], Yraw[:20], verbose=False)
+    osmse, omnlp = og.validate(Xraw[:20], Yraw[:20])
+    assert np.allclose(smse, osmse, rtol=1e-5, atol=1e-12) and np.allclose(mnlp, omnlp, rtol=1e-6, atol=1e-8)
+    # covar / covSEard
+    cv = gp.covar(g['Z'][:4])
+    assert cv.shape == (Nx, 4, 4)
+    assert np.max(np.abs(cv[:Ny] - g['ref_covar'][:, :4, :4]) / sf2[:, None, None]) <= 1e-10
+    ks = gp.covSEard(g['X'], g['Z'], g['hyper'][0, :Nx], sf2[0])
+    assert np.max(np.abs(ks - g['ref_ks'][0])) <= 1e-14 * sf2[0]
+    try:
+        gp.covSEard(g['X'], g['Z'][:, :Nx - 1], g['hyper'][0, :Nx], 1.0)
+        assert False
+    except ValueError:
+        pass
+    # save / load round trip in the reference's JSON layout
+    path = str(tmp_path / 'model')
+    gp.save_model(path)
+    import json
+    d = json.load(open(path + '.json'))
+    assert set(d['hyper'].keys()) == {'hyper', 'invK', 'alpha', 'chol', 'length_scale', 'signal_var', 'noise_var', 'mean'}
+    gp2 = GP.load_model(path, lib=lib)
+    gp2.set_method('TA')
+    m2, c2 = gp2.predict(x, u, S)
+    m1, c1 = gp.predict(x, u, S)
+    assert np.allclose(m1, m2, rtol=1e-12, atol=0) and np.allclose(c1, c2, rtol=0, atol=1e-12 * sf2.max())
+    # data replacement keeps the hyper-parameters and refits (gp_class.py:553-626)
+    gp2.replace_data_all(Xraw[:40], Yraw[:40])
+    assert gp2.get_size()[0] == 40
+    Xs = (Xraw[:40] - g['meta']['meanZ']) / g['meta']['stdZ'] if g['normalize'] else Xraw[:40]
+    Ys = (Yraw[:40] - g['meta']['meanY']) / g['meta']['stdY'] if g['normalize'] else Yraw[:40]
+    o2 = go.OracleGP(Xs, Ys, g['hyper'], normalize=g['normalize'], meta=g.get('meta'), gp_method='ME')
+    gp2.set_method('ME')
+    m3, c3 = gp2.predict(x, u, S)
+    om3, oc3 = o2.predict(x, u, S)
+    assert np.allclose(m3, om3, rtol=1e-8, atol=1e-9) and np.allclose(c3, oc3, rtol=0, atol=1e-10 * sf2.max())
+    gp2.update_data_all(Xraw[40:50], Yraw[40:50])
+    assert gp2.get_size()[0] == 50
+    for fn in (lambda: gp.update_data(Xraw[:2], Yraw[:2]), lambda: gp.predict_compare()):
+        try:
+            fn()
+            assert False
+        except NotImplementedError:
+            pass
+    gp.close()
+    gp2.close()
+
+
+def check_training(lib, t):
+    """a8: train from the reference's initial point with the reference's bounds; the optimum found
+    with device NLL + analytic gradient must be at least as good as train_gp_numpy's and, from the
+    same start, land on the same local optimum."""
+    from gp_mpc_amd.gp import GP
+    X, Y = t['X'], t['Y']
+    gp = GP(X, Y, normalize=False, multistart=1, gp_method='ME', lib=lib)
+    H = gp.train_info['hyper']
+    for a in range(Y.shape[1]):
+        ours = go.nll(H[a], X, Y[:, a])
+        assert ours <= t['nll'][a] + 1e-6 * abs(t['nll'][a]), (a, ours, t['nll'][a])
+        if abs(ours - t['nll'][a]) <= 1e-4 * abs(t['nll'][a]):     # same basin -> same hyper-parameters
+            assert np.allclose(H[a], t['hyper'][a], rtol=2e-2), (H[a], t['hyper'][a])
+    assert np.allclose(H[0], t['hyper'][0], rtol=2e-2)              # output 0 has a sharp optimum
+    # the fitted model predicts like a model built from the trained hyper-parameters
+    f = gp.handle.get_factors()
+    o = go.fit(X, Y, H, want_invK=False)
+    for a in range(Y.shape[1]):
+        assert relF(f['chol'][a], o['chol'][a]) <= 1e-9
+    gp.close()

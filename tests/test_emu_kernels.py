@@ -50,3 +50,31 @@ def test_emu_jitter_rule(emu, train_small):
 
 def test_emu_nll_gradient(emu, tank):
     pc.check_nll_gradient(emu, tank)
+
+
+def test_emu_moment_methods(emu, tank):
+    pc.check_moment_methods(emu)
+    pc.check_moment_methods(emu, tank)
+
+
+def test_emu_gp_class(emu, tank, tmp_path):
+    pc.check_gp_class(emu, tank, tmp_path)
+
+
+def test_emu_gp_class_car(emu, car, tmp_path):
+    from gp_mpc_amd.gp import GP
+    import numpy as np
+    import gp_oracle as go
+    g = car
+    gp = GP(g['X'], g['Y'], hyper=dict(hyper=g['hyper'], chol=g['chol'], alpha=g['alpha'], invK=g['invK']),
+            normalize=False, gp_method='ME', lib=emu)
+    og = go.OracleGP(g['X'], g['Y'], g['hyper'], g['chol'], g['alpha'], g['invK'], gp_method='ME')
+    x, u = g['X'][5, :3] * 1.02, g['X'][5, 3:]
+    m, c = gp.predict(x, u, np.eye(5) * 1e-6)
+    om, oc = og.predict(x, u, np.eye(5) * 1e-6)
+    assert np.allclose(m, om, rtol=1e-8, atol=1e-8) and np.allclose(c, oc, rtol=0, atol=1e-10 * (g['hyper'][:, 5] ** 2).max())
+    gp.close()
+
+
+def test_emu_training(emu, train_small):
+    pc.check_training(emu, train_small)

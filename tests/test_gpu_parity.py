@@ -86,3 +86,16 @@ def test_c2_full_size_vs_oracle_and_properties(lib):
     mt, vt = h.predict_mean_var(r['X'][:512])                                   # at training inputs
     assert np.max(np.abs(mt[:, 0] - r['Y'][:512, 0])) < 0.2 and np.all(vt < 1e-3)
     h.close()
+
+
+def test_moment_methods(lib, tank):
+    pc.check_moment_methods(lib)
+    pc.check_moment_methods(lib, tank)
+
+
+def test_gp_class(lib, tank, tmp_path):
+    pc.check_gp_class(lib, tank, tmp_path)
+
+
+def test_training(lib, train_small):
+    pc.check_training(lib, train_small)
