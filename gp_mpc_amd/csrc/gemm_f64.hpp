@@ -7,17 +7,24 @@
 //   * Cholesky panel  L21 = A21 invL11^T and trailing update A22 -= L21 L21^T   (a4, optimize.py:346)
 //   * triangular inverse  invL21 = -invL22 (L21 invL11)                          (a6, optimize.py:489)
 //   * K^-1 = invL^T invL                                                         (a6, optimize.py:490)
-//   * w = invL y, alpha = invL^T w as N = 1 products                             (a5, optimize.py:353-354)
 //   * predictive variance  sum_i (invL Ks)_ij^2                                  (a9, gp_functions.py:122-126)
 //
-// Design (MI355X): 256 threads = 4 waves in a 2 x 2 grid, block tile BM x BN (128, 64 or 32), K step BK.
-// Operand tiles are staged global -> registers -> LDS with a one-tile software pipeline (the global
-// loads of tile t+1 are in flight while tile t feeds the matrix pipe; one barrier per K step).  LDS
-// holds each operand in MFMA-fragment order [k/4][row][k%4], so the 64 lanes of a fragment read
-// fetch 64 consecutive doubles (512 contiguous bytes: conflict-free ds_read_b64).  With
-// v_mfma_f64_16x16x4_f64 at 64 cycles/instruction the kernel is MFMA-issue bound: per K step a wave
-// issues 64 (BM=128) MFMAs = 4096 cycles against 8 ds_read_b64 per 16 MFMAs and 32 KB of global
-// traffic per block.
+// Design for MI355X (measurements: tools/ubench/mfma_f64_bench.hip, profiles/):
+//   * v_mfma_f64_16x16x4_f64 holds a SIMD's matrix pipe for 64 cycles, but ONE wave can only issue
+//     one every ~142 cycles and two waves one every ~104: the pipe saturates only with >= 4 waves per
+//     SIMD.  So the large tile (128 x 128) is worked by 8 waves (512 threads, <= 128 VGPRs: two
+//     workgroups = 16 waves per CU), the small tiles by 4 waves with 4-5 workgroups per CU.
+//   * operand tiles go global -> registers -> LDS with a one-tile software pipeline (loads of tile t+1
+//     in flight while tile t feeds the matrix pipe, one barrier per K step).  LDS holds each operand in
+//     MFMA-fragment order [k/4][row][k%4]: the 64 lanes of a fragment read fetch 64 consecutive
+//     doubles (512 contiguous bytes, conflict-free).
+//   * triangular operands make the K range depend on the tile.  When every workgroup of the launch
+//     is resident at once (no back-filling), each workgroup computes a tile AND its mirror so that
+//     all workgroups carry the same work; otherwise heavy tiles are issued first.
+//   * tile order is plain row-major, heavy rows first; the hardware deals consecutive workgroups to
+//     the 8 XCDs round-robin, which spreads the heavy tiles of a triangular product evenly.  (An
+//     XCD-contiguous 8 x 8 patch order -- `remap` -- was measured 1.6x SLOWER on the variance GEMM:
+//     it hands all heavy rows to one XCD.  It is kept only for the micro-benchmark.)
 #pragma once
 #include "mfma_f64.hpp"
 
@@ -28,6 +35,7 @@ enum { KA_LE_M = 1,   // A(m,k) == 0 for k > m   (A lower triangular)
        KB_LE_N = 4,   // B(k,n) == 0 for k > n   (B = T^T, T lower triangular)
        KB_GE_N = 8 }; // B(k,n) == 0 for k < n   (B lower triangular)
 enum { EPI_STORE = 0, EPI_COLSUMSQ = 1 };
+enum { PAIR_NONE = 0, PAIR_M = 1, PAIR_N = 2 };
 
 struct GemmP {
     const double* A;
@@ -45,174 +53,212 @@ struct GemmP {
     double* part;         // EPI_COLSUMSQ: part[b*sPart + tile_m*ldpart + n]
     long ldpart, sPart;
     int crow_mode;
+    int pair;             // set by the launcher
+    int tilesMe, tilesNe; // effective tile grid (after pairing), set by the launcher
+    int remap;            // 1: XCD-contiguous 8 x 8 patch order, 0: plain row-major tile order
 };
 
-template <int BM, int BN, int BK>
-__global__ void __launch_bounds__(256, 2) gemm_f64_kernel(GemmP p) {
-    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
+template <int BM, int BN, int BK, int WGM, int WGN, bool AMC, bool BNC>
+__global__ void __launch_bounds__(64 * WGM * WGN, (WGM * WGN >= 8 ? 4 : 2)) gemm_f64_kernel(GemmP p) {
+    constexpr int NT = 64 * WGM * WGN;
+    constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 16, TN = WN / 16;
     constexpr int HK = BK / 2, QK = BK / 4;                    // double2 per tile row, MFMA k-groups
-    constexpr int LA = BM * HK / 256, LB = BN * HK / 256;       // double2 loads per thread per tile
-    static_assert(LA >= 1 && LB >= 1, "tile too small for 256 threads");
+    constexpr int LA = BM * HK / NT, LB = BN * HK / NT;         // double2 loads per thread per tile
+    static_assert(LA >= 1 && LB >= 1 && TM >= 1 && TN >= 1, "bad tile configuration");
     __shared__ __attribute__((aligned(16))) double As[2][QK][BM][4];
     __shared__ __attribute__((aligned(16))) double Bs[2][QK][BN][4];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WGN, wn = wave % WGN;
     const int tilesM = (p.M + BM - 1) / BM, tilesN = (p.N + BN - 1) / BN;
-    // heavy tiles first: with a lower-triangular A the K range grows with m, with B = T^T with n
-    const int tm = (p.kflags & KA_LE_M) ? tilesM - 1 - (int)blockIdx.y : (int)blockIdx.y;
-    const int tn = (p.kflags & KB_LE_N) ? tilesN - 1 - (int)blockIdx.x : (int)blockIdx.x;
-    const int m0 = tm * BM, n0 = tn * BN;
-    if (p.lower && n0 > m0 + BM - 1) return;
 
-    int klo = 0, khi = p.K;
-    if (p.kflags & KA_LE_M) khi = min(khi, m0 + BM);
-    if (p.kflags & KA_GE_M) klo = max(klo, m0);
-    if (p.kflags & KB_LE_N) khi = min(khi, n0 + BN);
-    if (p.kflags & KB_GE_N) klo = max(klo, n0);
-    klo = klo / BK * BK;
-    khi = min(p.K, (khi + BK - 1) / BK * BK);
-    const int nk = khi > klo ? (khi - klo) / BK : 0;
+    // ---- workgroup id -> tile: XCD-contiguous runs of 8 x 8 patches
+    int tme, tne;
+    if (p.remap) {
+        const int nb = (int)gridDim.x, b = (int)blockIdx.x;
+        const int xcd = b & 7, q = nb >> 3, r = nb & 7;
+        const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+        const int pcols = (p.tilesNe + 7) >> 3;
+        const int prow = lin / (64 * pcols), rem = lin % (64 * pcols);
+        tme = prow * 8 + ((rem & 63) >> 3);
+        tne = (rem >> 6) * 8 + (rem & 7);
+    } else {
+        tme = (int)blockIdx.x / p.tilesNe;
+        tne = (int)blockIdx.x % p.tilesNe;
+    }
+    if (tme >= p.tilesMe || tne >= p.tilesNe) return;
 
     const double* __restrict__ A = p.A + (long)blockIdx.z * p.sA;
     const double* __restrict__ B = p.B + (long)blockIdx.z * p.sB;
-
-    d4 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
-
-    double2 ra[LA], rb[LB];
-
-    auto load_tiles = [&](int k0) {
-#pragma unroll
-        for (int r = 0; r < LA; ++r) {
-            const int idx = tid + 256 * r;
-            if (!p.a_mc) {
-                const int row = idx / HK, k = (idx % HK) * 2;
-                ra[r] = (m0 + row < p.M)
-                            ? *reinterpret_cast<const double2*>(A + (long)(m0 + row) * p.lda + k0 + k)
-                            : double2{0.0, 0.0};
-            } else {
-                const int k = idx / (BM / 2), m = (idx % (BM / 2)) * 2;
-                ra[r] = (m0 + m < p.M)
-                            ? *reinterpret_cast<const double2*>(A + (long)(k0 + k) * p.lda + m0 + m)
-                            : double2{0.0, 0.0};
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < LB; ++r) {
-            const int idx = tid + 256 * r;
-            if (!p.b_nc) {
-                const int row = idx / HK, k = (idx % HK) * 2;
-                rb[r] = (n0 + row < p.N)
-                            ? *reinterpret_cast<const double2*>(B + (long)(n0 + row) * p.ldb + k0 + k)
-                            : double2{0.0, 0.0};
-            } else {
-                const int k = idx / (BN / 2), n = (idx % (BN / 2)) * 2;
-                rb[r] = (n0 + n < p.N)
-                            ? *reinterpret_cast<const double2*>(B + (long)(k0 + k) * p.ldb + n0 + n)
-                            : double2{0.0, 0.0};
-            }
-        }
-    };
-    auto store_tiles = [&](int buf) {
-#pragma unroll
-        for (int r = 0; r < LA; ++r) {
-            const int idx = tid + 256 * r;
-            if (!p.a_mc) {
-                const int row = idx / HK, k = (idx % HK) * 2;
-                *reinterpret_cast<double2*>(&As[buf][k >> 2][row][k & 3]) = ra[r];
-            } else {
-                const int k = idx / (BM / 2), m = (idx % (BM / 2)) * 2;
-                As[buf][k >> 2][m][k & 3] = ra[r].x;
-                As[buf][k >> 2][m + 1][k & 3] = ra[r].y;
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < LB; ++r) {
-            const int idx = tid + 256 * r;
-            if (!p.b_nc) {
-                const int row = idx / HK, k = (idx % HK) * 2;
-                *reinterpret_cast<double2*>(&Bs[buf][k >> 2][row][k & 3]) = rb[r];
-            } else {
-                const int k = idx / (BN / 2), n = (idx % (BN / 2)) * 2;
-                Bs[buf][k >> 2][n][k & 3] = rb[r].x;
-                Bs[buf][k >> 2][n + 1][k & 3] = rb[r].y;
-            }
-        }
-    };
-
-    if (nk > 0) {
-        load_tiles(klo);
-        store_tiles(0);
-    }
-    __syncthreads();
-    int cur = 0;
     const int fr = lane & 15, fk = lane >> 4;
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) load_tiles(klo + (kt + 1) * BK);
-#pragma unroll
-        for (int q = 0; q < QK; ++q) {
-            double a[TM], b[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = As[cur][q][wm * WM + i * 16 + fr][fk];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = Bs[cur][q][wn * WN + j * 16 + fr][fk];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = mfma16(a[i], b[j], acc[i][j]);
-        }
-        if (kt + 1 < nk) store_tiles(cur ^ 1);
-        __syncthreads();
-        cur ^= 1;
-    }
 
-    if (p.epi == EPI_STORE) {
-        double* __restrict__ C = p.C + (long)blockIdx.z * p.sC;
+    for (int pass = 0; pass < 2; ++pass) {
+        // heavy tiles first: with a lower-triangular A the K range grows with m, with B = T^T with n
+        int tm = (p.kflags & KA_LE_M) ? tilesM - 1 - tme : tme;
+        int tn = (p.kflags & KB_LE_N) ? tilesN - 1 - tne : tne;
+        if (pass == 1) {
+            if (p.pair == PAIR_M) {
+                if (tilesM - 1 - tm == tm) break;
+                tm = tilesM - 1 - tm;
+            } else if (p.pair == PAIR_N) {
+                if (tilesN - 1 - tn == tn) break;
+                tn = tilesN - 1 - tn;
+            } else {
+                break;
+            }
+        }
+        const int m0 = tm * BM, n0 = tn * BN;
+        if (p.lower && n0 > m0 + BM - 1) continue;
+
+        int klo = 0, khi = p.K;
+        if (p.kflags & KA_LE_M) khi = min(khi, m0 + BM);
+        if (p.kflags & KA_GE_M) klo = max(klo, m0);
+        if (p.kflags & KB_LE_N) khi = min(khi, n0 + BN);
+        if (p.kflags & KB_GE_N) klo = max(klo, n0);
+        klo = klo / BK * BK;
+        khi = min(p.K, (khi + BK - 1) / BK * BK);
+        const int nk = khi > klo ? (khi - klo) / BK : 0;
+
+        d4 acc[TM][TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
+            for (int j = 0; j < TN; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
+
+        double2 ra[LA], rb[LB];
+
+        auto load_tiles = [&](int k0) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int m = m0 + wm * WM + i * 16 + crow(lane, r, p.crow_mode);
-                    const int n = n0 + wn * WN + j * 16 + fr;
-                    if (m < p.M && n < p.N && (!p.lower || n <= m)) {
-                        double* c = C + (long)m * p.ldc + n;
-                        double v = p.alpha * acc[i][j][r];
-                        if (p.beta != 0.0) v += p.beta * (*c);
-                        *c = v;
-                    }
+            for (int r = 0; r < LA; ++r) {
+                const int idx = tid + NT * r;
+                if (!AMC) {
+                    const int row = idx / HK, k = (idx % HK) * 2;
+                    ra[r] = (m0 + row < p.M)
+                                ? *reinterpret_cast<const double2*>(A + (long)(m0 + row) * p.lda + k0 + k)
+                                : double2{0.0, 0.0};
+                } else {
+                    const int k = idx / (BM / 2), m = (idx % (BM / 2)) * 2;
+                    ra[r] = (m0 + m < p.M)
+                                ? *reinterpret_cast<const double2*>(A + (long)(k0 + k) * p.lda + m0 + m)
+                                : double2{0.0, 0.0};
                 }
-    } else {
-        // column sums of squares over this block's BM rows (rows >= M hold exact zeros)
-        double* red = &As[0][0][0][0];  // [2][BN], free after the final barrier of the K loop
+            }
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            double s = 0.0;
+            for (int r = 0; r < LB; ++r) {
+                const int idx = tid + NT * r;
+                if (!BNC) {
+                    const int row = idx / HK, k = (idx % HK) * 2;
+                    rb[r] = (n0 + row < p.N)
+                                ? *reinterpret_cast<const double2*>(B + (long)(n0 + row) * p.ldb + k0 + k)
+                                : double2{0.0, 0.0};
+                } else {
+                    const int k = idx / (BN / 2), n = (idx % (BN / 2)) * 2;
+                    rb[r] = (n0 + n < p.N)
+                                ? *reinterpret_cast<const double2*>(B + (long)(k0 + k) * p.ldb + n0 + n)
+                                : double2{0.0, 0.0};
+                }
+            }
+        };
+        auto store_tiles = [&](int buf) {
+#pragma unroll
+            for (int r = 0; r < LA; ++r) {
+                const int idx = tid + NT * r;
+                if (!AMC) {
+                    const int row = idx / HK, k = (idx % HK) * 2;
+                    *reinterpret_cast<double2*>(&As[buf][k >> 2][row][k & 3]) = ra[r];
+                } else {
+                    const int k = idx / (BM / 2), m = (idx % (BM / 2)) * 2;
+                    As[buf][k >> 2][m][k & 3] = ra[r].x;
+                    As[buf][k >> 2][m + 1][k & 3] = ra[r].y;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < LB; ++r) {
+                const int idx = tid + NT * r;
+                if (!BNC) {
+                    const int row = idx / HK, k = (idx % HK) * 2;
+                    *reinterpret_cast<double2*>(&Bs[buf][k >> 2][row][k & 3]) = rb[r];
+                } else {
+                    const int k = idx / (BN / 2), n = (idx % (BN / 2)) * 2;
+                    Bs[buf][k >> 2][n][k & 3] = rb[r].x;
+                    Bs[buf][k >> 2][n + 1][k & 3] = rb[r].y;
+                }
+            }
+        };
+
+        if (nk > 0) {
+            load_tiles(klo);
+            store_tiles(0);
+        }
+        __syncthreads();
+        int cur = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) load_tiles(klo + (kt + 1) * BK);
+#pragma unroll
+            for (int q = 0; q < QK; ++q) {
+                double a[TM], b[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[i] = As[cur][q][wm * WM + i * 16 + fr][fk];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[j] = Bs[cur][q][wn * WN + j * 16 + fr][fk];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = mfma16(a[i], b[j], acc[i][j]);
+            }
+            if (kt + 1 < nk) store_tiles(cur ^ 1);
+            __syncthreads();
+            cur ^= 1;
+        }
+
+        if (p.epi == EPI_STORE) {
+            double* __restrict__ C = p.C + (long)blockIdx.z * p.sC;
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) s += acc[i][j][r] * acc[i][j][r];
-            s += __shfl_xor(s, 16);
-            s += __shfl_xor(s, 32);
-            if (lane < 16) red[wm * BN + wn * WN + j * 16 + lane] = s;
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int m = m0 + wm * WM + i * 16 + crow(lane, r, p.crow_mode);
+                        const int n = n0 + wn * WN + j * 16 + fr;
+                        if (m < p.M && n < p.N && (!p.lower || n <= m)) {
+                            double* c = C + (long)m * p.ldc + n;
+                            double v = p.alpha * acc[i][j][r];
+                            if (p.beta != 0.0) v += p.beta * (*c);
+                            *c = v;
+                        }
+                    }
+        } else {
+            // column sums of squares over this tile's BM rows (rows >= M hold exact zeros)
+            double* red = &As[0][0][0][0];  // [WGM][BN], free after the final barrier of the K loop
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                double s = 0.0;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) s += acc[i][j][r] * acc[i][j][r];
+                s += __shfl_xor(s, 16);
+                s += __shfl_xor(s, 32);
+                if (lane < 16) red[wm * BN + wn * WN + j * 16 + lane] = s;
+            }
+            __syncthreads();
+            if (tid < BN && n0 + tid < p.N) {
+                double t = 0.0;
+#pragma unroll
+                for (int w = 0; w < WGM; ++w) t += red[w * BN + tid];
+                p.part[(long)blockIdx.z * p.sPart + (long)tm * p.ldpart + n0 + tid] = t;
+            }
         }
-        __syncthreads();
-        if (tid < BN && n0 + tid < p.N)
-            p.part[(long)blockIdx.z * p.sPart + (long)tm * p.ldpart + n0 + tid] = red[tid] + red[BN + tid];
+        __syncthreads();  // LDS (tiles / red) is reused by the next pass
     }
 }
 
-// Host-side launcher.  f64 MFMA on gfx950 is issue-latency limited per wave (one
-// v_mfma_f64_16x16x4_f64 per ~142 cycles from a single wave, ~47 TFLOP/s chip-wide only with >= 2 waves
-// per SIMD -- tools/ubench/mfma_f64_bench.hip), so the tile is chosen to put >= 2 workgroups of 4 waves
-// on every CU: 128^2 tiles for the large contractions, 64^2 below that, and 32^2 tiles with a 64-deep K
-// step for the small latency-bound products of the factorisation recursion.
-// Returns the tile edge used (the caller of EPI_COLSUMSQ sizes `part` with it).
+// ---- host side -------------------------------------------------------------------------------------
+struct GemmCfg { int tile; int resident; };   // tile edge, workgroups resident on the whole chip
+
+// Tile choice: >= 2 rounds of resident workgroups for the big tile, else smaller tiles (more
+// workgroups for the latency-bound products of the factorisation recursion).
 inline int gemm_pick_tile(const GemmP& p, int batch) {
     auto blocks = [&](int t) {
         const long b = (long)((p.M + t - 1) / t) * ((p.N + t - 1) / t) * batch;
@@ -223,17 +269,49 @@ inline int gemm_pick_tile(const GemmP& p, int batch) {
     return 32;
 }
 
+template <int BM, int BN, int BK, int WGM, int WGN>
+inline void launch_gemm_cfg(GemmP p, int batch, hipStream_t stream, int resident) {
+    // operand orientations are compile-time (fewer registers and no branches in the staging code)
+    const int tilesM = (p.M + BM - 1) / BM, tilesN = (p.N + BN - 1) / BN;
+    p.pair = PAIR_NONE;
+    p.tilesMe = tilesM;
+    p.tilesNe = tilesN;
+    // balanced pairing only when the whole launch is co-resident (no back-filling possible)
+    const bool one_flag = (p.kflags == KA_LE_M || p.kflags == KA_GE_M || p.kflags == KB_LE_N || p.kflags == KB_GE_N);
+    const long nblocks = (long)tilesM * tilesN * batch;
+    if (one_flag && !p.lower && nblocks <= (long)resident && nblocks >= 512) {   // small launches want parallelism, not balance
+        if ((p.kflags & (KA_LE_M | KA_GE_M)) && tilesM >= 2) {
+            p.pair = PAIR_M;
+            p.tilesMe = (tilesM + 1) / 2;
+        } else if ((p.kflags & (KB_LE_N | KB_GE_N)) && tilesN >= 2) {
+            p.pair = PAIR_N;
+            p.tilesNe = (tilesN + 1) / 2;
+        }
+    }
+    const int prows = (p.tilesMe + 7) / 8, pcols = (p.tilesNe + 7) / 8;
+    dim3 grid(p.remap ? prows * pcols * 64 : p.tilesMe * p.tilesNe, 1, batch);
+    const dim3 block(64 * WGM * WGN);
+    if (!p.a_mc && !p.b_nc)
+        hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, BK, WGM, WGN, false, false>), grid, block, 0, stream, p);
+    else if (!p.a_mc && p.b_nc)
+        hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, BK, WGM, WGN, false, true>), grid, block, 0, stream, p);
+    else if (p.a_mc && !p.b_nc)
+        hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, BK, WGM, WGN, true, false>), grid, block, 0, stream, p);
+    else
+        hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, BK, WGM, WGN, true, true>), grid, block, 0, stream, p);
+}
+
+// Returns the tile edge used (the caller of EPI_COLSUMSQ sizes `part` with it).
 inline int launch_gemm(const GemmP& p, int batch, hipStream_t stream, int force_tile = 0) {
     const int tile = force_tile ? force_tile : gemm_pick_tile(p, batch);
-    dim3 grid((p.N + tile - 1) / tile, (p.M + tile - 1) / tile, batch);
     if (tile == 128) {
-        hipLaunchKernelGGL((gemm_f64_kernel<128, 128, 16>), grid, dim3(256), 0, stream, p);
+        launch_gemm_cfg<128, 128, 16, 2, 4>(p, batch, stream, 512);
     } else if (tile == 64) {
-        hipLaunchKernelGGL((gemm_f64_kernel<64, 64, 16>), grid, dim3(256), 0, stream, p);
-    } else if (p.K % 64 == 0) {
-        hipLaunchKernelGGL((gemm_f64_kernel<32, 32, 64>), grid, dim3(256), 0, stream, p);
+        launch_gemm_cfg<64, 64, 16, 2, 2>(p, batch, stream, 1024);
+    } else if (p.K % 32 == 0) {
+        launch_gemm_cfg<32, 32, 32, 2, 2>(p, batch, stream, 1024);
     } else {
-        hipLaunchKernelGGL((gemm_f64_kernel<32, 32, 16>), grid, dim3(256), 0, stream, p);
+        launch_gemm_cfg<32, 32, 16, 2, 2>(p, batch, stream, 1024);
     }
     return tile;
 }
