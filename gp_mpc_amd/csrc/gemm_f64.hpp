@@ -28,6 +28,10 @@
 #pragma once
 #include "mfma_f64.hpp"
 
+#ifndef GPMPC_GEMM_SPLIT
+#define GPMPC_GEMM_SPLIT false
+#endif
+
 namespace gpmpc {
 
 enum { KA_LE_M = 1,   // A(m,k) == 0 for k > m   (A lower triangular)
@@ -43,6 +47,8 @@ struct GemmP {
     double* C;
     long lda, ldb, ldc;
     long sA, sB, sC;      // batch strides in elements
+    int zdiv;             // > 0: batch index z = z2 * zdiv + z1 with strides (sA, sA2) etc. (nodes x outputs)
+    long sA2, sB2, sC2;
     int M, N, K;
     double alpha, beta;
     int a_mc;             // 0: A(m,k) = A[m*lda + k] (K contiguous)   1: A(m,k) = A[k*lda + m]
@@ -58,7 +64,7 @@ struct GemmP {
     int remap;            // 1: XCD-contiguous 8 x 8 patch order, 0: plain row-major tile order
 };
 
-template <int BM, int BN, int BK, int WGM, int WGN, bool AMC, bool BNC>
+template <int BM, int BN, int BK, int WGM, int WGN, bool AMC, bool BNC, bool SPLIT = GPMPC_GEMM_SPLIT>
 __global__ void __launch_bounds__(64 * WGM * WGN, (WGM * WGN >= 8 ? 4 : 2)) gemm_f64_kernel(GemmP p) {
     constexpr int NT = 64 * WGM * WGN;
     constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 16, TN = WN / 16;
@@ -88,8 +94,10 @@ __global__ void __launch_bounds__(64 * WGM * WGN, (WGM * WGN >= 8 ? 4 : 2)) gemm
     }
     if (tme >= p.tilesMe || tne >= p.tilesNe) return;
 
-    const double* __restrict__ A = p.A + (long)blockIdx.z * p.sA;
-    const double* __restrict__ B = p.B + (long)blockIdx.z * p.sB;
+    const int z1 = p.zdiv > 0 ? (int)blockIdx.z % p.zdiv : (int)blockIdx.z;
+    const int z2 = p.zdiv > 0 ? (int)blockIdx.z / p.zdiv : 0;
+    const double* __restrict__ A = p.A + (long)z1 * p.sA + (long)z2 * p.sA2;
+    const double* __restrict__ B = p.B + (long)z1 * p.sB + (long)z2 * p.sB2;
     const int fr = lane & 15, fk = lane >> 4;
 
     for (int pass = 0; pass < 2; ++pass) {
@@ -192,10 +200,9 @@ __global__ void __launch_bounds__(64 * WGM * WGN, (WGM * WGN >= 8 ? 4 : 2)) gemm
         }
         __syncthreads();
         int cur = 0;
-        for (int kt = 0; kt < nk; ++kt) {
-            if (kt + 1 < nk) load_tiles(klo + (kt + 1) * BK);
+        auto mma_groups = [&](int q0, int q1) {
 #pragma unroll
-            for (int q = 0; q < QK; ++q) {
+            for (int q = q0; q < q1; ++q) {
                 double a[TM], b[TN];
 #pragma unroll
                 for (int i = 0; i < TM; ++i) a[i] = As[cur][q][wm * WM + i * 16 + fr][fk];
@@ -206,13 +213,20 @@ __global__ void __launch_bounds__(64 * WGM * WGN, (WGM * WGN >= 8 ? 4 : 2)) gemm
 #pragma unroll
                     for (int j = 0; j < TN; ++j) acc[i][j] = mfma16(a[i], b[j], acc[i][j]);
             }
+        };
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) load_tiles(klo + (kt + 1) * BK);
+            // the staging write of tile kt+1 sits between the two halves of the MFMA work so that the
+            // LDS write and the global-load wait are covered by queued matrix instructions
+            mma_groups(0, SPLIT ? QK / 2 : QK);
             if (kt + 1 < nk) store_tiles(cur ^ 1);
+            if (SPLIT) mma_groups(QK / 2, QK);
             __syncthreads();
             cur ^= 1;
         }
 
         if (p.epi == EPI_STORE) {
-            double* __restrict__ C = p.C + (long)blockIdx.z * p.sC;
+            double* __restrict__ C = p.C + (long)z1 * p.sC + (long)z2 * p.sC2;
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll

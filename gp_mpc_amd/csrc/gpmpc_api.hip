@@ -5,6 +5,8 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -195,49 +197,84 @@ static GemmP gemm_base(const Ctx& cx) {
     return p;
 }
 
-// Recursive blocked Cholesky fused with the triangular inverse (both end up as fp64 MFMA GEMMs):
-//   [L11 0; L21 L22]:  L11,inv11 <- rec(A11);  L21 = A21 inv11^T;  A22 -= L21 L21^T;
-//                      L22,inv22 <- rec(A22);  inv21 = -inv22 (L21 inv11).
-// K is consumed (trailing updates are applied in place), L and Inv are written; all [batch][Np x Np].
-static void factor_rec(const Ctx& cx, Workspace& ws, int off, int n, bool do_chol) {
-    const long ld = ws.Np, sM = ws.mat();
-    if (n <= 64) {
-        hipLaunchKernelGGL(leaf64_kernel, dim3(1, 1, ws.batch), dim3(256), 0, cx.stream,
-                           do_chol ? (const double*)ws.K : (const double*)ws.L, ws.L, ws.Inv, ld, sM, off,
-                           do_chol ? 1 : 0, ws.info, cx.crow_mode);
+// Fit factorisation = right-looking blocked Cholesky (NB = 64) + level-by-level batched triangular
+// inverse.  K is consumed (trailing updates in place), L and Inv = L^-1 are written; [batch][Np x Np].
+//
+//   for each 64-column panel k:   leaf: L_kk = chol(A_kk), inv_kk = L_kk^-1        (one workgroup)
+//                                 panel: L21 = A21 inv_kk^T                         (MFMA GEMM)
+//                                 trailing: A22 -= L21 L21^T  (lower)               (MFMA GEMM)
+//   then for s = 64, 128, ...:    every node [L11 0; L21 L22] with |L11| = s in ONE batched launch pair:
+//                                 W = L21 inv11,  inv21 = -inv22 W                  (MFMA GEMMs)
+//
+// Only the leaf, the 64-wide panel product and the trailing update are on the sequential chain
+// (3 launches per panel); the inverse needs 2 launches per level, each with all nodes of the level
+// as the batch dimension.  Measured alternatives that did NOT pay (r01): a second HIP stream running
+// the bulk of the trailing update and/or the inverse products concurrently with the chain (look-ahead)
+// -- the leaf and panel kernels slow down under the contention by as much as is hidden (4.4 vs 4.2 ms,
+// with or without stream priorities / CU masks).  (The first version recursed on [L11 0; L21 L22] with the inverse products
+// inside the recursion: 4 latency-bound launches per node on the chain, 5.5 ms at N = 4096.)
+static void trtri_levels(const Ctx& cx, Workspace& ws) {
+    const int Np = ws.Np;
+    const long ld = Np, sM = ws.mat();
+    const long hw = Np / 2 + 64;
+    for (int s = 64; s < Np; s *= 2) {
+        const int nfull = Np / (2 * s);                 // nodes with a full right child
+        const int rem = Np - nfull * 2 * s;             // tail: a partial node exists if rem > s
+        for (int part = 0; part < 2; ++part) {
+            int nodes, h2;
+            long base;
+            if (part == 0) { nodes = nfull; h2 = s; base = 0; }
+            else { nodes = rem > s ? 1 : 0; h2 = rem - s; base = (long)nfull * 2 * s; }
+            if (nodes == 0) continue;
+            const long o11 = base * ld + base, o21 = (base + s) * ld + base, o22 = (base + s) * ld + base + s;
+            const long snode = (long)2 * s * (ld + 1);
+            GemmP t = gemm_base(cx);                    // W = L21 inv11
+            t.A = ws.L + o21; t.lda = ld; t.a_mc = 0;
+            t.B = ws.Inv + o11; t.ldb = ld; t.b_nc = 1; t.kflags = KB_GE_N;
+            t.C = ws.W; t.ldc = s;
+            t.M = h2; t.N = s; t.K = s;
+            t.zdiv = nodes; t.sA = snode; t.sB = snode; t.sC = (long)s * s; t.sA2 = sM; t.sB2 = sM; t.sC2 = hw * hw;
+            launch_gemm(t, nodes * ws.batch, cx.stream);
+            GemmP u = gemm_base(cx);                    // inv21 = -inv22 W
+            u.A = ws.Inv + o22; u.lda = ld; u.a_mc = 0; u.kflags = KA_LE_M;
+            u.B = ws.W; u.ldb = s; u.b_nc = 1;
+            u.C = ws.Inv + o21; u.ldc = ld;
+            u.M = h2; u.N = s; u.K = h2; u.alpha = -1.0;
+            u.zdiv = nodes; u.sA = snode; u.sB = (long)s * s; u.sC = snode; u.sA2 = sM; u.sB2 = hw * hw; u.sC2 = sM;
+            launch_gemm(u, nodes * ws.batch, cx.stream);
+        }
+    }
+}
+
+static void factor_blocked(const Ctx& cx, Workspace& ws, bool do_chol) {
+    const int Np = ws.Np, nb = Np / 64;
+    const long ld = Np, sM = ws.mat();
+    if (!do_chol) {   // inverse only (gpmpc_set_factors): all diagonal blocks are independent
+        hipLaunchKernelGGL(leaf64_kernel, dim3(nb, 1, ws.batch), dim3(256), 0, cx.stream, (const double*)ws.L, ws.L,
+                           ws.Inv, ld, sM, 0, 0, ws.info, cx.crow_mode, 15);
+        trtri_levels(cx, ws);
         return;
     }
-    const int h1 = (n / 64 / 2) * 64, h2 = n - h1;
-    const long o11 = (long)off * ld + off, o21 = (long)(off + h1) * ld + off, o22 = (long)(off + h1) * ld + off + h1;
-    factor_rec(cx, ws, off, h1, do_chol);
-    if (do_chol) {
-        GemmP p = gemm_base(cx);  // L21 = A21 inv11^T
+    for (int k = 0; k < nb; ++k) {
+        const int off = 64 * k, M = Np - off - 64;
+        hipLaunchKernelGGL(leaf64_kernel, dim3(1, 1, ws.batch), dim3(256), 0, cx.stream, (const double*)ws.K, ws.L, ws.Inv,
+                           ld, sM, off, 1, ws.info, cx.crow_mode, 15);
+        if (M <= 0) break;
+        const long o11 = (long)off * ld + off, o21 = (long)(off + 64) * ld + off, o22 = (long)(off + 64) * ld + off + 64;
+        GemmP p = gemm_base(cx);                        // panel: L21 = A21 inv_kk^T
         p.A = ws.K + o21; p.lda = ld; p.sA = sM; p.a_mc = 0;
         p.B = ws.Inv + o11; p.ldb = ld; p.sB = sM; p.b_nc = 0; p.kflags = KB_LE_N;
         p.C = ws.L + o21; p.ldc = ld; p.sC = sM;
-        p.M = h2; p.N = h1; p.K = h1;
+        p.M = M; p.N = 64; p.K = 64;
         launch_gemm(p, ws.batch, cx.stream);
-        GemmP q = gemm_base(cx);  // A22 -= L21 L21^T (lower)
+        GemmP q = gemm_base(cx);                        // trailing update: A22 -= L21 L21^T (lower)
         q.A = ws.L + o21; q.lda = ld; q.sA = sM; q.a_mc = 0;
         q.B = ws.L + o21; q.ldb = ld; q.sB = sM; q.b_nc = 0;
         q.C = ws.K + o22; q.ldc = ld; q.sC = sM;
-        q.M = h2; q.N = h2; q.K = h1; q.alpha = -1.0; q.beta = 1.0; q.lower = 1;
+        q.M = M; q.N = M; q.K = 64; q.alpha = -1.0; q.beta = 1.0; q.lower = 1;
         launch_gemm(q, ws.batch, cx.stream);
     }
-    factor_rec(cx, ws, off + h1, h2, do_chol);
-    const long hw = ws.Np / 2 + 64;
-    GemmP t = gemm_base(cx);  // W = L21 inv11
-    t.A = ws.L + o21; t.lda = ld; t.sA = sM; t.a_mc = 0;
-    t.B = ws.Inv + o11; t.ldb = ld; t.sB = sM; t.b_nc = 1; t.kflags = KB_GE_N;
-    t.C = ws.W; t.ldc = h1; t.sC = hw * hw;
-    t.M = h2; t.N = h1; t.K = h1;
-    launch_gemm(t, ws.batch, cx.stream);
-    GemmP u = gemm_base(cx);  // inv21 = -inv22 W
-    u.A = ws.Inv + o22; u.lda = ld; u.sA = sM; u.a_mc = 0; u.kflags = KA_LE_M;
-    u.B = ws.W; u.ldb = h1; u.sB = hw * hw; u.b_nc = 1;
-    u.C = ws.Inv + o21; u.ldc = ld; u.sC = sM;
-    u.M = h2; u.N = h1; u.K = h2; u.alpha = -1.0;
-    launch_gemm(u, ws.batch, cx.stream);
+    trtri_levels(cx, ws);
 }
 
 // w = L^-1 y and alpha = L^-T w as two HBM-bound matrix-vector products with the explicit inverse.
@@ -472,7 +509,7 @@ static void gram_and_factor(gpmpc_gp* h, Workspace& ws) {
     {
         PhaseTimer t(h, GPMPC_PH_FACTOR);
         hipMemsetAsync(ws.info, 0, ws.batch * sizeof(int), cx.stream);
-        factor_rec(cx, ws, 0, ws.Np, true);
+        factor_blocked(cx, ws, true);
     }
 }
 
@@ -595,7 +632,7 @@ extern "C" int gpmpc_set_factors(gpmpc_gp* h, const double* hyper, const double*
     h->hyper.assign(hyper, hyper + (size_t)h->Ny * (h->d + 2));
     HIPCHK(hipMemcpy(h->ws.hyper, hyper, h->hyper.size() * sizeof(double), hipMemcpyHostToDevice));
     CHK(import_mats(h, chol, h->ws.L, true));
-    factor_rec(h->cx(), h->ws, 0, h->Np, false);  // L^-1 from the stored L
+    factor_blocked(h->cx(), h->ws, false);  // L^-1 from the stored L
     if (alpha) {
         std::vector<double> tmp((size_t)h->Ny * h->Np, 0.0);
         for (int a = 0; a < h->Ny; ++a) std::memcpy(tmp.data() + (size_t)a * h->Np, alpha + (size_t)a * h->N, h->N * sizeof(double));
@@ -879,7 +916,7 @@ extern "C" int gpmpc_cholesky(int device, int n, double* A, double* Ainv, int* i
     HIPCHK(hipMemcpy(ws.K, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice));
     Ctx cx{nullptr, g_crow_mode[device]};
     HIPCHK(hipMemset(ws.info, 0, sizeof(int)));
-    factor_rec(cx, ws, 0, Np, true);
+    factor_blocked(cx, ws, true);
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(info, ws.info, sizeof(int), hipMemcpyDeviceToHost));

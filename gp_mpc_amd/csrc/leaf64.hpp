@@ -2,11 +2,14 @@
 // block held in LDS and inverts the factor (a4 + a6 on a diagonal block; np.linalg.cholesky
 // optimize.py:346, invL optimize.py:489).
 //
-// Inside the block the same right-looking scheme runs at 16-column granularity: a 16 x 16
-// diagonal sub-block is factored and inverted by ONE wave with a row per lane in registers and
-// SGPR broadcasts (v_readlane) -- no LDS round trips, no barriers on the sequential chain -- and
-// the sub-panel solve, the rank-16 update and the assembly of the 64 x 64 inverse are
-// v_mfma_f64_16x16x4_f64 products on LDS-resident operands.
+// Inside the block the same right-looking scheme runs at 16-column granularity.  The sequential
+// chain is one wave factoring a 64 x 16 PANEL with a row per lane (all 64 lanes busy): column j is
+// scaled by rsqrt(pivot) and the rank-1 update of the remaining panel columns uses SGPR broadcasts
+// (v_readlane) of the diagonal block's rows -- the sub-panel triangular solve falls out of the same
+// instruction stream, with no LDS round trips or barriers inside the panel.  The rank-16 update of
+// the trailing tiles and the assembly of the 64 x 64 inverse are v_mfma_f64_16x16x4_f64 products on
+// LDS-resident operands; the 16 x 16 diagonal inverses are computed by an otherwise idle wave while
+// the next panel is being factored.
 #pragma once
 #include "mfma_f64.hpp"
 
@@ -42,7 +45,7 @@ __device__ __forceinline__ void lds_sub16(double* S, int r0, int c0, d4 v, int l
 // Lane r (< 16) owns row r in registers; lanes >= 16 shadow rows r & 15 so that every lane
 // executes the same broadcasts.  Returns the first non-positive pivot column (0-based, local) or -1.
 template <bool FACTOR>
-__device__ __forceinline__ int potrf16_inv16(double* S, double* T, int o, int lane) {
+__device__ __forceinline__ int potrf16_inv16(double* S, double* T, int o, int lane, const double* Drinv = nullptr) {
     const int r = lane & 15;
     double a[16], rinv[16], x[16];
     int bad = -1;
@@ -64,6 +67,9 @@ __device__ __forceinline__ int potrf16_inv16(double* S, double* T, int o, int la
 #pragma unroll
             for (int c = 0; c < 16; ++c) S[(o + r) * LS + o + c] = (c <= r) ? a[c] : 0.0;
         }
+    } else if (Drinv) {   // reciprocal pivots left in LDS by panel_potrf: no divisions on this path
+#pragma unroll
+        for (int j = 0; j < 16; ++j) rinv[j] = Drinv[o + j];
     } else {
 #pragma unroll
         for (int j = 0; j < 16; ++j) rinv[j] = 1.0 / bcast(a[j], j);
@@ -83,15 +89,49 @@ __device__ __forceinline__ int potrf16_inv16(double* S, double* T, int o, int la
     return bad;
 }
 
-// grid (1, 1, batch), 256 threads.  Ain: source of the diagonal block (the running K for a
-// factorisation, L itself for inverse-only); L / Inv: destinations.  All are [batch][ld x ld]
-// row-major, `off` is the block's first row/column.
+// One wave: Cholesky of the 64 x 16 panel = rows 16t..63 of columns 16t..16t+15 of S (LDS), lane = row.
+// Returns the first non-positive pivot column (0-based within the panel) or -1.
+__device__ __forceinline__ int panel_potrf(double* S, double* Drinv, int t, int lane) {
+    const int o = 16 * t, r = lane;
+    double a[16], rinv[16];
+    int bad = -1;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) a[c] = S[r * LS + o + c];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const double ajj = bcast(a[j], o + j);
+        if (!(ajj > 0.0) && bad < 0) bad = j;  // also catches NaN; wave-uniform
+        const double ri = rsqrt(ajj);
+        rinv[j] = ri;
+        const double lj = (r == o + j) ? ajj * ri : a[j] * ri;
+        a[j] = lj;
+#pragma unroll
+        for (int k = j + 1; k < 16; ++k) a[k] -= lj * bcast(lj, o + k);
+    }
+#pragma unroll
+    for (int c = 0; c < 16; ++c)
+        if (lane == c) Drinv[o + c] = rinv[c];   // 1 / L_cc for the diagonal-inverse wave
+    if (r >= o) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) S[r * LS + o + c] = (r - o >= 16 || c <= r - o) ? a[c] : 0.0;
+    }
+    return bad;
+}
+
+// grid (nblk, 1, batch), 256 threads: workgroup x handles the diagonal block starting at row/column
+// off + 64 x (nblk > 1 only for the inverse-only mode, where the blocks are independent).
+// Ain: source of the diagonal block (the running K for a factorisation, L itself for inverse-only);
+// L / Inv: destinations.  All are [batch][ld x ld] row-major.
 __global__ void __launch_bounds__(256) leaf64_kernel(const double* Ain, double* L, double* Inv, long ld,
-                                                     long sBatch, int off, int do_chol, int* info,
-                                                     int crow_mode) {
+                                                     long sBatch, int off0, int do_chol, int* info,
+                                                     int crow_mode, int phases = 15) {
+    // `phases` (bit 0 panel, 1 rank-16 update, 2 diagonal inverses, 3 inverse assembly) exists for the
+    // micro-benchmark tools/ubench/leaf_bench.hip only; the library always passes 15.
+    const int off = off0 + 64 * (int)blockIdx.x;
     __shared__ double S[64 * LS];
     __shared__ double T[64 * LS];
     __shared__ double U[64 * LS];
+    __shared__ double Dr[64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long base = (long)blockIdx.z * sBatch + (long)off * ld + off;
     const double* __restrict__ src = Ain + base;
@@ -105,30 +145,27 @@ __global__ void __launch_bounds__(256) leaf64_kernel(const double* Ain, double* 
     if (do_chol) {
         int bad = -1;
         for (int t = 0; t < 4; ++t) {
-            const int o = 16 * t;
-            if (wave == 0) {
-                const int b = potrf16_inv16<true>(S, T, o, lane);
-                if (b >= 0 && bad < 0) bad = o + b;
+            if (wave == 0 && (phases & 1)) {
+                const int b = panel_potrf(S, Dr, t, lane);
+                if (b >= 0 && bad < 0) bad = 16 * t + b;
+            } else if (wave == 1 && t >= 1 && (phases & 4)) {
+                potrf16_inv16<false>(S, T, 16 * (t - 1), lane, Dr);   // inverse of the previous diagonal block
             }
             __syncthreads();
-            // sub-panel: L_it = A_it inv(L_tt)^T, one 16 x 16 tile per wave
-            d4 acc = d4{0.0, 0.0, 0.0, 0.0};
-            const int ti = t + 1 + wave;
-            if (ti <= 3) acc = lds_mm16<true>(S, 16 * ti, o, T, o, o, 16, lane, acc);
-            __syncthreads();
-            if (ti <= 3) lds_put16(S, 16 * ti, o, acc, 1.0, lane, crow_mode);
-            __syncthreads();
             // rank-16 update of the remaining lower tiles: A_ij -= L_it L_jt^T, t < j <= i <= 3
+            const int o = 16 * t;
             int cnt = 0;
-            for (int i = t + 1; i <= 3; ++i)
+            for (int i = t + 1; i <= 3 && (phases & 2); ++i)
                 for (int j = t + 1; j <= i; ++j, ++cnt)
                     if ((cnt & 3) == wave) {
                         d4 pacc = d4{0.0, 0.0, 0.0, 0.0};
                         pacc = lds_mm16<true>(S, 16 * i, o, S, 16 * j, o, 16, lane, pacc);
                         lds_sub16(S, 16 * i, 16 * j, pacc, lane, crow_mode);
                     }
-            __syncthreads();
+            if (t < 3) __syncthreads();
         }
+        if (wave == 1 && (phases & 4)) potrf16_inv16<false>(S, T, 48, lane, Dr);
+        __syncthreads();
         if (wave == 0 && lane == 0 && bad >= 0) atomicCAS(&info[blockIdx.z], 0, off + bad + 1);
     } else {
         potrf16_inv16<false>(S, T, 16 * wave, lane);
@@ -137,7 +174,7 @@ __global__ void __launch_bounds__(256) leaf64_kernel(const double* Ain, double* 
 
     // assemble the 64 x 64 inverse from the four 16 x 16 diagonal inverses:
     // inv21 = -inv22 (L21 inv11), first for the two 32-blocks, then for the 64-block
-    {
+    if (phases & 8) {
         const int c1 = 32 * wave, r2 = c1 + 16;
         d4 acc = d4{0.0, 0.0, 0.0, 0.0};
         if (wave < 2) acc = lds_mm16<false>(S, r2, c1, T, c1, c1, 16, lane, acc);
@@ -148,7 +185,7 @@ __global__ void __launch_bounds__(256) leaf64_kernel(const double* Ain, double* 
         if (wave < 2) lds_put16(T, r2, c1, acc, -1.0, lane, crow_mode);
         __syncthreads();
     }
-    {
+    if (phases & 8) {
         const int pi = wave >> 1, pj = wave & 1;
         d4 acc = d4{0.0, 0.0, 0.0, 0.0};
         acc = lds_mm16<false>(S, 32 + 16 * pi, 0, T, 0, 16 * pj, 32, lane, acc);

@@ -96,6 +96,9 @@ inline hipError_t hipGetLastError() { return hipSuccess; }
 inline hipError_t hipPeekAtLastError() { return hipSuccess; }
 inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess" : "emulated HIP error"; }
 inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new emu_event{0.0}; return hipSuccess; }
+enum { hipEventDefault = 0, hipEventDisableTiming = 2 };
+inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = new emu_event{0.0}; return hipSuccess; }
+inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
 inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t = emu::now_ms(); return hipSuccess; }
 inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
