@@ -10,9 +10,10 @@
 //   cov_aa += sf_a^2 (:415),  cov -= mean mean^T (:416).
 //
 // maha(ii, -ij, S)_ij = ii_i S ii_i^T + ij_j S ij_j^T + 2 (ii_i S) . ij_j, so a tile of Q needs one
-// d-vector dot product and one exp per entry.  The pair kernel gives each workgroup a 64-row strip
-// i of one (input, pair) and sweeps all j: exp/VALU bound for a != b, additionally one coalesced
-// read of K_a^-1 (8 N^2 bytes) for a == b.
+// d-vector dot product and one exp per entry.  The dot products of a 16 x 16 tile are a depth-8 product
+// on the matrix pipe (two v_mfma_f64_16x16x4_f64); the VALU is left with one lean exp and the weighted
+// accumulation per entry: exp/VALU bound for a != b, additionally one read of the lower triangle of
+// K_a^-1 for a == b (symmetry halves those pairs).
 #pragma once
 #include "gp_kernels.hpp"
 
@@ -129,95 +130,168 @@ __global__ void __launch_bounds__(256) em_mean_kernel(const double* __restrict__
     if (tid == 0) mean[(long)b * Ny + a] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-// Pair sums.  grid (Np/64, P, B), 256 threads; partial[(b*P + p)*tiles + tile_i].
-// Thread t owns column c = t & 63 of the current j tile (its w_j, Lb_j, beta_bj in registers) and
-// rows r = (t >> 6) + 4 s, s < 16, of the i strip (u_i, La_i, beta_ai broadcast from LDS).
-template <int D>
-__global__ void __launch_bounds__(256) em_pair_kernel(const double* __restrict__ XT, const double* __restrict__ Z,
-                                                      const double* __restrict__ hyper, const double* __restrict__ beta,
-                                                      const double* __restrict__ invK, const double* __restrict__ prep,
-                                                      double* __restrict__ partial, int N, int Np, int Ny) {
-    const int ti = blockIdx.x, p = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
-    const int P = Ny * (Ny + 1) / 2, stride = D * D + 1, tiles = Np / 64;
+// exp(x) in fp64 without the library's special-case handling: n = rint(x log2 e), Cody-Waite reduction
+// r = x - n ln 2, degree-12 Taylor polynomial on |r| <= 0.347 (truncation 1.7e-16), v_ldexp_f64.
+// 18 VALU instructions; arguments here are <= O(10), underflow flushes to 0 through ldexp.
+__device__ __forceinline__ double exp_lean(double x) {
+    const double n = rint(x * 1.4426950408889634074);
+    double r = fma(-n, 6.93147180369123816490e-01, x);
+    r = fma(-n, 1.90821492927058770002e-10, r);
+    double p = 1.0 / 479001600.0;
+    p = fma(p, r, 1.0 / 39916800.0);
+    p = fma(p, r, 1.0 / 3628800.0);
+    p = fma(p, r, 1.0 / 362880.0);
+    p = fma(p, r, 1.0 / 40320.0);
+    p = fma(p, r, 1.0 / 5040.0);
+    p = fma(p, r, 1.0 / 720.0);
+    p = fma(p, r, 1.0 / 120.0);
+    p = fma(p, r, 1.0 / 24.0);
+    p = fma(p, r, 1.0 / 6.0);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, (int)n);
+}
+
+constexpr int EMK = 8;   // cross-term depth handled by the MFMA path (d <= 8: two 16x16x4 steps)
+
+// Per-(input, pair, point) operands of the pair kernel.  One thread per (b, p, i); arrays are
+// [b][p][...][Np] so that the pair kernel's loads are contiguous in the point index:
+//   U[k][i]  = (ii_i S)_k * 2        (A operand of the cross-term product, k < EMK, zero padded)
+//   Wt[k][j] = ij_j,k                 (B operand)
+//   La[i] = log_k[i,a] + ii_i S ii_i^T,   Lb[j] = log_k[j,b] + ij_j S ij_j^T
+// (gp_functions.py:394-396, :400-408 with maha expanded as in the header comment).
+__global__ void __launch_bounds__(256) em_operands_kernel(const double* __restrict__ XT, const double* __restrict__ Z,
+                                                          const double* __restrict__ hyper, const double* __restrict__ prep,
+                                                          double* __restrict__ ops, int N, int Np, int d, int Ny) {
+    const int P = Ny * (Ny + 1) / 2, stride = d * d + 1;
+    const int i = blockIdx.x * 256 + threadIdx.x, p = blockIdx.y, b = blockIdx.z;
+    if (i >= Np) return;
     int a = 0;
     while ((a + 1) * (a + 2) / 2 <= p) ++a;
     const int bb = p - a * (a + 1) / 2;
-    const double* pr = prep + ((long)b * (Ny + P) + Ny + p) * stride;
-    const double* ha = hyper + (long)a * (D + 2);
-    const double* hb = hyper + (long)bb * (D + 2);
-    __shared__ double S[D * D], mu[D], ia2[D], ib2[D];
-    __shared__ double U[64][D], La[64], Ba[64], red[4];
-    if (tid < D * D) S[tid] = pr[tid];
-    if (tid < D) {
-        mu[tid] = Z[(long)b * D + tid];
-        ia2[tid] = 1.0 / (ha[tid] * ha[tid]);
-        ib2[tid] = 1.0 / (hb[tid] * hb[tid]);
+    const double* S = prep + ((long)b * (Ny + P) + Ny + p) * stride;
+    const double* ha = hyper + (long)a * (d + 2);
+    const double* hb = hyper + (long)bb * (d + 2);
+    double* o = ops + ((long)b * P + p) * (2 * EMK + 2) * Np;
+    double v[DMAX], ii[DMAX], ij[DMAX];
+    double lka = 0.0, lkb = 0.0;
+    for (int k = 0; k < d; ++k) {
+        v[k] = (i < N) ? XT[(long)k * Np + i] - Z[(long)b * d + k] : 0.0;
+        ii[k] = v[k] / (ha[k] * ha[k]);
+        ij[k] = v[k] / (hb[k] * hb[k]);
+        lka += v[k] * v[k] / (ha[k] * ha[k]);
+        lkb += v[k] * v[k] / (hb[k] * hb[k]);
     }
-    __syncthreads();
-    const double lsfa = 2.0 * log(ha[D]), lsfb = 2.0 * log(hb[D]);
-    const int i0 = ti * 64;
-    if (tid < 64) {
-        const int i = i0 + tid;
-        double v[D], ii[D];
-        double lk = 0.0;
-#pragma unroll
-        for (int k = 0; k < D; ++k) {
-            v[k] = XT[(long)k * Np + i] - mu[k];
-            ii[k] = v[k] * ia2[k];
-            lk += v[k] * v[k] * ia2[k];
-        }
-        double quad = 0.0;
-#pragma unroll
-        for (int c = 0; c < D; ++c) {
-            double u = 0.0;
-#pragma unroll
-            for (int k = 0; k < D; ++k) u += ii[k] * S[k * D + c];      // (ii S)_c
-            U[tid][c] = u;
-            quad += u * ii[c];
-        }
-        La[tid] = (lsfa - 0.5 * lk) + quad;
-        Ba[tid] = (i < N) ? beta[(long)a * Np + i] : 0.0;
+    double qa = 0.0, qb = 0.0;
+    for (int c = 0; c < EMK; ++c) {
+        double ua = 0.0, ub = 0.0;
+        if (c < d)
+            for (int k = 0; k < d; ++k) { ua += ii[k] * S[k * d + c]; ub += ij[k] * S[k * d + c]; }
+        o[(long)c * Np + i] = 2.0 * ua;
+        o[(long)(EMK + c) * Np + i] = (c < d) ? ij[c] : 0.0;
+        if (c < d) { qa += ua * ii[c]; qb += ub * ij[c]; }
     }
-    __syncthreads();
-    const int c = tid & 63, r0 = tid >> 6;
-    const bool diag = (a == bb);
+    o[(long)(2 * EMK) * Np + i] = (2.0 * log(ha[d]) - 0.5 * lka) + qa;
+    o[(long)(2 * EMK + 1) * Np + i] = (2.0 * log(hb[d]) - 0.5 * lkb) + qb;
+}
+
+// Pair sums on a 64-row strip.  grid (Np/64, P, B), 256 threads = 4 waves; wave w owns rows 16w..16w+15 of
+// the strip and sweeps the columns in 64-wide tiles without any barrier: the cross terms
+// 2 (ii_i S) . ij_j of a 16 x 16 tile are two v_mfma_f64_16x16x4_f64 (depth EMK = 8, zero padded); the VALU
+// adds La_i + Lb_j, takes the lean exp and accumulates (beta_ai beta_bj - [a==b] K^-1_ij) Q_ij.  For a == b
+// the summand is symmetric in (i, j): only column tiles up to the diagonal are visited, off-diagonal
+// tiles counted twice.  partial[(b*P + p)*tiles + strip].
+template <bool DIAG>
+__global__ void __launch_bounds__(256) em_pair_kernel(const double* __restrict__ ops, const double* __restrict__ beta,
+                                                      const double* __restrict__ invK, double* __restrict__ partial,
+                                                      int N, int Np, int Ny, int crow_mode) {
+    const int ti = blockIdx.x, p = blockIdx.y, b = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int P = Ny * (Ny + 1) / 2, tiles = Np / 64;
+    int a = 0;
+    while ((a + 1) * (a + 2) / 2 <= p) ++a;
+    const int bb = p - a * (a + 1) / 2;
+    if ((a == bb) != DIAG) return;   // launched once per kind: the a == b variant carries the K^-1 registers
+    constexpr bool diag = DIAG;
+    const double* __restrict__ o = ops + ((long)b * P + p) * (2 * EMK + 2) * Np;
+    const double* __restrict__ Wt = o + (long)EMK * Np;
+    const double* __restrict__ La = o + (long)(2 * EMK) * Np;
+    const double* __restrict__ Lb = o + (long)(2 * EMK + 1) * Np;
+    const double* __restrict__ ba = beta + (long)a * Np;
+    const double* __restrict__ bbv = beta + (long)bb * Np;
     const double* __restrict__ iK = invK + (long)a * Np * Np;
+    __shared__ double red[4];
+    // column-tile operands (shared by the 4 waves) are staged through LDS with a one-tile prefetch:
+    // rows 0..7 Wt, row 8 Lb, row 9 beta_b  -> 640 doubles per tile
+    __shared__ double Cs[2][EMK + 2][64];
+    const int fr = lane & 15, fk = lane >> 4, i0 = ti * 64 + 16 * wave;
+    // A fragments (constant over the sweep) and the row data of this lane's 4 accumulator rows
+    const double a0 = o[(long)fk * Np + i0 + fr], a1 = o[(long)(4 + fk) * Np + i0 + fr];
+    double la[4], bai[4];
+    int irow[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        irow[r] = i0 + crow(lane, r, crow_mode);
+        la[r] = La[irow[r]];
+        bai[r] = (irow[r] < N) ? ba[irow[r]] : 0.0;
+    }
     double acc = 0.0;
-    for (int tj = 0; tj < tiles; ++tj) {
-        const int j = tj * 64 + c;
-        double w[D];
-        double lk = 0.0;
+    const int jt_end = diag ? ti + 1 : tiles;
+    double st[3];
+    auto fetch = [&](int jt) {   // 640 values / 256 threads: element e = tid + 256 q -> (row e / 64, col e % 64)
 #pragma unroll
-        for (int k = 0; k < D; ++k) {
-            const double v = XT[(long)k * Np + j] - mu[k];
-            w[k] = v * ib2[k];
-            lk += v * v * ib2[k];
+        for (int q = 0; q < 3; ++q) {
+            const int e = tid + 256 * q, rw = e >> 6, cl = e & 63, j = jt * 64 + cl;
+            double v = 0.0;
+            if (rw < EMK) v = Wt[(long)rw * Np + j];
+            else if (rw == EMK) v = Lb[j];
+            else if (rw == EMK + 1) v = (j < N) ? bbv[j] : 0.0;
+            st[q] = v;
         }
-        double quad = 0.0;
+    };
+    auto stage = [&](int buf) {
 #pragma unroll
-        for (int cc = 0; cc < D; ++cc) {
-            double u = 0.0;
-#pragma unroll
-            for (int k = 0; k < D; ++k) u += w[k] * S[k * D + cc];
-            quad += u * w[cc];
+        for (int q = 0; q < 3; ++q) {
+            const int e = tid + 256 * q, rw = e >> 6, cl = e & 63;
+            if (rw < EMK + 2) Cs[buf][rw][cl] = st[q];
         }
-        const double Lb = (lsfb - 0.5 * lk) + quad;
-        const double bj = (j < N) ? beta[(long)bb * Np + j] : 0.0;
-        const bool jlive = j < N;
-#pragma unroll 4
-        for (int s = 0; s < 16; ++s) {
-            const int r = r0 + 4 * s, i = i0 + r;
-            double dot = 0.0;
+    };
+    fetch(0);
+    stage(0);
+    __syncthreads();
+    int cur = 0;
+    for (int jt = 0; jt < jt_end; ++jt) {
+        if (jt + 1 < jt_end) fetch(jt + 1);
+        const double mult = (diag && jt < ti) ? 2.0 : 1.0;
+        double ik[4][4];
+        if (diag) {
 #pragma unroll
-            for (int k = 0; k < D; ++k) dot += U[r][k] * w[k];
-            const double q = exp(La[r] + Lb + 2.0 * dot);
-            double wgt = Ba[r] * bj;
-            if (diag && jlive && i < N) wgt -= iK[(long)i * Np + j];
-            acc += (jlive && i < N) ? wgt * q : 0.0;
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ik[t][r] = iK[(long)irow[r] * Np + jt * 64 + 16 * t + fr];
         }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int cl = 16 * t + fr, j = jt * 64 + cl;
+            d4 c = d4{0.0, 0.0, 0.0, 0.0};
+            c = mfma16(a0, Cs[cur][fk][cl], c);
+            c = mfma16(a1, Cs[cur][4 + fk][cl], c);
+            const double lbj = Cs[cur][EMK][cl];
+            const double bj = Cs[cur][EMK + 1][cl];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double q = exp_lean((la[r] + lbj) + c[r]);
+                double wgt = bai[r] * bj;
+                if (diag) wgt -= ik[t][r];
+                acc += (j < N && irow[r] < N) ? mult * wgt * q : 0.0;
+            }
+        }
+        if (jt + 1 < jt_end) stage(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
     }
     acc = wave_sum(acc);
-    if ((tid & 63) == 0) red[tid >> 6] = acc;
+    if (lane == 0) red[wave] = acc;
     __syncthreads();
     if (tid == 0) partial[((long)b * P + p) * tiles + ti] = (red[0] + red[1]) + (red[2] + red[3]);
 }
@@ -242,25 +316,6 @@ __global__ void __launch_bounds__(64) em_finish_kernel(const double* __restrict_
     v -= mean[(long)b * Ny + a] * mean[(long)b * Ny + bb];
     cov[((long)b * Ny + a) * Ny + bb] = v;
     cov[((long)b * Ny + bb) * Ny + a] = v;
-}
-
-template <int D>
-inline void launch_em_pair_d(hipStream_t st, dim3 grid, const double* XT, const double* Z, const double* hyper,
-                             const double* beta, const double* invK, const double* prep, double* partial, int N,
-                             int Np, int Ny) {
-    hipLaunchKernelGGL((em_pair_kernel<D>), grid, dim3(256), 0, st, XT, Z, hyper, beta, invK, prep, partial, N, Np, Ny);
-}
-
-inline void launch_em_pair(hipStream_t st, int d, dim3 grid, const double* XT, const double* Z, const double* hyper,
-                           const double* beta, const double* invK, const double* prep, double* partial, int N, int Np,
-                           int Ny) {
-#define GPMPC_EMD(DD) case DD: launch_em_pair_d<DD>(st, grid, XT, Z, hyper, beta, invK, prep, partial, N, Np, Ny); break;
-    switch (d) {
-        GPMPC_EMD(1) GPMPC_EMD(2) GPMPC_EMD(3) GPMPC_EMD(4) GPMPC_EMD(5) GPMPC_EMD(6) GPMPC_EMD(7) GPMPC_EMD(8)
-        GPMPC_EMD(9) GPMPC_EMD(10) GPMPC_EMD(11) GPMPC_EMD(12) GPMPC_EMD(13) GPMPC_EMD(14) GPMPC_EMD(15) GPMPC_EMD(16)
-        default: break;
-    }
-#undef GPMPC_EMD
 }
 
 // ---- legacy methods a12 ------------------------------------------------------------------------------

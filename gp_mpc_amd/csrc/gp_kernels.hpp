@@ -161,21 +161,75 @@ inline void launch_crosscov(hipStream_t st, int d, const double* XT, const doubl
 }
 
 // a9 (second half): var_a(z_j) = sf_a^2 - sum over row tiles of the column sums of squares
-// written by the variance GEMM (gp_functions.py:125-126,136: kss = sf^2, no noise), and the
-// transposition of mean to the caller's [B][Ny] layout.  One thread per test point.
+// written by the variance kernels (gp_functions.py:125-126,136: kss = sf^2, no noise), and the
+// transposition of mean to the caller's [B][Ny] layout.  One workgroup per test point, fixed-order
+// (deterministic) reduction over the row tiles.  grid (B), 256 threads.
 __global__ void __launch_bounds__(256) var_finish_kernel(const double* __restrict__ part, const double* __restrict__ meanT,
                                                          const double* __restrict__ hyper, double* __restrict__ mean,
                                                          double* __restrict__ var, int B, int Bp, int Ny, int d,
                                                          int tilesM) {
-    const int b = blockIdx.x * 256 + threadIdx.x;
-    if (b >= B) return;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    __shared__ double red[4];
     for (int a = 0; a < Ny; ++a) {
-        const double sf = hyper[(long)a * (d + 2) + d];
-        double s = 0.0;
-        for (int t = 0; t < tilesM; ++t) s += part[((long)a * tilesM + t) * Bp + b];
-        if (var) var[(long)b * Ny + a] = sf * sf - s;
-        if (mean) mean[(long)b * Ny + a] = meanT[(long)a * Bp + b];
+        if (var) {
+            double s = 0.0;
+            for (int t = tid; t < tilesM; t += 256) s += part[((long)a * tilesM + t) * Bp + b];
+            s = wave_sum(s);
+            if ((tid & 63) == 0) red[tid >> 6] = s;
+            __syncthreads();
+            if (tid == 0) {
+                const double sf = hyper[(long)a * (d + 2) + d];
+                var[(long)b * Ny + a] = sf * sf - ((red[0] + red[1]) + (red[2] + red[3]));
+            }
+            __syncthreads();
+        }
+        if (mean && tid == 0) mean[(long)b * Ny + a] = meanT[(long)a * Bp + b];
     }
+}
+
+// Small-batch predictive variance (the per-shooting-node pattern of the MPC, B <= 8): stream the lower
+// triangle of L^-1 ONCE from HBM and form v_i = sum_k invL[i][k] ks_j[k] for all NB test points at once,
+// one wave per row (16 B per lane, 1 KB per wave-instruction), rows dealt so that every workgroup gets
+// the same amount of the triangle.  HBM-read bound: 4 N (N+1) bytes per output for up to 8 predictions.
+// grid (Np/32, Ny), 256 threads: 4 waves x 8 rows; part[a][blockIdx.x][j] = sum over the block's rows of v_i^2.
+template <int NB>
+__global__ void __launch_bounds__(256) var_small_kernel(const double* __restrict__ Inv, const double* __restrict__ KsT,
+                                                        double* __restrict__ part, int Np, int Bp) {
+    const int a = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nblk = gridDim.x;
+    __shared__ double red[4][NB];
+    const double* __restrict__ Ia = Inv + (long)a * Np * Np;
+    const double* __restrict__ ks = KsT + (long)a * Bp * Np;
+    double sq[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) sq[j] = 0.0;
+    for (int rr = 0; rr < 8; ++rr) {
+        // rows are dealt block-cyclically over the workgroups: balanced triangular work
+        const int i = ((rr * 4 + wave) * nblk + (int)blockIdx.x);
+        const double* __restrict__ row = Ia + (long)i * Np;
+        double acc[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc[j] = 0.0;
+        for (int k = 2 * lane; k <= i; k += 128) {
+            const double2 l = *reinterpret_cast<const double2*>(row + k);   // row[i+1] is an exact zero (upper part)
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const double2 x = *reinterpret_cast<const double2*>(ks + (long)j * Np + k);
+                acc[j] += l.x * x.x + l.y * x.y;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const double v = wave_sum(acc[j]);
+            sq[j] += v * v;
+        }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < NB; ++j) red[wave][j] = sq[j];
+    }
+    __syncthreads();
+    if (tid < NB) part[((long)a * nblk + blockIdx.x) * Bp + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
 }
 
 // Analytic mean Jacobian J[b][a][dd] = sum_i alpha_i ks_i (X_i,dd - z_dd) / ell_dd^2 (what CasADi's

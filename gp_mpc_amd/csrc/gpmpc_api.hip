@@ -695,7 +695,15 @@ static int predict_chunk(gpmpc_gp* h, int B, const double* dZ, double* dMean, do
         launch_crosscov(cx.stream, h->d, h->XT, h->ws.hyper, h->ws.alpha, dZ, h->KsT, h->meanT, h->N, Np, B, Bp, Ny);
     }
     int tilesM = 0;
-    if (dVar) {
+    if (dVar && B <= 8) {
+        PhaseTimer t(h, GPMPC_PH_VARGEMM);   // small batch: stream L^-1 once (HBM-bound), no MFMA padding waste
+        tilesM = Np / 32;
+        const dim3 grid(tilesM, Ny);
+        if (B == 1) hipLaunchKernelGGL((var_small_kernel<1>), grid, dim3(256), 0, cx.stream, h->ws.Inv, h->KsT, h->part, Np, Bp);
+        else if (B == 2) hipLaunchKernelGGL((var_small_kernel<2>), grid, dim3(256), 0, cx.stream, h->ws.Inv, h->KsT, h->part, Np, Bp);
+        else if (B <= 4) hipLaunchKernelGGL((var_small_kernel<4>), grid, dim3(256), 0, cx.stream, h->ws.Inv, h->KsT, h->part, Np, Bp);
+        else hipLaunchKernelGGL((var_small_kernel<8>), grid, dim3(256), 0, cx.stream, h->ws.Inv, h->KsT, h->part, Np, Bp);
+    } else if (dVar) {
         PhaseTimer t(h, GPMPC_PH_VARGEMM);
         GemmP p = gemm_base(cx);  // V = L^-1 Ks, reduced to column sums of squares in the epilogue
         p.A = h->ws.Inv; p.lda = Np; p.sA = (long)Np * Np; p.a_mc = 0; p.kflags = KA_LE_M;
@@ -709,7 +717,7 @@ static int predict_chunk(gpmpc_gp* h, int B, const double* dZ, double* dMean, do
     }
     {
         PhaseTimer t(h, GPMPC_PH_FINISH);
-        hipLaunchKernelGGL(var_finish_kernel, dim3((B + 255) / 256), dim3(256), 0, cx.stream, h->part, h->meanT,
+        hipLaunchKernelGGL(var_finish_kernel, dim3(B), dim3(256), 0, cx.stream, h->part, h->meanT,
                            h->ws.hyper, dMean, dVar, B, Bp, Ny, h->d, tilesM);
         if (dJ)
             hipLaunchKernelGGL(mean_jac_kernel, dim3(B, Ny), dim3(256), 0, cx.stream, h->XT, h->ws.hyper,

@@ -30,18 +30,25 @@ static int predict_moments_chunk(gpmpc_gp* h, int method, int B, const double* d
     CHK(ensure_beta(h));
     if (method == GPMPC_EM) {
         PhaseTimer t(h, GPMPC_PH_EM);
+        if (d > EMK) return fail(GPMPC_EINVAL, "EM: input dimension d=%d exceeds the MFMA cross-term depth %d", d, EMK);
         const int P = Ny * (Ny + 1) / 2, tiles = Np / 64;
         const long prepN = (long)B * (Ny + P) * (d * d + 1), partN = (long)B * P * tiles;
-        CHK(ensure_em_scratch(h, (prepN + partN) * (long)sizeof(double)));
+        const long opsN = (long)B * P * (2 * EMK + 2) * Np;
+        CHK(ensure_em_scratch(h, (prepN + partN + opsN) * (long)sizeof(double)));
         double* prep = h->em;
         double* partial = h->em + prepN;
+        double* ops = partial + partN;
         const long items = (long)B * (Ny + P);
         hipLaunchKernelGGL(em_prep_kernel, dim3((unsigned)((items + 63) / 64)), dim3(64), 0, cx.stream, h->ws.hyper, dSigma,
                            prep, B, Ny, d);
         hipLaunchKernelGGL(em_mean_kernel, dim3(Ny, B), dim3(256), 0, cx.stream, h->XT, dZ, h->beta, prep, dMean, N, Np, d,
                            Ny);
-        launch_em_pair(cx.stream, d, dim3(tiles, P, B), h->XT, dZ, h->ws.hyper, h->beta, h->ws.InvK, prep, partial, N, Np,
-                       Ny);
+        hipLaunchKernelGGL(em_operands_kernel, dim3((Np + 255) / 256, P, B), dim3(256), 0, cx.stream, h->XT, dZ, h->ws.hyper,
+                           prep, ops, N, Np, d, Ny);
+        hipLaunchKernelGGL((em_pair_kernel<false>), dim3(tiles, P, B), dim3(256), 0, cx.stream, ops, h->beta, h->ws.InvK,
+                           partial, N, Np, Ny, cx.crow_mode);
+        hipLaunchKernelGGL((em_pair_kernel<true>), dim3(tiles, P, B), dim3(256), 0, cx.stream, ops, h->beta, h->ws.InvK,
+                           partial, N, Np, Ny, cx.crow_mode);
         hipLaunchKernelGGL(em_finish_kernel, dim3((unsigned)(((long)B * P + 63) / 64)), dim3(64), 0, cx.stream, partial, prep,
                            h->ws.hyper, dMean, dCov, B, Ny, d, tiles);
         HIPCHK(hipGetLastError());
