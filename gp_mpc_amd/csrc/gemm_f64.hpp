@@ -26,6 +26,7 @@
 //     XCD-contiguous 8 x 8 patch order -- `remap` -- was measured 1.6x SLOWER on the variance GEMM:
 //     it hands all heavy rows to one XCD.  It is kept only for the micro-benchmark.)
 #pragma once
+#include <cstdlib>
 #include "mfma_f64.hpp"
 
 #ifndef GPMPC_GEMM_SPLIT
@@ -62,6 +63,7 @@ struct GemmP {
     int pair;             // set by the launcher
     int tilesMe, tilesNe; // effective tile grid (after pairing), set by the launcher
     int remap;            // 1: XCD-contiguous 8 x 8 patch order, 0: plain row-major tile order
+    int npad;             // row-major order: padded width of the tile grid (set by the launcher)
 };
 
 template <int BM, int BN, int BK, int WGM, int WGN, bool AMC, bool BNC, bool SPLIT = GPMPC_GEMM_SPLIT>
@@ -89,8 +91,12 @@ __global__ void __launch_bounds__(64 * WGM * WGN, (WGM * WGN >= 8 ? 4 : 2)) gemm
         tme = prow * 8 + ((rem & 63) >> 3);
         tne = (rem >> 6) * 8 + (rem & 7);
     } else {
-        tme = (int)blockIdx.x / p.tilesNe;
-        tne = (int)blockIdx.x % p.tilesNe;
+        // row-major tile order, heavy rows first; optionally over a grid whose width is padded to a
+        // multiple of 8 so that XCD x (which receives workgroups x, x+8, ...) always works on tile
+        // columns = x (mod 8) and its concurrent workgroups share operand panels in its private L2.
+        const int wpad = p.npad;
+        tme = (int)blockIdx.x / wpad;
+        tne = (int)blockIdx.x % wpad;
     }
     if (tme >= p.tilesMe || tne >= p.tilesNe) return;
 
@@ -303,7 +309,12 @@ inline void launch_gemm_cfg(GemmP p, int batch, hipStream_t stream, int resident
         }
     }
     const int prows = (p.tilesMe + 7) / 8, pcols = (p.tilesNe + 7) / 8;
-    dim3 grid(p.remap ? prows * pcols * 64 : p.tilesMe * p.tilesNe, 1, batch);
+    // XCD-consistent column residues (pad the grid width to a multiple of 8) cut the fetched bytes of the
+    // variance GEMM by 27 % (3.33 -> 2.43 GB raw FETCH_SIZE) but cost 1-3 % time on every shape measured
+    // (the kernels are MFMA-issue bound, not L2 bound): off by default, GPMPC_PAD_MIN=<tiles> enables it.
+    static const int pad_min = getenv("GPMPC_PAD_MIN") ? atoi(getenv("GPMPC_PAD_MIN")) : (1 << 30);
+    p.npad = (p.tilesNe >= pad_min) ? ((p.tilesNe + 7) & ~7) : p.tilesNe;
+    dim3 grid(p.remap ? prows * pcols * 64 : p.tilesMe * p.npad, 1, batch);
     const dim3 block(64 * WGM * WGN);
     if (!p.a_mc && !p.b_nc)
         hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, BK, WGM, WGN, false, false>), grid, block, 0, stream, p);

@@ -89,7 +89,9 @@ static int mfma_selftest(int device, int* layout_out, double* tflops_out) {
 #ifndef GPMPC_EMULATED
         hipDeviceProp_t prop;
         HIPCHK(hipGetDeviceProperties(&prop, device));
-        const int blocks = prop.multiProcessorCount * 2, iters = 4096;
+        // 4 workgroups x 4 waves per CU = 4 waves per SIMD (one wave alone can only issue an f64 MFMA every
+        // ~142 cycles); long enough that the ramp and tail of the launch do not matter
+        const int blocks = prop.multiProcessorCount * 4, iters = 16384;
         double* dOut;
         HIPCHK(hipMalloc(&dOut, (size_t)blocks * 256 * sizeof(double)));
         hipEvent_t e0, e1;
