@@ -67,7 +67,7 @@ struct GemmP {
 };
 
 template <int BM, int BN, int BK, int WGM, int WGN, bool AMC, bool BNC, bool SPLIT = GPMPC_GEMM_SPLIT>
-__global__ void __launch_bounds__(64 * WGM * WGN, (WGM * WGN >= 8 ? 4 : 2)) gemm_f64_kernel(GemmP p) {
+__global__ void __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) gemm_f64_kernel(GemmP p) {
     constexpr int NT = 64 * WGM * WGN;
     constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 16, TN = WN / 16;
     constexpr int HK = BK / 2, QK = BK / 4;                    // double2 per tile row, MFMA k-groups

@@ -41,40 +41,23 @@ __device__ __forceinline__ void lds_sub16(double* S, int r0, int c0, d4 v, int l
     for (int r = 0; r < 4; ++r) S[(r0 + crow(lane, r, mode)) * LS + c0 + (lane & 15)] -= v[r];
 }
 
-// One wave: Cholesky of the 16 x 16 block at (o,o) of S (if FACTOR) and its inverse into T.
-// Lane r (< 16) owns row r in registers; lanes >= 16 shadow rows r & 15 so that every lane
-// executes the same broadcasts.  Returns the first non-positive pivot column (0-based, local) or -1.
-template <bool FACTOR>
-__device__ __forceinline__ int potrf16_inv16(double* S, double* T, int o, int lane, const double* Drinv = nullptr) {
+// One wave: inverse of the 16 x 16 lower-triangular block at (o,o) of S into T.  Lane r (< 16) owns row r
+// of the block in registers and builds COLUMN r of the inverse by forward substitution; l_ik comes from
+// lane i's register a[k] through an SGPR broadcast.  Lanes >= 16 shadow rows r & 15 so that every lane
+// executes the same broadcasts.  Drinv: reciprocal pivots left in LDS by panel_potrf (no divisions on the
+// factorisation path); nullptr (inverse-only entry, gpmpc_set_factors) divides.
+__device__ __forceinline__ void inv16(const double* S, double* T, int o, int lane, const double* Drinv) {
     const int r = lane & 15;
     double a[16], rinv[16], x[16];
-    int bad = -1;
 #pragma unroll
     for (int c = 0; c < 16; ++c) a[c] = (c <= r) ? S[(o + r) * LS + o + c] : 0.0;
-    if (FACTOR) {
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const double ajj = bcast(a[j], j);
-            if (!(ajj > 0.0) && bad < 0) bad = j;  // also catches NaN; wave-uniform
-            const double ri = rsqrt(ajj);
-            rinv[j] = ri;
-            const double lj = (r == j) ? ajj * ri : a[j] * ri;
-            a[j] = lj;
-#pragma unroll
-            for (int k = j + 1; k < 16; ++k) a[k] -= lj * bcast(lj, k);
-        }
-        if (lane < 16) {
-#pragma unroll
-            for (int c = 0; c < 16; ++c) S[(o + r) * LS + o + c] = (c <= r) ? a[c] : 0.0;
-        }
-    } else if (Drinv) {   // reciprocal pivots left in LDS by panel_potrf: no divisions on this path
+    if (Drinv) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) rinv[j] = Drinv[o + j];
     } else {
 #pragma unroll
         for (int j = 0; j < 16; ++j) rinv[j] = 1.0 / bcast(a[j], j);
     }
-    // column r of the inverse by forward substitution; l_ik comes from lane i's register a[k]
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
         double s = (i == r) ? 1.0 : 0.0;
@@ -86,7 +69,6 @@ __device__ __forceinline__ int potrf16_inv16(double* S, double* T, int o, int la
 #pragma unroll
         for (int i = 0; i < 16; ++i) T[(o + i) * LS + o + r] = x[i];
     }
-    return bad;
 }
 
 // One wave: Cholesky of the 64 x 16 panel = rows 16t..63 of columns 16t..16t+15 of S (LDS), lane = row.
@@ -149,7 +131,7 @@ __global__ void __launch_bounds__(256) leaf64_kernel(const double* Ain, double* 
                 const int b = panel_potrf(S, Dr, t, lane);
                 if (b >= 0 && bad < 0) bad = 16 * t + b;
             } else if (wave == 1 && t >= 1 && (phases & 4)) {
-                potrf16_inv16<false>(S, T, 16 * (t - 1), lane, Dr);   // inverse of the previous diagonal block
+                inv16(S, T, 16 * (t - 1), lane, Dr);   // inverse of the previous diagonal block
             }
             __syncthreads();
             // rank-16 update of the remaining lower tiles: A_ij -= L_it L_jt^T, t < j <= i <= 3
@@ -164,11 +146,11 @@ __global__ void __launch_bounds__(256) leaf64_kernel(const double* Ain, double* 
                     }
             if (t < 3) __syncthreads();
         }
-        if (wave == 1 && (phases & 4)) potrf16_inv16<false>(S, T, 48, lane, Dr);
+        if (wave == 1 && (phases & 4)) inv16(S, T, 48, lane, Dr);
         __syncthreads();
         if (wave == 0 && lane == 0 && bad >= 0) atomicCAS(&info[blockIdx.z], 0, off + bad + 1);
     } else {
-        potrf16_inv16<false>(S, T, 16 * wave, lane);
+        inv16(S, T, 16 * wave, lane, nullptr);
         __syncthreads();
     }
 

@@ -228,24 +228,19 @@ class GP:
                     noise_var=self.__hyper_noise_variance, mean=self.__hyper_mean)
 
     def print_hyper_parameters(self):
-        """gp_class.py:293-312."""
-        print('\n________________________________________')
-        print('# Hyper-parameters')
-        print('----------------------------------------')
-        print('* Num samples:', self.__N)
-        print('* Ny:', self.__Ny)
-        print('* Nu:', self.__Nu)
-        print('* Normalization:', self.__normalize)
-        for state in range(self.__Ny):
-            print('----------------------------------------')
-            print('* Lengthscale: ', state)
-            for i in range(self.__Ny + self.__Nu):
-                print(('-- l{a}: {l}').format(a=i, l=self.__hyper_length_scales[state, i]))
-            print('* Signal variance: ', state)
-            print('-- sf2:', self.__hyper_signal_variance[state])
-            print('* Noise variance: ', state)
-            print('-- sn2:', self.__hyper_noise_variance[state])
-        print('----------------------------------------')
+        """Print all hyper-parameters (what gp_class.py:293-312 reports: sizes, per output the d
+        length scales, signal variance sf^2 and noise variance sn^2)."""
+        rule = '-' * 40
+        lines = ['', '_' * 40, '# Hyper-parameters', rule,
+                 f'* Num samples: {self.__N}', f'* Ny: {self.__Ny}', f'* Nu: {self.__Nu}',
+                 f'* Normalization: {self.__normalize}']
+        for a in range(self.__Ny):
+            lines += [rule, f'* Lengthscale:  {a}']
+            lines += [f'-- l{i}: {ell}' for i, ell in enumerate(self.__hyper_length_scales[a])]
+            lines += [f'* Signal variance:  {a}', f'-- sf2: {self.__hyper_signal_variance[a]}',
+                      f'* Noise variance:  {a}', f'-- sn2: {self.__hyper_noise_variance[a]}']
+        lines.append(rule)
+        print('\n'.join(lines))
 
     def covSEard(self, X, Z, ell, sf2):
         """GP squared exponential kernel k(X, Z) (gp_class.py:314-350), evaluated on the device."""
@@ -340,27 +335,22 @@ class GP:
 
     # ------------------------------------------------------------------ persistence (gp_class.py:693-743)
     def _to_dict(self):
+        """Model as plain lists under the key names of the reference's file format
+        (gp_class.py:693-726), factors exported from the device."""
         f = self._h.get_factors(chol=True, alpha=True, invK=True)
-        gp_dict = {}
-        gp_dict['X'] = self.__X.tolist()
-        gp_dict['Y'] = self.__Y.tolist()
-        gp_dict['hyper'] = dict(
-            hyper=self.__hyper.tolist(), invK=f['invK'].tolist(), alpha=f['alpha'].tolist(),
-            chol=f['chol'].tolist(), length_scale=self.__hyper_length_scales.tolist(),
-            signal_var=self.__hyper_signal_variance.tolist(), noise_var=self.__hyper_noise_variance.tolist(),
-            mean=self.__hyper_mean.tolist())
-        gp_dict['mean_func'] = self.__mean_func
-        gp_dict['normalize'] = self.__normalize
+        as_list = lambda v: np.asarray(v).tolist()
+        out = {'X': as_list(self.__X), 'Y': as_list(self.__Y),
+               'hyper': {k: as_list(v) for k, v in (
+                   ('hyper', self.__hyper), ('invK', f['invK']), ('alpha', f['alpha']), ('chol', f['chol']),
+                   ('length_scale', self.__hyper_length_scales), ('signal_var', self.__hyper_signal_variance),
+                   ('noise_var', self.__hyper_noise_variance), ('mean', self.__hyper_mean))},
+               'mean_func': self.__mean_func, 'normalize': self.__normalize}
         if self.__normalize:
-            gp_dict['xlb'] = self.__xlb.tolist()
-            gp_dict['xub'] = self.__xub.tolist()
-            gp_dict['ulb'] = self.__ulb.tolist()
-            gp_dict['uub'] = self.__uub.tolist()
-            gp_dict['meta'] = dict(
-                meanY=self.__meanY.tolist(), stdY=self.__stdY.tolist(), meanZ=self.__meanZ.tolist(),
-                stdZ=self.__stdZ.tolist(), meanX=self.__meanX.tolist(), stdX=self.__stdX.tolist(),
-                meanU=self.__meanU.tolist(), stdU=self.__stdU.tolist())
-        return gp_dict
+            for k in ('xlb', 'xub', 'ulb', 'uub'):
+                out[k] = as_list(getattr(self, '_GP__' + k))
+            out['meta'] = {k: as_list(getattr(self, '_GP__' + k))
+                           for k in ('meanY', 'stdY', 'meanZ', 'stdZ', 'meanX', 'stdX', 'meanU', 'stdU')}
+        return out
 
     def save_model(self, filename):
         """Save model to `filename`.json in the reference's format (gp_class.py:729-734)."""

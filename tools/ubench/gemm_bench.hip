@@ -37,6 +37,9 @@ int main() {
     VAR(128, 128, 16, 2, 2, 512)
     VAR(128, 128, 16, 2, 4, 512)
     VAR(128, 128, 16, 4, 2, 512)
+    VAR(128, 128, 16, 4, 4, 512)
+    VAR(256, 128, 16, 4, 4, 256)
+    VAR(128, 256, 16, 4, 4, 256)
     //VAR(128, 64, 16, 2, 2, 768)
     //VAR(64,128,16,2,2,768)
     VAR(64, 64, 16, 2, 2, 1024)
