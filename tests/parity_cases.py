@@ -372,3 +372,57 @@ def check_training(lib, t):
     for a in range(Y.shape[1]):
         assert relF(f['chol'][a], o['chol'][a]) <= 1e-9
     gp.close()
+
+
+def check_edge_cases(lib):
+    """Ragged / minimal / maximal shapes and the error behaviour of the C ABI."""
+    from gp_mpc_amd._lib import GpmpcError, EINVAL, ENOTFIT
+    rng = np.random.default_rng(11)
+    for (N, d, Ny) in [(1, 1, 1), (2, 3, 2), (63, 2, 1), (64, 16, 1), (65, 5, 3), (130, 1, 2)]:
+        X = rng.standard_normal((N, d))
+        Y = rng.standard_normal((N, Ny))
+        H = np.hstack([rng.uniform(0.7, 2.0, (Ny, d)), rng.uniform(0.8, 1.5, (Ny, 1)), np.full((Ny, 1), 0.1)])
+        h = Handle(lib, X, Y)
+        assert np.all(h.fit(H, want_invK=True) == 0)
+        o = go.fit(X, Y, H)
+        f = h.get_factors(invK=True)
+        for a in range(Ny):
+            assert relF(f['chol'][a], o['chol'][a]) <= 1e-12 and relF(f['invK'][a], o['invK'][a]) <= 1e-10
+            assert relF(f['alpha'][a], o['alpha'][a]) <= 1e-10
+        for B in (1, 7, 8, 9, 64, 65):
+            Z = rng.standard_normal((B, d))
+            mean, var = h.predict_mean_var(Z)
+            om, ov, oJ = go.mean_var_jac(Z, X, H, o['alpha'], o['chol'])
+            assert np.max(np.abs(mean - om)) <= 1e-11 * max(1.0, np.abs(om).max())
+            assert np.max(np.abs(var - ov) / (H[:, d] ** 2)) <= 1e-12
+            _, J = h.mean_jac(Z)
+            assert np.max(np.abs(J - oJ)) <= 1e-10 * max(1.0, np.abs(oJ).max())
+        if d <= 8:
+            S = go.synthetic_problem(4, d, 1, 3, seed=2)['Sigma'] * 20
+            Z3 = rng.standard_normal((3, d))
+            m, c = h.predict('EM', Z3, S)
+            for b in range(3):
+                om, oc = go.exact_moment(f['invK'], X, Y, H, Z3[b], S[b])
+                assert np.max(np.abs(m[b] - om)) <= 1e-9 * max(1.0, np.abs(om).max())
+                assert np.max(np.abs(c[b] - oc)) <= 1e-8 * max(1.0, np.abs(oc).max(), (H[:, d] ** 2).max())
+        h.close()
+    # error behaviour: status codes, no silent fallbacks
+    X, Y = rng.standard_normal((10, 3)), rng.standard_normal((10, 1))
+    h = Handle(lib, X, Y)
+    for fn, code in ((lambda: h.predict_mean_var(X[:2]), ENOTFIT),
+                     (lambda: h.fit(np.array([[1.0, 1.0, np.nan, 1.0, 0.1]])), EINVAL),
+                     (lambda: h.fit(np.array([[1.0, 0.0, 1.0, 1.0, 0.1]])), EINVAL)):
+        try:
+            fn()
+            assert False
+        except GpmpcError as e:
+            assert e.code == code, (e.code, code)
+    h.fit(np.array([[1.0, 1.0, 1.0, 1.0, 0.1]]))
+    for fn in (lambda: h.predict(7, X[:2], None), lambda: h.predict('TA', X[:2], None),
+               lambda: Handle(lib, rng.standard_normal((5, 17)), rng.standard_normal((5, 1)))):
+        try:
+            fn()
+            assert False
+        except GpmpcError as e:
+            assert e.code == EINVAL
+    h.close()

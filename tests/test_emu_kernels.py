@@ -78,3 +78,7 @@ def test_emu_gp_class_car(emu, car, tmp_path):
 
 def test_emu_training(emu, train_small):
     pc.check_training(emu, train_small)
+
+
+def test_emu_edge_cases(emu):
+    pc.check_edge_cases(emu)

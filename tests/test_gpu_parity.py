@@ -102,3 +102,35 @@ def test_gp_class(lib, tank, tmp_path):
 
 def test_training(lib, train_small):
     pc.check_training(lib, train_small)
+
+
+def test_edge_cases(lib):
+    pc.check_edge_cases(lib)
+
+
+def test_c3_size_properties(lib):
+    """BASELINE config C3 size (6 outputs, N=8192, d=8): too large for the oracle in seconds, so
+    size-independent properties: mean at training inputs satisfies K alpha = y exactly
+    (mean(x_i) = y_i - sn^2 alpha_i), 0 < var <= sf^2, ME/TA/EM agree for a vanishing input covariance, EM covariance symmetric PSD."""
+    from gp_mpc_amd._lib import Handle
+    p = go.synthetic_problem(8192, 8, 6, 16, seed=1234, sn=1e-2)
+    h = Handle(lib, p['X'], p['Y'])
+    assert np.all(h.fit(p['hyper'], want_invK=True) == 0)
+    mt, vt = h.predict_mean_var(p['X'][:64])
+    al = h.get_factors(chol=False)['alpha']
+    sn2 = p['hyper'][:, 9] ** 2
+    resid = mt - (p['Y'][:64] - sn2[None, :] * al[:, :64].T)
+    assert np.max(np.abs(resid)) <= 1e-8 * np.abs(al).max()      # (K_se + sn^2 I) alpha = y, cond-scaled
+    assert np.all(vt > 0) and np.all(vt < 1.0)
+    Z = p['Z'][:4]
+    m0, v0 = h.predict_mean_var(Z)
+    tiny = np.tile(np.eye(8) * 1e-12, (4, 1, 1))
+    mT, cT = h.predict('TA', Z, tiny)
+    mE, cE = h.predict('EM', Z, tiny)
+    assert np.allclose(mT, m0, rtol=0, atol=1e-12) and np.allclose(mE, m0, rtol=1e-6, atol=1e-6)
+    assert np.allclose(np.einsum('baa->ba', cT), v0, rtol=1e-6, atol=1e-10)   # + J (1e-12 I) J^T
+    assert np.allclose(np.einsum('baa->ba', cE), v0, rtol=0, atol=1e-4)    # N^2-term sum against K^-1: cancellation-limited
+    mS, cS = h.predict('EM', Z, p['Sigma'][:4])
+    for b in range(4):
+        assert np.array_equal(cS[b], cS[b].T) and np.linalg.eigvalsh(cS[b]).min() > -1e-8
+    h.close()
