@@ -284,13 +284,14 @@ inline int gemm_pick_tile(const GemmP& p, int batch) {
         const long b = (long)((p.M + t - 1) / t) * ((p.N + t - 1) / t) * batch;
         return p.lower ? (b + 1) / 2 : b;
     };
+    if (p.N <= 32 || p.M <= 32) return 32;     // skinny products (a handful of prediction points)
     if (blocks(128) >= 512) return 128;
     if (blocks(64) >= 512) return 64;
     return 32;
 }
 
 template <int BM, int BN, int BK, int WGM, int WGN>
-inline void launch_gemm_cfg(GemmP p, int batch, hipStream_t stream, int resident) {
+inline void launch_gemm_cfg(GemmP p, int batch, hipStream_t stream, int resident, int min_pair_blocks = 512) {
     // operand orientations are compile-time (fewer registers and no branches in the staging code)
     const int tilesM = (p.M + BM - 1) / BM, tilesN = (p.N + BN - 1) / BN;
     p.pair = PAIR_NONE;
@@ -299,7 +300,7 @@ inline void launch_gemm_cfg(GemmP p, int batch, hipStream_t stream, int resident
     // balanced pairing only when the whole launch is co-resident (no back-filling possible)
     const bool one_flag = (p.kflags == KA_LE_M || p.kflags == KA_GE_M || p.kflags == KB_LE_N || p.kflags == KB_GE_N);
     const long nblocks = (long)tilesM * tilesN * batch;
-    if (one_flag && !p.lower && nblocks <= (long)resident && nblocks >= 512) {   // small launches want parallelism, not balance
+    if (one_flag && !p.lower && nblocks <= (long)resident && nblocks >= min_pair_blocks) {   // small launches want parallelism, not balance
         if ((p.kflags & (KA_LE_M | KA_GE_M)) && tilesM >= 2) {
             p.pair = PAIR_M;
             p.tilesMe = (tilesM + 1) / 2;

@@ -89,16 +89,19 @@ __global__ void __launch_bounds__(256) kernel_matrix_kernel(const double* __rest
 }
 
 // a9 (first half): ks_a(X, z_j) for JT test points per workgroup, written as KsT[a][j][:], fused
-// with mean_a(z_j) = ks^T alpha_a (gp_functions.py:114-120,135).  grid (Bp/JT, Ny), 256 threads.
+// with mean_a(z_j) = ks^T alpha_a (gp_functions.py:114-120,135) and, if JAC, with the analytic mean
+// Jacobian J[j][a][dd] = sum_i alpha_i ks_i (X_i,dd - z_dd) / ell_dd^2 (what CasADi's AD yields for
+// mean_jac_z, gp_functions.py:146-147).  grid (Bp/JT, Ny), 256 threads.
 // D (the GP input dimension) is a template parameter so that a training point's coordinates live in
 // registers and the distance loop is fully unrolled; the JT test points are wave-uniform LDS reads.
-template <int D, int JT>
+template <int D, int JT, bool JAC>
 __global__ void __launch_bounds__(256) crosscov_kernel(const double* __restrict__ XT, const double* __restrict__ hyper,
                                                        const double* __restrict__ alpha, const double* __restrict__ Z,
                                                        double* __restrict__ KsT, double* __restrict__ meanT,
-                                                       int N, int Np, int B, int Bp) {
+                                                       double* __restrict__ J, int N, int Np, int B, int Bp, int Ny) {
     const int j0 = blockIdx.x * JT, a = blockIdx.y, tid = threadIdx.x;
-    __shared__ double Zs[JT][D], w[D], red[4][JT];
+    constexpr int NR = JAC ? JT * (D + 1) : JT;
+    __shared__ double Zs[JT][D], w[D], red[4][NR];
     const double* hy = hyper + (long)a * (D + 2);
     if (tid < JT * D) {
         const int jj = tid / D, dd = tid % D;
@@ -107,9 +110,15 @@ __global__ void __launch_bounds__(256) crosscov_kernel(const double* __restrict_
     if (tid < D) w[tid] = 1.0 / (hy[tid] * hy[tid]);
     const double sf2 = hy[D] * hy[D];
     __syncthreads();
-    double macc[JT];
+    double macc[JT], jacc[JAC ? JT : 1][D];
 #pragma unroll
     for (int jj = 0; jj < JT; ++jj) macc[jj] = 0.0;
+    if (JAC) {
+#pragma unroll
+        for (int jj = 0; jj < JT; ++jj)
+#pragma unroll
+            for (int dd = 0; dd < D; ++dd) jacc[jj][dd] = 0.0;
+    }
     const double* __restrict__ al = alpha + (long)a * Np;
     double* __restrict__ out = KsT + ((long)a * Bp + j0) * Np;
     for (int i = tid; i < Np; i += 256) {
@@ -120,38 +129,61 @@ __global__ void __launch_bounds__(256) crosscov_kernel(const double* __restrict_
         const bool live = i < N;
 #pragma unroll
         for (int jj = 0; jj < JT; ++jj) {
-            double dist = 0.0;
+            double dist = 0.0, df[D];
 #pragma unroll
             for (int dd = 0; dd < D; ++dd) {
-                const double df = x[dd] - Zs[jj][dd];
-                dist += df * df * w[dd];
+                df[dd] = x[dd] - Zs[jj][dd];
+                dist += df[dd] * df[dd] * w[dd];
             }
             const double ks = (live && j0 + jj < B) ? sf2 * exp(-0.5 * dist) : 0.0;
             out[(long)jj * Np + i] = ks;
-            macc[jj] += ks * ai;
+            const double ka = ks * ai;
+            macc[jj] += ka;
+            if (JAC) {
+#pragma unroll
+                for (int dd = 0; dd < D; ++dd) jacc[jj][dd] += ka * df[dd];
+            }
         }
     }
 #pragma unroll
     for (int jj = 0; jj < JT; ++jj) {
         const double s = wave_sum(macc[jj]);
         if ((tid & 63) == 0) red[tid >> 6][jj] = s;
+        if (JAC) {
+#pragma unroll
+            for (int dd = 0; dd < D; ++dd) {
+                const double t = wave_sum(jacc[jj][dd]);
+                if ((tid & 63) == 0) red[tid >> 6][JT + jj * D + dd] = t;
+            }
+        }
     }
     __syncthreads();
-    if (tid < JT) meanT[(long)a * Bp + j0 + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+    if (tid < JT) meanT[(long)a * Bp + j0 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+    if (JAC && tid >= JT && tid < NR) {
+        const int e = tid - JT, jj = e / D, dd = e % D;
+        if (j0 + jj < B)
+            J[((long)(j0 + jj) * Ny + a) * D + dd] = ((red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid])) * w[dd];
+    }
 }
 
-constexpr int CROSSCOV_JT = 8;
+constexpr int CROSSCOV_JT = 8;       // test points per workgroup (4 when the Jacobian is accumulated as well)
 
 template <int D>
 inline void launch_crosscov_d(hipStream_t st, const double* XT, const double* hyper, const double* alpha,
-                              const double* Z, double* KsT, double* meanT, int N, int Np, int B, int Bp, int Ny) {
-    hipLaunchKernelGGL((crosscov_kernel<D, CROSSCOV_JT>), dim3(Bp / CROSSCOV_JT, Ny), dim3(256), 0, st, XT, hyper, alpha,
-                       Z, KsT, meanT, N, Np, B, Bp);
+                              const double* Z, double* KsT, double* meanT, double* J, int N, int Np, int B, int Bp,
+                              int Ny) {
+    if (J)
+        hipLaunchKernelGGL((crosscov_kernel<D, 4, true>), dim3(Bp / 4, Ny), dim3(256), 0, st, XT, hyper, alpha, Z, KsT,
+                           meanT, J, N, Np, B, Bp, Ny);
+    else
+        hipLaunchKernelGGL((crosscov_kernel<D, CROSSCOV_JT, false>), dim3(Bp / CROSSCOV_JT, Ny), dim3(256), 0, st, XT,
+                           hyper, alpha, Z, KsT, meanT, J, N, Np, B, Bp, Ny);
 }
 
 inline void launch_crosscov(hipStream_t st, int d, const double* XT, const double* hyper, const double* alpha,
-                            const double* Z, double* KsT, double* meanT, int N, int Np, int B, int Bp, int Ny) {
-#define GPMPC_CC(DD) case DD: launch_crosscov_d<DD>(st, XT, hyper, alpha, Z, KsT, meanT, N, Np, B, Bp, Ny); break;
+                            const double* Z, double* KsT, double* meanT, double* J, int N, int Np, int B, int Bp,
+                            int Ny) {
+#define GPMPC_CC(DD) case DD: launch_crosscov_d<DD>(st, XT, hyper, alpha, Z, KsT, meanT, J, N, Np, B, Bp, Ny); break;
     switch (d) {
         GPMPC_CC(1) GPMPC_CC(2) GPMPC_CC(3) GPMPC_CC(4) GPMPC_CC(5) GPMPC_CC(6) GPMPC_CC(7) GPMPC_CC(8)
         GPMPC_CC(9) GPMPC_CC(10) GPMPC_CC(11) GPMPC_CC(12) GPMPC_CC(13) GPMPC_CC(14) GPMPC_CC(15) GPMPC_CC(16)
@@ -230,42 +262,6 @@ __global__ void __launch_bounds__(256) var_small_kernel(const double* __restrict
     }
     __syncthreads();
     if (tid < NB) part[((long)a * nblk + blockIdx.x) * Bp + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
-}
-
-// Analytic mean Jacobian J[b][a][dd] = sum_i alpha_i ks_i (X_i,dd - z_dd) / ell_dd^2 (what CasADi's
-// AD yields for mean_jac_z, gp_functions.py:146-147).  grid (B, Ny), 256 threads; reads the ks
-// vector the cross-covariance kernel left in KsT.
-__global__ void __launch_bounds__(256) mean_jac_kernel(const double* __restrict__ XT, const double* __restrict__ hyper,
-                                                       const double* __restrict__ alpha, const double* __restrict__ Z,
-                                                       const double* __restrict__ KsT, double* __restrict__ J,
-                                                       int N, int Np, int d, int Bp, int Ny) {
-    const int b = blockIdx.x, a = blockIdx.y, tid = threadIdx.x;
-    __shared__ double red[4][DMAX];
-    const double* hy = hyper + (long)a * (d + 2);
-    const double* __restrict__ ks = KsT + ((long)a * Bp + b) * Np;
-    const double* __restrict__ al = alpha + (long)a * Np;
-    double z[DMAX], acc[DMAX];
-#pragma unroll
-    for (int dd = 0; dd < DMAX; ++dd) {
-        z[dd] = (dd < d) ? Z[(long)b * d + dd] : 0.0;
-        acc[dd] = 0.0;
-    }
-    for (int i = tid; i < N; i += 256) {
-        const double c = ks[i] * al[i];
-#pragma unroll
-        for (int dd = 0; dd < DMAX; ++dd)
-            if (dd < d) acc[dd] += c * (XT[(long)dd * Np + i] - z[dd]);
-    }
-#pragma unroll
-    for (int dd = 0; dd < DMAX; ++dd) {
-        const double s = wave_sum(acc[dd]);
-        if ((tid & 63) == 0) red[tid >> 6][dd] = s;
-    }
-    __syncthreads();
-    if (tid < d) {
-        const double s = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
-        J[((long)b * Ny + a) * d + tid] = s / (hy[tid] * hy[tid]);
-    }
 }
 
 // a10 build_TA_cov gp_functions.py:152-173: cov[b] = diag(var[b]) + J[b] Sigma[b] J[b]^T

@@ -61,7 +61,7 @@ static int predict_moments_chunk(gpmpc_gp* h, int method, int B, const double* d
     CHK(ensure_em_scratch(h, (long)B * Ny * 4 * (long)sizeof(double)));
     {
         PhaseTimer t(h, GPMPC_PH_CROSSCOV);
-        launch_crosscov(cx.stream, d, h->XT, h->ws.hyper, h->ws.alpha, dZ, h->KsT, h->meanT, N, Np, B, Bp, Ny);
+        launch_crosscov(cx.stream, d, h->XT, h->ws.hyper, h->ws.alpha, dZ, h->KsT, h->meanT, nullptr, N, Np, B, Bp, Ny);
     }
     PhaseTimer t(h, GPMPC_PH_EM);
     GemmP p = gemm_base(cx);

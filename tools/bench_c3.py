@@ -49,11 +49,14 @@ for method in ('ME', 'TA', 'EM'):
 Z = p['Z'][:30]
 Sg = p['Sigma'][:30]
 h.predict('TA', Z, Sg)
+h.profile_read()
 t0 = time.perf_counter()
 for it in range(50):
     m, c = h.predict('TA', Z, Sg)
     m2, J = h.mean_jac(Z)
 dt = time.perf_counter() - t0
+prof = h.profile_read()
+print(json.dumps({'bench': 'C5 phases', 'phases_ms_per_call': {k: v[0] / 50 for k, v in prof.items() if v[1]}}))
 print(json.dumps({'bench': 'C5 IPOPT-pattern (Nt=30, value+J+TA cov per call)', 'calls': 50, 'ms_per_call': dt / 50 * 1e3,
                   'node_evals_per_s': 50 * 30 / dt}))
 h.close()
