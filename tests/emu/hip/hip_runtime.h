@@ -50,8 +50,10 @@ inline double __hiloint2double(int hi, int lo) {
 // ---------------------------------------------------------------- host runtime API subset
 typedef int hipError_t;
 enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorNoDevice = 100 };
-typedef struct emu_stream* hipStream_t;
-typedef struct emu_event { double t; } * hipEvent_t;
+struct emu_stream { int id; };
+typedef emu_stream* hipStream_t;
+struct emu_event { double t; long seq_recorded; long seq_done; };
+typedef emu_event* hipEvent_t;
 enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost,
                      hipMemcpyDeviceToDevice, hipMemcpyDefault };
 struct hipDeviceProp_t { char name[256]; int multiProcessorCount; char gcnArchName[256]; size_t totalGlobalMem; };
@@ -59,7 +61,20 @@ typedef struct emu_graph* hipGraph_t;
 typedef struct emu_graphexec* hipGraphExec_t;
 
 namespace emu {
-void launch(dim3 grid, dim3 block, const std::function<void()>& body);
+// shmem == 0: workgroups run one after another (static __shared__ arrays are shared by construction).
+// shmem  > 0: ALL workgroups run concurrently as fibers, each with its own dynamic-LDS buffer
+//             (emu::dyn_smem()), so kernels that synchronise BETWEEN workgroups through global
+//             memory (persistent task-queue kernels) can be executed and can dead-lock like on a GPU.
+// Launches are ASYNCHRONOUS like on a GPU: they are queued on their stream (nullptr = stream 0) and
+// executed at the next synchronisation point (stream/event/device synchronise, memcpy, memset, free).
+// Streams are in-order queues; the head kernels of different streams run concurrently (fiber
+// interleaving), events order work across streams.
+void launch(dim3 grid, dim3 block, const std::function<void()>& body, size_t shmem = 0, hipStream_t stream = nullptr);
+void drain();                                   // run everything that is queued
+void record(hipEvent_t e, hipStream_t s);
+void wait_event(hipStream_t s, hipEvent_t e);
+void* dyn_smem();
+void yield_thread();
 void syncthreads();
 double wave_xchg(double v, int src_lane);                 // value held by src_lane (all 64 lanes call)
 void mfma_f64_16x16x4(double a, double b, const double* c, double* d);
@@ -83,29 +98,29 @@ template <class T> inline hipError_t hipMalloc(T** p, size_t bytes) {
     *p = (T*)q;
     return hipSuccess;
 }
-inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
-inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { std::memcpy(d, s, n); return hipSuccess; }
-inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { std::memcpy(d, s, n); return hipSuccess; }
-inline hipError_t hipMemset(void* d, int v, size_t n) { std::memset(d, v, n); return hipSuccess; }
-inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { std::memset(d, v, n); return hipSuccess; }
-inline hipError_t hipStreamCreate(hipStream_t* s) { *s = nullptr; return hipSuccess; }
-inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
-inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
-inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+inline hipError_t hipFree(void* p) { emu::drain(); std::free(p); return hipSuccess; }
+inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { emu::drain(); std::memcpy(d, s, n); return hipSuccess; }
+inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { emu::drain(); std::memcpy(d, s, n); return hipSuccess; }
+inline hipError_t hipMemset(void* d, int v, size_t n) { emu::drain(); std::memset(d, v, n); return hipSuccess; }
+inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { emu::drain(); std::memset(d, v, n); return hipSuccess; }
+inline hipError_t hipStreamCreate(hipStream_t* s) { static int next_id = 1; *s = new emu_stream{next_id++}; return hipSuccess; }
+inline hipError_t hipStreamDestroy(hipStream_t s) { emu::drain(); delete s; return hipSuccess; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { emu::drain(); return hipSuccess; }
+inline hipError_t hipDeviceSynchronize() { emu::drain(); return hipSuccess; }
 inline hipError_t hipGetLastError() { return hipSuccess; }
 inline hipError_t hipPeekAtLastError() { return hipSuccess; }
 inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess" : "emulated HIP error"; }
 inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new emu_event{0.0}; return hipSuccess; }
 enum { hipEventDefault = 0, hipEventDisableTiming = 2 };
-inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = new emu_event{0.0}; return hipSuccess; }
-inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = new emu_event{0.0, 0, 0}; return hipSuccess; }
+inline hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned) { emu::wait_event(s, e); return hipSuccess; }
 inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
 inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t = emu::now_ms(); return hipSuccess; }
 inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
-inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(b->t - a->t); return hipSuccess; }
+inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) { emu::drain(); *ms = (float)(b->t - a->t); return hipSuccess; }
 
 #define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...) \
-    ::emu::launch(dim3(grid), dim3(block), [=]() { kern(__VA_ARGS__); })
+    ::emu::launch(dim3(grid), dim3(block), [=]() { kern(__VA_ARGS__); }, (size_t)(shmem), (hipStream_t)(stream))
 
 // ---------------------------------------------------------------- device-side subset
 inline void __syncthreads() { emu::syncthreads(); }
@@ -120,6 +135,22 @@ inline int emu_readlane(int v, int src) { return (int)emu::wave_xchg((double)v, 
 #define __builtin_amdgcn_readlane(v, l) emu_readlane((v), (l))
 #define __builtin_amdgcn_readfirstlane(v) emu_readlane((v), 0)
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
+#define __builtin_amdgcn_s_sleep(x) ::emu::yield_thread()
+// memory-model builtins: the emulator is sequentially consistent, fences are no-ops
+#define __builtin_amdgcn_fence(order, scope) ((void)0)
+#define __HIP_MEMORY_SCOPE_AGENT 4
+#define __HIP_MEMORY_SCOPE_WORKGROUP 2
+template <class T> inline T __hip_atomic_load(const T* p, int, int) { return *p; }
+template <class T> inline void __hip_atomic_store(T* p, T v, int, int) { *p = v; }
+template <class T> inline T __hip_atomic_fetch_add(T* p, T v, int, int) { T o = *p; *p = o + v; return o; }
+template <class T> inline bool __hip_atomic_compare_exchange_strong(T* p, T* expected, T desired, int, int, int) {
+    if (*p == *expected) { *p = desired; return true; }
+    *expected = *p;
+    return false;
+}
+inline void __threadfence() {}
+inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
+enum { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 
 typedef double emu_d4 __attribute__((vector_size(32)));

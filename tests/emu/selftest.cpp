@@ -19,15 +19,16 @@ __global__ void k_mfma(const double* A, const double* B, double* D) {  // A 16x4
 int main() {
     double in_[1000], out_[3]; double *in = in_, *out = out_;
     for (int i = 0; i < 1000; ++i) in[i] = i;
-    hipLaunchKernelGGL(k_reduce, dim3(3), dim3(256), 0, 0, in, out, 1000);
+    hipLaunchKernelGGL(k_reduce, dim3(3), dim3(256), 0, 0, in, out, 1000); hipDeviceSynchronize();
     for (int b = 0; b < 3; ++b) if (out[b] != 499500.0) { printf("reduce FAIL %g\n", out[b]); return 1; }
     double A_[64], B_[64], D_[256]; double *A = A_, *B = B_, *D = D_;
     for (int i = 0; i < 64; ++i) { A[i] = i + 1; B[i] = 2 * i - 7; }
-    hipLaunchKernelGGL(k_mfma, dim3(1), dim3(64), 0, 0, A, B, D);
+    hipLaunchKernelGGL(k_mfma, dim3(1), dim3(64), 0, 0, A, B, D); hipDeviceSynchronize();
     for (int i = 0; i < 16; ++i) for (int j = 0; j < 16; ++j) {
         double s = 0; for (int k = 0; k < 4; ++k) s += A[i * 4 + k] * B[k * 16 + j];
         if (s != D[i * 16 + j]) { printf("mfma FAIL %d %d\n", i, j); return 1; }
     }
+    hipDeviceSynchronize();
     printf("emu selftest OK\n");
     return 0;
 }
