@@ -1,0 +1,120 @@
+// Persistent chain kernel of the blocked Cholesky: ONE workgroup per matrix owns a CU for the whole
+// factorisation and runs the sequential part of every panel step back to back,
+//
+//     leaf(k):  L_kk = chol(A_kk), inv_kk = L_kk^-1                    (leaf_body, LDS resident)
+//     tile (k+1,k):    L_{k+1,k} = A_{k+1,k} inv_kk^T                   (MFMA on LDS operands)
+//     tile (k+1,k+1):  A_{k+1,k+1} -= L_{k+1,k} L_{k+1,k}^T             (stays in LDS: next leaf's input)
+//
+// while the bulk of each step -- the panel rows below and the trailing update -- runs in ordinary GEMM
+// launches on a second stream.  The two sides meet through global flags (wg_sync.hpp):
+//     leafdone[k]  chain -> panel(k) workgroups        (L_kk^-1 is in memory)
+//     pan1[k]      chain -> trailing(k) workgroups     (L_{k+1,k} is in memory)
+//     tdone[k][2]  trailing(k) -> chain                (tiles (k+2,k+1) and (k+2,k+2) carry step k's update)
+// Why: measured on MI355X, the leaf slows down 3-8x as soon as it shares a CU with MFMA-heavy waves
+// (tools/ubench/contention_bench.hip) and CU-masked streams do not isolate it, so overlapping the chain
+// with the bulk work needs a workgroup that keeps a CU to itself: this kernel asks for ~150 KB of LDS,
+// which no other workgroup of this library fits beside.
+// grid (1, 1, batch), 256 threads, dynamic LDS CHAIN_LDS_BYTES.
+#pragma once
+#include "leaf64.hpp"
+#include "wg_sync.hpp"
+
+namespace gpmpc {
+
+constexpr int CHAIN_LDS_BYTES = 150000;
+
+// flag layout per matrix (ints): [0] error, [1 .. nb] leafdone, [1+nb .. 2nb] pan1, [1+2nb .. 1+4nb) tdone[k][2]
+__host__ __device__ inline int chain_flag_count(int nb) { return 1 + 4 * nb; }
+
+#ifdef GPMPC_EMULATED
+#define GPMPC_DYN_SMEM() ((double*)::emu::dyn_smem())
+#else
+extern __shared__ __attribute__((aligned(16))) double gpmpc_dyn_smem[];
+#define GPMPC_DYN_SMEM() (gpmpc_dyn_smem)
+#endif
+
+// Gate for the side queue: one tiny workgroup per matrix that returns once the chain kernel has
+// published its first leaf, i.e. once every chain workgroup is resident.  Without it a batch of bulk
+// workgroups could fill the LDS of all CUs while polling and keep the chain from ever being placed.
+__global__ void __launch_bounds__(64) chain_gate_kernel(int* flags, long sFlags, int spin_limit) {
+    __shared__ int slot;
+    int* fl = flags + (long)blockIdx.x * sFlags;
+    wg_wait2(fl + 1, 1, nullptr, 0, fl, spin_limit, &slot);
+}
+
+__global__ void __launch_bounds__(256) chol_chain_kernel(const double* Kmat, double* L, double* Inv, long ld, long sBatch,
+                                                         int nb, int* flags, long sFlags, int* info, int crow_mode,
+                                                         int spin_limit) {
+    double* smem = GPMPC_DYN_SMEM();
+    double* S = smem;
+    double* T = S + 64 * LS;
+    double* U = T + 64 * LS;
+    double* Dr = U + 64 * LS;
+    int* slot = (int*)(Dr + 64);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long mb = (long)blockIdx.z * sBatch;
+    const double* __restrict__ Kb = Kmat + mb;
+    double* __restrict__ Lb = L + mb;
+    double* __restrict__ Ib = Inv + mb;
+    int* fl = flags + (long)blockIdx.z * sFlags;
+    int* err = fl;
+    int* leafdone = fl + 1;
+    int* pan1 = fl + 1 + nb;
+    int* tdone = fl + 1 + 2 * nb;
+
+    for (int idx = tid; idx < 4096; idx += 256) {
+        const int rr = idx >> 6, cc = idx & 63;
+        S[rr * LS + cc] = (cc <= rr) ? Kb[(long)rr * ld + cc] : 0.0;
+        T[rr * LS + cc] = 0.0;
+    }
+    __syncthreads();
+    for (int k = 0; k < nb; ++k) {
+        const long o = (long)(64 * k) * ld + 64 * k;
+        const int bad = leaf_body(S, T, U, Dr, 1, 15, crow_mode);
+        if (tid == 0 && bad >= 0) atomicCAS(&info[blockIdx.z], 0, 64 * k + bad + 1);
+        for (int idx = tid; idx < 4096; idx += 256) {
+            const int rr = idx >> 6, cc = idx & 63;
+            Lb[o + (long)rr * ld + cc] = (cc <= rr) ? S[rr * LS + cc] : 0.0;
+            Ib[o + (long)rr * ld + cc] = (cc <= rr) ? T[rr * LS + cc] : 0.0;
+        }
+        wg_publish(&leafdone[k], 1);
+        if (k + 1 == nb) break;
+        // the two tiles below/right of the diagonal block must carry the trailing update of step k-1
+        if (k >= 1 && !wg_wait2(&tdone[2 * (k - 1)], 1, &tdone[2 * (k - 1) + 1], 1, err, spin_limit, slot)) return;
+        const long o10 = o + 64 * ld, o11 = o10 + 64;
+        for (int idx = tid; idx < 4096; idx += 256) {
+            const int rr = idx >> 6, cc = idx & 63;
+            U[rr * LS + cc] = Kb[o10 + (long)rr * ld + cc];
+        }
+        __syncthreads();
+        // L_{k+1,k} = A_{k+1,k} inv_kk^T: wave w computes the 16-row strip w (4 tiles, depth 64)
+        d4 acc[4];
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj) {
+            acc[tj] = d4{0.0, 0.0, 0.0, 0.0};
+            acc[tj] = lds_mm16<true>(U, 16 * wave, 0, T, 16 * tj, 0, 64, lane, acc[tj]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj) lds_put16(U, 16 * wave, 16 * tj, acc[tj], 1.0, lane, crow_mode);
+        __syncthreads();
+        for (int idx = tid; idx < 4096; idx += 256) {
+            const int rr = idx >> 6, cc = idx & 63;
+            Lb[o10 + (long)rr * ld + cc] = U[rr * LS + cc];
+            S[rr * LS + cc] = (cc <= rr) ? Kb[o11 + (long)rr * ld + cc] : 0.0;    // next diagonal block
+        }
+        wg_publish(&pan1[k], 1);     // (contains the barrier that also orders the S loads above)
+        // A_{k+1,k+1} -= L_{k+1,k} L_{k+1,k}^T on the 10 lower 16 x 16 tiles
+        int cnt = 0;
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j <= i; ++j, ++cnt)
+                if ((cnt & 3) == wave) {
+                    d4 pacc = d4{0.0, 0.0, 0.0, 0.0};
+                    pacc = lds_mm16<true>(U, 16 * i, 0, U, 16 * j, 0, 64, lane, pacc);
+                    lds_sub16(S, 16 * i, 16 * j, pacc, lane, crow_mode);
+                }
+        __syncthreads();
+    }
+}
+
+}  // namespace gpmpc

@@ -28,6 +28,7 @@
 #pragma once
 #include <cstdlib>
 #include "mfma_f64.hpp"
+#include "wg_sync.hpp"
 
 #ifndef GPMPC_GEMM_SPLIT
 #define GPMPC_GEMM_SPLIT false
@@ -64,6 +65,13 @@ struct GemmP {
     int tilesMe, tilesNe; // effective tile grid (after pairing), set by the launcher
     int remap;            // 1: XCD-contiguous 8 x 8 patch order, 0: plain row-major tile order
     int npad;             // row-major order: padded width of the tile grid (set by the launcher)
+    // hand-offs with the persistent chain kernel (chol_chain.hpp); all null/0 for ordinary launches
+    const int* wait_flag; // every workgroup waits for *wait_flag >= 1 before touching its operands
+    int* err;             // shared error word (time-out)
+    int spin_limit;
+    int skip00;           // tile (0,0) belongs to the chain kernel
+    int* done_flags;      // tiles (1,0) and (1,1) publish done_flags[0] / done_flags[1] = 1
+    long sFlags;          // batch stride of the three flag pointers
 };
 
 template <int BM, int BN, int BK, int WGM, int WGN, bool AMC, bool BNC, bool SPLIT = GPMPC_GEMM_SPLIT>
@@ -99,6 +107,12 @@ __global__ void __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) gemm_f64_kernel
         tne = (int)blockIdx.x % wpad;
     }
     if (tme >= p.tilesMe || tne >= p.tilesNe) return;
+    if (p.wait_flag) {
+        __shared__ int wslot;
+        if (!wg_wait2(p.wait_flag + (long)blockIdx.z * p.sFlags, 1, nullptr, 0, p.err + (long)blockIdx.z * p.sFlags,
+                      p.spin_limit, &wslot))
+            return;
+    }
 
     const int z1 = p.zdiv > 0 ? (int)blockIdx.z % p.zdiv : (int)blockIdx.z;
     const int z2 = p.zdiv > 0 ? (int)blockIdx.z / p.zdiv : 0;
@@ -123,6 +137,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) gemm_f64_kernel
         }
         const int m0 = tm * BM, n0 = tn * BN;
         if (p.lower && n0 > m0 + BM - 1) continue;
+        if (p.skip00 && tm == 0 && tn == 0) continue;
 
         int klo = 0, khi = p.K;
         if (p.kflags & KA_LE_M) khi = min(khi, m0 + BM);
@@ -270,6 +285,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) gemm_f64_kernel
                 p.part[(long)blockIdx.z * p.sPart + (long)tm * p.ldpart + n0 + tid] = t;
             }
         }
+        if (p.done_flags && tm == 1 && tn <= 1) wg_publish(p.done_flags + (long)blockIdx.z * p.sFlags + tn, 1);
         __syncthreads();  // LDS (tiles / red) is reused by the next pass
     }
 }

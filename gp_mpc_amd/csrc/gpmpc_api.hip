@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../include/gpmpc.h"
+#include "chol_chain.hpp"
 #include "em_kernels.hpp"
 #include "gemm_f64.hpp"
 #include "gp_kernels.hpp"
@@ -148,6 +149,7 @@ struct Workspace {
     double *K = nullptr, *L = nullptr, *Inv = nullptr, *InvK = nullptr, *W = nullptr;
     double *w = nullptr, *alpha = nullptr, *hyper = nullptr, *jitter = nullptr, *nll = nullptr;
     int* info = nullptr;
+    int* flags = nullptr;   // hand-off words of the chain kernel, [batch][chain_flag_count(Np/64)]
     long mat() const { return (long)Np * Np; }
 };
 
@@ -167,6 +169,7 @@ static int ws_alloc(Workspace& ws, int batch, int Np, int d) {
     HIPCHK(hipMalloc(&ws.jitter, (size_t)batch * sizeof(double)));
     HIPCHK(hipMalloc(&ws.nll, (size_t)batch * sizeof(double)));
     HIPCHK(hipMalloc(&ws.info, (size_t)batch * sizeof(int)));
+    HIPCHK(hipMalloc(&ws.flags, (size_t)batch * chain_flag_count(Np / 64) * sizeof(int)));
     HIPCHK(hipMemset(ws.K, 0, mb));
     HIPCHK(hipMemset(ws.L, 0, mb));
     HIPCHK(hipMemset(ws.Inv, 0, mb));
@@ -177,7 +180,7 @@ static int ws_alloc(Workspace& ws, int batch, int Np, int d) {
 
 static void ws_free(Workspace& ws) {
     hipFree(ws.K); hipFree(ws.L); hipFree(ws.Inv); hipFree(ws.InvK); hipFree(ws.W);
-    hipFree(ws.w); hipFree(ws.alpha); hipFree(ws.hyper); hipFree(ws.jitter); hipFree(ws.nll); hipFree(ws.info);
+    hipFree(ws.w); hipFree(ws.alpha); hipFree(ws.hyper); hipFree(ws.jitter); hipFree(ws.nll); hipFree(ws.info); hipFree(ws.flags);
     ws = Workspace();
 }
 
@@ -189,6 +192,8 @@ static int ws_need_invK(Workspace& ws) {
 struct Ctx {
     hipStream_t stream;
     int crow_mode;
+    hipStream_t side = nullptr;     // second queue for the bulk work of the chained factorisation
+    hipEvent_t fork = nullptr, join = nullptr;
 };
 
 static GemmP gemm_base(const Ctx& cx) {
@@ -279,6 +284,62 @@ static void factor_blocked(const Ctx& cx, Workspace& ws, bool do_chol) {
     trtri_levels(cx, ws);
 }
 
+// Chained factorisation: the sequential part of every panel step runs in ONE persistent workgroup
+// (chol_chain_kernel, main queue) that keeps a CU to itself, the bulk -- panel rows >= k+2 and the
+// trailing update -- in ordinary GEMM launches on the side queue; flags in ws.flags couple the two.
+// Returns false if the path is unavailable (no side queue).  A time-out inside the kernels is reported
+// through ws.flags[0] and handled by the caller (fallback to factor_blocked).
+static bool factor_chain(const Ctx& cx, Workspace& ws, int spin_limit) {
+    if (!cx.side || ws.Np < 128) return false;
+    const int Np = ws.Np, nb = Np / 64, nf = chain_flag_count(nb);
+    const long ld = Np, sM = ws.mat();
+    hipMemsetAsync(ws.flags, 0, (size_t)ws.batch * nf * sizeof(int), cx.stream);
+    hipEventRecord(cx.fork, cx.stream);
+    hipStreamWaitEvent(cx.side, cx.fork, 0);
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipFuncSetAttribute((const void*)chol_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CHAIN_LDS_BYTES);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(chol_chain_kernel, dim3(1, 1, ws.batch), dim3(256), CHAIN_LDS_BYTES, cx.stream, (const double*)ws.K,
+                       ws.L, ws.Inv, ld, sM, nb, ws.flags, (long)nf, ws.info, cx.crow_mode, spin_limit);
+    hipLaunchKernelGGL(chain_gate_kernel, dim3(ws.batch), dim3(64), 0, cx.side, ws.flags, (long)nf, spin_limit);
+    int* leafdone = ws.flags + 1;
+    int* pan1 = ws.flags + 1 + nb;
+    int* tdone = ws.flags + 1 + 2 * nb;
+    for (int k = 0; k + 1 < nb; ++k) {
+        const int off = 64 * k;
+        const long o11 = (long)off * ld + off;
+        const int M2 = Np - off - 128;                       // panel rows >= k+2 (row k+1 is the chain's)
+        if (M2 > 0) {
+            const long o2 = (long)(off + 128) * ld + off;
+            GemmP p = gemm_base(cx);
+            p.A = ws.K + o2; p.lda = ld; p.sA = sM; p.a_mc = 0;
+            p.B = ws.Inv + o11; p.ldb = ld; p.sB = sM; p.b_nc = 0; p.kflags = KB_LE_N;
+            p.C = ws.L + o2; p.ldc = ld; p.sC = sM;
+            p.M = M2; p.N = 64; p.K = 64;
+            p.wait_flag = leafdone + k; p.err = ws.flags; p.spin_limit = spin_limit; p.sFlags = nf;
+            launch_gemm(p, ws.batch, cx.side);
+        }
+        const int M1 = Np - off - 64;                        // trailing update from block k+1 on, minus tile (k+1,k+1)
+        if (M1 > 64) {
+            const long o1 = (long)(off + 64) * ld;
+            GemmP q = gemm_base(cx);
+            q.A = ws.L + o1 + off; q.lda = ld; q.sA = sM; q.a_mc = 0;
+            q.B = ws.L + o1 + off; q.ldb = ld; q.sB = sM; q.b_nc = 0;
+            q.C = ws.K + o1 + off + 64; q.ldc = ld; q.sC = sM;
+            q.M = M1; q.N = M1; q.K = 64; q.alpha = -1.0; q.beta = 1.0; q.lower = 1;
+            q.wait_flag = pan1 + k; q.err = ws.flags; q.spin_limit = spin_limit; q.sFlags = nf;
+            q.skip00 = 1; q.done_flags = tdone + 2 * k;
+            launch_gemm(q, ws.batch, cx.side, 64);           // flags are defined on 64 x 64 tiles
+        }
+    }
+    hipEventRecord(cx.join, cx.side);
+    hipStreamWaitEvent(cx.stream, cx.join, 0);
+    trtri_levels(cx, ws);
+    return true;
+}
+
 // w = L^-1 y and alpha = L^-T w as two HBM-bound matrix-vector products with the explicit inverse.
 // y: [batch] vectors with stride sy.
 static void solve_alpha(const Ctx& cx, Workspace& ws, const double* y, long sy) {
@@ -318,7 +379,14 @@ struct Prof {
 
 struct gpmpc_gp {
     int device = 0, N = 0, Np = 0, d = 0, Ny = 0;
-    hipStream_t own_stream = nullptr, stream = nullptr;
+    hipStream_t own_stream = nullptr, stream = nullptr, side_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int chain_mode = 1;      // 1: chained factorisation (falls back to 0 after a hand-off time-out)
+#ifdef GPMPC_EMULATED
+    int spin_limit = 1 << 30;   // the emulator's polls are scheduler passes, not time
+#else
+    int spin_limit = 400000;    // ~0.3 s of polling with s_sleep before a waiter gives up
+#endif
     int ptr_mode = GPMPC_PTR_HOST;
     int crow_mode = 0;
     bool fitted = false, have_invK = false;
@@ -338,7 +406,7 @@ struct gpmpc_gp {
     double* UT = nullptr;    // legacy: K^-1 ks per test point
     bool have_beta = false;
     Prof prof;
-    Ctx cx() const { return Ctx{stream, crow_mode}; }
+    Ctx cx() const { return Ctx{stream, crow_mode, side_stream, ev_fork, ev_join}; }
 };
 
 struct PhaseTimer {
@@ -417,6 +485,10 @@ int gpmpc_create(int device, int N, int d, int Ny, const double* X, const double
     h->crow_mode = g_crow_mode[device];
     HIPCHK(hipStreamCreate(&h->own_stream));
     h->stream = h->own_stream;
+    HIPCHK(hipStreamCreate(&h->side_stream));
+    HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+    if (const char* e = getenv("GPMPC_CHAIN")) h->chain_mode = atoi(e);
     const int Np = h->Np;
     std::vector<double> xt((size_t)d * Np, 0.0), yt((size_t)Ny * Np, 0.0);
     for (int i = 0; i < N; ++i) {
@@ -447,6 +519,9 @@ int gpmpc_destroy(gpmpc_gp* h) {
     for (int ph = 0; ph < GPMPC_PH_COUNT; ++ph)
         for (auto& pr : h->prof.ev[ph]) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     for (auto e : h->prof.pool) hipEventDestroy(e);
+    if (h->ev_fork) hipEventDestroy(h->ev_fork);
+    if (h->ev_join) hipEventDestroy(h->ev_join);
+    if (h->side_stream) hipStreamDestroy(h->side_stream);
     if (h->own_stream) hipStreamDestroy(h->own_stream);
     delete h;
     return GPMPC_OK;
@@ -511,7 +586,7 @@ static void gram_and_factor(gpmpc_gp* h, Workspace& ws) {
     {
         PhaseTimer t(h, GPMPC_PH_FACTOR);
         hipMemsetAsync(ws.info, 0, ws.batch * sizeof(int), cx.stream);
-        factor_blocked(cx, ws, true);
+        if (!(h->chain_mode && factor_chain(cx, ws, h->spin_limit))) factor_blocked(cx, ws, true);
     }
 }
 
@@ -528,6 +603,20 @@ static int factor_with_jitter(gpmpc_gp* h, Workspace& ws, const double* hyper_ho
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(info.data(), ws.info, nb * sizeof(int), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
+        if (h->chain_mode && h->side_stream && ws.Np >= 128) {   // did a hand-off of the chained factorisation time out?
+            std::vector<int> cerr((size_t)nb * chain_flag_count(ws.Np / 64));
+            HIPCHK(hipMemcpy(cerr.data(), ws.flags, cerr.size() * sizeof(int), hipMemcpyDeviceToHost));
+            bool bad = false;
+            for (int b = 0; b < nb; ++b) bad |= cerr[(size_t)b * chain_flag_count(ws.Np / 64)] != 0;
+            if (bad) {
+                fprintf(stderr, "gpmpc: chained factorisation timed out on a hand-off; using the single-queue path\n");
+                h->chain_mode = 0;
+                HIPCHK(hipStreamSynchronize(h->side_stream));
+                gram_and_factor(h, ws);
+                HIPCHK(hipMemcpyAsync(info.data(), ws.info, nb * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+                HIPCHK(hipStreamSynchronize(h->stream));
+            }
+        }
         bool any = false;
         for (int b = 0; b < nb; ++b)
             if (info[b] != 0) {

@@ -100,32 +100,17 @@ __device__ __forceinline__ int panel_potrf(double* S, double* Drinv, int t, int 
     return bad;
 }
 
-// grid (nblk, 1, batch), 256 threads: workgroup x handles the diagonal block starting at row/column
-// off + 64 x (nblk > 1 only for the inverse-only mode, where the blocks are independent).
-// Ain: source of the diagonal block (the running K for a factorisation, L itself for inverse-only);
-// L / Inv: destinations.  All are [batch][ld x ld] row-major.
-__global__ void __launch_bounds__(256) leaf64_kernel(const double* Ain, double* L, double* Inv, long ld,
-                                                     long sBatch, int off0, int do_chol, int* info,
-                                                     int crow_mode, int phases = 15) {
-    // `phases` (bit 0 panel, 1 rank-16 update, 2 diagonal inverses, 3 inverse assembly) exists for the
-    // micro-benchmark tools/ubench/leaf_bench.hip only; the library always passes 15.
-    const int off = off0 + 64 * (int)blockIdx.x;
-    __shared__ double S[64 * LS];
-    __shared__ double T[64 * LS];
-    __shared__ double U[64 * LS];
-    __shared__ double Dr[64];
+// The factor + invert body shared by leaf64_kernel and the persistent chain kernel (chol_chain.hpp).
+// 256 threads; S holds the (lower) 64 x 64 block on entry and L on exit, T receives L^-1 (its strictly
+// upper 16 x 16 blocks must be zero on entry and stay zero), U and Dr are scratch.  Returns the first
+// non-positive pivot column (0-based) or -1 (meaningful in wave 0).
+// `phases` (bit 0 panel, 1 rank-16 update, 2 diagonal inverses, 3 inverse assembly) exists for the
+// micro-benchmark tools/ubench/leaf_bench.hip only; the library always passes 15.
+__device__ __forceinline__ int leaf_body(double* S, double* T, double* U, double* Dr, int do_chol, int phases,
+                                         int crow_mode) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const long base = (long)blockIdx.z * sBatch + (long)off * ld + off;
-    const double* __restrict__ src = Ain + base;
-    for (int idx = tid; idx < 4096; idx += 256) {
-        const int rr = idx >> 6, cc = idx & 63;
-        S[rr * LS + cc] = (cc <= rr) ? src[(long)rr * ld + cc] : 0.0;
-        T[rr * LS + cc] = 0.0;
-    }
-    __syncthreads();
-
+    int bad = -1;
     if (do_chol) {
-        int bad = -1;
         for (int t = 0; t < 4; ++t) {
             if (wave == 0 && (phases & 1)) {
                 const int b = panel_potrf(S, Dr, t, lane);
@@ -148,12 +133,10 @@ __global__ void __launch_bounds__(256) leaf64_kernel(const double* Ain, double* 
         }
         if (wave == 1 && (phases & 4)) inv16(S, T, 48, lane, Dr);
         __syncthreads();
-        if (wave == 0 && lane == 0 && bad >= 0) atomicCAS(&info[blockIdx.z], 0, off + bad + 1);
     } else {
-        inv16(S, T, 16 * wave, lane, nullptr);
+        if (wave < 4) inv16(S, T, 16 * wave, lane, nullptr);
         __syncthreads();
     }
-
     // assemble the 64 x 64 inverse from the four 16 x 16 diagonal inverses:
     // inv21 = -inv22 (L21 inv11), first for the two 32-blocks, then for the 64-block
     if (phases & 8) {
@@ -168,7 +151,7 @@ __global__ void __launch_bounds__(256) leaf64_kernel(const double* Ain, double* 
         __syncthreads();
     }
     if (phases & 8) {
-        const int pi = wave >> 1, pj = wave & 1;
+        const int pi = (wave >> 1) & 1, pj = wave & 1;
         d4 acc = d4{0.0, 0.0, 0.0, 0.0};
         acc = lds_mm16<false>(S, 32 + 16 * pi, 0, T, 0, 16 * pj, 32, lane, acc);
         lds_put16(U, 32 + 16 * pi, 16 * pj, acc, 1.0, lane, crow_mode);
@@ -179,7 +162,32 @@ __global__ void __launch_bounds__(256) leaf64_kernel(const double* Ain, double* 
         lds_put16(T, 32 + 16 * pi, 16 * pj, acc, -1.0, lane, crow_mode);
         __syncthreads();
     }
+    return bad;
+}
 
+// grid (nblk, 1, batch), 256 threads: workgroup x handles the diagonal block starting at row/column
+// off + 64 x (nblk > 1 only for the inverse-only mode, where the blocks are independent).
+// Ain: source of the diagonal block (the running K for a factorisation, L itself for inverse-only);
+// L / Inv: destinations.  All are [batch][ld x ld] row-major.
+__global__ void __launch_bounds__(256) leaf64_kernel(const double* Ain, double* L, double* Inv, long ld,
+                                                     long sBatch, int off0, int do_chol, int* info,
+                                                     int crow_mode, int phases = 15) {
+    const int off = off0 + 64 * (int)blockIdx.x;
+    __shared__ double S[64 * LS];
+    __shared__ double T[64 * LS];
+    __shared__ double U[64 * LS];
+    __shared__ double Dr[64];
+    const int tid = threadIdx.x;
+    const long base = (long)blockIdx.z * sBatch + (long)off * ld + off;
+    const double* __restrict__ src = Ain + base;
+    for (int idx = tid; idx < 4096; idx += 256) {
+        const int rr = idx >> 6, cc = idx & 63;
+        S[rr * LS + cc] = (cc <= rr) ? src[(long)rr * ld + cc] : 0.0;
+        T[rr * LS + cc] = 0.0;
+    }
+    __syncthreads();
+    const int bad = leaf_body(S, T, U, Dr, do_chol, phases, crow_mode);
+    if (do_chol && tid == 0 && bad >= 0) atomicCAS(&info[blockIdx.z], 0, off + bad + 1);
     double* __restrict__ dl = L + base;
     double* __restrict__ di = Inv + base;
     for (int idx = tid; idx < 4096; idx += 256) {

@@ -1,0 +1,58 @@
+// Inter-workgroup hand-offs inside/between concurrently running kernels (gfx950: 8 XCDs with private,
+// mutually non-coherent L2s; a CU's L1 is never refreshed by other CUs' stores).  Protocol of
+// /opt/skills/guides/cdna_hip_programming.md Guideline 16, counter/flag form:
+//   producer: every wave drains its stores -> barrier -> ONE lane: agent-scope release fence, drain again,
+//             relaxed agent-scope flag store;
+//   consumer: ONE lane polls the flag relaxed (bounded, with s_sleep), ONE agent-scope acquire fence,
+//             barrier, then plain loads by everybody.
+// Flags are monotone ints, zeroed by a hipMemsetAsync before every use.  Every spin is bounded; on a
+// time-out the error word is set, all waiters give up and the host falls back to the barrier-free path.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace gpmpc {
+
+#ifdef GPMPC_EMULATED
+#define GPMPC_DRAIN_VM() ((void)0)
+#else
+#define GPMPC_DRAIN_VM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#endif
+
+__device__ __forceinline__ int flag_load(const int* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void flag_store(int* p, int v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// called by ALL threads of the workgroup after their plain global stores
+__device__ __forceinline__ void wg_publish(int* flag, int value) {
+    GPMPC_DRAIN_VM();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        GPMPC_DRAIN_VM();
+        flag_store(flag, value);
+    }
+}
+
+// called by ALL threads: wait until *f0 >= v0 (and *f1 >= v1 if f1); false on time-out / global error.
+// `slot` is an int in LDS used to broadcast the outcome.
+__device__ __forceinline__ bool wg_wait2(const int* f0, int v0, const int* f1, int v1, int* err, int limit, int* slot) {
+    if (threadIdx.x == 0) {
+        int ok = 1, spins = 0;
+        while (flag_load(f0) < v0 || (f1 && flag_load(f1) < v1)) {
+            __builtin_amdgcn_s_sleep(8);
+            if (flag_load(err) != 0) { ok = 0; break; }
+            if (++spins > limit) { flag_store(err, 2); ok = 0; break; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        *slot = ok;
+    }
+    __syncthreads();
+    const bool r = *slot != 0;
+    __syncthreads();
+    return r;
+}
+
+}  // namespace gpmpc
