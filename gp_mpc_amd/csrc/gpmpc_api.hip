@@ -144,6 +144,14 @@ static int ensure_device(int device) {
 // ------------------------------------------------------------------------------------------------
 // factorisation workspace: K (destroyed), L, L^-1, scratch, w, alpha for `batch` matrices
 // ------------------------------------------------------------------------------------------------
+// rows per segment of the pipelined triangular inverse (power of two times 64); small in the emulated
+// build so that the CPU tests reach the pipelined path at N ~ 600
+#ifdef GPMPC_EMULATED
+static const int SEGR = 128;
+#else
+static const int SEGR = 512;
+#endif
+
 struct Workspace {
     int batch = 0, Np = 0, d = 0;
     double *K = nullptr, *L = nullptr, *Inv = nullptr, *InvK = nullptr, *W = nullptr;
@@ -151,6 +159,14 @@ struct Workspace {
     int* info = nullptr;
     int* flags = nullptr;   // hand-off words of the chain kernel, [batch][chain_flag_count(Np/64)]
     long mat() const { return (long)Np * Np; }
+    // scratch of the triangular inverse per matrix: [0, hw^2) level scratch, then one slot per high-level node
+    long hw() const { return Np / 2 + 64; }
+    long wstride() const {
+        long slots = 0;                 // sum of h2 * s over the nodes above the segment level (trtri_segment)
+        for (long s = SEGR; s < Np; s *= 2)
+            for (long base = 0; base + s < Np; base += 2 * s) slots += std::min(s, Np - base - s) * s;
+        return hw() * hw() + slots;
+    }
 };
 
 static int ws_alloc(Workspace& ws, int batch, int Np, int d) {
@@ -161,8 +177,7 @@ static int ws_alloc(Workspace& ws, int batch, int Np, int d) {
     HIPCHK(hipMalloc(&ws.K, mb));
     HIPCHK(hipMalloc(&ws.L, mb));
     HIPCHK(hipMalloc(&ws.Inv, mb));
-    const long hw = Np / 2 + 64;
-    HIPCHK(hipMalloc(&ws.W, (size_t)batch * hw * hw * sizeof(double)));
+    HIPCHK(hipMalloc(&ws.W, (size_t)batch * ws.wstride() * sizeof(double)));
     HIPCHK(hipMalloc(&ws.w, (size_t)batch * Np * sizeof(double)));
     HIPCHK(hipMalloc(&ws.alpha, (size_t)batch * Np * sizeof(double)));
     HIPCHK(hipMalloc(&ws.hyper, (size_t)batch * (d + 2) * sizeof(double)));
@@ -194,6 +209,9 @@ struct Ctx {
     int crow_mode;
     hipStream_t side = nullptr;     // second queue for the bulk work of the chained factorisation
     hipEvent_t fork = nullptr, join = nullptr;
+    hipStream_t aux = nullptr;      // third queue: pipelined pieces of the triangular inverse
+    hipEvent_t* seg = nullptr;      // pool of n_seg events (segment hand-offs side -> aux, aux -> main)
+    int n_seg = 0;
 };
 
 static GemmP gemm_base(const Ctx& cx) {
@@ -220,18 +238,17 @@ static GemmP gemm_base(const Ctx& cx) {
 // -- the leaf and panel kernels slow down under the contention by as much as is hidden (4.4 vs 4.2 ms,
 // with or without stream priorities / CU masks).  (The first version recursed on [L11 0; L21 L22] with the inverse products
 // inside the recursion: 4 latency-bound launches per node on the chain, 5.5 ms at N = 4096.)
-static void trtri_levels(const Ctx& cx, Workspace& ws) {
-    const int Np = ws.Np;
-    const long ld = Np, sM = ws.mat();
-    const long hw = Np / 2 + 64;
-    for (int s = 64; s < Np; s *= 2) {
-        const int nfull = Np / (2 * s);                 // nodes with a full right child
-        const int rem = Np - nfull * 2 * s;             // tail: a partial node exists if rem > s
+// level-by-level batched inverse of the diagonal range [base, base + n) (rows), given its 64-blocks
+static void trtri_range(const Ctx& cx, Workspace& ws, hipStream_t stream, long base0, int n) {
+    const long ld = ws.Np, sM = ws.mat(), sW = ws.wstride();
+    for (int s = 64; s < n; s *= 2) {
+        const int nfull = n / (2 * s);                  // nodes with a full right child
+        const int rem = n - nfull * 2 * s;              // tail: a partial node exists if rem > s
         for (int part = 0; part < 2; ++part) {
             int nodes, h2;
             long base;
-            if (part == 0) { nodes = nfull; h2 = s; base = 0; }
-            else { nodes = rem > s ? 1 : 0; h2 = rem - s; base = (long)nfull * 2 * s; }
+            if (part == 0) { nodes = nfull; h2 = s; base = base0; }
+            else { nodes = rem > s ? 1 : 0; h2 = rem - s; base = base0 + (long)nfull * 2 * s; }
             if (nodes == 0) continue;
             const long o11 = base * ld + base, o21 = (base + s) * ld + base, o22 = (base + s) * ld + base + s;
             const long snode = (long)2 * s * (ld + 1);
@@ -240,17 +257,63 @@ static void trtri_levels(const Ctx& cx, Workspace& ws) {
             t.B = ws.Inv + o11; t.ldb = ld; t.b_nc = 1; t.kflags = KB_GE_N;
             t.C = ws.W; t.ldc = s;
             t.M = h2; t.N = s; t.K = s;
-            t.zdiv = nodes; t.sA = snode; t.sB = snode; t.sC = (long)s * s; t.sA2 = sM; t.sB2 = sM; t.sC2 = hw * hw;
-            launch_gemm(t, nodes * ws.batch, cx.stream);
+            t.zdiv = nodes; t.sA = snode; t.sB = snode; t.sC = (long)s * s; t.sA2 = sM; t.sB2 = sM; t.sC2 = sW;
+            launch_gemm(t, nodes * ws.batch, stream);
             GemmP u = gemm_base(cx);                    // inv21 = -inv22 W
             u.A = ws.Inv + o22; u.lda = ld; u.a_mc = 0; u.kflags = KA_LE_M;
             u.B = ws.W; u.ldb = s; u.b_nc = 1;
             u.C = ws.Inv + o21; u.ldc = ld;
             u.M = h2; u.N = s; u.K = h2; u.alpha = -1.0;
-            u.zdiv = nodes; u.sA = snode; u.sB = (long)s * s; u.sC = snode; u.sA2 = sM; u.sB2 = hw * hw; u.sC2 = sM;
-            launch_gemm(u, nodes * ws.batch, cx.stream);
+            u.zdiv = nodes; u.sA = snode; u.sB = (long)s * s; u.sC = snode; u.sA2 = sM; u.sB2 = sW; u.sC2 = sM;
+            launch_gemm(u, nodes * ws.batch, stream);
         }
     }
+}
+
+static void trtri_levels(const Ctx& cx, Workspace& ws) { trtri_range(cx, ws, cx.stream, 0, ws.Np); }
+
+// One node [L11 0; L21 L22] of the inverse tree above the segment level, split in its two products so
+// that the first can run as soon as the left child is inverted: W = L21 inv11 (into the node's own
+// slot `wo` of ws.W), later inv21 = -inv22 W.
+static void trtri_node_w(const Ctx& cx, Workspace& ws, hipStream_t stream, long base, int s, int h2, long wo) {
+    const long ld = ws.Np, sM = ws.mat();
+    GemmP t = gemm_base(cx);
+    t.A = ws.L + (base + s) * ld + base; t.lda = ld; t.sA = sM; t.a_mc = 0;
+    t.B = ws.Inv + base * ld + base; t.ldb = ld; t.sB = sM; t.b_nc = 1; t.kflags = KB_GE_N;
+    t.C = ws.W + wo; t.ldc = s; t.sC = ws.wstride();
+    t.M = h2; t.N = s; t.K = s;
+    launch_gemm(t, ws.batch, stream);
+}
+static void trtri_node_inv(const Ctx& cx, Workspace& ws, hipStream_t stream, long base, int s, int h2, long wo) {
+    const long ld = ws.Np, sM = ws.mat();
+    GemmP u = gemm_base(cx);
+    u.A = ws.Inv + (base + s) * ld + base + s; u.lda = ld; u.sA = sM; u.a_mc = 0; u.kflags = KA_LE_M;
+    u.B = ws.W + wo; u.ldb = s; u.sB = ws.wstride(); u.b_nc = 1;
+    u.C = ws.Inv + (base + s) * ld + base; u.ldc = ld; u.sC = sM;
+    u.M = h2; u.N = s; u.K = h2; u.alpha = -1.0;
+    launch_gemm(u, ws.batch, stream);
+}
+
+// The part of the inverse that becomes computable when rows [seg0, seg1) are factored (seg0 a multiple of
+// SEGR): the levels inside the segment, then, smallest first, the second product of every higher node
+// whose right child ends at seg1 and the first product of every node whose left child ends there.
+static void trtri_segment(const Ctx& cx, Workspace& ws, hipStream_t stream, int seg0, int seg1) {
+    const int Np = ws.Np;
+    trtri_range(cx, ws, stream, seg0, seg1 - seg0);
+    long wo = ws.hw() * ws.hw();
+    for (int s = SEGR; s < Np; s *= 2)
+        for (long base = 0; base + s < Np; base += 2 * (long)s) {
+            const int h2 = (int)std::min<long>(s, Np - base - s);
+            if (base + s + h2 == seg1) trtri_node_inv(cx, ws, stream, base, s, h2, wo);
+            wo += (long)h2 * s;
+        }
+    wo = ws.hw() * ws.hw();
+    for (int s = SEGR; s < Np; s *= 2)
+        for (long base = 0; base + s < Np; base += 2 * (long)s) {
+            const int h2 = (int)std::min<long>(s, Np - base - s);
+            if (base + s == seg1) trtri_node_w(cx, ws, stream, base, s, h2, wo);
+            wo += (long)h2 * s;
+        }
 }
 
 static void factor_blocked(const Ctx& cx, Workspace& ws, bool do_chol) {
@@ -304,6 +367,8 @@ static bool factor_chain(const Ctx& cx, Workspace& ws, int spin_limit) {
     hipLaunchKernelGGL(chol_chain_kernel, dim3(1, 1, ws.batch), dim3(256), CHAIN_LDS_BYTES, cx.stream, (const double*)ws.K,
                        ws.L, ws.Inv, ld, sM, nb, ws.flags, (long)nf, ws.info, cx.crow_mode, spin_limit);
     hipLaunchKernelGGL(chain_gate_kernel, dim3(ws.batch), dim3(64), 0, cx.side, ws.flags, (long)nf, spin_limit);
+    const bool pipelined = cx.aux && cx.seg && Np >= 4 * SEGR;   // inverse pipelined behind the chain
+    int seg_done = 0;
     int* leafdone = ws.flags + 1;
     int* pan1 = ws.flags + 1 + nb;
     int* tdone = ws.flags + 1 + 2 * nb;
@@ -332,11 +397,22 @@ static bool factor_chain(const Ctx& cx, Workspace& ws, int spin_limit) {
             q.wait_flag = pan1 + k; q.err = ws.flags; q.spin_limit = spin_limit; q.sFlags = nf;
             q.skip00 = 1; q.done_flags = tdone + 2 * k;
             launch_gemm(q, ws.batch, cx.side, 64);           // flags are defined on 64 x 64 tiles
+            // rows [.., 64(k+1)) are final once this update has consumed panel k: a finished segment goes to aux
+            if (pipelined && (off + 64) % SEGR == 0 && seg_done < cx.n_seg - 1) {
+                hipEventRecord(cx.seg[seg_done], cx.side);
+                hipStreamWaitEvent(cx.aux, cx.seg[seg_done], 0);
+                trtri_segment(cx, ws, cx.aux, seg_done * SEGR, (seg_done + 1) * SEGR);
+                ++seg_done;
+            }
         }
     }
     hipEventRecord(cx.join, cx.side);
     hipStreamWaitEvent(cx.stream, cx.join, 0);
-    trtri_levels(cx, ws);
+    if (!pipelined) { trtri_levels(cx, ws); return true; }
+    // segments the side queue could not hand over (the last ones) are inverted after the chain, on the main queue
+    hipEventRecord(cx.seg[cx.n_seg - 1], cx.aux);
+    hipStreamWaitEvent(cx.stream, cx.seg[cx.n_seg - 1], 0);
+    for (int sg = seg_done; sg * SEGR < Np; ++sg) trtri_segment(cx, ws, cx.stream, sg * SEGR, std::min(Np, (sg + 1) * SEGR));
     return true;
 }
 
@@ -381,6 +457,8 @@ struct gpmpc_gp {
     int device = 0, N = 0, Np = 0, d = 0, Ny = 0;
     hipStream_t own_stream = nullptr, stream = nullptr, side_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t aux_stream = nullptr;
+    std::vector<hipEvent_t> seg_events;
     int chain_mode = 1;      // 1: chained factorisation (falls back to 0 after a hand-off time-out)
 #ifdef GPMPC_EMULATED
     int spin_limit = 1 << 30;   // the emulator's polls are scheduler passes, not time
@@ -406,7 +484,10 @@ struct gpmpc_gp {
     double* UT = nullptr;    // legacy: K^-1 ks per test point
     bool have_beta = false;
     Prof prof;
-    Ctx cx() const { return Ctx{stream, crow_mode, side_stream, ev_fork, ev_join}; }
+    Ctx cx() {
+        return Ctx{stream, crow_mode, side_stream, ev_fork, ev_join, chain_mode >= 2 ? aux_stream : nullptr,
+                   seg_events.data(), (int)seg_events.size()};
+    }
 };
 
 struct PhaseTimer {
@@ -488,6 +569,10 @@ int gpmpc_create(int device, int N, int d, int Ny, const double* X, const double
     HIPCHK(hipStreamCreate(&h->side_stream));
     HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+    HIPCHK(hipStreamCreate(&h->aux_stream));
+    h->seg_events.resize(std::max(2, round_up(N, 64) / SEGR + 1));
+    for (auto& e : h->seg_events) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    h->chain_mode = 2;       // 0: single queue; 1: chained Cholesky; 2: + inverse pipelined behind the chain
     if (const char* e = getenv("GPMPC_CHAIN")) h->chain_mode = atoi(e);
     const int Np = h->Np;
     std::vector<double> xt((size_t)d * Np, 0.0), yt((size_t)Ny * Np, 0.0);
@@ -521,6 +606,8 @@ int gpmpc_destroy(gpmpc_gp* h) {
     for (auto e : h->prof.pool) hipEventDestroy(e);
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
     if (h->ev_join) hipEventDestroy(h->ev_join);
+    for (auto e : h->seg_events) hipEventDestroy(e);
+    if (h->aux_stream) hipStreamDestroy(h->aux_stream);
     if (h->side_stream) hipStreamDestroy(h->side_stream);
     if (h->own_stream) hipStreamDestroy(h->own_stream);
     delete h;
@@ -695,7 +782,7 @@ extern "C" int gpmpc_get_factors(gpmpc_gp* h, double* hyper, double* chol, doubl
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipStreamSynchronize(h->stream));
     if (hyper) std::memcpy(hyper, h->hyper.data(), h->hyper.size() * sizeof(double));
-    if (chol) CHK(export_mats(h, h->ws.L, chol));
+    if (chol) CHK(export_mats(h, getenv("GPMPC_DEBUG_INV") ? h->ws.Inv : h->ws.L, chol));
     if (alpha) {
         std::vector<double> tmp((size_t)h->Ny * h->Np);
         HIPCHK(hipMemcpy(tmp.data(), h->ws.alpha, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));

@@ -223,8 +223,18 @@ Running* start_kernel(const Op& op) {
     return r;
 }
 
+// Static __shared__ arrays are plain C++ statics here, so two workgroups that use them must never
+// interleave -- not even workgroups of different kernels on different streams (same template
+// instantiation = same statics).  A workgroup of a static-LDS kernel therefore holds this token from
+// its first to its last instruction; dynamic-LDS (concurrent) kernels are not affected.
+Running* static_lds_owner = nullptr;
+
 // one scheduling pass over a running kernel; returns true when the kernel has finished
 bool step_kernel(Running& r) {
+    if (!r.concurrent) {
+        if (static_lds_owner && static_lds_owner != &r) return false;
+        static_lds_owner = &r;
+    }
     bool any = false;
     for (size_t i = 0; i < r.fibs.size(); ++i) {
         Fiber* f = r.fibs[i];
@@ -243,6 +253,7 @@ bool step_kernel(Running& r) {
     if (!alldone) return false;
     for (Fiber* f : r.fibs) free_fiber(f);
     r.fibs.clear();
+    if (!r.concurrent) static_lds_owner = nullptr;
     if (!r.concurrent && r.next_block < r.nblocks) {   // next workgroup of a sequential kernel
         start_block(r, 0, r.next_block++);
         return false;

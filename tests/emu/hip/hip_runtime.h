@@ -115,8 +115,8 @@ enum { hipEventDefault = 0, hipEventDisableTiming = 2 };
 inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = new emu_event{0.0, 0, 0}; return hipSuccess; }
 inline hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned) { emu::wait_event(s, e); return hipSuccess; }
 inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
-inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t = emu::now_ms(); return hipSuccess; }
-inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t s) { emu::record(e, s); return hipSuccess; }
+inline hipError_t hipEventSynchronize(hipEvent_t) { emu::drain(); return hipSuccess; }
 inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) { emu::drain(); *ms = (float)(b->t - a->t); return hipSuccess; }
 
 #define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...) \

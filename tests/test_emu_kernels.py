@@ -44,6 +44,11 @@ def test_emu_synthetic(emu):
     pc.check_synthetic(emu, N=150, d=3, Ny=1, B=70, sn=1e-2, strict_rel=False)
 
 
+def test_emu_pipelined_inverse(emu):
+    # Np = 576 = 4.5 emulator segments: chained Cholesky with the inverse pipelined behind it (odd tail)
+    pc.check_synthetic(emu, N=560, d=4, Ny=2, B=30, sn=0.1, strict_rel=True)
+
+
 def test_emu_jitter_rule(emu, train_small):
     pc.check_jitter_rule(emu, train_small)
 
