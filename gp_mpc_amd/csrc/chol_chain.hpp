@@ -44,7 +44,13 @@ __global__ void __launch_bounds__(64) chain_gate_kernel(int* flags, long sFlags,
 
 __global__ void __launch_bounds__(256) chol_chain_kernel(const double* Kmat, double* L, double* Inv, long ld, long sBatch,
                                                          int nb, int* flags, long sFlags, int* info, int crow_mode,
-                                                         int spin_limit) {
+                                                         int spin_limit, long long* trace) {
+    // optional time stamps (100 MHz wall clock), 8 per step, for tools/chain_trace.py
+#ifdef GPMPC_EMULATED
+#define CHAIN_STAMP(i) ((void)0)
+#else
+#define CHAIN_STAMP(i) do { if (trace && threadIdx.x == 0) trace[((long)blockIdx.z * nb + k) * 8 + (i)] = wall_clock64(); } while (0)
+#endif
     double* smem = GPMPC_DYN_SMEM();
     double* S = smem;
     double* T = S + 64 * LS;
@@ -70,7 +76,35 @@ __global__ void __launch_bounds__(256) chol_chain_kernel(const double* Kmat, dou
     __syncthreads();
     for (int k = 0; k < nb; ++k) {
         const long o = (long)(64 * k) * ld + 64 * k;
+        const long o10 = o + 64 * ld, o11 = o10 + 64;
+        CHAIN_STAMP(0);
+        // Prefetch for the second half of the step: if the two tiles A(k+1,k), A(k+1,k+1) already carry
+        // the trailing update of step k-1 (always true once the chain is the bottleneck), their loads are
+        // issued now, into registers, and their HBM latency hides behind the leaf.
+        bool pre = false;
+        double pu[16], ps[16];
+        if (k + 1 < nb) {
+            if (k == 0) pre = true;
+            else {
+                if (tid == 0) {
+                    const int ok = flag_load(&tdone[2 * (k - 1)]) >= 1 && flag_load(&tdone[2 * (k - 1) + 1]) >= 1;
+                    if (ok) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    *slot = ok;
+                }
+                __syncthreads();
+                pre = *slot != 0;
+            }
+            if (pre) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int idx = tid + 256 * i, rr = idx >> 6, cc = idx & 63;
+                    pu[i] = Kb[o10 + (long)rr * ld + cc];
+                    ps[i] = (cc <= rr) ? Kb[o11 + (long)rr * ld + cc] : 0.0;
+                }
+            }
+        }
         const int bad = leaf_body(S, T, U, Dr, 1, 15, crow_mode);
+        CHAIN_STAMP(1);
         if (tid == 0 && bad >= 0) atomicCAS(&info[blockIdx.z], 0, 64 * k + bad + 1);
         for (int idx = tid; idx < 4096; idx += 256) {
             const int rr = idx >> 6, cc = idx & 63;
@@ -78,15 +112,33 @@ __global__ void __launch_bounds__(256) chol_chain_kernel(const double* Kmat, dou
             Ib[o + (long)rr * ld + cc] = (cc <= rr) ? T[rr * LS + cc] : 0.0;
         }
         wg_publish(&leafdone[k], 1);
+        CHAIN_STAMP(2);
         if (k + 1 == nb) break;
-        // the two tiles below/right of the diagonal block must carry the trailing update of step k-1
-        if (k >= 1 && !wg_wait2(&tdone[2 * (k - 1)], 1, &tdone[2 * (k - 1) + 1], 1, err, spin_limit, slot)) return;
-        const long o10 = o + 64 * ld, o11 = o10 + 64;
-        for (int idx = tid; idx < 4096; idx += 256) {
-            const int rr = idx >> 6, cc = idx & 63;
-            U[rr * LS + cc] = Kb[o10 + (long)rr * ld + cc];
+        if (pre) {
+            CHAIN_STAMP(3);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int idx = tid + 256 * i, rr = idx >> 6, cc = idx & 63;
+                U[rr * LS + cc] = pu[i];
+            }
+        } else {
+            // the two tiles below/right of the diagonal block must carry the trailing update of step k-1
+            if (!wg_wait2(&tdone[2 * (k - 1)], 1, &tdone[2 * (k - 1) + 1], 1, err, spin_limit, slot)) return;
+            CHAIN_STAMP(3);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int idx = tid + 256 * i, rr = idx >> 6, cc = idx & 63;
+                pu[i] = Kb[o10 + (long)rr * ld + cc];
+                ps[i] = (cc <= rr) ? Kb[o11 + (long)rr * ld + cc] : 0.0;
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int idx = tid + 256 * i, rr = idx >> 6, cc = idx & 63;
+                U[rr * LS + cc] = pu[i];
+            }
         }
         __syncthreads();
+        CHAIN_STAMP(4);
         // L_{k+1,k} = A_{k+1,k} inv_kk^T: wave w computes the 16-row strip w (4 tiles, depth 64)
         d4 acc[4];
 #pragma unroll
@@ -98,12 +150,15 @@ __global__ void __launch_bounds__(256) chol_chain_kernel(const double* Kmat, dou
 #pragma unroll
         for (int tj = 0; tj < 4; ++tj) lds_put16(U, 16 * wave, 16 * tj, acc[tj], 1.0, lane, crow_mode);
         __syncthreads();
-        for (int idx = tid; idx < 4096; idx += 256) {
-            const int rr = idx >> 6, cc = idx & 63;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int idx = tid + 256 * i, rr = idx >> 6, cc = idx & 63;
             Lb[o10 + (long)rr * ld + cc] = U[rr * LS + cc];
-            S[rr * LS + cc] = (cc <= rr) ? Kb[o11 + (long)rr * ld + cc] : 0.0;    // next diagonal block
+            S[rr * LS + cc] = ps[i];                                              // next diagonal block
         }
+        CHAIN_STAMP(5);
         wg_publish(&pan1[k], 1);     // (contains the barrier that also orders the S loads above)
+        CHAIN_STAMP(6);
         // A_{k+1,k+1} -= L_{k+1,k} L_{k+1,k}^T on the 10 lower 16 x 16 tiles
         int cnt = 0;
         for (int i = 0; i < 4; ++i)
@@ -114,7 +169,9 @@ __global__ void __launch_bounds__(256) chol_chain_kernel(const double* Kmat, dou
                     lds_sub16(S, 16 * i, 16 * j, pacc, lane, crow_mode);
                 }
         __syncthreads();
+        CHAIN_STAMP(7);
     }
+#undef CHAIN_STAMP
 }
 
 }  // namespace gpmpc

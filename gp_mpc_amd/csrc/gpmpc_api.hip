@@ -352,6 +352,8 @@ static void factor_blocked(const Ctx& cx, Workspace& ws, bool do_chol) {
 // trailing update -- in ordinary GEMM launches on the side queue; flags in ws.flags couple the two.
 // Returns false if the path is unavailable (no side queue).  A time-out inside the kernels is reported
 // through ws.flags[0] and handled by the caller (fallback to factor_blocked).
+static long long* g_chain_trace = nullptr;   // developer aid: GPMPC_CHAIN_TRACE=<file> dumps the chain's time stamps
+
 static bool factor_chain(const Ctx& cx, Workspace& ws, int spin_limit) {
     if (!cx.side || ws.Np < 128) return false;
     const int Np = ws.Np, nb = Np / 64, nf = chain_flag_count(nb);
@@ -365,7 +367,7 @@ static bool factor_chain(const Ctx& cx, Workspace& ws, int spin_limit) {
         attr_done = true;
     }
     hipLaunchKernelGGL(chol_chain_kernel, dim3(1, 1, ws.batch), dim3(256), CHAIN_LDS_BYTES, cx.stream, (const double*)ws.K,
-                       ws.L, ws.Inv, ld, sM, nb, ws.flags, (long)nf, ws.info, cx.crow_mode, spin_limit);
+                       ws.L, ws.Inv, ld, sM, nb, ws.flags, (long)nf, ws.info, cx.crow_mode, spin_limit, g_chain_trace);
     hipLaunchKernelGGL(chain_gate_kernel, dim3(ws.batch), dim3(64), 0, cx.side, ws.flags, (long)nf, spin_limit);
     const bool pipelined = cx.aux && cx.seg && Np >= 4 * SEGR;   // inverse pipelined behind the chain
     int seg_done = 0;
@@ -572,6 +574,10 @@ int gpmpc_create(int device, int N, int d, int Ny, const double* X, const double
     HIPCHK(hipStreamCreate(&h->aux_stream));
     h->seg_events.resize(std::max(2, round_up(N, 64) / SEGR + 1));
     for (auto& e : h->seg_events) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    if (getenv("GPMPC_CHAIN_TRACE") && !g_chain_trace) {
+        HIPCHK(hipMalloc(&g_chain_trace, (size_t)(1 << 20) * sizeof(long long)));
+        HIPCHK(hipMemset(g_chain_trace, 0, (size_t)(1 << 20) * sizeof(long long)));
+    }
     h->chain_mode = 2;       // 0: single queue; 1: chained Cholesky; 2: + inverse pipelined behind the chain
     if (const char* e = getenv("GPMPC_CHAIN")) h->chain_mode = atoi(e);
     const int Np = h->Np;
@@ -690,6 +696,12 @@ static int factor_with_jitter(gpmpc_gp* h, Workspace& ws, const double* hyper_ho
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(info.data(), ws.info, nb * sizeof(int), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
+        if (g_chain_trace && h->chain_mode) {
+            const size_t cnt = std::min<size_t>(1 << 20, (size_t)nb * (ws.Np / 64) * 8);
+            std::vector<long long> tr(cnt);
+            HIPCHK(hipMemcpy(tr.data(), g_chain_trace, cnt * sizeof(long long), hipMemcpyDeviceToHost));
+            if (FILE* f = fopen(getenv("GPMPC_CHAIN_TRACE"), "wb")) { fwrite(tr.data(), sizeof(long long), cnt, f); fclose(f); }
+        }
         if (h->chain_mode && h->side_stream && ws.Np >= 128) {   // did a hand-off of the chained factorisation time out?
             std::vector<int> cerr((size_t)nb * chain_flag_count(ws.Np / 64));
             HIPCHK(hipMemcpy(cerr.data(), ws.flags, cerr.size() * sizeof(int), hipMemcpyDeviceToHost));
