@@ -23,8 +23,10 @@ namespace gpmpc {
 
 constexpr int CHAIN_LDS_BYTES = 150000;
 
-// flag layout per matrix (ints): [0] error, [1 .. nb] leafdone, [1+nb .. 2nb] pan1, [1+2nb .. 1+4nb) tdone[k][2]
-__host__ __device__ inline int chain_flag_count(int nb) { return 1 + 4 * nb; }
+// flag layout per matrix (ints): [0] error, [1 .. nb] leafdone, [1+nb .. 2nb] pan1, [1+2nb .. 1+4nb) tdone[k][2],
+// and for the tile-owner workers (chol_worker.hpp): [1+4nb .. 1+5nb) pancount, [1+5nb .. 1+6nb) row2done,
+// [1+6nb .. 1+7nb) colready, [1+7nb .. 1+7nb+256) progress word of worker w (1 + 4 k + phase; diagnostics)
+__host__ __device__ inline int chain_flag_count(int nb) { return 1 + 7 * nb + 512; }
 
 #ifdef GPMPC_EMULATED
 #define GPMPC_DYN_SMEM() ((double*)::emu::dyn_smem())
@@ -40,6 +42,14 @@ __global__ void __launch_bounds__(64) chain_gate_kernel(int* flags, long sFlags,
     __shared__ int slot;
     int* fl = flags + (long)blockIdx.x * sFlags;
     wg_wait2(fl + 1, 1, nullptr, 0, fl, spin_limit, &slot);
+}
+
+// Gate of the inverse pipeline next to the worker kernel: returns once panel column e is complete, i.e.
+// L(:, 0..e) and the diagonal inverses up to block e are final.
+__global__ void __launch_bounds__(64) chain_seg_gate_kernel(int* flags, long sFlags, int nb, int e, int spin_limit) {
+    __shared__ int slot;
+    int* fl = flags + (long)blockIdx.x * sFlags;
+    wg_wait2(fl + 1 + 6 * nb + e, 1, fl + 1 + nb + e, 1, fl, spin_limit, &slot, 5000000 + 1000 * e);
 }
 
 __global__ void __launch_bounds__(256) chol_chain_kernel(const double* Kmat, double* L, double* Inv, long ld, long sBatch,
@@ -78,32 +88,38 @@ __global__ void __launch_bounds__(256) chol_chain_kernel(const double* Kmat, dou
         const long o = (long)(64 * k) * ld + 64 * k;
         const long o10 = o + 64 * ld, o11 = o10 + 64;
         CHAIN_STAMP(0);
-        // Prefetch for the second half of the step: if the two tiles A(k+1,k), A(k+1,k+1) already carry
-        // the trailing update of step k-1 (always true once the chain is the bottleneck), their loads are
-        // issued now, into registers, and their HBM latency hides behind the leaf.
+        // Prefetch for the second half of the step: as soon as the two tiles A(k+1,k), A(k+1,k+1) carry
+        // the trailing update of step k-1 their loads are issued, into registers, and the HBM latency hides
+        // behind the leaf.  Two attempts: at the start of the step and two thirds into the leaf.
         bool pre = false;
         double pu[16], ps[16];
-        if (k + 1 < nb) {
-            if (k == 0) pre = true;
-            else {
-                if (tid == 0) {
-                    const int ok = flag_load(&tdone[2 * (k - 1)]) >= 1 && flag_load(&tdone[2 * (k - 1) + 1]) >= 1;
-                    if (ok) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        struct Prefetch {
+            const double* Kb; long o10, o11, ld; const int* f0; const int* f1; int* slot; int tid; bool active;
+            bool* pre; double* pu; double* ps;
+            __device__ __forceinline__ void before() {
+                if (active && !*pre && tid == 0) {
+                    const int ok = !f0 || (flag_load(f0) >= 1 && flag_load(f1) >= 1);
+                    if (ok && f0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                     *slot = ok;
                 }
-                __syncthreads();
-                pre = *slot != 0;
             }
-            if (pre) {
+            __device__ __forceinline__ void after() {
+                if (active && !*pre && *slot != 0) {
+                    *pre = true;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int idx = tid + 256 * i, rr = idx >> 6, cc = idx & 63;
-                    pu[i] = Kb[o10 + (long)rr * ld + cc];
-                    ps[i] = (cc <= rr) ? Kb[o11 + (long)rr * ld + cc] : 0.0;
+                    for (int i = 0; i < 16; ++i) {
+                        const int idx = tid + 256 * i, rr = idx >> 6, cc = idx & 63;
+                        pu[i] = Kb[o10 + (long)rr * ld + cc];
+                        ps[i] = (cc <= rr) ? Kb[o11 + (long)rr * ld + cc] : 0.0;
+                    }
                 }
             }
-        }
-        const int bad = leaf_body(S, T, U, Dr, 1, 15, crow_mode);
+        } pf{Kb, o10, o11, ld, k ? &tdone[2 * (k - 1)] : nullptr, k ? &tdone[2 * (k - 1) + 1] : nullptr, slot, tid,
+             k + 1 < nb, &pre, pu, ps};
+        pf.before();
+        __syncthreads();
+        pf.after();
+        const int bad = leaf_body(S, T, U, Dr, 1, 15, crow_mode, pf);
         CHAIN_STAMP(1);
         if (tid == 0 && bad >= 0) atomicCAS(&info[blockIdx.z], 0, 64 * k + bad + 1);
         for (int idx = tid; idx < 4096; idx += 256) {
@@ -123,7 +139,7 @@ __global__ void __launch_bounds__(256) chol_chain_kernel(const double* Kmat, dou
             }
         } else {
             // the two tiles below/right of the diagonal block must carry the trailing update of step k-1
-            if (!wg_wait2(&tdone[2 * (k - 1)], 1, &tdone[2 * (k - 1) + 1], 1, err, spin_limit, slot)) return;
+            if (!wg_wait2(&tdone[2 * (k - 1)], 1, &tdone[2 * (k - 1) + 1], 1, err, spin_limit, slot, 1000000 + 1000 * k)) return;
             CHAIN_STAMP(3);
 #pragma unroll
             for (int i = 0; i < 16; ++i) {

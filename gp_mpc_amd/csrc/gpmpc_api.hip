@@ -13,6 +13,7 @@
 
 #include "../../include/gpmpc.h"
 #include "chol_chain.hpp"
+#include "chol_worker.hpp"
 #include "em_kernels.hpp"
 #include "gemm_f64.hpp"
 #include "gp_kernels.hpp"
@@ -54,6 +55,7 @@ static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 // device bring-up + fp64 MFMA self-test
 // ------------------------------------------------------------------------------------------------
 static int g_crow_mode[64];
+static int g_cu_count[64];
 static bool g_dev_ready[64];
 
 static int mfma_selftest(int device, int* layout_out, double* tflops_out) {
@@ -132,6 +134,9 @@ static int ensure_device(int device) {
         HIPCHK(hipGetDeviceProperties(&prop, device));
         if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
             return fail(GPMPC_EHIP, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+        g_cu_count[device] = prop.multiProcessorCount;
+#else
+        g_cu_count[device] = getenv("GPMPC_EMU_CUS") ? atoi(getenv("GPMPC_EMU_CUS")) : 8;
 #endif
         int layout = -1;
         CHK(mfma_selftest(device, &layout, nullptr));
@@ -184,7 +189,22 @@ static int ws_alloc(Workspace& ws, int batch, int Np, int d) {
     HIPCHK(hipMalloc(&ws.jitter, (size_t)batch * sizeof(double)));
     HIPCHK(hipMalloc(&ws.nll, (size_t)batch * sizeof(double)));
     HIPCHK(hipMalloc(&ws.info, (size_t)batch * sizeof(int)));
-    HIPCHK(hipMalloc(&ws.flags, (size_t)batch * chain_flag_count(Np / 64) * sizeof(int)));
+    // The hand-off words live in UNCACHED device memory.  Measured on MI355X: a flag word cached in the L2 of
+    // a polling workgroup's XCD is not refreshed by another XCD's store -- sc1 loads and even atomic RMWs keep
+    // returning the stale line until somebody on that XCD happens to execute an acquire (buffer_inv sc1); with
+    // every workgroup of an XCD polling at once nobody does, and the poll never ends.  (Data still travels
+    // through the release / acquire protocol of wg_sync.hpp.)
+    {
+        const size_t fb = (size_t)batch * chain_flag_count(Np / 64) * sizeof(int);
+        void* fp = nullptr;
+        const char* mode = getenv("GPMPC_FLAG_MEM");      // experiment switch: "cached" = plain hipMalloc
+        if ((mode && !strcmp(mode, "cached")) || hipExtMallocWithFlags(&fp, fb, hipDeviceMallocUncached) != hipSuccess) {
+            (void)hipGetLastError();
+            HIPCHK(hipMalloc(&fp, fb));
+            if (getenv("GPMPC_VERBOSE")) fprintf(stderr, "gpmpc: hand-off flags in ordinary (cached) device memory\n");
+        }
+        ws.flags = (int*)fp;
+    }
     HIPCHK(hipMemset(ws.K, 0, mb));
     HIPCHK(hipMemset(ws.L, 0, mb));
     HIPCHK(hipMemset(ws.Inv, 0, mb));
@@ -212,6 +232,7 @@ struct Ctx {
     hipStream_t aux = nullptr;      // third queue: pipelined pieces of the triangular inverse
     hipEvent_t* seg = nullptr;      // pool of n_seg events (segment hand-offs side -> aux, aux -> main)
     int n_seg = 0;
+    int workers = 0;                // > 0: tile-owner worker kernel with this many CUs to share (chain mode 3)
 };
 
 static GemmP gemm_base(const Ctx& cx) {
@@ -368,9 +389,33 @@ static bool factor_chain(const Ctx& cx, Workspace& ws, int spin_limit) {
     }
     hipLaunchKernelGGL(chol_chain_kernel, dim3(1, 1, ws.batch), dim3(256), CHAIN_LDS_BYTES, cx.stream, (const double*)ws.K,
                        ws.L, ws.Inv, ld, sM, nb, ws.flags, (long)nf, ws.info, cx.crow_mode, spin_limit, g_chain_trace);
-    hipLaunchKernelGGL(chain_gate_kernel, dim3(ws.batch), dim3(64), 0, cx.side, ws.flags, (long)nf, spin_limit);
-    const bool pipelined = cx.aux && cx.seg && Np >= 4 * SEGR;   // inverse pipelined behind the chain
+    // bulk work as tile-owner workers: 7 of 8 CUs run one, the trailing matrix lives in their registers
+    // A worker fills a CU (512 threads x ~250 VGPRs) and the chain needs an empty CU too.  Measured on MI355X
+    // (start-time stamps of the workers): workgroups are dealt to the shader engines (8 CUs each) in a fixed
+    // rotation and a workgroup that does not fit on "its" engine waits there even when CUs are free elsewhere
+    // -- with 8 workers on the engine that also got the chain, the 8th started 234 ms late, after the others'
+    // polls had timed out.  So: 7 workers per engine, nothing else in flight but the chain (one matrix only).
+    const int ntiles = (nb - 1) * nb / 2 - 1;            // tiles kept in registers (chol_worker.hpp)
+    int NW = ws.batch == 1 ? cx.workers - cx.workers / 8 : 0;
+    if (NW > ntiles) NW = ntiles;
+    const bool use_workers = NW >= 1 && nb >= 3 && (ntiles + NW - 1) / NW <= WORKER_MAXT;
+    // inverse pipelined behind the chain: only next to GEMM launches (the workers leave it no room)
+    const bool pipelined = !use_workers && cx.aux && cx.seg && Np >= 4 * SEGR;
     int seg_done = 0;
+    static const bool verbose = getenv("GPMPC_VERBOSE") != nullptr;
+    if (verbose)
+        fprintf(stderr, "gpmpc: factor Np=%d batch=%d: chain kernel + %s, inverse %s\n", Np, ws.batch,
+                use_workers ? "tile-owner workers" : "GEMM launches", pipelined ? "pipelined" : "at the end");
+    if (use_workers) {
+        static bool wattr_done = false;
+        if (!wattr_done) {
+            hipFuncSetAttribute((const void*)chol_worker_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WORKER_LDS_BYTES);
+            wattr_done = true;
+        }
+        hipLaunchKernelGGL(chol_worker_kernel, dim3(NW, 1, ws.batch), dim3(WORKER_THREADS), WORKER_LDS_BYTES, cx.side, ws.K, ws.L,
+                           (const double*)ws.Inv, ld, sM, nb, ws.flags, (long)nf, cx.crow_mode, spin_limit);
+    } else {
+    hipLaunchKernelGGL(chain_gate_kernel, dim3(ws.batch), dim3(64), 0, cx.side, ws.flags, (long)nf, spin_limit);
     int* leafdone = ws.flags + 1;
     int* pan1 = ws.flags + 1 + nb;
     int* tdone = ws.flags + 1 + 2 * nb;
@@ -407,6 +452,7 @@ static bool factor_chain(const Ctx& cx, Workspace& ws, int spin_limit) {
                 ++seg_done;
             }
         }
+    }
     }
     hipEventRecord(cx.join, cx.side);
     hipStreamWaitEvent(cx.stream, cx.join, 0);
@@ -488,7 +534,7 @@ struct gpmpc_gp {
     Prof prof;
     Ctx cx() {
         return Ctx{stream, crow_mode, side_stream, ev_fork, ev_join, chain_mode >= 2 ? aux_stream : nullptr,
-                   seg_events.data(), (int)seg_events.size()};
+                   seg_events.data(), (int)seg_events.size(), chain_mode >= 3 ? g_cu_count[device] : 0};
     }
 };
 
@@ -574,11 +620,19 @@ int gpmpc_create(int device, int N, int d, int Ny, const double* X, const double
     HIPCHK(hipStreamCreate(&h->aux_stream));
     h->seg_events.resize(std::max(2, round_up(N, 64) / SEGR + 1));
     for (auto& e : h->seg_events) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+#ifndef GPMPC_EMULATED
+    if (const char* e = getenv("GPMPC_POLL")) {
+        const int m = atoi(e);
+        HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_poll_mode), &m, sizeof(int)));
+    }
+#endif
     if (getenv("GPMPC_CHAIN_TRACE") && !g_chain_trace) {
         HIPCHK(hipMalloc(&g_chain_trace, (size_t)(1 << 20) * sizeof(long long)));
         HIPCHK(hipMemset(g_chain_trace, 0, (size_t)(1 << 20) * sizeof(long long)));
     }
-    h->chain_mode = 2;       // 0: single queue; 1: chained Cholesky; 2: + inverse pipelined behind the chain
+    // 0: single queue; 1: chained Cholesky, bulk in GEMM launches; 2: + inverse pipelined behind the chain;
+    // 3: + bulk in the persistent tile-owner kernel where the matrix fits its registers (else as 2)
+    h->chain_mode = 3;
     if (const char* e = getenv("GPMPC_CHAIN")) h->chain_mode = atoi(e);
     const int Np = h->Np;
     std::vector<double> xt((size_t)d * Np, 0.0), yt((size_t)Ny * Np, 0.0);
@@ -705,10 +759,29 @@ static int factor_with_jitter(gpmpc_gp* h, Workspace& ws, const double* hyper_ho
         if (h->chain_mode && h->side_stream && ws.Np >= 128) {   // did a hand-off of the chained factorisation time out?
             std::vector<int> cerr((size_t)nb * chain_flag_count(ws.Np / 64));
             HIPCHK(hipMemcpy(cerr.data(), ws.flags, cerr.size() * sizeof(int), hipMemcpyDeviceToHost));
-            bool bad = false;
-            for (int b = 0; b < nb; ++b) bad |= cerr[(size_t)b * chain_flag_count(ws.Np / 64)] != 0;
+            int bad = 0;
+            for (int b = 0; b < nb; ++b)
+                if (cerr[(size_t)b * chain_flag_count(ws.Np / 64)] != 0) bad = cerr[(size_t)b * chain_flag_count(ws.Np / 64)];
             if (bad) {
-                fprintf(stderr, "gpmpc: chained factorisation timed out on a hand-off; using the single-queue path\n");
+                fprintf(stderr, "gpmpc: chained factorisation timed out on a hand-off (code %d); using the single-queue path\n", bad);
+                if (getenv("GPMPC_VERBOSE")) {
+                    const int nbk = ws.Np / 64;
+                    fprintf(stderr, "  worker progress (1 + 4k + phase; 0 = never started):");
+                    for (int wq = 0; wq < 256; ++wq) fprintf(stderr, "%s%d", wq % 32 ? " " : "\n    ", cerr[1 + 7 * nbk + wq]);
+                    fprintf(stderr, "\n");
+                    int tmin = 0x7fffffff;
+                    for (int wq = 0; wq < 256; ++wq)
+                        if (cerr[1 + 7 * nbk + wq]) tmin = std::min(tmin, cerr[1 + 7 * nbk + 256 + wq]);
+                    fprintf(stderr, "  worker start times (us after the first):");
+                    for (int wq = 0; wq < 256; ++wq)
+                        fprintf(stderr, "%s%d", wq % 32 ? " " : "\n    ", cerr[1 + 7 * nbk + wq] ? cerr[1 + 7 * nbk + 256 + wq] - tmin : -1);
+                    fprintf(stderr, "\n");
+                    for (int q = 0; q < 7; ++q) {
+                        fprintf(stderr, "  flags[%d]:", q);
+                        for (int k = 0; k < std::min(nbk, 12); ++k) fprintf(stderr, " %d", cerr[1 + q * nbk + k]);
+                        fprintf(stderr, "\n");
+                    }
+                }
                 h->chain_mode = 0;
                 HIPCHK(hipStreamSynchronize(h->side_stream));
                 gram_and_factor(h, ws);

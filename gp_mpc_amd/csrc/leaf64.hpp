@@ -106,8 +106,19 @@ __device__ __forceinline__ int panel_potrf(double* S, double* Drinv, int t, int 
 // non-positive pivot column (0-based) or -1 (meaningful in wave 0).
 // `phases` (bit 0 panel, 1 rank-16 update, 2 diagonal inverses, 3 inverse assembly) exists for the
 // micro-benchmark tools/ubench/leaf_bench.hip only; the library always passes 15.
+//
+// `hook` lets the caller slip work of its own behind the factorisation: hook.before() runs (all threads)
+// just before the barrier that follows the third 16-column panel, hook.after() right after it -- about
+// two thirds into the leaf.  The chain kernel uses it to poll a flag (before) and to issue the global
+// loads of its next tiles (after), whose latency then hides behind the rest of the leaf.
+struct LeafNoHook {
+    __device__ __forceinline__ void before() {}
+    __device__ __forceinline__ void after() {}
+};
+
+template <class Hook>
 __device__ __forceinline__ int leaf_body(double* S, double* T, double* U, double* Dr, int do_chol, int phases,
-                                         int crow_mode) {
+                                         int crow_mode, Hook& hook) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int bad = -1;
     if (do_chol) {
@@ -118,7 +129,9 @@ __device__ __forceinline__ int leaf_body(double* S, double* T, double* U, double
             } else if (wave == 1 && t >= 1 && (phases & 4)) {
                 inv16(S, T, 16 * (t - 1), lane, Dr);   // inverse of the previous diagonal block
             }
+            if (t == 2) hook.before();
             __syncthreads();
+            if (t == 2) hook.after();
             // rank-16 update of the remaining lower tiles: A_ij -= L_it L_jt^T, t < j <= i <= 3
             const int o = 16 * t;
             int cnt = 0;
@@ -163,6 +176,12 @@ __device__ __forceinline__ int leaf_body(double* S, double* T, double* U, double
         __syncthreads();
     }
     return bad;
+}
+
+__device__ __forceinline__ int leaf_body(double* S, double* T, double* U, double* Dr, int do_chol, int phases,
+                                         int crow_mode) {
+    LeafNoHook h;
+    return leaf_body(S, T, U, Dr, do_chol, phases, crow_mode, h);
 }
 
 // grid (nblk, 1, batch), 256 threads: workgroup x handles the diagonal block starting at row/column

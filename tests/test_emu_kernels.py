@@ -49,6 +49,13 @@ def test_emu_pipelined_inverse(emu):
     pc.check_synthetic(emu, N=560, d=4, Ny=2, B=30, sn=0.1, strict_rel=True)
 
 
+def test_emu_tile_owner_workers(emu):
+    # one output: 7 emulated workers own the 45 tiles of Np = 576 (7 each) -> persistent worker kernel +
+    # chain kernel + pipelined inverse; Ny = 2 above exceeds the register budget and takes the GEMM path
+    pc.check_synthetic(emu, N=560, d=4, Ny=1, B=30, sn=0.1, strict_rel=True)
+    pc.check_synthetic(emu, N=300, d=3, Ny=1, B=10, sn=1e-2, strict_rel=False)
+
+
 def test_emu_jitter_rule(emu, train_small):
     pc.check_jitter_rule(emu, train_small)
 
