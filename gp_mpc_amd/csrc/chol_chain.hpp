@@ -44,17 +44,9 @@ __global__ void __launch_bounds__(64) chain_gate_kernel(int* flags, long sFlags,
     wg_wait2(fl + 1, 1, nullptr, 0, fl, spin_limit, &slot);
 }
 
-// Gate of the inverse pipeline next to the worker kernel: returns once panel column e is complete, i.e.
-// L(:, 0..e) and the diagonal inverses up to block e are final.
-__global__ void __launch_bounds__(64) chain_seg_gate_kernel(int* flags, long sFlags, int nb, int e, int spin_limit) {
-    __shared__ int slot;
-    int* fl = flags + (long)blockIdx.x * sFlags;
-    wg_wait2(fl + 1 + 6 * nb + e, 1, fl + 1 + nb + e, 1, fl, spin_limit, &slot, 5000000 + 1000 * e);
-}
-
 __global__ void __launch_bounds__(256) chol_chain_kernel(const double* Kmat, double* L, double* Inv, long ld, long sBatch,
                                                          int nb, int* flags, long sFlags, int* info, int crow_mode,
-                                                         int spin_limit, long long* trace) {
+                                                         int spin_limit, long long* trace, int merge_publish) {
     // optional time stamps (100 MHz wall clock), 8 per step, for tools/chain_trace.py
 #ifdef GPMPC_EMULATED
 #define CHAIN_STAMP(i) ((void)0)
@@ -127,7 +119,9 @@ __global__ void __launch_bounds__(256) chol_chain_kernel(const double* Kmat, dou
             Lb[o + (long)rr * ld + cc] = (cc <= rr) ? S[rr * LS + cc] : 0.0;
             Ib[o + (long)rr * ld + cc] = (cc <= rr) ? T[rr * LS + cc] : 0.0;
         }
-        wg_publish(&leafdone[k], 1);
+        // merge_publish (tile-owner workers, which have slack): leafdone[k] goes out together with pan1[k]
+        // a few microseconds later, saving one L2 write-back per step on this critical path
+        if (!merge_publish || k + 1 == nb) wg_publish(&leafdone[k], 1);
         CHAIN_STAMP(2);
         if (k + 1 == nb) break;
         if (pre) {
@@ -173,7 +167,8 @@ __global__ void __launch_bounds__(256) chol_chain_kernel(const double* Kmat, dou
             S[rr * LS + cc] = ps[i];                                              // next diagonal block
         }
         CHAIN_STAMP(5);
-        wg_publish(&pan1[k], 1);     // (contains the barrier that also orders the S loads above)
+        if (merge_publish) wg_publish(&leafdone[k], 1, &pan1[k]);
+        else wg_publish(&pan1[k], 1);     // (contains the barrier that also orders the S loads above)
         CHAIN_STAMP(6);
         // A_{k+1,k+1} -= L_{k+1,k} L_{k+1,k}^T on the 10 lower 16 x 16 tiles
         int cnt = 0;

@@ -163,9 +163,9 @@ __global__ void __launch_bounds__(WORKER_THREADS) chol_worker_kernel(double* Kma
             if (tid == 0) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                 GPMPC_DRAIN_VM();
-                if (i == 2) flag_post(&row2done[0], 1);
+                if (i == 2) flag_store(&row2done[0], 1);
                 const int before = __hip_atomic_fetch_add(&pancount[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (before + 1 == nb - 2) flag_post(&colready[0], 1);
+                if (before + 1 == nb - 2) flag_store(&colready[0], 1);
             }
             __syncthreads();
         }
@@ -194,11 +194,10 @@ __global__ void __launch_bounds__(WORKER_THREADS) chol_worker_kernel(double* Kma
             if (tid == 0) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                 GPMPC_DRAIN_VM();
-                if (i == k + 2) flag_post(&row2done[k], 1);
-                // Count the tile; whoever completes the column raises the flag the consumers poll (the value
-                // RETURNED by the add is exact; a polling LOAD of the counter may lag, see flag_post).
+                if (i == k + 2) flag_store(&row2done[k], 1);
+                // count the tile; whoever completes the column raises the flag the consumers poll
                 const int before = __hip_atomic_fetch_add(&pancount[k], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (before + 1 == nb - k - 2) flag_post(&colready[k], 1);
+                if (before + 1 == nb - k - 2) flag_store(&colready[k], 1);
                 ti[n] = -1;
             }
             __syncthreads();

@@ -189,22 +189,7 @@ static int ws_alloc(Workspace& ws, int batch, int Np, int d) {
     HIPCHK(hipMalloc(&ws.jitter, (size_t)batch * sizeof(double)));
     HIPCHK(hipMalloc(&ws.nll, (size_t)batch * sizeof(double)));
     HIPCHK(hipMalloc(&ws.info, (size_t)batch * sizeof(int)));
-    // The hand-off words live in UNCACHED device memory.  Measured on MI355X: a flag word cached in the L2 of
-    // a polling workgroup's XCD is not refreshed by another XCD's store -- sc1 loads and even atomic RMWs keep
-    // returning the stale line until somebody on that XCD happens to execute an acquire (buffer_inv sc1); with
-    // every workgroup of an XCD polling at once nobody does, and the poll never ends.  (Data still travels
-    // through the release / acquire protocol of wg_sync.hpp.)
-    {
-        const size_t fb = (size_t)batch * chain_flag_count(Np / 64) * sizeof(int);
-        void* fp = nullptr;
-        const char* mode = getenv("GPMPC_FLAG_MEM");      // experiment switch: "cached" = plain hipMalloc
-        if ((mode && !strcmp(mode, "cached")) || hipExtMallocWithFlags(&fp, fb, hipDeviceMallocUncached) != hipSuccess) {
-            (void)hipGetLastError();
-            HIPCHK(hipMalloc(&fp, fb));
-            if (getenv("GPMPC_VERBOSE")) fprintf(stderr, "gpmpc: hand-off flags in ordinary (cached) device memory\n");
-        }
-        ws.flags = (int*)fp;
-    }
+    HIPCHK(hipMalloc(&ws.flags, (size_t)batch * chain_flag_count(Np / 64) * sizeof(int)));
     HIPCHK(hipMemset(ws.K, 0, mb));
     HIPCHK(hipMemset(ws.L, 0, mb));
     HIPCHK(hipMemset(ws.Inv, 0, mb));
@@ -387,8 +372,6 @@ static bool factor_chain(const Ctx& cx, Workspace& ws, int spin_limit) {
         hipFuncSetAttribute((const void*)chol_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CHAIN_LDS_BYTES);
         attr_done = true;
     }
-    hipLaunchKernelGGL(chol_chain_kernel, dim3(1, 1, ws.batch), dim3(256), CHAIN_LDS_BYTES, cx.stream, (const double*)ws.K,
-                       ws.L, ws.Inv, ld, sM, nb, ws.flags, (long)nf, ws.info, cx.crow_mode, spin_limit, g_chain_trace);
     // bulk work as tile-owner workers: 7 of 8 CUs run one, the trailing matrix lives in their registers
     // A worker fills a CU (512 threads x ~250 VGPRs) and the chain needs an empty CU too.  Measured on MI355X
     // (start-time stamps of the workers): workgroups are dealt to the shader engines (8 CUs each) in a fixed
@@ -402,6 +385,9 @@ static bool factor_chain(const Ctx& cx, Workspace& ws, int spin_limit) {
     // inverse pipelined behind the chain: only next to GEMM launches (the workers leave it no room)
     const bool pipelined = !use_workers && cx.aux && cx.seg && Np >= 4 * SEGR;
     int seg_done = 0;
+    hipLaunchKernelGGL(chol_chain_kernel, dim3(1, 1, ws.batch), dim3(256), CHAIN_LDS_BYTES, cx.stream, (const double*)ws.K,
+                       ws.L, ws.Inv, ld, sM, nb, ws.flags, (long)nf, ws.info, cx.crow_mode, spin_limit, g_chain_trace,
+                       use_workers ? 1 : 0);
     static const bool verbose = getenv("GPMPC_VERBOSE") != nullptr;
     if (verbose)
         fprintf(stderr, "gpmpc: factor Np=%d batch=%d: chain kernel + %s, inverse %s\n", Np, ws.batch,
@@ -415,44 +401,44 @@ static bool factor_chain(const Ctx& cx, Workspace& ws, int spin_limit) {
         hipLaunchKernelGGL(chol_worker_kernel, dim3(NW, 1, ws.batch), dim3(WORKER_THREADS), WORKER_LDS_BYTES, cx.side, ws.K, ws.L,
                            (const double*)ws.Inv, ld, sM, nb, ws.flags, (long)nf, cx.crow_mode, spin_limit);
     } else {
-    hipLaunchKernelGGL(chain_gate_kernel, dim3(ws.batch), dim3(64), 0, cx.side, ws.flags, (long)nf, spin_limit);
-    int* leafdone = ws.flags + 1;
-    int* pan1 = ws.flags + 1 + nb;
-    int* tdone = ws.flags + 1 + 2 * nb;
-    for (int k = 0; k + 1 < nb; ++k) {
-        const int off = 64 * k;
-        const long o11 = (long)off * ld + off;
-        const int M2 = Np - off - 128;                       // panel rows >= k+2 (row k+1 is the chain's)
-        if (M2 > 0) {
-            const long o2 = (long)(off + 128) * ld + off;
-            GemmP p = gemm_base(cx);
-            p.A = ws.K + o2; p.lda = ld; p.sA = sM; p.a_mc = 0;
-            p.B = ws.Inv + o11; p.ldb = ld; p.sB = sM; p.b_nc = 0; p.kflags = KB_LE_N;
-            p.C = ws.L + o2; p.ldc = ld; p.sC = sM;
-            p.M = M2; p.N = 64; p.K = 64;
-            p.wait_flag = leafdone + k; p.err = ws.flags; p.spin_limit = spin_limit; p.sFlags = nf;
-            launch_gemm(p, ws.batch, cx.side);
-        }
-        const int M1 = Np - off - 64;                        // trailing update from block k+1 on, minus tile (k+1,k+1)
-        if (M1 > 64) {
-            const long o1 = (long)(off + 64) * ld;
-            GemmP q = gemm_base(cx);
-            q.A = ws.L + o1 + off; q.lda = ld; q.sA = sM; q.a_mc = 0;
-            q.B = ws.L + o1 + off; q.ldb = ld; q.sB = sM; q.b_nc = 0;
-            q.C = ws.K + o1 + off + 64; q.ldc = ld; q.sC = sM;
-            q.M = M1; q.N = M1; q.K = 64; q.alpha = -1.0; q.beta = 1.0; q.lower = 1;
-            q.wait_flag = pan1 + k; q.err = ws.flags; q.spin_limit = spin_limit; q.sFlags = nf;
-            q.skip00 = 1; q.done_flags = tdone + 2 * k;
-            launch_gemm(q, ws.batch, cx.side, 64);           // flags are defined on 64 x 64 tiles
-            // rows [.., 64(k+1)) are final once this update has consumed panel k: a finished segment goes to aux
-            if (pipelined && (off + 64) % SEGR == 0 && seg_done < cx.n_seg - 1) {
-                hipEventRecord(cx.seg[seg_done], cx.side);
-                hipStreamWaitEvent(cx.aux, cx.seg[seg_done], 0);
-                trtri_segment(cx, ws, cx.aux, seg_done * SEGR, (seg_done + 1) * SEGR);
-                ++seg_done;
+        hipLaunchKernelGGL(chain_gate_kernel, dim3(ws.batch), dim3(64), 0, cx.side, ws.flags, (long)nf, spin_limit);
+        int* leafdone = ws.flags + 1;
+        int* pan1 = ws.flags + 1 + nb;
+        int* tdone = ws.flags + 1 + 2 * nb;
+        for (int k = 0; k + 1 < nb; ++k) {
+            const int off = 64 * k;
+            const long o11 = (long)off * ld + off;
+            const int M2 = Np - off - 128;                       // panel rows >= k+2 (row k+1 is the chain's)
+            if (M2 > 0) {
+                const long o2 = (long)(off + 128) * ld + off;
+                GemmP p = gemm_base(cx);
+                p.A = ws.K + o2; p.lda = ld; p.sA = sM; p.a_mc = 0;
+                p.B = ws.Inv + o11; p.ldb = ld; p.sB = sM; p.b_nc = 0; p.kflags = KB_LE_N;
+                p.C = ws.L + o2; p.ldc = ld; p.sC = sM;
+                p.M = M2; p.N = 64; p.K = 64;
+                p.wait_flag = leafdone + k; p.err = ws.flags; p.spin_limit = spin_limit; p.sFlags = nf;
+                launch_gemm(p, ws.batch, cx.side);
+            }
+            const int M1 = Np - off - 64;                        // trailing update from block k+1 on, minus tile (k+1,k+1)
+            if (M1 > 64) {
+                const long o1 = (long)(off + 64) * ld;
+                GemmP q = gemm_base(cx);
+                q.A = ws.L + o1 + off; q.lda = ld; q.sA = sM; q.a_mc = 0;
+                q.B = ws.L + o1 + off; q.ldb = ld; q.sB = sM; q.b_nc = 0;
+                q.C = ws.K + o1 + off + 64; q.ldc = ld; q.sC = sM;
+                q.M = M1; q.N = M1; q.K = 64; q.alpha = -1.0; q.beta = 1.0; q.lower = 1;
+                q.wait_flag = pan1 + k; q.err = ws.flags; q.spin_limit = spin_limit; q.sFlags = nf;
+                q.skip00 = 1; q.done_flags = tdone + 2 * k;
+                launch_gemm(q, ws.batch, cx.side, 64);           // flags are defined on 64 x 64 tiles
+                // rows [.., 64(k+1)) are final once this update has consumed panel k: a finished segment goes to aux
+                if (pipelined && (off + 64) % SEGR == 0 && seg_done < cx.n_seg - 1) {
+                    hipEventRecord(cx.seg[seg_done], cx.side);
+                    hipStreamWaitEvent(cx.aux, cx.seg[seg_done], 0);
+                    trtri_segment(cx, ws, cx.aux, seg_done * SEGR, (seg_done + 1) * SEGR);
+                    ++seg_done;
+                }
             }
         }
-    }
     }
     hipEventRecord(cx.join, cx.side);
     hipStreamWaitEvent(cx.stream, cx.join, 0);
@@ -620,12 +606,6 @@ int gpmpc_create(int device, int N, int d, int Ny, const double* X, const double
     HIPCHK(hipStreamCreate(&h->aux_stream));
     h->seg_events.resize(std::max(2, round_up(N, 64) / SEGR + 1));
     for (auto& e : h->seg_events) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-#ifndef GPMPC_EMULATED
-    if (const char* e = getenv("GPMPC_POLL")) {
-        const int m = atoi(e);
-        HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_poll_mode), &m, sizeof(int)));
-    }
-#endif
     if (getenv("GPMPC_CHAIN_TRACE") && !g_chain_trace) {
         HIPCHK(hipMalloc(&g_chain_trace, (size_t)(1 << 20) * sizeof(long long)));
         HIPCHK(hipMemset(g_chain_trace, 0, (size_t)(1 << 20) * sizeof(long long)));

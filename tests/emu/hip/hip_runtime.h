@@ -92,8 +92,6 @@ inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
     p->multiProcessorCount = 1;
     return hipSuccess;
 }
-enum { hipDeviceMallocFinegrained = 1, hipDeviceMallocUncached = 3 };
-inline hipError_t hipExtMallocWithFlags(void** p, size_t bytes, unsigned) { *p = std::malloc(bytes ? bytes : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 template <class T> inline hipError_t hipMalloc(T** p, size_t bytes) {
     void* q = nullptr;
     if (posix_memalign(&q, 256, bytes ? bytes : 256) != 0) return hipErrorOutOfMemory;
