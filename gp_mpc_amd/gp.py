@@ -13,6 +13,7 @@ calls the (device) predictor in the GP's own units and un-standardises the MEAN 
 from __future__ import annotations
 
 import json
+import os
 
 import numpy as np
 
@@ -20,6 +21,15 @@ from . import _lib
 from .train import train_gp
 
 METHODS = ('ME', 'TA', 'EM', 'old_ME', 'old_TA')
+
+
+def _listify(v):
+    """numpy arrays -> nested lists, recursively through dicts (json.dump input)."""
+    if isinstance(v, dict):
+        return {k: _listify(x) for k, x in v.items()}
+    if isinstance(v, np.ndarray):
+        return v.tolist()
+    return v
 
 
 class GP:
@@ -334,11 +344,11 @@ class GP:
         return None
 
     # ------------------------------------------------------------------ persistence (gp_class.py:693-743)
-    def _to_dict(self):
-        """Model as plain lists under the key names of the reference's file format
-        (gp_class.py:693-726), factors exported from the device."""
+    def _to_dict(self, as_arrays=False):
+        """Model under the key names of the reference's file format (gp_class.py:693-726), factors
+        exported from the device; plain lists unless `as_arrays`."""
         f = self._h.get_factors(chol=True, alpha=True, invK=True)
-        as_list = lambda v: np.asarray(v).tolist()
+        as_list = (lambda v: np.asarray(v)) if as_arrays else (lambda v: np.asarray(v).tolist())
         out = {'X': as_list(self.__X), 'Y': as_list(self.__Y),
                'hyper': {k: as_list(v) for k, v in (
                    ('hyper', self.__hyper), ('invK', f['invK']), ('alpha', f['alpha']), ('chol', f['chol']),
@@ -352,17 +362,48 @@ class GP:
                            for k in ('meanY', 'stdY', 'meanZ', 'stdZ', 'meanX', 'stdX', 'meanU', 'stdU')}
         return out
 
-    def save_model(self, filename):
-        """Save model to `filename`.json in the reference's format (gp_class.py:729-734)."""
+    SIDECAR_MIN_N = 1024     # from this many training points on, save_model moves the matrices out of the JSON
+
+    def save_model(self, filename, sidecar=None):
+        """Save model to `filename`.json in the reference's format (gp_class.py:729-734).
+
+        `sidecar` (default: N >= SIDECAR_MIN_N): write the big arrays -- X, Y and hyper's chol, invK,
+        alpha -- to `filename`.npz instead and leave `{"__sidecar__": key}` placeholders in the JSON
+        (a JSON of Ny x N x N doubles is impractical beyond a few thousand points: 6 x 8192^2
+        numbers are ~9 GB of text).  Files without a sidecar are byte-for-byte the reference's layout
+        and load with the reference's GP.load_model; files with one need this class."""
+        d = self._to_dict(as_arrays=True)
+        if sidecar is None:
+            sidecar = self.__N >= self.SIDECAR_MIN_N
+        if sidecar:
+            big = {'X': d['X'], 'Y': d['Y']}
+            for k in ('chol', 'invK', 'alpha'):
+                big['hyper_' + k] = d['hyper'][k]
+                d['hyper'][k] = {'__sidecar__': 'hyper_' + k}
+            d['X'] = {'__sidecar__': 'X'}
+            d['Y'] = {'__sidecar__': 'Y'}
+            d['sidecar_file'] = os.path.basename(filename) + '.npz'
+            np.savez(filename + '.npz', **big)
         with open(filename + ".json", "w") as outfile:
-            json.dump(self._to_dict(), outfile)
+            json.dump(_listify(d), outfile)
 
     @classmethod
     def load_model(cls, filename, **kwargs):
         """Create a new model from `filename`.json (gp_class.py:737-743); files written by the
-        reference load unchanged.  kwargs: device=, lib=."""
+        reference load unchanged, `__sidecar__` placeholders are resolved from the .npz next to the
+        JSON.  kwargs: device=, lib=."""
         with open(filename + ".json") as json_data:
             input_dict = json.load(json_data)
+        side = input_dict.pop('sidecar_file', None)
+        if side is not None:
+            with np.load(os.path.join(os.path.dirname(filename + '.json'), side)) as z:
+                def resolve(v):
+                    if isinstance(v, dict) and '__sidecar__' in v:
+                        return z[v['__sidecar__']]
+                    if isinstance(v, dict):
+                        return {k: resolve(x) for k, x in v.items()}
+                    return v
+                input_dict = resolve(input_dict)
         input_dict.update(kwargs)
         return cls(**input_dict)
 

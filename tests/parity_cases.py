@@ -330,6 +330,15 @@ def check_gp_class(lib, g, tmp_path):
     m2, c2 = gp2.predict(x, u, S)
     m1, c1 = gp.predict(x, u, S)
     assert np.allclose(m1, m2, rtol=1e-12, atol=0) and np.allclose(c1, c2, rtol=0, atol=1e-12 * sf2.max())
+    # the same with the matrices in a binary sidecar (what large models use by default)
+    gp.save_model(path + '_bin', sidecar=True)
+    d = json.load(open(path + '_bin.json'))
+    assert d['hyper']['chol'] == {'__sidecar__': 'hyper_chol'} and d['sidecar_file'] == 'model_bin.npz'
+    gp3 = GP.load_model(path + '_bin', lib=lib)
+    gp3.set_method('TA')
+    m3b, c3b = gp3.predict(x, u, S)
+    assert np.array_equal(m1, m3b) and np.array_equal(c1, c3b)          # binary round trip is exact
+    gp3.close()
     # data replacement keeps the hyper-parameters and refits (gp_class.py:553-626)
     gp2.replace_data_all(Xraw[:40], Yraw[:40])
     assert gp2.get_size()[0] == 40
