@@ -48,6 +48,7 @@ SIGNATURES = {
     'gpmpc_set_factors': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp]),
     'gpmpc_predict_mean_var': (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp]),
     'gpmpc_mean_jac': (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp]),
+    'gpmpc_predict_sens': (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp, _vp, _vp, _vp]),
     'gpmpc_predict': (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, _vp]),
     'gpmpc_covar': (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp]),
     'gpmpc_nll': (ctypes.c_int, [_vp, ctypes.c_int, _vp, _dp, _vp, _ip]),
@@ -233,6 +234,17 @@ class Handle:
         mean, J = np.zeros((B, self.Ny)), np.zeros((B, self.Ny, self.d))
         self.lib.check(self.lib.dll.gpmpc_mean_jac(self.h, B, _ptr(Z), _ptr(mean), _ptr(J)))
         return mean, J
+
+    def predict_sens(self, Z):
+        """mean[B,Ny], var[B,Ny], J[B,Ny,d] = d mean/dz, Hm[B,Ny,d,d] = d2 mean/dz2, dvar[B,Ny,d] = d var/dz."""
+        Z = _f64(Z).reshape(-1, self.d)
+        B = Z.shape[0]
+        mean, var = np.zeros((B, self.Ny)), np.zeros((B, self.Ny))
+        J, Hm = np.zeros((B, self.Ny, self.d)), np.zeros((B, self.Ny, self.d, self.d))
+        dvar = np.zeros((B, self.Ny, self.d))
+        self.lib.check(self.lib.dll.gpmpc_predict_sens(self.h, B, _ptr(Z), _ptr(mean), _ptr(var), _ptr(J), _ptr(Hm),
+                                                       _ptr(dvar)))
+        return mean, var, J, Hm, dvar
 
     def predict(self, method, Z, Sigma=None):
         code = METHODS[method] if isinstance(method, str) else int(method)

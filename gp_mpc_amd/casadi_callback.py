@@ -3,14 +3,16 @@
 In the reference `GP.predict` returns a symbolic `ca.Function` call that is inlined into the NLP
 graph (gp_class.py:207-242,259; mpc_class.py:412-413).  A GPU predictor cannot be inlined, so an
 MPC layer uses it through this callback instead: same signature `(x[Ny], u[Nu], covar[Nx x Nx])
--> (mean[Ny], cov[Ny x Ny])` as `__predict` (gp_class.py:212-224), with `get_jacobian` served by
-the analytic mean Jacobian kernel and central differences of the device predictor for the
+-> (mean[Ny], cov[Ny x Ny])` as `__predict` (gp_class.py:212-224), with `get_jacobian` served for the
+'ME' and 'TA' methods by exact derivatives from one device call (`GP.predict_derivatives` ->
+`gpmpc_predict_sens`: mean Jacobian, mean Hessian and variance gradient kernels), and for the other
+methods by the analytic mean Jacobian plus central differences of the device predictor for the
 covariance block.  Use it with IPOPT options `expand=False` (a Callback cannot be flattened to SX;
 note mpc_class.py:169 reads solver_opts['expand']) and `hessian_approximation='limited-memory'`.
 
 casadi is not installable in the build image, so this module is import-guarded and
 cannot be exercised by the test-suite here; it only composes entry points that are tested
-(`GP.predict`, `GP.discrete_linearize`).
+(`GP.predict`, `GP.predict_derivatives`, `GP.discrete_linearize`).
 """
 try:
     import casadi as ca
@@ -50,6 +52,12 @@ def make_predict_callback(gp, name='gp_hip', fd_eps=1e-6):
             x = np.array(arg[0]).reshape(-1)
             u = np.array(arg[1]).reshape(-1)
             S = np.array(arg[2]).reshape(Nx, Nx)
+            if gp._GP__gp_method in ('ME', 'TA'):                # exact, one device call
+                _, _, D = gp.predict_derivatives(x, u, S)
+                col = lambda T, n: T.reshape(Ny * Ny, n, order='F') if T.ndim == 3 else T   # vec(cov) is column-major
+                dcS = D['dcov_dcov'].reshape(Ny * Ny, Nx, Nx, order='F').reshape(Ny * Ny, Nx * Nx, order='F')
+                return [D['dmean_dx'], D['dmean_du'], np.zeros((Ny, Nx * Nx)),
+                        col(D['dcov_dx'], Ny), col(D['dcov_du'], Nu), dcS]
             A, B = gp.discrete_linearize(x, u, S)              # analytic, on the device
             if gp._GP__normalize:                                # d mean_raw / d x_raw
                 A = A * gp._GP__stdY[:, None] / gp._GP__stdX[None, :]

@@ -287,6 +287,79 @@ __global__ void __launch_bounds__(256) cov_assemble_kernel(const double* __restr
     cov[e] = v;
 }
 
+// Second-order information of the predictor at a test point (what a casadi Callback for
+// GP.__predict must hand to IPOPT; the reference gets it from CasADi's AD of gp_functions.py:114-147):
+//   Hm[b][a][p][q] = d^2 mean_a / dz_p dz_q = sum_i alpha_i ks_i r_ip r_iq - delta_pq mean_a / l_p^2,
+//   dvar[b][a][p]  = d var_a / dz_p        = -2 sum_i u_i ks_i r_ip,
+// with r_ip = (X_ip - z_p) / l_ap^2 and u = K_a^-1 ks (UT, one GEMM for the batch).  HBM-read bound: the two
+// N-vectors ks and u per (point, output).  D is a template parameter: the D (D + 1) / 2 + D running sums live
+// in registers.  grid (B, Ny), 256 threads; fixed-order reduction (deterministic).
+template <int D>
+__global__ void __launch_bounds__(256) sens_kernel(const double* __restrict__ XT, const double* __restrict__ Z,
+                                                   const double* __restrict__ hyper, const double* __restrict__ alpha,
+                                                   const double* __restrict__ KsT, const double* __restrict__ UT,
+                                                   double* __restrict__ Hm, double* __restrict__ dvar, int N, int Np,
+                                                   int Bp, int Ny) {
+    constexpr int NH = D * (D + 1) / 2, NS = NH + D + 1;
+    const int b = blockIdx.x, a = blockIdx.y, tid = threadIdx.x;
+    __shared__ double red[4][NS];
+    __shared__ double zs[D], w[D];
+    const double* hy = hyper + (long)a * (D + 2);
+    if (tid < D) {
+        zs[tid] = Z[(long)b * D + tid];
+        w[tid] = 1.0 / (hy[tid] * hy[tid]);
+    }
+    __syncthreads();
+    const double* __restrict__ ks = KsT + ((long)a * Bp + b) * Np;
+    const double* __restrict__ u = UT + ((long)a * Bp + b) * Np;
+    const double* __restrict__ al = alpha + (long)a * Np;
+    double acc[NS];
+#pragma unroll
+    for (int e = 0; e < NS; ++e) acc[e] = 0.0;
+    for (int i = tid; i < N; i += 256) {
+        const double k = ks[i], ka = k * al[i], ku = k * u[i];
+        double r[D];
+#pragma unroll
+        for (int p = 0; p < D; ++p) r[p] = (XT[(long)p * Np + i] - zs[p]) * w[p];
+        int e = 0;
+#pragma unroll
+        for (int p = 0; p < D; ++p)
+#pragma unroll
+            for (int q = 0; q <= p; ++q, ++e) acc[e] += ka * r[p] * r[q];
+#pragma unroll
+        for (int p = 0; p < D; ++p) acc[NH + p] += ku * r[p];
+        acc[NH + D] += ka;
+    }
+#pragma unroll
+    for (int e = 0; e < NS; ++e) {
+        const double t = wave_sum(acc[e]);
+        if ((tid & 63) == 0) red[tid >> 6][e] = t;
+    }
+    __syncthreads();
+    if (tid < NS) red[0][tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+    __syncthreads();
+    const double mean = red[0][NH + D];
+    if (tid < D * D) {
+        const int p = tid / D, q = tid % D, hi = p > q ? p : q, lo = p > q ? q : p;
+        double v = red[0][hi * (hi + 1) / 2 + lo];
+        if (p == q) v -= mean * w[p];
+        Hm[(((long)b * Ny + a) * D + p) * D + q] = v;
+    }
+    if (tid < D) dvar[((long)b * Ny + a) * D + tid] = -2.0 * red[0][NH + tid];
+}
+
+inline void launch_sens(hipStream_t st, int d, const double* XT, const double* Z, const double* hyper, const double* alpha,
+                        const double* KsT, const double* UT, double* Hm, double* dvar, int N, int Np, int B, int Bp, int Ny) {
+#define GPMPC_SK(DD) case DD: hipLaunchKernelGGL((sens_kernel<DD>), dim3(B, Ny), dim3(256), 0, st, XT, Z, hyper, alpha, KsT, \
+                                                 UT, Hm, dvar, N, Np, Bp, Ny); break;
+    switch (d) {
+        GPMPC_SK(1) GPMPC_SK(2) GPMPC_SK(3) GPMPC_SK(4) GPMPC_SK(5) GPMPC_SK(6) GPMPC_SK(7) GPMPC_SK(8)
+        GPMPC_SK(9) GPMPC_SK(10) GPMPC_SK(11) GPMPC_SK(12) GPMPC_SK(13) GPMPC_SK(14) GPMPC_SK(15) GPMPC_SK(16)
+        default: break;
+    }
+#undef GPMPC_SK
+}
+
 // Matrix-vector products with the explicit factors (a5: alpha = L^-T (L^-1 y), optimize.py:353-354,494;
 // beta = K^-1 y, gp_functions.py:383).  HBM-read bound: 4 N^2 bytes for a triangular operand.
 // out[i] = sum_{k < (lower ? i+1 : Np)} A[i][k] x[k]: one wave per row, lanes stride the row (512 B

@@ -515,7 +515,8 @@ struct gpmpc_gp {
     double* em = nullptr;  // exact-moment / legacy scratch
     long emBytes = 0;
     double* beta = nullptr;  // K^-1 y, [Ny][Np]
-    double* UT = nullptr;    // legacy: K^-1 ks per test point
+    double* UT = nullptr;    // K^-1 ks per test point (legacy methods, sensitivities)
+    double *sensH = nullptr, *sensV = nullptr;   // staging of gpmpc_predict_sens outputs in host-pointer mode
     bool have_beta = false;
     Prof prof;
     Ctx cx() {
@@ -640,7 +641,7 @@ int gpmpc_destroy(gpmpc_gp* h) {
     hipFree(h->XT); hipFree(h->Y); hipFree(h->gradPartial); hipFree(h->gradOut);
     hipFree(h->Z); hipFree(h->Sigma); hipFree(h->KsT); hipFree(h->part); hipFree(h->meanT);
     hipFree(h->mean); hipFree(h->var); hipFree(h->J); hipFree(h->cov); hipFree(h->em);
-    hipFree(h->beta); hipFree(h->UT);
+    hipFree(h->beta); hipFree(h->UT); hipFree(h->sensH); hipFree(h->sensV);
     for (int ph = 0; ph < GPMPC_PH_COUNT; ++ph)
         for (auto& pr : h->prof.ev[ph]) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     for (auto e : h->prof.pool) hipEventDestroy(e);
@@ -912,7 +913,8 @@ static int ensure_scratch(gpmpc_gp* h, int B) {
     HIPCHK(hipStreamSynchronize(h->stream));
     hipFree(h->Z); hipFree(h->Sigma); hipFree(h->KsT); hipFree(h->part); hipFree(h->meanT);
     hipFree(h->mean); hipFree(h->var); hipFree(h->J); hipFree(h->cov); hipFree(h->UT);
-    h->UT = nullptr;
+    hipFree(h->sensH); hipFree(h->sensV);
+    h->UT = h->sensH = h->sensV = nullptr;
     h->Z = h->Sigma = h->KsT = h->part = h->meanT = h->mean = h->var = h->J = h->cov = nullptr;
     h->Bcap = 0;
     const size_t d = h->d, Ny = h->Ny, Np = h->Np, Bc = need;
@@ -1054,6 +1056,64 @@ extern "C" int gpmpc_predict_mean_var(gpmpc_gp* h, int B, const double* Z, doubl
 extern "C" int gpmpc_mean_jac(gpmpc_gp* h, int B, const double* Z, double* mean, double* J) {
     if (!J) return fail(GPMPC_EINVAL, "J is NULL");
     return predict_driver(h, GPMPC_ME, B, Z, nullptr, mean, nullptr, J, nullptr);
+}
+
+extern "C" int gpmpc_predict_sens(gpmpc_gp* h, int B, const double* Z, double* mean, double* var, double* J, double* Hm,
+                                  double* dvar) {
+    if (!h) return fail(GPMPC_EINVAL, "NULL handle");
+    if (!h->fitted) return fail(GPMPC_ENOTFIT, "model has no factors (call gpmpc_fit or gpmpc_set_factors)");
+    if (B <= 0 || !Z) return fail(GPMPC_EINVAL, "bad B or NULL Z");
+    HIPCHK(hipSetDevice(h->device));
+    CHK(ensure_scratch(h, B));
+    const int d = h->d, Ny = h->Ny, Np = h->Np;
+    const bool host = h->ptr_mode == GPMPC_PTR_HOST;
+    const bool second = Hm || dvar;
+    if (second && !h->have_invK) {
+        PhaseTimer t(h, GPMPC_PH_INVK);
+        CHK(compute_invK(h->cx(), h->ws));
+        h->have_invK = true;
+    }
+    if (second && !h->UT) HIPCHK(hipMalloc(&h->UT, (size_t)Ny * h->Bcap * Np * sizeof(double)));
+    if (second && !h->sensH) {
+        HIPCHK(hipMalloc(&h->sensH, (size_t)h->Bcap * Ny * d * d * sizeof(double)));
+        HIPCHK(hipMalloc(&h->sensV, (size_t)h->Bcap * Ny * d * sizeof(double)));
+    }
+    const Ctx cx = h->cx();
+    for (int b0 = 0; b0 < B; b0 += h->Bcap) {
+        const int nb = (B - b0 < h->Bcap) ? B - b0 : h->Bcap;
+        const double* dZ = Z + (size_t)b0 * d;
+        if (host) {
+            HIPCHK(hipMemcpyAsync(h->Z, dZ, (size_t)nb * d * sizeof(double), hipMemcpyHostToDevice, h->stream));
+            dZ = h->Z;
+        }
+        double* oMean = mean ? (host ? h->mean : mean + (size_t)b0 * Ny) : nullptr;
+        double* oVar = var ? (host ? h->var : var + (size_t)b0 * Ny) : nullptr;
+        double* oJ = J ? (host ? h->J : J + (size_t)b0 * Ny * d) : nullptr;
+        double* oH = host ? h->sensH : (Hm ? Hm + (size_t)b0 * Ny * d * d : h->sensH);
+        double* oV = host ? h->sensV : (dvar ? dvar + (size_t)b0 * Ny * d : h->sensV);
+        CHK(predict_chunk(h, nb, dZ, oMean, oVar, oJ));
+        if (second) {
+            const int Bp = round_up(nb, 32);            // the layout predict_chunk left in KsT
+            PhaseTimer t(h, GPMPC_PH_FINISH);
+            GemmP p = gemm_base(cx);                     // UT[j][:] = KsT[j][:] K^-1
+            p.A = h->KsT; p.lda = Np; p.sA = (long)Bp * Np; p.a_mc = 0;
+            p.B = h->ws.InvK; p.ldb = Np; p.sB = h->ws.mat(); p.b_nc = 1;
+            p.C = h->UT; p.ldc = Np; p.sC = (long)Bp * Np;
+            p.M = Bp; p.N = Np; p.K = Np;
+            launch_gemm(p, Ny, cx.stream);
+            launch_sens(cx.stream, d, h->XT, dZ, h->ws.hyper, h->ws.alpha, h->KsT, h->UT, oH, oV, h->N, Np, nb, Bp, Ny);
+        }
+        if (host) {
+            if (mean) HIPCHK(hipMemcpyAsync(mean + (size_t)b0 * Ny, h->mean, (size_t)nb * Ny * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+            if (var) HIPCHK(hipMemcpyAsync(var + (size_t)b0 * Ny, h->var, (size_t)nb * Ny * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+            if (J) HIPCHK(hipMemcpyAsync(J + (size_t)b0 * Ny * d, h->J, (size_t)nb * Ny * d * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+            if (Hm) HIPCHK(hipMemcpyAsync(Hm + (size_t)b0 * Ny * d * d, h->sensH, (size_t)nb * Ny * d * d * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+            if (dvar) HIPCHK(hipMemcpyAsync(dvar + (size_t)b0 * Ny * d, h->sensV, (size_t)nb * Ny * d * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+        }
+    }
+    HIPCHK(hipGetLastError());
+    return GPMPC_OK;
 }
 
 extern "C" int gpmpc_predict(gpmpc_gp* h, int method, int B, const double* Z, const double* Sigma, double* mean,

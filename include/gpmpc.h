@@ -105,6 +105,13 @@ int gpmpc_predict_mean_var(gpmpc_gp* h, int B, const double* Z, double* mean, do
 /* mean[B x Ny] and J[B x Ny x d] = d mean / d z: mean_jac_z gp_functions.py:146-147 (CasADi AD
  * there, analytic here); the operand of GP.discrete_linearize / jacobian gp_class.py:647-672. */
 int gpmpc_mean_jac(gpmpc_gp* h, int B, const double* Z, double* mean, double* J);
+/* Derivative outputs for a casadi Callback around GP.__predict (the reference obtains them
+ * from CasADi's AD of build_gp / build_TA_cov, gp_functions.py:114-173): besides mean[B x Ny], var[B x Ny]
+ * and J[B x Ny x d] = d mean/dz also Hm[B x Ny x d x d] = d2 mean/dz2 and dvar[B x Ny x d] = d var/dz, from
+ * which d cov/dz and d cov/dSigma of the 'ME' and 'TA' methods follow in closed form
+ * (cov = diag(var) + J Sigma J^T).  Any output pointer may be NULL. */
+int gpmpc_predict_sens(gpmpc_gp* h, int B, const double* Z, double* mean, double* var, double* J,
+                       double* Hm, double* dvar);
 /* GP.__predict (gp_class.py:212-235) batched over B input distributions:
  * Z[B x d], Sigma[B x d x d] (ignored for ME/old_ME, may be NULL) -> mean[B x Ny],
  * cov[B x Ny x Ny] in standardised units (gp_class.py:262 leaves cov unscaled). */

@@ -270,6 +270,45 @@ def mean_var_jac(Z, X, hyper, alpha, chol, want_jac=True):
     return mean, var, J
 
 
+def mean_var_sens(Z, X, hyper, alpha, chol):
+    """Second-order information of `build_gp`'s functions (the reference gets
+    it from CasADi AD of gp_functions.py:114-147 inside IPOPT, there is no reference function):
+    Hm[b,a,p,q] = d2 mean_a/dz_p dz_q, dvar[b,a,p] = d var_a/dz_p.  With r_ip = (X_ip - z_p)/l_p^2:
+    d ks_i/dz_p = ks_i r_ip, d2 ks_i/dz_p dz_q = ks_i (r_ip r_iq - delta_pq/l_p^2), and
+    var = sf^2 - ks^T K^-1 ks gives dvar_p = -2 (K^-1 ks)^T d ks/dz_p (K^-1 from chol, two
+    triangular solves).  Pinned by finite differences of `mean_var_jac` in tests/test_oracle.py."""
+    from scipy.linalg import solve_triangular
+    Z = np.atleast_2d(np.asarray(Z, dtype=np.float64))
+    B, d = Z.shape
+    Ny = hyper.shape[0]
+    Hm = np.zeros((B, Ny, d, d))
+    dvar = np.zeros((B, Ny, d))
+    for a in range(Ny):
+        ell2 = hyper[a, :d] ** 2
+        sf2 = hyper[a, d] ** 2
+        ks = cov_se_ard_direct(X, Z, hyper[a, :d], sf2)                     # [N, B]
+        u = solve_triangular(chol[a], solve_triangular(chol[a], ks, lower=True), lower=True, trans='T')
+        for b in range(B):
+            r = (X - Z[b]) / ell2                                            # [N, d]
+            ka = ks[:, b] * alpha[a]
+            Hm[b, a] = (r * ka[:, None]).T @ r - np.diag(ka.sum() / ell2)
+            dvar[b, a] = -2.0 * (r * (u[:, b] * ks[:, b])[:, None]).sum(axis=0)
+    return Hm, dvar
+
+
+def ta_cov_sens(var, J, Hm, dvar, Sigma):
+    """Derivatives of the 'TA' covariance cov = diag(var) + J Sigma J^T (gp_functions.py:167-171)
+    with respect to the input mean z and the input covariance Sigma, for ONE input:
+    dcov_dz[a,c,p] = delta_ac dvar[a,p] + sum_de (Hm[a,d,p] S_de J[c,e] + J[a,d] S_de Hm[c,e,p]),
+    dcov_dS[a,c,d,e] = J[a,d] J[c,e].  ('ME': Sigma = 0 leaves dcov_dz = diag(dvar), dcov_dS = 0.)"""
+    Ny, d = J.shape
+    dz = np.einsum('adp,de,ce->acp', Hm, Sigma, J) + np.einsum('ad,de,cep->acp', J, Sigma, Hm)
+    for a in range(Ny):
+        dz[a, a] += dvar[a]
+    dS = np.einsum('ad,ce->acde', J, J)
+    return dz, dS
+
+
 def ta_cov(var, J, Sigma):
     """a10: `build_TA_cov` gp_functions.py:152-173:
     cov = diag(var) + J Sigma J^T, batched: var[B,Ny], J[B,Ny,d], Sigma[B,d,d]."""

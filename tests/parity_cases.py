@@ -254,6 +254,34 @@ def check_moment_methods(lib, g=None):
     h.close()
 
 
+def check_sensitivities(lib, g, nprobe=12):
+    """gpmpc_predict_sens (second-order outputs for a casadi Callback) against the oracle's
+    closed forms, which tests/test_oracle.py pins by finite differences of the first-order functions."""
+    X, Y, H = g['X'], g['Y'], g['hyper']
+    d = X.shape[1]
+    sf2 = H[:, d] ** 2
+    h = Handle(lib, X, Y)
+    h.fit(H)
+    f = h.get_factors()
+    Z = g['Z'][:nprobe]
+    mean, var, J, Hm, dvar = h.predict_sens(Z)
+    om, ov, oJ = go.mean_var_jac(Z, X, H, f['alpha'], f['chol'])
+    oH, odv = go.mean_var_sens(Z, X, H, f['alpha'], f['chol'])
+    ms = mean_scale(X, Z, H, f['alpha'])
+    assert np.max(np.abs(mean - om) / ms) <= 1e-10 and np.max(np.abs(var - ov) / sf2) <= 1e-10
+    ell_min = H[:, :d].min(axis=1)
+    # scale of a derivative: the value scale over the shortest length scale (squared for the Hessian)
+    assert np.max(np.abs(J - oJ) / (ms / ell_min)[..., None]) <= 1e-10
+    assert np.max(np.abs(Hm - oH) / (ms / ell_min ** 2)[..., None, None]) <= 1e-10
+    cond = max(np.linalg.cond(f['chol'][a]) ** 2 for a in range(H.shape[0]))
+    tol = max(1e-10, 50 * np.finfo(float).eps * cond)                     # u = K^-1 ks is cond-limited
+    assert np.max(np.abs(dvar - odv) / (sf2 / ell_min)[None, :, None]) <= tol
+    # chunked evaluation (more points than fit one scratch chunk is not reachable here; at least B = 1)
+    m1, v1, J1, H1, d1 = h.predict_sens(Z[:1])
+    assert np.allclose(H1, Hm[:1], rtol=0, atol=1e-12 * np.abs(Hm).max()) and np.allclose(d1, dvar[:1], rtol=0, atol=1e-12 * np.abs(dvar).max() + 1e-300)
+    h.close()
+
+
 def check_gp_class(lib, g, tmp_path):
     """The Python `GP` surface (reference gp_class.py) against `OracleGP` on a saved reference model."""
     from gp_mpc_amd.gp import GP
@@ -319,6 +347,34 @@ def check_gp_class(lib, g, tmp_path):
         assert False
     except ValueError:
         pass
+    # exact derivatives of predict (what a casadi Callback hands to IPOPT) vs central differences of predict
+    for method in ('TA', 'ME'):
+        gp.set_method(method)
+        m0, c0, D = gp.predict_derivatives(x, u, S)
+        mm, cc = gp.predict(x, u, S)
+        assert np.array_equal(m0, mm) and np.allclose(c0, cc, rtol=0, atol=1e-13 * sf2.max())
+        zraw = np.concatenate([x, u])
+        dm = np.concatenate([D['dmean_dx'], D['dmean_du']], axis=1)
+        dc = np.concatenate([D['dcov_dx'], D['dcov_du']], axis=2)
+        for k in range(Nx):
+            e = np.zeros(Nx)
+            e[k] = 1e-4 * max(1.0, abs(zraw[k]))
+            mp, cp = gp.predict((zraw + e)[:Ny], (zraw + e)[Ny:], S)
+            mn, cn = gp.predict((zraw - e)[:Ny], (zraw - e)[Ny:], S)
+            assert np.allclose((mp - mn)[:, 0] / (2 * e[k]), dm[:, k], rtol=1e-5, atol=1e-6 * np.abs(dm).max())
+            # (the variance carries ~1e-13 sf^2 of cancellation noise, which the difference quotient amplifies)
+            assert np.allclose((cp - cn) / (2 * e[k]), dc[:, :, k], rtol=1e-4, atol=1e-5 * np.abs(dc).max() + 1e-12 * sf2.max() / e[k])
+        E = np.zeros((Nx, Nx))
+        E[0, 1] = 1e-3
+        _, cp = gp.predict(x, u, S + E)
+        assert np.allclose((cp - cc) / 1e-3, D['dcov_dcov'][:, :, 0, 1], rtol=1e-9, atol=1e-12 * sf2.max() / 1e-3)
+    gp.set_method('EM')
+    try:
+        gp.predict_derivatives(x, u, S)
+        assert False
+    except NotImplementedError:
+        pass
+    gp.set_method('TA')
     # save / load round trip in the reference's JSON layout
     path = str(tmp_path / 'model')
     gp.save_model(path)

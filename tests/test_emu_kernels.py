@@ -69,6 +69,11 @@ def test_emu_moment_methods(emu, tank):
     pc.check_moment_methods(emu, tank)
 
 
+def test_emu_sensitivities(emu, tank, car):
+    pc.check_sensitivities(emu, tank)
+    pc.check_sensitivities(emu, car, nprobe=5)
+
+
 def test_emu_gp_class(emu, tank, tmp_path):
     pc.check_gp_class(emu, tank, tmp_path)
 

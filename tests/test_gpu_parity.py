@@ -96,6 +96,11 @@ def test_moment_methods(lib, tank):
     pc.check_moment_methods(lib, tank)
 
 
+def test_sensitivities(lib, tank, car):
+    pc.check_sensitivities(lib, tank)
+    pc.check_sensitivities(lib, car, nprobe=20)
+
+
 def test_gp_class(lib, tank, tmp_path):
     pc.check_gp_class(lib, tank, tmp_path)
 

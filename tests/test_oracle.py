@@ -208,3 +208,35 @@ def test_predict_standardisation_and_rollout(tank):
     assert np.allclose(mr[0, 1], mr[2, 1], rtol=1e-3, atol=1e-3)
     A, Bm = gp.discrete_linearize(x, u, np.eye(6) * 1e-6)
     assert A.shape == (4, 4) and Bm.shape == (4, 2)
+
+
+def test_sensitivities_match_finite_differences(tank):
+    """mean_var_sens / ta_cov_sens (closed forms behind gpmpc_predict_sens; no reference function --
+    CasADi AD does this inside IPOPT) against central differences of mean_var_jac / ta_cov."""
+    X, Y, H = tank['X'], tank['Y'], tank['hyper']
+    d = X.shape[1]
+    o = go.fit(X, Y, H, want_invK=False)
+    Z = tank['Z'][:3]
+    mean, var, J = go.mean_var_jac(Z, X, H, o['alpha'], o['chol'])
+    Hm, dvar = go.mean_var_sens(Z, X, H, o['alpha'], o['chol'])
+    eps = 1e-4            # alpha ~ 1e3 on this model: smaller steps drown in cancellation noise
+    rng = np.random.default_rng(0)
+    A = rng.standard_normal((d, d))
+    S = A @ A.T * 1e-3 + 1e-6 * np.eye(d)
+    cov0 = go.ta_cov(var, J, np.tile(S, (len(Z), 1, 1)))
+    for p in range(d):
+        dz = np.zeros(d); dz[p] = eps
+        mp, vp, Jp = go.mean_var_jac(Z + dz, X, H, o['alpha'], o['chol'])
+        mm, vm, Jm = go.mean_var_jac(Z - dz, X, H, o['alpha'], o['chol'])
+        assert np.allclose((Jp - Jm) / (2 * eps), Hm[..., p], rtol=1e-6, atol=1e-7 * np.abs(Hm).max())
+        assert np.allclose((vp - vm) / (2 * eps), dvar[..., p], rtol=1e-5, atol=1e-5 * np.abs(dvar).max())
+        cp = go.ta_cov(vp, Jp, np.tile(S, (len(Z), 1, 1)))
+        cm = go.ta_cov(vm, Jm, np.tile(S, (len(Z), 1, 1)))
+        for b in range(len(Z)):
+            dcz, dcS = go.ta_cov_sens(var[b], J[b], Hm[b], dvar[b], S)
+            assert np.allclose((cp[b] - cm[b]) / (2 * eps), dcz[..., p], rtol=1e-5, atol=1e-5 * np.abs(dcz).max())
+    # cov is linear in Sigma: d cov / d Sigma_de = J[:, d] J[:, e]^T exactly
+    dcz, dcS = go.ta_cov_sens(var[0], J[0], Hm[0], dvar[0], S)
+    E = np.zeros((d, d)); E[1, 2] = 1.0
+    c1 = go.ta_cov(var[:1], J[:1], (S + E)[None])[0]
+    assert np.allclose(c1 - cov0[0], dcS[:, :, 1, 2], rtol=1e-12, atol=1e-14)
