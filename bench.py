@@ -11,7 +11,7 @@ objects shard trivially, no data-path collective): weak scaling.
 Extra objects on the JSON line:
   roofline     -- the dominant kernel (variance GEMM V = L^-1 Ks with fused column sums of squares):
                   algorithmic flops per launch N(N+1) B / HIP-event time of that launch, vs the fp64
-                  MFMA peak (78.6 TFLOP/s spec; the measured issue-bound rate is reported beside it).
+                  MFMA peak (78.6 TFLOP/s spec; the rate of a pure MFMA loop measured at library load is reported beside it).
   cpu_baseline -- the oracle's reference-formulation CPU path (numpy/LAPACK, same box, rank 0, N=1):
                   one full fit + 1000 of the 10 000 predictions (prediction time scaled x10).
 """

@@ -36,6 +36,30 @@
 
 namespace gpmpc {
 
+// raw buffer resource over [base, base + bytes): loads beyond the range return 0 (gfx9 family word 3: 0x00020000)
+#ifdef GPMPC_EMULATED
+struct gpmpc_rsrc_t { const char* base; unsigned bytes; };
+inline gpmpc_rsrc_t gpmpc_make_rsrc(const void* base, unsigned bytes) { return gpmpc_rsrc_t{(const char*)base, bytes}; }
+inline double2 gpmpc_buffer_load_d2(const gpmpc_rsrc_t& r, unsigned voff, int soff) {
+    const unsigned long o = (unsigned long)voff + (unsigned long)(unsigned)soff;
+    if (o + 16 > r.bytes) return double2{0.0, 0.0};
+    return *reinterpret_cast<const double2*>(r.base + o);
+}
+#else
+typedef __amdgpu_buffer_rsrc_t gpmpc_rsrc_t;
+__device__ __forceinline__ gpmpc_rsrc_t gpmpc_make_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ double2 gpmpc_buffer_load_d2(gpmpc_rsrc_t r, unsigned voff, int soff) {
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    const u4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, soff, 0);
+    double2 d;
+    __builtin_memcpy(&d, &v, 16);
+    return d;
+}
+#endif
+
+
 enum { KA_LE_M = 1,   // A(m,k) == 0 for k > m   (A lower triangular)
        KA_GE_M = 2,   // A(m,k) == 0 for k < m   (A = T^T, T lower triangular)
        KB_LE_N = 4,   // B(k,n) == 0 for k > n   (B = T^T, T lower triangular)
@@ -74,7 +98,7 @@ struct GemmP {
     long sFlags;          // batch stride of the three flag pointers
 };
 
-template <int BM, int BN, int BK, int WGM, int WGN, bool AMC, bool BNC, bool SPLIT = GPMPC_GEMM_SPLIT>
+template <int BM, int BN, int BK, int WGM, int WGN, bool AMC, bool BNC, bool SPLIT = GPMPC_GEMM_SPLIT, bool BUF = false>
 __global__ void __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) gemm_f64_kernel(GemmP p) {
     constexpr int NT = 64 * WGM * WGN;
     constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 16, TN = WN / 16;
@@ -119,6 +143,16 @@ __global__ void __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) gemm_f64_kernel
     const double* __restrict__ A = p.A + (long)z1 * p.sA + (long)z2 * p.sA2;
     const double* __restrict__ B = p.B + (long)z1 * p.sB + (long)z2 * p.sB2;
     const int fr = lane & 15, fk = lane >> 4;
+    // BUF (both operands K-contiguous, < 4 GB each): tile loads are buffer_load_dwordx4 through a resource whose
+    // range check returns zeros for rows >= M / N -- no exec-mask branches, no 64-bit address arithmetic and no
+    // zero-fill moves in the main loop (each VALU instruction there costs matrix-pipe issue time, measured with
+    // tools/ubench/mfma_issue_bench.hip: +8 ns per MFMA for one v_fma per MFMA); the per-iteration K offset rides
+    // in the instruction's scalar offset.
+    gpmpc_rsrc_t rsA, rsB;
+    if (BUF) {
+        rsA = gpmpc_make_rsrc(A, (unsigned)((long)p.M * p.lda * 8));
+        rsB = gpmpc_make_rsrc(B, (unsigned)((long)p.N * p.ldb * 8));
+    }
 
     for (int pass = 0; pass < 2; ++pass) {
         // heavy tiles first: with a lower-triangular A the K range grows with m, with B = T^T with n
@@ -155,8 +189,28 @@ __global__ void __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) gemm_f64_kernel
             for (int j = 0; j < TN; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
 
         double2 ra[LA], rb[LB];
+        unsigned voA[LA], voB[LB];      // BUF: byte offset of this thread's r-th 16-byte piece at k0 = 0
+        if (BUF) {
+#pragma unroll
+            for (int r = 0; r < LA; ++r) {
+                const int idx = tid + NT * r, row = idx / HK, k = (idx % HK) * 2;
+                voA[r] = (unsigned)(((long)(m0 + row) * p.lda + k) * 8);
+            }
+#pragma unroll
+            for (int r = 0; r < LB; ++r) {
+                const int idx = tid + NT * r, row = idx / HK, k = (idx % HK) * 2;
+                voB[r] = (unsigned)(((long)(n0 + row) * p.ldb + k) * 8);
+            }
+        }
 
         auto load_tiles = [&](int k0) {
+            if (BUF) {
+#pragma unroll
+                for (int r = 0; r < LA; ++r) ra[r] = gpmpc_buffer_load_d2(rsA, voA[r], k0 * 8);
+#pragma unroll
+                for (int r = 0; r < LB; ++r) rb[r] = gpmpc_buffer_load_d2(rsB, voB[r], k0 * 8);
+                return;
+            }
 #pragma unroll
             for (int r = 0; r < LA; ++r) {
                 const int idx = tid + NT * r;
@@ -333,7 +387,12 @@ inline void launch_gemm_cfg(GemmP p, int batch, hipStream_t stream, int resident
     p.npad = (p.tilesNe >= pad_min) ? ((p.tilesNe + 7) & ~7) : p.tilesNe;
     dim3 grid(p.remap ? prows * pcols * 64 : p.tilesMe * p.npad, 1, batch);
     const dim3 block(64 * WGM * WGN);
-    if (!p.a_mc && !p.b_nc)
+    static const bool use_buf = !(getenv("GPMPC_GEMM_BUF") && atoi(getenv("GPMPC_GEMM_BUF")) == 0);
+    const bool small = (long)p.M * p.lda * 8 < (1L << 32) && (long)p.N * p.ldb * 8 < (1L << 32);
+    if (!p.a_mc && !p.b_nc && use_buf && small)
+        hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, BK, WGM, WGN, false, false, GPMPC_GEMM_SPLIT, true>), grid, block, 0,
+                           stream, p);
+    else if (!p.a_mc && !p.b_nc)
         hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, BK, WGM, WGN, false, false>), grid, block, 0, stream, p);
     else if (!p.a_mc && p.b_nc)
         hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, BK, WGM, WGN, false, true>), grid, block, 0, stream, p);

@@ -522,7 +522,10 @@ __global__ void __launch_bounds__(64) mfma_probe_kernel(const double* __restrict
     for (int r = 0; r < 4; ++r) D[l * 4 + r] = c[r];
 }
 
-__global__ void __launch_bounds__(256) mfma_rate_kernel(double* __restrict__ out, int iters) {
+// (min 4 waves per SIMD in the launch bounds = at most 128 registers = accumulators stay in arch VGPRs: with
+// the default bounds the compiler keeps them in AGPRs and copies 64 registers in and out of the loop body on
+// every iteration, which once made this benchmark report 45 instead of 77 TFLOP/s)
+__global__ void __launch_bounds__(256, 4) mfma_rate_kernel(double* __restrict__ out, int iters) {
     const double a = 1.0 + 1e-9 * threadIdx.x, b = 1.0 - 1e-9 * threadIdx.x;
     d4 c0 = d4{0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
     for (int i = 0; i < iters; ++i) {
