@@ -46,6 +46,7 @@ SIGNATURES = {
     'gpmpc_fit': (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp]),
     'gpmpc_get_factors': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp]),
     'gpmpc_set_factors': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    'gpmpc_append': (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp]),
     'gpmpc_predict_mean_var': (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp]),
     'gpmpc_mean_jac': (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp]),
     'gpmpc_predict_sens': (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -234,6 +235,16 @@ class Handle:
         mean, J = np.zeros((B, self.Ny)), np.zeros((B, self.Ny, self.d))
         self.lib.check(self.lib.dll.gpmpc_mean_jac(self.h, B, _ptr(Z), _ptr(mean), _ptr(J)))
         return mean, J
+
+    def append(self, Xnew, Ynew):
+        """Append training points, keep the hyper-parameters (rank-n update of the factors)."""
+        Xnew = _f64(Xnew).reshape(-1, self.d)
+        Ynew = _f64(Ynew).reshape(Xnew.shape[0], self.Ny)
+        info = np.zeros(self.Ny, dtype=np.int32)
+        self.lib.check(self.lib.dll.gpmpc_append(self.h, Xnew.shape[0], _ptr(Xnew), _ptr(Ynew),
+                                                 info.ctypes.data_as(ctypes.c_void_p)))
+        self.N += Xnew.shape[0]
+        return info
 
     def predict_sens(self, Z):
         """mean[B,Ny], var[B,Ny], J[B,Ny,d] = d mean/dz, Hm[B,Ny,d,d] = d2 mean/dz2, dvar[B,Ny,d] = d var/dz."""

@@ -29,9 +29,9 @@ __device__ __forceinline__ double wave_sum(double v) {
 // 4 N (N+1) bytes per output.
 __global__ void __launch_bounds__(256) gram_kernel(const double* __restrict__ XT, const double* __restrict__ hyper,
                                                    const double* __restrict__ jitter, double* __restrict__ K,
-                                                   int N, int Np, int d) {
+                                                   int N, int Np, int d, int tm0 = 0) {
 #pragma clang fp contract(off)
-    const int tn = blockIdx.x, tm = blockIdx.y, a = blockIdx.z;
+    const int tn = blockIdx.x, tm = blockIdx.y + tm0, a = blockIdx.z;   // tm0: first tile row (gpmpc_append)
     if (tn > tm) return;
     __shared__ double Xr[DMAX][64], Xc[DMAX][64], Qr[DMAX][64], Qc[DMAX][64], e2[DMAX];
     const int tid = threadIdx.x, m0 = tm * 64, n0 = tn * 64;

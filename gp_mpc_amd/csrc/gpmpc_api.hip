@@ -322,7 +322,7 @@ static void trtri_segment(const Ctx& cx, Workspace& ws, hipStream_t stream, int 
         }
 }
 
-static void factor_blocked(const Ctx& cx, Workspace& ws, bool do_chol) {
+static void factor_blocked(const Ctx& cx, Workspace& ws, bool do_chol, int k0 = 0) {
     const int Np = ws.Np, nb = Np / 64;
     const long ld = Np, sM = ws.mat();
     if (!do_chol) {   // inverse only (gpmpc_set_factors): all diagonal blocks are independent
@@ -331,7 +331,7 @@ static void factor_blocked(const Ctx& cx, Workspace& ws, bool do_chol) {
         trtri_levels(cx, ws);
         return;
     }
-    for (int k = 0; k < nb; ++k) {
+    for (int k = k0; k < nb; ++k) {     // k0 > 0: block columns < k0 are already factored and applied (gpmpc_append)
         const int off = 64 * k, M = Np - off - 64;
         hipLaunchKernelGGL(leaf64_kernel, dim3(1, 1, ws.batch), dim3(256), 0, cx.stream, (const double*)ws.K, ws.L, ws.Inv,
                            ld, sM, off, 1, ws.info, cx.crow_mode, 15);
@@ -350,7 +350,7 @@ static void factor_blocked(const Ctx& cx, Workspace& ws, bool do_chol) {
         q.M = M; q.N = M; q.K = 64; q.alpha = -1.0; q.beta = 1.0; q.lower = 1;
         launch_gemm(q, ws.batch, cx.stream);
     }
-    trtri_levels(cx, ws);
+    if (k0 == 0) trtri_levels(cx, ws);
 }
 
 // Chained factorisation: the sequential part of every panel step runs in ONE persistent workgroup
@@ -367,11 +367,6 @@ static bool factor_chain(const Ctx& cx, Workspace& ws, int spin_limit) {
     hipMemsetAsync(ws.flags, 0, (size_t)ws.batch * nf * sizeof(int), cx.stream);
     hipEventRecord(cx.fork, cx.stream);
     hipStreamWaitEvent(cx.side, cx.fork, 0);
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipFuncSetAttribute((const void*)chol_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CHAIN_LDS_BYTES);
-        attr_done = true;
-    }
     // bulk work as tile-owner workers: 7 of 8 CUs run one, the trailing matrix lives in their registers
     // A worker fills a CU (512 threads x ~250 VGPRs) and the chain needs an empty CU too.  Measured on MI355X
     // (start-time stamps of the workers): workgroups are dealt to the shader engines (8 CUs each) in a fixed
@@ -393,11 +388,6 @@ static bool factor_chain(const Ctx& cx, Workspace& ws, int spin_limit) {
         fprintf(stderr, "gpmpc: factor Np=%d batch=%d: chain kernel + %s, inverse %s\n", Np, ws.batch,
                 use_workers ? "tile-owner workers" : "GEMM launches", pipelined ? "pipelined" : "at the end");
     if (use_workers) {
-        static bool wattr_done = false;
-        if (!wattr_done) {
-            hipFuncSetAttribute((const void*)chol_worker_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WORKER_LDS_BYTES);
-            wattr_done = true;
-        }
         hipLaunchKernelGGL(chol_worker_kernel, dim3(NW, 1, ws.batch), dim3(WORKER_THREADS), WORKER_LDS_BYTES, cx.side, ws.K, ws.L,
                            (const double*)ws.Inv, ld, sM, nb, ws.flags, (long)nf, cx.crow_mode, spin_limit);
     } else {
@@ -605,6 +595,9 @@ int gpmpc_create(int device, int N, int d, int Ny, const double* X, const double
     HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
     HIPCHK(hipStreamCreate(&h->aux_stream));
+    // the persistent kernels ask for more than the default 64 KB of dynamic LDS (per device: set for every handle)
+    HIPCHK(hipFuncSetAttribute((const void*)chol_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CHAIN_LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void*)chol_worker_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WORKER_LDS_BYTES));
     h->seg_events.resize(std::max(2, round_up(N, 64) / SEGR + 1));
     for (auto& e : h->seg_events) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     if (getenv("GPMPC_CHAIN_TRACE") && !g_chain_trace) {
@@ -813,6 +806,139 @@ extern "C" int gpmpc_fit(gpmpc_gp* h, const double* hyper, int want_invK, int* i
     HIPCHK(hipGetLastError());
     h->hyper.assign(hyper, hyper + (size_t)h->Ny * (h->d + 2));
     h->fitted = true;
+    return GPMPC_OK;
+}
+
+// ---- data update: a15 (GP.update_data_all gp_class.py:474-550 = append + full recomputation with the
+// existing hyper-parameters) as a rank-n extension of the factors.
+// With R0 = 64 floor(N/64) the rows < R0 of L and L^-1 do not change.  For the strip of m = Np' - R0 rows
+// below (the last partial block of old points, the new points, padding):
+//     K' rows >= R0 from the K build;   L21 = K21 inv11^T;   S = K22 - L21 L21^T;   L22 = chol(S) (blocked);
+//     inv22 = L22^-1;   inv21 = -inv22 (L21 inv11)
+// i.e. four GEMMs with K = R0 plus a factorisation of m rows -- O(N^2 m) instead of O(N^3).
+static void free_predict_scratch(gpmpc_gp* h) {
+    hipFree(h->Z); hipFree(h->Sigma); hipFree(h->KsT); hipFree(h->part); hipFree(h->meanT);
+    hipFree(h->mean); hipFree(h->var); hipFree(h->J); hipFree(h->cov); hipFree(h->UT);
+    hipFree(h->sensH); hipFree(h->sensV); hipFree(h->em); hipFree(h->beta); hipFree(h->gradPartial);
+    h->Z = h->Sigma = h->KsT = h->part = h->meanT = h->mean = h->var = h->J = h->cov = h->UT = nullptr;
+    h->sensH = h->sensV = h->em = h->beta = h->gradPartial = nullptr;
+    h->Bcap = 0;
+    h->emBytes = 0;
+    h->have_beta = false;
+    ws_free(h->tws);
+}
+
+extern "C" int gpmpc_append(gpmpc_gp* h, int n, const double* Xnew, const double* Ynew, int* info) {
+    if (!h || n <= 0 || !Xnew || !Ynew) return fail(GPMPC_EINVAL, "NULL handle/data or n <= 0");
+    if (!h->fitted) return fail(GPMPC_ENOTFIT, "model has no factors (call gpmpc_fit or gpmpc_set_factors)");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const int N0 = h->N, N1 = N0 + n, d = h->d, Ny = h->Ny, Np0 = h->Np, Np1 = round_up(N1, 64);
+    const int R0 = (N0 / 64) * 64, m = Np1 - R0;
+    // new data buffers: old points back from the device, new ones appended
+    std::vector<double> xt0((size_t)d * Np0), yt0((size_t)Ny * Np0), xt((size_t)d * Np1, 0.0), yt((size_t)Ny * Np1, 0.0);
+    HIPCHK(hipMemcpy(xt0.data(), h->XT, xt0.size() * sizeof(double), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(yt0.data(), h->Y, yt0.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (int k = 0; k < d; ++k) {
+        std::memcpy(&xt[(size_t)k * Np1], &xt0[(size_t)k * Np0], N0 * sizeof(double));
+        for (int i = 0; i < n; ++i) xt[(size_t)k * Np1 + N0 + i] = Xnew[(size_t)i * d + k];
+    }
+    for (int a = 0; a < Ny; ++a) {
+        std::memcpy(&yt[(size_t)a * Np1], &yt0[(size_t)a * Np0], N0 * sizeof(double));
+        for (int i = 0; i < n; ++i) yt[(size_t)a * Np1 + N0 + i] = Ynew[(size_t)i * Ny + a];
+    }
+    double *XT1 = nullptr, *Y1 = nullptr;
+    HIPCHK(hipMalloc(&XT1, xt.size() * sizeof(double)));
+    HIPCHK(hipMalloc(&Y1, yt.size() * sizeof(double)));
+    HIPCHK(hipMemcpy(XT1, xt.data(), xt.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(Y1, yt.data(), yt.size() * sizeof(double), hipMemcpyHostToDevice));
+    Workspace ws1;
+    int rc = ws_alloc(ws1, Ny, Np1, d);
+    if (rc != GPMPC_OK) { hipFree(XT1); hipFree(Y1); return rc; }
+    HIPCHK(hipMemcpy(ws1.hyper, h->ws.hyper, (size_t)Ny * (d + 2) * sizeof(double), hipMemcpyDeviceToDevice));
+    HIPCHK(hipMemcpy(ws1.jitter, h->ws.jitter, (size_t)Ny * sizeof(double), hipMemcpyDeviceToDevice));
+    const long slot_cap = ws1.wstride() - ws1.hw() * ws1.hw();
+    const bool strip = R0 >= 64 && m <= Np1 / 4 && (long)m * R0 <= slot_cap;
+    auto install = [&]() {                                  // the handle takes the new data set
+        hipFree(h->XT); hipFree(h->Y);
+        ws_free(h->ws);
+        free_predict_scratch(h);
+        h->XT = XT1; h->Y = Y1; h->ws = ws1;
+        h->N = N1; h->Np = Np1;
+        h->have_invK = false;
+        const size_t need = Np1 / SEGR + 1;
+        while (h->seg_events.size() < need) {
+            hipEvent_t e;
+            hipEventCreateWithFlags(&e, hipEventDisableTiming);
+            h->seg_events.push_back(e);
+        }
+    };
+    if (!strip) {                                           // too many new rows for the update to pay: plain refit
+        install();
+        std::vector<double> hy = h->hyper;
+        return gpmpc_fit(h, hy.data(), 0, info);
+    }
+    const Ctx cx = h->cx();
+    const long ld = Np1, sM = ws1.mat(), sW = ws1.wstride();
+    for (int a = 0; a < Ny; ++a) {                          // unchanged rows < R0 of L and L^-1
+        HIPCHK(hipMemcpy2DAsync(ws1.L + a * sM, ld * sizeof(double), h->ws.L + (size_t)a * Np0 * Np0, Np0 * sizeof(double),
+                                R0 * sizeof(double), R0, hipMemcpyDeviceToDevice, cx.stream));
+        HIPCHK(hipMemcpy2DAsync(ws1.Inv + a * sM, ld * sizeof(double), h->ws.Inv + (size_t)a * Np0 * Np0,
+                                Np0 * sizeof(double), R0 * sizeof(double), R0, hipMemcpyDeviceToDevice, cx.stream));
+    }
+    HIPCHK(hipMemsetAsync(ws1.info, 0, Ny * sizeof(int), cx.stream));
+    hipLaunchKernelGGL(gram_kernel, dim3(Np1 / 64, m / 64, Ny), dim3(256), 0, cx.stream, XT1, ws1.hyper, ws1.jitter, ws1.K, N1,
+                       Np1, d, R0 / 64);
+    const long oS = (long)R0 * ld;                          // first strip row
+    {
+        GemmP p = gemm_base(cx);                            // L21 = K21 inv11^T
+        p.A = ws1.K + oS; p.lda = ld; p.sA = sM; p.a_mc = 0;
+        p.B = ws1.Inv; p.ldb = ld; p.sB = sM; p.b_nc = 0; p.kflags = KB_LE_N;
+        p.C = ws1.L + oS; p.ldc = ld; p.sC = sM;
+        p.M = m; p.N = R0; p.K = R0;
+        launch_gemm(p, Ny, cx.stream);
+        GemmP q = gemm_base(cx);                            // S = K22 - L21 L21^T (lower)
+        q.A = ws1.L + oS; q.lda = ld; q.sA = sM; q.a_mc = 0;
+        q.B = ws1.L + oS; q.ldb = ld; q.sB = sM; q.b_nc = 0;
+        q.C = ws1.K + oS + R0; q.ldc = ld; q.sC = sM;
+        q.M = m; q.N = m; q.K = R0; q.alpha = -1.0; q.beta = 1.0; q.lower = 1;
+        launch_gemm(q, Ny, cx.stream);
+    }
+    factor_blocked(cx, ws1, true, R0 / 64);                 // L22 and its diagonal-block inverses
+    trtri_range(cx, ws1, cx.stream, R0, m);                 // inv22
+    {
+        double* W = ws1.W + ws1.hw() * ws1.hw();
+        GemmP t = gemm_base(cx);                            // W = L21 inv11
+        t.A = ws1.L + oS; t.lda = ld; t.sA = sM; t.a_mc = 0;
+        t.B = ws1.Inv; t.ldb = ld; t.sB = sM; t.b_nc = 1; t.kflags = KB_GE_N;
+        t.C = W; t.ldc = R0; t.sC = sW;
+        t.M = m; t.N = R0; t.K = R0;
+        launch_gemm(t, Ny, cx.stream);
+        GemmP u = gemm_base(cx);                            // inv21 = -inv22 W
+        u.A = ws1.Inv + oS + R0; u.lda = ld; u.sA = sM; u.a_mc = 0; u.kflags = KA_LE_M;
+        u.B = W; u.ldb = R0; u.sB = sW; u.b_nc = 1;
+        u.C = ws1.Inv + oS; u.ldc = ld; u.sC = sM;
+        u.M = m; u.N = R0; u.K = m; u.alpha = -1.0;
+        launch_gemm(u, Ny, cx.stream);
+    }
+    std::vector<int> inf(Ny, 0);
+    HIPCHK(hipMemcpyAsync(inf.data(), ws1.info, Ny * sizeof(int), hipMemcpyDeviceToHost, cx.stream));
+    HIPCHK(hipStreamSynchronize(cx.stream));
+    HIPCHK(hipGetLastError());
+    bool bad = false;
+    for (int a = 0; a < Ny; ++a) {
+        if (info) info[a] = inf[a] ? -inf[a] : 0;
+        bad |= inf[a] != 0;
+    }
+    if (bad) {                                              // leave the model as it was
+        ws_free(ws1);
+        hipFree(XT1); hipFree(Y1);
+        return fail(GPMPC_ENOTPD, "the extended K is not positive definite with the stored hyper-parameters and jitter");
+    }
+    install();
+    solve_alpha(h->cx(), h->ws, h->Y, h->Np);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipGetLastError());
     return GPMPC_OK;
 }
 

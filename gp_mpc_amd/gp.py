@@ -325,14 +325,18 @@ class GP:
         self._refit()
 
     def update_data_all(self, X_new, Y_new):
-        """Append all new observations and recompute chol/alpha/invK with the EXISTING
-        hyper-parameters (gp_class.py:474-550)."""
-        X_new = np.array(X_new, dtype=np.float64).copy()
-        Y_new = np.array(Y_new, dtype=np.float64).copy()
+        """Append all new observations and bring chol/alpha/invK up to date with the EXISTING
+        hyper-parameters (gp_class.py:474-550).  The reference recomputes everything, O(N^3); here
+        the factors are extended on the device (`gpmpc_append`, O(N^2 n)) -- same result to rounding."""
+        X_new = np.array(X_new, dtype=np.float64).copy().reshape(-1, self.__Nx)
+        Y_new = np.array(Y_new, dtype=np.float64).copy().reshape(-1, self.__Ny)
         if self.__normalize:
             Y_new = self.standardize(Y_new, self.__meanY, self.__stdY)
             X_new = self.standardize(X_new, self.__meanZ, self.__stdZ)
-        self._set_data_and_refit(np.vstack([self.__X, X_new]), np.vstack([self.__Y, Y_new]))
+        self._h.append(X_new, Y_new)
+        self.__X = np.vstack([self.__X, X_new])
+        self.__Y = np.vstack([self.__Y, Y_new])
+        self.__N = self.__X.shape[0]
 
     def replace_data_all(self, X_new, Y_new):
         """Replace the training data, keep the hyper-parameters (gp_class.py:553-626)."""

@@ -92,6 +92,12 @@ int gpmpc_fit(gpmpc_gp* h, const double* hyper, int want_invK, int* info);
 /* Export in the reference's save_model layout (gp_class.py:693-704): hyper[Ny x (d+2)],
  * chol[Ny x N x N] (lower, zeros above), alpha[Ny x N], invK[Ny x N x N]; any pointer may be NULL. */
 int gpmpc_get_factors(gpmpc_gp* h, double* hyper, double* chol, double* alpha, double* invK);
+/* Append n training points and update L, L^-1, alpha with the EXISTING hyper-parameters: the result of
+ * GP.update_data_all (gp_class.py:474-550, which recomputes everything from scratch) as a rank-n extension of
+ * the factors, O(N^2 n) instead of O(N^3).  info[Ny]: 0 ok, <0 = -(first non-positive pivot); on
+ * GPMPC_ENOTPD the model is left unchanged.  Large n (more than a quarter of the new size) refits instead. */
+int gpmpc_append(gpmpc_gp* h, int n, const double* Xnew, const double* Ynew, int* info);
+
 /* Import a saved model (GP.load_model -> ctor branch gp_class.py:58-66): chol and hyper are
  * required; alpha == NULL recomputes it from Y; invK == NULL computes it lazily when a method
  * needs it.  L^-1 (the predict operand) is rebuilt on the device. */

@@ -101,6 +101,12 @@ template <class T> inline hipError_t hipMalloc(T** p, size_t bytes) {
 inline hipError_t hipFree(void* p) { emu::drain(); std::free(p); return hipSuccess; }
 inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { emu::drain(); std::memcpy(d, s, n); return hipSuccess; }
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { emu::drain(); std::memcpy(d, s, n); return hipSuccess; }
+inline hipError_t hipMemcpy2DAsync(void* d, size_t dpitch, const void* s, size_t spitch, size_t width, size_t height,
+                                   hipMemcpyKind, hipStream_t) {
+    emu::drain();
+    for (size_t r = 0; r < height; ++r) std::memcpy((char*)d + r * dpitch, (const char*)s + r * spitch, width);
+    return hipSuccess;
+}
 inline hipError_t hipMemset(void* d, int v, size_t n) { emu::drain(); std::memset(d, v, n); return hipSuccess; }
 inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { emu::drain(); std::memset(d, v, n); return hipSuccess; }
 inline hipError_t hipStreamCreate(hipStream_t* s) { static int next_id = 1; *s = new emu_stream{next_id++}; return hipSuccess; }

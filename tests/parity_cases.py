@@ -254,6 +254,38 @@ def check_moment_methods(lib, g=None):
     h.close()
 
 
+def check_append(lib, N0, n, d=4, Ny=2, sn=0.1, seed=5):
+    """gpmpc_append (rank-n extension of L, L^-1, alpha with the stored hyper-parameters; the reference's
+    update_data_all recomputes from scratch, gp_class.py:474-550) against the oracle's full fit on all points."""
+    p = go.synthetic_problem(N0 + n, d, Ny, 25, seed=seed, sn=sn)
+    X, Y, H, Z = p['X'], p['Y'], p['hyper'], p['Z']
+    sf2 = H[:, d] ** 2
+    h = Handle(lib, X[:N0], Y[:N0])
+    assert np.all(h.fit(H) == 0)
+    info = h.append(X[N0:], Y[N0:])
+    assert np.all(info == 0) and h.N == N0 + n
+    f = h.get_factors()
+    o = go.fit(X, Y, H, want_invK=False)
+    for a in range(Ny):
+        assert relF(f['chol'][a], o['chol'][a]) <= 1e-10
+        assert np.all(np.triu(f['chol'][a], 1) == 0.0)
+    mean, var = h.predict_mean_var(Z)
+    om, ov, _ = go.mean_var_jac(Z, X, H, o['alpha'], o['chol'], False)
+    assert np.max(np.abs(mean - om) / mean_scale(X, Z, H, o['alpha'])) <= 1e-10
+    assert np.max(np.abs(var - ov) / sf2) <= 1e-10
+    # a second append on top, and the NLL path (its own workspace is rebuilt for the new size)
+    q = go.synthetic_problem(7, d, Ny, 1, seed=seed + 1, sn=sn)
+    h.append(q['X'], q['Y'])
+    X2, Y2 = np.vstack([X, q['X']]), np.vstack([Y, q['Y']])
+    o2 = go.fit(X2, Y2, H, want_invK=False)
+    m2, v2 = h.predict_mean_var(Z)
+    om2, ov2, _ = go.mean_var_jac(Z, X2, H, o2['alpha'], o2['chol'], False)
+    assert np.max(np.abs(m2 - om2) / mean_scale(X2, Z, H, o2['alpha'])) <= 1e-10 and np.max(np.abs(v2 - ov2) / sf2) <= 1e-10
+    ref = go.nll(H[0], X2, Y2[:, 0])
+    assert abs(h.nll(0, H[0]) - ref) / (abs(ref) + len(X2)) <= 1e-10
+    h.close()
+
+
 def check_sensitivities(lib, g, nprobe=12):
     """gpmpc_predict_sens (second-order outputs for a casadi Callback) against the oracle's
     closed forms, which tests/test_oracle.py pins by finite differences of the first-order functions."""
@@ -407,6 +439,12 @@ def check_gp_class(lib, g, tmp_path):
     assert np.allclose(m3, om3, rtol=1e-8, atol=1e-9) and np.allclose(c3, oc3, rtol=0, atol=1e-10 * sf2.max())
     gp2.update_data_all(Xraw[40:50], Yraw[40:50])
     assert gp2.get_size()[0] == 50
+    Xs5 = (Xraw[:50] - g['meta']['meanZ']) / g['meta']['stdZ'] if g['normalize'] else Xraw[:50]
+    Ys5 = (Yraw[:50] - g['meta']['meanY']) / g['meta']['stdY'] if g['normalize'] else Yraw[:50]
+    o5 = go.OracleGP(Xs5, Ys5, g['hyper'], normalize=g['normalize'], meta=g.get('meta'), gp_method='ME')
+    m5, c5 = gp2.predict(x, u, S)
+    om5, oc5 = o5.predict(x, u, S)
+    assert np.allclose(m5, om5, rtol=1e-8, atol=1e-9) and np.allclose(c5, oc5, rtol=0, atol=1e-10 * sf2.max())
     for fn in (lambda: gp.update_data(Xraw[:2], Yraw[:2]), lambda: gp.predict_compare()):
         try:
             fn()

@@ -69,6 +69,12 @@ def test_emu_moment_methods(emu, tank):
     pc.check_moment_methods(emu, tank)
 
 
+def test_emu_append(emu):
+    pc.check_append(emu, N0=300, n=10)      # strip update: rows >= 256 re-factored on top of the stored factors
+    pc.check_append(emu, N0=250, n=70)      # too many new rows for the update to pay: refit path
+    pc.check_append(emu, N0=40, n=30, Ny=1)  # fewer than 64 old points: refit path
+
+
 def test_emu_sensitivities(emu, tank, car):
     pc.check_sensitivities(emu, tank)
     pc.check_sensitivities(emu, car, nprobe=5)

@@ -96,6 +96,12 @@ def test_moment_methods(lib, tank):
     pc.check_moment_methods(lib, tank)
 
 
+def test_append(lib):
+    pc.check_append(lib, N0=300, n=10)
+    pc.check_append(lib, N0=250, n=70)
+    pc.check_append(lib, N0=2000, n=90, d=6, Ny=1, sn=1e-2)
+
+
 def test_sensitivities(lib, tank, car):
     pc.check_sensitivities(lib, tank)
     pc.check_sensitivities(lib, car, nprobe=20)
