@@ -608,6 +608,7 @@ int gpmpc_create(int device, int N, int d, int Ny, const double* X, const double
     // 3: + bulk in the persistent tile-owner kernel where the matrix fits its registers (else as 2)
     h->chain_mode = 3;
     if (const char* e = getenv("GPMPC_CHAIN")) h->chain_mode = atoi(e);
+    if (const char* e = getenv("GPMPC_SPIN_LIMIT")) h->spin_limit = atoi(e);   // tests: force the hand-off time-out path
     const int Np = h->Np;
     std::vector<double> xt((size_t)d * Np, 0.0), yt((size_t)Ny * Np, 0.0);
     for (int i = 0; i < N; ++i) {

@@ -254,6 +254,29 @@ def check_moment_methods(lib, g=None):
     h.close()
 
 
+def check_timeout_fallback(lib, N=560, d=4):
+    """A hand-off time-out inside the persistent factorisation kernels (forced by a poll budget of 1) must
+    leave a correct model behind: the host repeats the factorisation on the single-stream path."""
+    import os
+    os.environ['GPMPC_SPIN_LIMIT'] = '1'
+    try:
+        p = go.synthetic_problem(N, d, 1, 20, seed=9, sn=0.1)
+        h = Handle(lib, p['X'], p['Y'])
+    finally:
+        del os.environ['GPMPC_SPIN_LIMIT']
+    X, Y, H, Z = p['X'], p['Y'], p['hyper'], p['Z']
+    for rep in range(2):                       # first fit: time-out + fallback; second: already on the fallback path
+        assert np.all(h.fit(H) == 0)
+        f = h.get_factors()
+        o = go.fit(X, Y, H, want_invK=False)
+        assert relF(f['chol'][0], o['chol'][0]) <= 1e-10
+        mean, var = h.predict_mean_var(Z)
+        om, ov, _ = go.mean_var_jac(Z, X, H, o['alpha'], o['chol'], False)
+        assert np.max(np.abs(mean - om) / mean_scale(X, Z, H, o['alpha'])) <= 1e-10
+        assert np.max(np.abs(var - ov) / H[:, d] ** 2) <= 1e-10
+    h.close()
+
+
 def check_append(lib, N0, n, d=4, Ny=2, sn=0.1, seed=5):
     """gpmpc_append (rank-n extension of L, L^-1, alpha with the stored hyper-parameters; the reference's
     update_data_all recomputes from scratch, gp_class.py:474-550) against the oracle's full fit on all points."""

@@ -69,6 +69,11 @@ def test_emu_moment_methods(emu, tank):
     pc.check_moment_methods(emu, tank)
 
 
+def test_emu_timeout_fallback(emu, capfd):
+    pc.check_timeout_fallback(emu)
+    assert 'timed out on a hand-off' in capfd.readouterr().err
+
+
 def test_emu_append(emu):
     pc.check_append(emu, N0=300, n=10)      # strip update: rows >= 256 re-factored on top of the stored factors
     pc.check_append(emu, N0=250, n=70)      # too many new rows for the update to pay: refit path

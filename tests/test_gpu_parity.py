@@ -96,6 +96,11 @@ def test_moment_methods(lib, tank):
     pc.check_moment_methods(lib, tank)
 
 
+def test_timeout_fallback(lib, capfd):
+    pc.check_timeout_fallback(lib, N=1500)
+    assert 'timed out on a hand-off' in capfd.readouterr().err
+
+
 def test_append(lib):
     pc.check_append(lib, N0=300, n=10)
     pc.check_append(lib, N0=250, n=70)
