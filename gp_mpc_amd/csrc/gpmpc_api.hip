@@ -975,7 +975,7 @@ extern "C" int gpmpc_get_factors(gpmpc_gp* h, double* hyper, double* chol, doubl
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipStreamSynchronize(h->stream));
     if (hyper) std::memcpy(hyper, h->hyper.data(), h->hyper.size() * sizeof(double));
-    if (chol) CHK(export_mats(h, getenv("GPMPC_DEBUG_INV") ? h->ws.Inv : h->ws.L, chol));
+    if (chol) CHK(export_mats(h, h->ws.L, chol));
     if (alpha) {
         std::vector<double> tmp((size_t)h->Ny * h->Np);
         HIPCHK(hipMemcpy(tmp.data(), h->ws.alpha, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
