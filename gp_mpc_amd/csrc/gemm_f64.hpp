@@ -30,6 +30,11 @@
 #include "mfma_f64.hpp"
 #include "wg_sync.hpp"
 
+// Ablation bits for tools/ubench/gemm_ablate_bench.hip only (the results are then wrong; timing study):
+// 1 no global tile loads, 2 no LDS tile stores, 4 no barrier in the K loop, 8 no LDS fragment reads.
+#ifndef GPMPC_GEMM_ABLATE
+#define GPMPC_GEMM_ABLATE 0
+#endif
 #ifndef GPMPC_GEMM_SPLIT
 #define GPMPC_GEMM_SPLIT false
 #endif
@@ -204,6 +209,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) gemm_f64_kernel
         }
 
         auto load_tiles = [&](int k0) {
+            if (GPMPC_GEMM_ABLATE & 1) return;
             if (BUF) {
 #pragma unroll
                 for (int r = 0; r < LA; ++r) ra[r] = gpmpc_buffer_load_d2(rsA, voA[r], k0 * 8);
@@ -243,6 +249,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) gemm_f64_kernel
             }
         };
         auto store_tiles = [&](int buf) {
+            if (GPMPC_GEMM_ABLATE & 2) return;
 #pragma unroll
             for (int r = 0; r < LA; ++r) {
                 const int idx = tid + NT * r;
@@ -280,9 +287,9 @@ __global__ void __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) gemm_f64_kernel
             for (int q = q0; q < q1; ++q) {
                 double a[TM], b[TN];
 #pragma unroll
-                for (int i = 0; i < TM; ++i) a[i] = As[cur][q][wm * WM + i * 16 + fr][fk];
+                for (int i = 0; i < TM; ++i) a[i] = (GPMPC_GEMM_ABLATE & 8) ? 1.0 + i + q + lane : As[cur][q][wm * WM + i * 16 + fr][fk];
 #pragma unroll
-                for (int j = 0; j < TN; ++j) b[j] = Bs[cur][q][wn * WN + j * 16 + fr][fk];
+                for (int j = 0; j < TN; ++j) b[j] = (GPMPC_GEMM_ABLATE & 8) ? 2.0 + j + q + lane : Bs[cur][q][wn * WN + j * 16 + fr][fk];
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -296,7 +303,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) gemm_f64_kernel
             mma_groups(0, SPLIT ? QK / 2 : QK);
             if (kt + 1 < nk) store_tiles(cur ^ 1);
             if (SPLIT) mma_groups(QK / 2, QK);
-            __syncthreads();
+            if (!(GPMPC_GEMM_ABLATE & 4)) __syncthreads();
             cur ^= 1;
         }
 

@@ -1,3 +1,9 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out
-timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+GPMPC_GEMM_BUF=0 timeout 120 tools/ubench/gemm_ablate_0
+GPMPC_GEMM_BUF=1 timeout 120 tools/ubench/gemm_ablate_0
+for rep in 1 2; do for cfg in "GPMPC_GEMM_BUF=0" "GPMPC_GEMM_BUF=1"; do
+env $cfg timeout 120 python bench.py --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "
+import json,sys
+d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('$cfg value %8.0f  ms/step %.3f  factor %.3f vargemm %.3f (%.1f TF)' % (d['value'], d['ms_per_step'], d['phases_ms_per_step']['factor'], d['phases_ms_per_step']['vargemm'], d['roofline']['achieved']))"
+done; done
