@@ -25,8 +25,9 @@ constexpr int CHAIN_LDS_BYTES = 150000;
 
 // flag layout per matrix (ints): [0] error, [1 .. nb] leafdone, [1+nb .. 2nb] pan1, [1+2nb .. 1+4nb) tdone[k][2],
 // and for the tile-owner workers (chol_worker.hpp): [1+4nb .. 1+5nb) pancount, [1+5nb .. 1+6nb) row2done,
-// [1+6nb .. 1+7nb) colready, [1+7nb .. 1+7nb+256) progress word of worker w (1 + 4 k + phase; diagnostics)
-__host__ __device__ inline int chain_flag_count(int nb) { return 1 + 7 * nb + 512; }
+// [1+6nb .. 1+7nb) colready, [1+7nb .. 1+7nb+512) progress / start time of worker w (diagnostics),
+// [1+7nb+512 .. +2) arrival counter and "all resident" flag of the second worker launch
+__host__ __device__ inline int chain_flag_count(int nb) { return 1 + 7 * nb + 512 + 2; }
 
 #ifdef GPMPC_EMULATED
 #define GPMPC_DYN_SMEM() ((double*)::emu::dyn_smem())
@@ -42,6 +43,14 @@ __global__ void __launch_bounds__(64) chain_gate_kernel(int* flags, long sFlags,
     __shared__ int slot;
     int* fl = flags + (long)blockIdx.x * sFlags;
     wg_wait2(fl + 1, 1, nullptr, 0, fl, spin_limit, &slot);
+}
+
+// Generic gate for a queue: returns once *f0 >= v0 (and *f1 >= v1 if f1 is given), per matrix of the batch.
+__global__ void __launch_bounds__(64) flag_gate_kernel(int* flags, long sFlags, int i0, int v0, int i1, int v1,
+                                                       int spin_limit) {
+    __shared__ int slot;
+    int* fl = flags + (long)blockIdx.x * sFlags;
+    wg_wait2(fl + i0, v0, i1 >= 0 ? fl + i1 : nullptr, v1, fl, spin_limit, &slot, 5000000 + i0);
 }
 
 __global__ void __launch_bounds__(256) chol_chain_kernel(const double* Kmat, double* L, double* Inv, long ld, long sBatch,

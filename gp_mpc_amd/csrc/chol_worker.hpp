@@ -24,6 +24,9 @@
 // and every worker does its panel tiles first; all NW workers plus the chain must be co-resident (one
 // workgroup per CU: the LDS request below is > 80 KB), which the host guarantees by sizing NW to the CU
 // count.  Every spin is bounded (wg_sync.hpp) and a time-out makes the host fall back to GEMM launches.
+// A factorisation may be cut in two launches (kb, ksteps): the first covers the early steps with all tiles
+// resident, the second the rest -- a quarter of the tiles -- with fewer workers, so that the CUs it leaves free
+// can run the part of the triangular inverse that is already computable.
 // grid (NW, 1, batch), 512 threads, dynamic LDS WORKER_LDS_BYTES.
 #pragma once
 #include "chol_chain.hpp"
@@ -67,8 +70,9 @@ __device__ __forceinline__ void regs_to_lds(double* dst, const double* r, int ti
 }
 
 __global__ void __launch_bounds__(WORKER_THREADS) chol_worker_kernel(double* Kmat, double* L, const double* Inv, long ld,
-                                                                     long sBatch, int nb, int* flags, long sFlags,
-                                                                     int crow_mode, int spin_limit) {
+                                                                     long sBatch, int nb_all, int* flags, long sFlags,
+                                                                     int crow_mode, int spin_limit, int kb, int ksteps,
+                                                                     int* ready) {
     double* smem = GPMPC_DYN_SMEM();
     double* A = smem;
     double* B = A + 64 * LS;
@@ -76,20 +80,27 @@ __global__ void __launch_bounds__(WORKER_THREADS) chol_worker_kernel(double* Kma
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;                 // this wave's 16 x 32 piece: rows 16 wr, columns 32 wc
     const int w = blockIdx.x, NW = gridDim.x;
-    const long mb = (long)blockIdx.z * sBatch;
+    // A launch works on the trailing matrix from block kb on, for `ksteps` panel steps: everything below is
+    // written for kb = 0 and made relative by shifting the base pointers and the flag arrays by kb.
+    const int nb = nb_all - kb;
+    const long mb = (long)blockIdx.z * sBatch + (long)(64 * kb) * ld + 64 * kb;
     double* __restrict__ Kb = Kmat + mb;
     double* __restrict__ Lb = L + mb;
     const double* __restrict__ Ib = Inv + mb;
     int* fl = flags + (long)blockIdx.z * sFlags;
     int* err = fl;
-    int* leafdone = fl + 1;
-    int* pan1 = fl + 1 + nb;
-    int* tdone = fl + 1 + 2 * nb;
-    int* pancount = fl + 1 + 4 * nb;
-    int* row2done = fl + 1 + 5 * nb;
-    int* colready = fl + 1 + 6 * nb;
-    int* progress = fl + 1 + 7 * nb + (w & 255);
+    int* leafdone = fl + 1 + kb;
+    int* pan1 = fl + 1 + nb_all + kb;
+    int* tdone = fl + 1 + 2 * nb_all + 2 * kb;
+    int* pancount = fl + 1 + 4 * nb_all + kb;
+    int* row2done = fl + 1 + 5 * nb_all + kb;
+    int* colready = fl + 1 + 6 * nb_all + kb;
+    int* progress = fl + 1 + 7 * nb_all + (w & 255);
     if (tid == 0) flag_store(progress, 1);
+    if (ready && tid == 0) {                       // "all workgroups of this launch are resident" for the host's gates
+        int* rd = ready + (long)blockIdx.z * sFlags;
+        if (__hip_atomic_fetch_add(rd, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 == NW) flag_store(rd + 1, 1);
+    }
 #ifndef GPMPC_EMULATED
     if (tid == 0) flag_store(progress + 256, (int)((wall_clock64() / 100) & 0x3fffffff));   // start time, us
 #endif
@@ -138,7 +149,8 @@ __global__ void __launch_bounds__(WORKER_THREADS) chol_worker_kernel(double* Kma
         }
     }
 
-    for (int k = 0; k + 2 < nb; ++k) {
+    int k = 0;
+    for (; k + 2 < nb && k < ksteps; ++k) {
         // ---- 1. panel tiles of column k.  Column 0 never receives an update, so its tiles are not kept in
         //         registers: at k = 0 worker w takes rows 2 + w, 2 + w + NW, ... straight from K.
         for (int i = 2 + w; k == 0 && i < nb; i += NW) {
@@ -254,6 +266,21 @@ __global__ void __launch_bounds__(WORKER_THREADS) chol_worker_kernel(double* Kma
             lds_mm_tile(A, 16 * wr, B, 32 * wc, lane, C[n], -1.0);
             __syncthreads();                           // A, B free again
             cur = nxt;
+        }
+    }
+    // a launch that stops before the last step hands its live tiles back through K: the next launch (from block
+    // kb + ksteps on, with fewer workers -- the freed CUs take the inverse pipeline) reloads them
+    if (k + 2 < nb) {
+#pragma unroll
+        for (int n = 0; n < WORKER_MAXT; ++n) {
+            const int i = __builtin_amdgcn_readfirstlane(ti[n]), j = __builtin_amdgcn_readfirstlane(tj[n]);
+            if (i < 0) continue;
+            double* dst = Kb + (long)(64 * i) * ld + 64 * j;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                at_byte(dst, csub[r]) = C[n][0][r];
+                at_byte(dst, csub[r] + 128u) = C[n][1][r];
+            }
         }
     }
 }

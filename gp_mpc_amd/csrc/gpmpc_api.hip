@@ -377,7 +377,19 @@ static bool factor_chain(const Ctx& cx, Workspace& ws, int spin_limit) {
     int NW = ws.batch == 1 ? cx.workers - cx.workers / 8 : 0;
     if (NW > ntiles) NW = ntiles;
     const bool use_workers = NW >= 1 && nb >= 3 && (ntiles + NW - 1) / NW <= WORKER_MAXT;
-    // inverse pipelined behind the chain: only next to GEMM launches (the workers leave it no room)
+    // Worker split: after the first half of the steps three quarters of the tiles are finished.  A second,
+    // smaller worker launch takes over the rest and the CUs it does not need run the part of the inverse that
+    // is computable by then (rows of the first half, W products), gated by flags as next to GEMM launches.
+    int s_top = 64;                                         // rows of the left child of the inverse tree's root
+    while (2 * s_top < Np) s_top *= 2;
+    const int kb2 = s_top / 64;                             // first block of the second launch
+    const int nb2 = nb - kb2, ntiles2 = (nb2 - 1) * nb2 / 2 - 1;
+    int NW2 = std::max(1, cx.workers / 2);                  // half of the CUs: <= 4 tiles per worker at Np = 4096
+    if (NW2 > ntiles2) NW2 = std::max(1, ntiles2);
+    static const bool split_ok = !(getenv("GPMPC_WORKER_SPLIT") && atoi(getenv("GPMPC_WORKER_SPLIT")) == 0);
+    const bool split = use_workers && split_ok && cx.aux && cx.seg && s_top >= SEGR && nb2 >= 3 &&
+                       (ntiles2 + NW2 - 1) / NW2 <= WORKER_MAXT;
+    // inverse pipelined segment by segment behind the chain: next to GEMM launches only
     const bool pipelined = !use_workers && cx.aux && cx.seg && Np >= 4 * SEGR;
     int seg_done = 0;
     hipLaunchKernelGGL(chol_chain_kernel, dim3(1, 1, ws.batch), dim3(256), CHAIN_LDS_BYTES, cx.stream, (const double*)ws.K,
@@ -386,10 +398,28 @@ static bool factor_chain(const Ctx& cx, Workspace& ws, int spin_limit) {
     static const bool verbose = getenv("GPMPC_VERBOSE") != nullptr;
     if (verbose)
         fprintf(stderr, "gpmpc: factor Np=%d batch=%d: chain kernel + %s, inverse %s\n", Np, ws.batch,
-                use_workers ? "tile-owner workers" : "GEMM launches", pipelined ? "pipelined" : "at the end");
-    if (use_workers) {
+                split ? "tile-owner workers in two launches" : use_workers ? "tile-owner workers" : "GEMM launches",
+                split ? "left half behind the second launch" : pipelined ? "pipelined" : "at the end");
+    if (use_workers && !split) {
         hipLaunchKernelGGL(chol_worker_kernel, dim3(NW, 1, ws.batch), dim3(WORKER_THREADS), WORKER_LDS_BYTES, cx.side, ws.K, ws.L,
-                           (const double*)ws.Inv, ld, sM, nb, ws.flags, (long)nf, cx.crow_mode, spin_limit);
+                           (const double*)ws.Inv, ld, sM, nb, ws.flags, (long)nf, cx.crow_mode, spin_limit, 0, nb,
+                           (int*)nullptr);
+    } else if (use_workers) {
+        int* ready = ws.flags + 1 + 7 * nb + 512;           // arrival counter + flag of the second launch
+        hipLaunchKernelGGL(chol_worker_kernel, dim3(NW, 1, ws.batch), dim3(WORKER_THREADS), WORKER_LDS_BYTES, cx.side, ws.K, ws.L,
+                           (const double*)ws.Inv, ld, sM, nb, ws.flags, (long)nf, cx.crow_mode, spin_limit, 0, kb2,
+                           (int*)nullptr);
+        hipEventRecord(cx.seg[cx.n_seg - 2], cx.side);      // first launch finished: L(:, < kb2) is final
+        hipLaunchKernelGGL(chol_worker_kernel, dim3(NW2, 1, ws.batch), dim3(WORKER_THREADS), WORKER_LDS_BYTES, cx.side, ws.K,
+                           ws.L, (const double*)ws.Inv, ld, sM, nb, ws.flags, (long)nf, cx.crow_mode, spin_limit, kb2, nb,
+                           ready);
+        // the left half of the inverse and the first product of the root, on the CUs the second launch leaves
+        // free -- but not before that launch is resident (its workgroups need whole CUs)
+        hipStreamWaitEvent(cx.aux, cx.seg[cx.n_seg - 2], 0);
+        hipLaunchKernelGGL(flag_gate_kernel, dim3(ws.batch), dim3(64), 0, cx.aux, ws.flags, (long)nf, 1 + 7 * nb + 512 + 1, 1,
+                           -1, 0, spin_limit);
+        trtri_range(cx, ws, cx.aux, 0, s_top);
+        trtri_node_w(cx, ws, cx.aux, 0, s_top, Np - s_top, ws.hw() * ws.hw());
     } else {
         hipLaunchKernelGGL(chain_gate_kernel, dim3(ws.batch), dim3(64), 0, cx.side, ws.flags, (long)nf, spin_limit);
         int* leafdone = ws.flags + 1;
@@ -432,6 +462,13 @@ static bool factor_chain(const Ctx& cx, Workspace& ws, int spin_limit) {
     }
     hipEventRecord(cx.join, cx.side);
     hipStreamWaitEvent(cx.stream, cx.join, 0);
+    if (split) {                                            // right half and the second product of the root
+        hipEventRecord(cx.seg[cx.n_seg - 1], cx.aux);
+        hipStreamWaitEvent(cx.stream, cx.seg[cx.n_seg - 1], 0);
+        trtri_range(cx, ws, cx.stream, s_top, Np - s_top);
+        trtri_node_inv(cx, ws, cx.stream, 0, s_top, Np - s_top, ws.hw() * ws.hw());
+        return true;
+    }
     if (!pipelined) { trtri_levels(cx, ws); return true; }
     // segments the side queue could not hand over (the last ones) are inverted after the chain, on the main queue
     hipEventRecord(cx.seg[cx.n_seg - 1], cx.aux);
@@ -598,7 +635,7 @@ int gpmpc_create(int device, int N, int d, int Ny, const double* X, const double
     // the persistent kernels ask for more than the default 64 KB of dynamic LDS (per device: set for every handle)
     HIPCHK(hipFuncSetAttribute((const void*)chol_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CHAIN_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)chol_worker_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WORKER_LDS_BYTES));
-    h->seg_events.resize(std::max(2, round_up(N, 64) / SEGR + 1));
+    h->seg_events.resize(std::max(3, round_up(N, 64) / SEGR + 2));
     for (auto& e : h->seg_events) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     if (getenv("GPMPC_CHAIN_TRACE") && !g_chain_trace) {
         HIPCHK(hipMalloc(&g_chain_trace, (size_t)(1 << 20) * sizeof(long long)));
@@ -867,7 +904,7 @@ extern "C" int gpmpc_append(gpmpc_gp* h, int n, const double* Xnew, const double
         h->XT = XT1; h->Y = Y1; h->ws = ws1;
         h->N = N1; h->Np = Np1;
         h->have_invK = false;
-        const size_t need = Np1 / SEGR + 1;
+        const size_t need = Np1 / SEGR + 2;
         while (h->seg_events.size() < need) {
             hipEvent_t e;
             hipEventCreateWithFlags(&e, hipEventDisableTiming);

@@ -54,6 +54,9 @@ def test_emu_tile_owner_workers(emu):
     # chain kernel + pipelined inverse; Ny = 2 above exceeds the register budget and takes the GEMM path
     pc.check_synthetic(emu, N=560, d=4, Ny=1, B=30, sn=0.1, strict_rel=True)
     pc.check_synthetic(emu, N=300, d=3, Ny=1, B=10, sn=1e-2, strict_rel=False)
+    # Np = 704: the workers run as two launches (blocks 0-7 with 7 workers, blocks 8-10 with 2) and the left half
+    # of the inverse is computed behind the second one
+    pc.check_synthetic(emu, N=700, d=3, Ny=1, B=10, sn=0.1, strict_rel=True)
 
 
 def test_emu_jitter_rule(emu, train_small):
