@@ -377,28 +377,44 @@ __global__ void __launch_bounds__(256) gemv_rows_kernel(const double* __restrict
     if (lane == 0) out[(long)blockIdx.y * so + i] = s;
 }
 
-// out[k] = sum_{i >= k} A[i][k] x[i] (A lower triangular, i.e. A^T x): a workgroup owns 64 columns,
-// its 16 waves take rows i = k0 + v, k0 + v + 16, ... (each row read is one 512 B line), fixed-order
-// reduction over the waves.  grid (Np/64, batch), 1024 threads.
-__global__ void __launch_bounds__(1024) gemv_lowerT_kernel(const double* __restrict__ A, const double* __restrict__ x,
-                                                           double* __restrict__ out, int Np, long sA, long sx, long so) {
-    __shared__ double red[16][64];
+// out[k] = sum_{i >= k} A[i][k] x[i] (A lower triangular, i.e. A^T x), HBM-read bound, in two launches:
+// a workgroup owns 64 columns x GEMVT_ROWS rows (its 4 waves take rows v, v + 4, ...; each row read is one
+// 512 B line; workgroups above the diagonal exit at once) and leaves a partial sum per column; the second
+// kernel adds the row chunks in a fixed order (deterministic).  (One launch with a workgroup per 64 columns
+// and all rows kept only 64 CUs busy: 75 us at N = 4096 against 22 us.)
+constexpr int GEMVT_ROWS = 256;
+// grid (Np/64, ceil(Np/GEMVT_ROWS), batch), 256 threads; part: [batch][chunks][Np]
+__global__ void __launch_bounds__(256) gemv_lowerT_part_kernel(const double* __restrict__ A, const double* __restrict__ x,
+                                                               double* __restrict__ part, int Np, long sA, long sx,
+                                                               long sPart) {
+    __shared__ double red[4][64];
     const int lane = threadIdx.x & 63, v = threadIdx.x >> 6, k0 = blockIdx.x * 64, k = k0 + lane;
-    const double* __restrict__ Ab = A + (long)blockIdx.y * sA;
-    const double* __restrict__ xv = x + (long)blockIdx.y * sx;
+    const int r0 = blockIdx.y * GEMVT_ROWS, r1 = min(Np, r0 + GEMVT_ROWS);
+    double* __restrict__ po = part + (long)blockIdx.z * sPart + (long)blockIdx.y * Np;
+    if (r1 <= k0) {                                     // entirely above the diagonal
+        if (v == 0) po[k] = 0.0;
+        return;
+    }
+    const double* __restrict__ Ab = A + (long)blockIdx.z * sA;
+    const double* __restrict__ xv = x + (long)blockIdx.z * sx;
     double s = 0.0;
-    for (int i = k0 + v; i < Np; i += 16) {
+    for (int i = max(r0, k0) + v; i < r1; i += 4) {
         const double a = (k <= i) ? Ab[(long)i * Np + k] : 0.0;
         s += a * xv[i];
     }
     red[v][lane] = s;
     __syncthreads();
-    if (v == 0) {
-        double t = 0.0;
-#pragma unroll
-        for (int w = 0; w < 16; ++w) t += red[w][lane];
-        out[(long)blockIdx.y * so + k] = t;
-    }
+    if (v == 0) po[k] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+}
+// grid (Np/256, batch), 256 threads
+__global__ void __launch_bounds__(256) gemv_lowerT_finish_kernel(const double* __restrict__ part, double* __restrict__ out,
+                                                                 int Np, int chunks, long sPart, long so) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= Np) return;
+    const double* __restrict__ p = part + (long)blockIdx.y * sPart + k;
+    double t = 0.0;
+    for (int c = k / GEMVT_ROWS; c < chunks; ++c) t += p[(long)c * Np];
+    out[(long)blockIdx.y * so + k] = t;
 }
 
 // a7 tail: nll[a] = 1/2 w^T w + sum_i log|L_ii| with w = L^-1 y (= 1/2 y^T alpha + 1/2 logdet K,

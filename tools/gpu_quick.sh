@@ -1,8 +1,8 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out
-for rep in 1 2; do for cfg in "GPMPC_SPINE_DEPTH=1" "GPMPC_SPINE_DEPTH=2" "GPMPC_SPINE_DEPTH=3"; do
-env $cfg timeout 120 python bench.py --steps 20 --warmup 3 --no-cpu-baseline 2>gpurun_out/q_err.log | python -c "
+timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -2
+for rep in 1 2; do
+timeout 120 python bench.py --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "
 import json,sys
-d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('$cfg value %8.0f  ms/step %.3f  factor %.3f vargemm %.3f' % (d['value'], d['ms_per_step'], d['phases_ms_per_step']['factor'], d['phases_ms_per_step']['vargemm']))"
-grep "timed" gpurun_out/q_err.log | head -2
-done; done
+d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('value %8.0f  ms/step %.3f  phases %s' % (d['value'], d['ms_per_step'], {k: round(v,3) for k,v in d['phases_ms_per_step'].items()}))"
+done
