@@ -94,7 +94,7 @@ static int mfma_selftest(int device, int* layout_out, double* tflops_out) {
         HIPCHK(hipGetDeviceProperties(&prop, device));
         // 4 workgroups x 4 waves per CU = 4 waves per SIMD (one wave alone can only issue an f64 MFMA every
         // ~142 cycles); long enough that the ramp and tail of the launch do not matter
-        const int blocks = prop.multiProcessorCount * 4, iters = 16384;
+        const int blocks = prop.multiProcessorCount * 4, iters = 4096;   // ~1 ms
         double* dOut;
         HIPCHK(hipMalloc(&dOut, (size_t)blocks * 256 * sizeof(double)));
         hipEvent_t e0, e1;

@@ -96,6 +96,13 @@ def test_moment_methods(lib, tank):
     pc.check_moment_methods(lib, tank)
 
 
+def test_worker_path_odd_size(lib):
+    # Np = 4032 = 63 blocks: tile-owner workers in two launches (32 + 31 blocks), tree with an unbalanced root
+    pc.check_synthetic(lib, N=4000, d=6, Ny=1, B=200, sn=1e-2, strict_rel=False)
+    # Np = 4160 = 65 blocks: one tile too many for the workers' registers -> chain kernel + flagged GEMM launches
+    pc.check_synthetic(lib, N=4100, d=6, Ny=1, B=50, sn=1e-2, strict_rel=False)
+
+
 def test_timeout_fallback(lib, capfd):
     pc.check_timeout_fallback(lib, N=1500)
     assert 'timed out on a hand-off' in capfd.readouterr().err
