@@ -5,8 +5,9 @@
 //     tile (k+1,k):    L_{k+1,k} = A_{k+1,k} inv_kk^T                   (MFMA on LDS operands)
 //     tile (k+1,k+1):  A_{k+1,k+1} -= L_{k+1,k} L_{k+1,k}^T             (stays in LDS: next leaf's input)
 //
-// while the bulk of each step -- the panel rows below and the trailing update -- runs in ordinary GEMM
-// launches on a second stream.  The two sides meet through global flags (wg_sync.hpp):
+// while the bulk of each step -- the panel rows below and the trailing update -- runs either in ordinary GEMM
+// launches on a second stream or in the persistent tile-owner workers (chol_worker.hpp).  The two sides meet
+// through global flags (wg_sync.hpp):
 //     leafdone[k]  chain -> panel(k) workgroups        (L_kk^-1 is in memory)
 //     pan1[k]      chain -> trailing(k) workgroups     (L_{k+1,k} is in memory)
 //     tdone[k][2]  trailing(k) -> chain                (tiles (k+2,k+1) and (k+2,k+2) carry step k's update)

@@ -232,18 +232,23 @@ static GemmP gemm_base(const Ctx& cx) {
 // inverse.  K is consumed (trailing updates in place), L and Inv = L^-1 are written; [batch][Np x Np].
 //
 //   for each 64-column panel k:   leaf: L_kk = chol(A_kk), inv_kk = L_kk^-1        (one workgroup)
-//                                 panel: L21 = A21 inv_kk^T                         (MFMA GEMM)
-//                                 trailing: A22 -= L21 L21^T  (lower)               (MFMA GEMM)
+//                                 panel: L21 = A21 inv_kk^T                         (MFMA)
+//                                 trailing: A22 -= L21 L21^T  (lower)               (MFMA)
 //   then for s = 64, 128, ...:    every node [L11 0; L21 L22] with |L11| = s in ONE batched launch pair:
 //                                 W = L21 inv11,  inv21 = -inv22 W                  (MFMA GEMMs)
 //
-// Only the leaf, the 64-wide panel product and the trailing update are on the sequential chain
-// (3 launches per panel); the inverse needs 2 launches per level, each with all nodes of the level
-// as the batch dimension.  Measured alternatives that did NOT pay (r01): a second HIP stream running
-// the bulk of the trailing update and/or the inverse products concurrently with the chain (look-ahead)
-// -- the leaf and panel kernels slow down under the contention by as much as is hidden (4.4 vs 4.2 ms,
-// with or without stream priorities / CU masks).  (The first version recursed on [L11 0; L21 L22] with the inverse products
-// inside the recursion: 4 latency-bound launches per node on the chain, 5.5 ms at N = 4096.)
+// Three executions of this algorithm, chosen per call by factor_chain / its caller:
+//   * factor_blocked: one queue, three launches per panel (fallback, gpmpc_cholesky, gpmpc_append);
+//   * factor_chain with flagged GEMM launches: the leaf / row k+1 / diagonal-tile chain in ONE persistent
+//     workgroup (chol_chain.hpp), panel and trailing GEMMs on a side queue coupled through flags, the
+//     inverse pipelined behind the chain on a third queue (trtri_segment);
+//   * factor_chain with tile-owner workers (chol_worker.hpp): the trailing matrix lives in the registers
+//     of persistent workgroups, in two launches so that the CUs the second one leaves free invert the left
+//     half while the chain finishes.
+// (The first version recursed on [L11 0; L21 L22] with the inverse products inside the recursion: 4
+// latency-bound launches per node on the chain, 5.5 ms at N = 4096; a plain second stream next to the
+// single-queue version did not pay because the leaf slows down 3-8x when it shares a CU with MFMA waves.)
+
 // level-by-level batched inverse of the diagonal range [base, base + n) (rows), given its 64-blocks
 static void trtri_range(const Ctx& cx, Workspace& ws, hipStream_t stream, long base0, int n) {
     const long ld = ws.Np, sM = ws.mat(), sW = ws.wstride();
