@@ -1,4 +1,4 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out
-C3_N=4096 GPMPC_VERBOSE=1 timeout 300 python tools/bench_c3.py 2>&1 | grep -E "C3 fit|factor Np" | sort | uniq -c | cut -c1-330
-C3_N=2048 GPMPC_VERBOSE=1 timeout 300 python tools/bench_c3.py 2>&1 | grep -E "C3 fit|factor Np" | sort | uniq -c | cut -c1-330
+timeout 900 python -m pytest tests -m gpu -x -q -k "moment or gp_class" 2>&1 | tail -2
+timeout 300 python tools/bench_c3.py 2>/dev/null | grep "rollout EM" | cut -c1-200
