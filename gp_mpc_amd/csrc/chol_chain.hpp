@@ -29,6 +29,9 @@ constexpr int CHAIN_LDS_BYTES = 150000;
 // [1+6nb .. 1+7nb) colready, [1+7nb .. 1+7nb+512) progress / start time of worker w (diagnostics),
 // [1+7nb+512 .. +2) arrival counter and "all resident" flag of the second worker launch
 __host__ __device__ inline int chain_flag_count(int nb) { return 1 + 7 * nb + 512 + 2; }
+__host__ __device__ inline int chain_colready_index(int nb, int k) { return 1 + 6 * nb + k; }
+__host__ __device__ inline int chain_pan1_index(int nb, int k) { return 1 + nb + k; }
+__host__ __device__ inline int chain_ready_index(int nb) { return 1 + 7 * nb + 512; }   // counter; the flag is the next word
 
 #ifdef GPMPC_EMULATED
 #define GPMPC_DYN_SMEM() ((double*)::emu::dyn_smem())

@@ -410,7 +410,7 @@ static bool factor_chain(const Ctx& cx, Workspace& ws, int spin_limit) {
                            (const double*)ws.Inv, ld, sM, nb, ws.flags, (long)nf, cx.crow_mode, spin_limit, 0, nb,
                            (int*)nullptr);
     } else if (use_workers) {
-        int* ready = ws.flags + 1 + 7 * nb + 512;           // arrival counter + flag of the second launch
+        int* ready = ws.flags + chain_ready_index(nb);      // arrival counter + flag of the second launch
         hipLaunchKernelGGL(chol_worker_kernel, dim3(NW, 1, ws.batch), dim3(WORKER_THREADS), WORKER_LDS_BYTES, cx.side, ws.K, ws.L,
                            (const double*)ws.Inv, ld, sM, nb, ws.flags, (long)nf, cx.crow_mode, spin_limit, 0, kb2,
                            (int*)nullptr);
@@ -421,7 +421,7 @@ static bool factor_chain(const Ctx& cx, Workspace& ws, int spin_limit) {
         // the left half of the inverse and the first product of the root, on the CUs the second launch leaves
         // free -- but not before that launch is resident (its workgroups need whole CUs)
         hipStreamWaitEvent(cx.aux, cx.seg[cx.n_seg - 2], 0);
-        hipLaunchKernelGGL(flag_gate_kernel, dim3(ws.batch), dim3(64), 0, cx.aux, ws.flags, (long)nf, 1 + 7 * nb + 512 + 1, 1,
+        hipLaunchKernelGGL(flag_gate_kernel, dim3(ws.batch), dim3(64), 0, cx.aux, ws.flags, (long)nf, chain_ready_index(nb) + 1, 1,
                            -1, 0, spin_limit);
         trtri_range(cx, ws, cx.aux, 0, s_top);
         trtri_node_w(cx, ws, cx.aux, 0, s_top, Np - s_top, ws.hw() * ws.hw());
