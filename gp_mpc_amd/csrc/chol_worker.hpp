@@ -50,16 +50,17 @@ __device__ __forceinline__ void lds_mm_tile(const double* A, int ar, const doubl
 }
 
 // a 64 x 64 block between global memory, WORKER_EPT registers per thread, and LDS.  Addresses are a
-// workgroup-uniform base plus per-thread UNSIGNED 32-bit BYTE offsets (toff[i] = 8 (row * ld + col) of the
-// thread's i-th element) so that the accesses take the SGPR-base form and no 64-bit address lives in VGPRs.
+// workgroup-uniform base plus ONE per-thread unsigned 32-bit BYTE offset (8 (row * ld + col) of the thread's
+// first element) so that the accesses can take the SGPR-base form and the addresses cost one register.
 __device__ __forceinline__ const double& at_byte(const double* base, unsigned byte_off) {
     return *(const double*)((const char*)base + byte_off);
 }
 __device__ __forceinline__ double& at_byte(double* base, unsigned byte_off) { return *(double*)((char*)base + byte_off); }
 
-__device__ __forceinline__ void block_to_regs(double* r, const double* __restrict__ src, const unsigned* toff) {
+// (the thread's i-th element sits 8 i rows below its first: a uniform pointer step, one offset register)
+__device__ __forceinline__ void block_to_regs(double* r, const double* __restrict__ src, unsigned toff0, long ld) {
 #pragma unroll
-    for (int i = 0; i < WORKER_EPT; ++i) r[i] = at_byte(src, toff[i]);
+    for (int i = 0; i < WORKER_EPT; ++i) r[i] = at_byte(src + (long)(WORKER_THREADS / 64) * i * ld, toff0);
 }
 __device__ __forceinline__ void regs_to_lds(double* dst, const double* r, int tid) {
 #pragma unroll
@@ -106,16 +107,12 @@ __global__ void __launch_bounds__(WORKER_THREADS) chol_worker_kernel(double* Kma
 #endif
     const int ntiles = (nb - 1) * nb / 2 - 1;    // resident tiles: (i, j), 1 <= j <= i, without (1,1)
     // per-thread BYTE offsets inside a 64 x 64 tile of an [ld]-strided matrix: csub[r] = the thread's
-    // r-th accumulator element (sub-tile row crow(lane, r), column lane & 15), toff[i] = its i-th copy element
-    unsigned csub[4], toff[WORKER_EPT];
+    // r-th accumulator element (sub-tile row crow(lane, r), column lane & 15), toff = its first copy element
+    unsigned csub[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r)
         csub[r] = 8u * (unsigned)((16 * wr + crow(lane, r, crow_mode)) * (int)ld + 32 * wc + (lane & 15));
-#pragma unroll
-    for (int i = 0; i < WORKER_EPT; ++i) {
-        const int idx = tid + WORKER_THREADS * i;
-        toff[i] = 8u * (unsigned)((idx >> 6) * (int)ld + (idx & 63));
-    }
+    const unsigned toff = 8u * (unsigned)((tid >> 6) * (int)ld + (tid & 63));
 
     // my tiles: (ti[n], tj[n]) in LDS (workgroup-uniform; ti < 0 = none / finished), the tiles themselves in
     // registers C[n].  The slot index is a run-time value: the code that touches a tile is
@@ -157,8 +154,8 @@ __global__ void __launch_bounds__(WORKER_THREADS) chol_worker_kernel(double* Kma
             if (tid == 0) flag_store(progress, 1 + 4 * k + 1);
             if (!wg_wait2(&leafdone[0], 1, nullptr, 0, err, spin_limit, slot, 2000000 + w)) return;
             double ra[WORKER_EPT], rb[WORKER_EPT];
-            block_to_regs(ra, Kb + (long)(64 * i) * ld, toff);
-            block_to_regs(rb, Ib, toff);                                        // inv_00
+            block_to_regs(ra, Kb + (long)(64 * i) * ld, toff, ld);
+            block_to_regs(rb, Ib, toff, ld);                                        // inv_00
             regs_to_lds(A, ra, tid);
             regs_to_lds(B, rb, tid);
             __syncthreads();
@@ -188,7 +185,7 @@ __global__ void __launch_bounds__(WORKER_THREADS) chol_worker_kernel(double* Kma
             if (tid == 0) flag_store(progress, 1 + 4 * k + 1);
             if (!wg_wait2(&leafdone[k], 1, nullptr, 0, err, spin_limit, slot, 2000000 + 1000 * k + w)) return;
             double rb[WORKER_EPT];
-            block_to_regs(rb, Ib + (long)(64 * k) * ld + 64 * k, toff);        // inv_kk (zeros above the diagonal)
+            block_to_regs(rb, Ib + (long)(64 * k) * ld + 64 * k, toff, ld);        // inv_kk (zeros above the diagonal)
             lds_put16(A, 16 * wr, 32 * wc, C[n][0], 1.0, lane, crow_mode);
             lds_put16(A, 16 * wr, 32 * wc + 16, C[n][1], 1.0, lane, crow_mode);
             regs_to_lds(B, rb, tid);
@@ -223,8 +220,8 @@ __global__ void __launch_bounds__(WORKER_THREADS) chol_worker_kernel(double* Kma
             if (!wg_wait2(&row2done[k], 1, j == k + 1 ? &pan1[k] : nullptr, 1, err, spin_limit, slot, 3000000 + 1000 * k + w))
                 return;
             double ra[WORKER_EPT], rb[WORKER_EPT];
-            block_to_regs(ra, Lb + (long)(64 * (k + 2)) * ld + 64 * k, toff);
-            block_to_regs(rb, Lb + (long)(64 * j) * ld + 64 * k, toff);
+            block_to_regs(ra, Lb + (long)(64 * (k + 2)) * ld + 64 * k, toff, ld);
+            block_to_regs(rb, Lb + (long)(64 * j) * ld + 64 * k, toff, ld);
             regs_to_lds(A, ra, tid);
             regs_to_lds(B, rb, tid);
             __syncthreads();
@@ -248,8 +245,8 @@ __global__ void __launch_bounds__(WORKER_THREADS) chol_worker_kernel(double* Kma
         if (tid == 0) flag_store(progress, 1 + 4 * k + 3);
         if (!wg_wait2(&colready[k], 1, &pan1[k], 1, err, spin_limit, slot, 4000000 + 1000 * k + w)) return;
         double ra[WORKER_EPT], rb[WORKER_EPT];
-        block_to_regs(ra, Lb + (long)(64 * __builtin_amdgcn_readfirstlane(ti[cur])) * ld + 64 * k, toff);
-        block_to_regs(rb, Lb + (long)(64 * __builtin_amdgcn_readfirstlane(tj[cur])) * ld + 64 * k, toff);
+        block_to_regs(ra, Lb + (long)(64 * __builtin_amdgcn_readfirstlane(ti[cur])) * ld + 64 * k, toff, ld);
+        block_to_regs(rb, Lb + (long)(64 * __builtin_amdgcn_readfirstlane(tj[cur])) * ld + 64 * k, toff, ld);
 #pragma unroll
         for (int n = 0; n < WORKER_MAXT; ++n) {
             if (n != cur) continue;                    // (slots before the first / between live tiles)
@@ -260,8 +257,8 @@ __global__ void __launch_bounds__(WORKER_THREADS) chol_worker_kernel(double* Kma
             for (int m = WORKER_MAXT - 1; m > n; --m)
                 if (__builtin_amdgcn_readfirstlane(ti[m]) >= 0 && __builtin_amdgcn_readfirstlane(tj[m]) > k) nxt = m;
             if (nxt >= 0) {
-                block_to_regs(ra, Lb + (long)(64 * __builtin_amdgcn_readfirstlane(ti[nxt])) * ld + 64 * k, toff);
-                block_to_regs(rb, Lb + (long)(64 * __builtin_amdgcn_readfirstlane(tj[nxt])) * ld + 64 * k, toff);
+                block_to_regs(ra, Lb + (long)(64 * __builtin_amdgcn_readfirstlane(ti[nxt])) * ld + 64 * k, toff, ld);
+                block_to_regs(rb, Lb + (long)(64 * __builtin_amdgcn_readfirstlane(tj[nxt])) * ld + 64 * k, toff, ld);
             }
             lds_mm_tile(A, 16 * wr, B, 32 * wc, lane, C[n], -1.0);
             __syncthreads();                           // A, B free again
