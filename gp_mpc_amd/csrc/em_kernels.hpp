@@ -130,29 +130,6 @@ __global__ void __launch_bounds__(256) em_mean_kernel(const double* __restrict__
     if (tid == 0) mean[(long)b * Ny + a] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-// exp(x) in fp64 without the library's special-case handling: n = rint(x log2 e), Cody-Waite reduction
-// r = x - n ln 2, degree-12 Taylor polynomial on |r| <= 0.347 (truncation 1.7e-16), v_ldexp_f64.
-// 18 VALU instructions; arguments here are <= O(10), underflow flushes to 0 through ldexp.
-__device__ __forceinline__ double exp_lean(double x) {
-    const double n = rint(x * 1.4426950408889634074);
-    double r = fma(-n, 6.93147180369123816490e-01, x);
-    r = fma(-n, 1.90821492927058770002e-10, r);
-    double p = 1.0 / 479001600.0;
-    p = fma(p, r, 1.0 / 39916800.0);
-    p = fma(p, r, 1.0 / 3628800.0);
-    p = fma(p, r, 1.0 / 362880.0);
-    p = fma(p, r, 1.0 / 40320.0);
-    p = fma(p, r, 1.0 / 5040.0);
-    p = fma(p, r, 1.0 / 720.0);
-    p = fma(p, r, 1.0 / 120.0);
-    p = fma(p, r, 1.0 / 24.0);
-    p = fma(p, r, 1.0 / 6.0);
-    p = fma(p, r, 0.5);
-    p = fma(p, r, 1.0);
-    p = fma(p, r, 1.0);
-    return ldexp(p, (int)n);
-}
-
 constexpr int EMK = 8;   // cross-term depth handled by the MFMA path (d <= 8: two 16x16x4 steps)
 
 // Per-(input, pair, point) operands of the pair kernel.  One thread per (b, p, i); arrays are

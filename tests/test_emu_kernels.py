@@ -79,6 +79,7 @@ def test_emu_timeout_fallback(emu, capfd):
 
 def test_emu_append(emu):
     pc.check_append(emu, N0=300, n=10)      # strip update: rows >= 256 re-factored on top of the stored factors
+    pc.check_append(emu, N0=256, n=5, Ny=1)  # old size a multiple of the block: the strip holds new rows only
     pc.check_append(emu, N0=250, n=70)      # too many new rows for the update to pay: refit path
     pc.check_append(emu, N0=40, n=30, Ny=1)  # fewer than 64 old points: refit path
 
