@@ -121,8 +121,14 @@ template <int D, int JT, bool JAC>
 __global__ void __launch_bounds__(256) crosscov_kernel(const double* __restrict__ XT, const double* __restrict__ hyper,
                                                        const double* __restrict__ alpha, const double* __restrict__ Z,
                                                        double* __restrict__ KsT, double* __restrict__ meanT,
-                                                       double* __restrict__ J, int N, int Np, int B, int Bp, int Ny) {
+                                                       double* __restrict__ J, int N, int Np, int B, int Bp, int Ny,
+                                                       double* __restrict__ cpart) {
+    // gridDim.z > 1 (small batches, the MPC's shooting nodes): the training points are cut into gridDim.z
+    // chunks so that more than Bp/JT x Ny workgroups exist; the partial sums go to cpart[chunk][a][j][1 + D]
+    // and crosscov_finish_kernel adds them in a fixed order.
     const int j0 = blockIdx.x * JT, a = blockIdx.y, tid = threadIdx.x;
+    const int nch = gridDim.z, clen = ((Np + nch - 1) / nch + 255) / 256 * 256;
+    const int ibeg = blockIdx.z * clen, iend = min(Np, ibeg + clen);
     constexpr int NR = JAC ? JT * (D + 1) : JT;
     __shared__ double Zs[JT][D], w[D], red[4][NR];
     const double* hy = hyper + (long)a * (D + 2);
@@ -144,7 +150,7 @@ __global__ void __launch_bounds__(256) crosscov_kernel(const double* __restrict_
     }
     const double* __restrict__ al = alpha + (long)a * Np;
     double* __restrict__ out = KsT + ((long)a * Bp + j0) * Np;
-    for (int i = tid; i < Np; i += 256) {
+    for (int i = ibeg + tid; i < iend; i += 256) {
         double x[D];
 #pragma unroll
         for (int dd = 0; dd < D; ++dd) x[dd] = XT[(long)dd * Np + i];
@@ -182,6 +188,14 @@ __global__ void __launch_bounds__(256) crosscov_kernel(const double* __restrict_
         }
     }
     __syncthreads();
+    if (nch > 1) {
+        if (tid < NR) {
+            const double v = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+            const int jj = tid < JT ? tid : (tid - JT) / D, e = tid < JT ? 0 : 1 + (tid - JT) % D;
+            cpart[(((long)blockIdx.z * Ny + a) * Bp + j0 + jj) * (D + 1) + e] = e ? v * w[e - 1] : v;
+        }
+        return;
+    }
     if (tid < JT) meanT[(long)a * Bp + j0 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
     if (JAC && tid >= JT && tid < NR) {
         const int e = tid - JT, jj = e / D, dd = e % D;
@@ -190,24 +204,52 @@ __global__ void __launch_bounds__(256) crosscov_kernel(const double* __restrict_
     }
 }
 
+// adds the chunk partials of crosscov_kernel: one thread per (output a, point j, entry e); e = 0 mean, e > 0 J
+__global__ void __launch_bounds__(256) crosscov_finish_kernel(const double* __restrict__ cpart, double* __restrict__ meanT,
+                                                              double* __restrict__ J, int nch, int Ny, int B, int Bp,
+                                                              int D, int with_jac) {
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    const int ne = D + 1;
+    if (gid >= (long)Ny * Bp * ne) return;
+    const int e = (int)(gid % ne), j = (int)((gid / ne) % Bp), a = (int)(gid / ((long)ne * Bp));
+    if (e > 0 && !with_jac) return;
+    double s = 0.0;
+    for (int c = 0; c < nch; ++c) s += cpart[(((long)c * Ny + a) * Bp + j) * ne + e];
+    if (e == 0) meanT[(long)a * Bp + j] = s;
+    else if (j < B) J[((long)j * Ny + a) * D + e - 1] = s;
+}
+
 constexpr int CROSSCOV_JT = 8;       // test points per workgroup (4 when the Jacobian is accumulated as well)
+constexpr int CROSSCOV_SMALL_B = 64; // up to this many (padded) test points the training points are chunked ...
+constexpr int CROSSCOV_CHUNKS = 8;   // ... into this many pieces (gridDim.z)
+#ifdef GPMPC_EMULATED
+constexpr int CROSSCOV_CHUNK_MIN_NP = 512;    // (small in the emulated build so that the CPU tests reach the path)
+#else
+constexpr int CROSSCOV_CHUNK_MIN_NP = 2048;
+#endif
 
 template <int D>
 inline void launch_crosscov_d(hipStream_t st, const double* XT, const double* hyper, const double* alpha,
                               const double* Z, double* KsT, double* meanT, double* J, int N, int Np, int B, int Bp,
-                              int Ny) {
+                              int Ny, double* cpart, int nch) {
+    if (!cpart) nch = 1;
     if (J)
-        hipLaunchKernelGGL((crosscov_kernel<D, 4, true>), dim3(Bp / 4, Ny), dim3(256), 0, st, XT, hyper, alpha, Z, KsT,
-                           meanT, J, N, Np, B, Bp, Ny);
+        hipLaunchKernelGGL((crosscov_kernel<D, 4, true>), dim3(Bp / 4, Ny, nch), dim3(256), 0, st, XT, hyper, alpha, Z, KsT,
+                           meanT, J, N, Np, B, Bp, Ny, cpart);
     else
-        hipLaunchKernelGGL((crosscov_kernel<D, CROSSCOV_JT, false>), dim3(Bp / CROSSCOV_JT, Ny), dim3(256), 0, st, XT,
-                           hyper, alpha, Z, KsT, meanT, J, N, Np, B, Bp, Ny);
+        hipLaunchKernelGGL((crosscov_kernel<D, CROSSCOV_JT, false>), dim3(Bp / CROSSCOV_JT, Ny, nch), dim3(256), 0, st, XT,
+                           hyper, alpha, Z, KsT, meanT, J, N, Np, B, Bp, Ny, cpart);
+    if (nch > 1) {
+        const long items = (long)Ny * Bp * (D + 1);
+        hipLaunchKernelGGL(crosscov_finish_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, cpart, meanT, J, nch,
+                           Ny, B, Bp, D, J ? 1 : 0);
+    }
 }
 
 inline void launch_crosscov(hipStream_t st, int d, const double* XT, const double* hyper, const double* alpha,
                             const double* Z, double* KsT, double* meanT, double* J, int N, int Np, int B, int Bp,
-                            int Ny) {
-#define GPMPC_CC(DD) case DD: launch_crosscov_d<DD>(st, XT, hyper, alpha, Z, KsT, meanT, J, N, Np, B, Bp, Ny); break;
+                            int Ny, double* cpart = nullptr, int nch = 1) {
+#define GPMPC_CC(DD) case DD: launch_crosscov_d<DD>(st, XT, hyper, alpha, Z, KsT, meanT, J, N, Np, B, Bp, Ny, cpart, nch); break;
     switch (d) {
         GPMPC_CC(1) GPMPC_CC(2) GPMPC_CC(3) GPMPC_CC(4) GPMPC_CC(5) GPMPC_CC(6) GPMPC_CC(7) GPMPC_CC(8)
         GPMPC_CC(9) GPMPC_CC(10) GPMPC_CC(11) GPMPC_CC(12) GPMPC_CC(13) GPMPC_CC(14) GPMPC_CC(15) GPMPC_CC(16)

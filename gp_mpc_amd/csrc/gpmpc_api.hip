@@ -554,6 +554,7 @@ struct gpmpc_gp {
     double* beta = nullptr;  // K^-1 y, [Ny][Np]
     double* UT = nullptr;    // K^-1 ks per test point (legacy methods, sensitivities)
     double *sensH = nullptr, *sensV = nullptr;   // staging of gpmpc_predict_sens outputs in host-pointer mode
+    double* ccpart = nullptr;                    // chunk partials of the small-batch cross-covariance kernel
     bool have_beta = false;
     Prof prof;
     Ctx cx() {
@@ -682,7 +683,7 @@ int gpmpc_destroy(gpmpc_gp* h) {
     hipFree(h->XT); hipFree(h->Y); hipFree(h->gradPartial); hipFree(h->gradOut);
     hipFree(h->Z); hipFree(h->Sigma); hipFree(h->KsT); hipFree(h->part); hipFree(h->meanT);
     hipFree(h->mean); hipFree(h->var); hipFree(h->J); hipFree(h->cov); hipFree(h->em);
-    hipFree(h->beta); hipFree(h->UT); hipFree(h->sensH); hipFree(h->sensV);
+    hipFree(h->beta); hipFree(h->UT); hipFree(h->sensH); hipFree(h->sensV); hipFree(h->ccpart);
     for (int ph = 0; ph < GPMPC_PH_COUNT; ++ph)
         for (auto& pr : h->prof.ev[ph]) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     for (auto e : h->prof.pool) hipEventDestroy(e);
@@ -867,9 +868,9 @@ extern "C" int gpmpc_fit(gpmpc_gp* h, const double* hyper, int want_invK, int* i
 static void free_predict_scratch(gpmpc_gp* h) {
     hipFree(h->Z); hipFree(h->Sigma); hipFree(h->KsT); hipFree(h->part); hipFree(h->meanT);
     hipFree(h->mean); hipFree(h->var); hipFree(h->J); hipFree(h->cov); hipFree(h->UT);
-    hipFree(h->sensH); hipFree(h->sensV); hipFree(h->em); hipFree(h->beta); hipFree(h->gradPartial);
+    hipFree(h->sensH); hipFree(h->sensV); hipFree(h->em); hipFree(h->beta); hipFree(h->gradPartial); hipFree(h->ccpart);
     h->Z = h->Sigma = h->KsT = h->part = h->meanT = h->mean = h->var = h->J = h->cov = h->UT = nullptr;
-    h->sensH = h->sensV = h->em = h->beta = h->gradPartial = nullptr;
+    h->sensH = h->sensV = h->em = h->beta = h->gradPartial = h->ccpart = nullptr;
     h->Bcap = 0;
     h->emBytes = 0;
     h->have_beta = false;
@@ -1087,8 +1088,8 @@ static int ensure_scratch(gpmpc_gp* h, int B) {
     HIPCHK(hipStreamSynchronize(h->stream));
     hipFree(h->Z); hipFree(h->Sigma); hipFree(h->KsT); hipFree(h->part); hipFree(h->meanT);
     hipFree(h->mean); hipFree(h->var); hipFree(h->J); hipFree(h->cov); hipFree(h->UT);
-    hipFree(h->sensH); hipFree(h->sensV);
-    h->UT = h->sensH = h->sensV = nullptr;
+    hipFree(h->sensH); hipFree(h->sensV); hipFree(h->ccpart);
+    h->UT = h->sensH = h->sensV = h->ccpart = nullptr;
     h->Z = h->Sigma = h->KsT = h->part = h->meanT = h->mean = h->var = h->J = h->cov = nullptr;
     h->Bcap = 0;
     const size_t d = h->d, Ny = h->Ny, Np = h->Np, Bc = need;
@@ -1101,6 +1102,7 @@ static int ensure_scratch(gpmpc_gp* h, int B) {
     HIPCHK(hipMalloc(&h->var, Bc * Ny * sizeof(double)));
     HIPCHK(hipMalloc(&h->J, Bc * Ny * d * sizeof(double)));
     HIPCHK(hipMalloc(&h->cov, Bc * Ny * Ny * sizeof(double)));
+    HIPCHK(hipMalloc(&h->ccpart, (size_t)CROSSCOV_CHUNKS * Ny * CROSSCOV_SMALL_B * (d + 1) * sizeof(double)));
     h->Bcap = need;
     return GPMPC_OK;
 }
@@ -1111,7 +1113,10 @@ static int predict_chunk(gpmpc_gp* h, int B, const double* dZ, double* dMean, do
     const int Bp = round_up(B, 32), Np = h->Np, Ny = h->Ny;
     {
         PhaseTimer t(h, GPMPC_PH_CROSSCOV);
-        launch_crosscov(cx.stream, h->d, h->XT, h->ws.hyper, h->ws.alpha, dZ, h->KsT, h->meanT, dJ, h->N, Np, B, Bp, Ny);
+        // few test points (an MPC's shooting nodes): cut the training points in chunks so that the launch fills the chip
+        const int nch = (Bp <= CROSSCOV_SMALL_B && Np >= CROSSCOV_CHUNK_MIN_NP) ? CROSSCOV_CHUNKS : 1;
+        launch_crosscov(cx.stream, h->d, h->XT, h->ws.hyper, h->ws.alpha, dZ, h->KsT, h->meanT, dJ, h->N, Np, B, Bp, Ny,
+                        h->ccpart, nch);
     }
     int tilesM = 0;
     if (dVar && B <= 8) {

@@ -254,6 +254,30 @@ def check_moment_methods(lib, g=None):
     h.close()
 
 
+def check_small_batch_chunks(lib, N=600, d=5, Ny=2):
+    """Few test points on a larger model: the cross-covariance kernel cuts the training points into chunks and a
+    second kernel adds the partial means / Jacobians (the MPC's shooting-node pattern)."""
+    p = go.synthetic_problem(N, d, Ny, 64, seed=21, sn=0.1)
+    X, Y, H = p['X'], p['Y'], p['hyper']
+    h = Handle(lib, X, Y)
+    assert np.all(h.fit(H) == 0)
+    f = h.get_factors()
+    for B in (1, 5, 30, 64):
+        Z = p['Z'][:B]
+        om, ov, oJ = go.mean_var_jac(Z, X, H, f['alpha'], f['chol'])
+        mean, J = h.mean_jac(Z)
+        m2, var = h.predict_mean_var(Z)
+        ms = mean_scale(X, Z, H, f['alpha'])
+        assert np.max(np.abs(mean - om) / ms) <= 1e-10 and np.max(np.abs(m2 - om) / ms) <= 1e-10
+        assert np.max(np.abs(var - ov) / H[:, d] ** 2) <= 1e-10
+        assert np.max(np.abs(J - oJ) / (ms / H[:, :d].min(axis=1))[..., None]) <= 1e-10
+        S = np.tile(np.eye(d) * 1e-3, (B, 1, 1))
+        mt, ct = h.predict('TA', Z, S)
+        oc = go.ta_cov(ov, oJ, S)
+        assert np.max(np.abs(ct - oc)) <= 1e-10 * max(1.0, np.abs(oc).max())
+    h.close()
+
+
 def check_timeout_fallback(lib, N=560, d=4):
     """A hand-off time-out inside the persistent factorisation kernels (forced by a poll budget of 1) must
     leave a correct model behind: the host repeats the factorisation on the single-stream path."""

@@ -72,6 +72,10 @@ def test_emu_moment_methods(emu, tank):
     pc.check_moment_methods(emu, tank)
 
 
+def test_emu_small_batch_chunks(emu):
+    pc.check_small_batch_chunks(emu)
+
+
 def test_emu_timeout_fallback(emu, capfd):
     pc.check_timeout_fallback(emu)
     assert 'timed out on a hand-off' in capfd.readouterr().err

@@ -103,6 +103,10 @@ def test_worker_path_odd_size(lib):
     pc.check_synthetic(lib, N=4100, d=6, Ny=1, B=50, sn=1e-2, strict_rel=False)
 
 
+def test_small_batch_chunks(lib):
+    pc.check_small_batch_chunks(lib, N=2500, d=6, Ny=3)
+
+
 def test_timeout_fallback(lib, capfd):
     pc.check_timeout_fallback(lib, N=1500)
     assert 'timed out on a hand-off' in capfd.readouterr().err
