@@ -50,6 +50,7 @@ SIGNATURES = {
     'gpmpc_predict_mean_var': (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp]),
     'gpmpc_mean_jac': (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp]),
     'gpmpc_predict_sens': (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'gpmpc_rollout': (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'gpmpc_predict': (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, _vp]),
     'gpmpc_covar': (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp]),
     'gpmpc_nll': (ctypes.c_int, [_vp, ctypes.c_int, _vp, _dp, _vp, _ip]),
@@ -245,6 +246,21 @@ class Handle:
                                                  info.ctypes.data_as(ctypes.c_void_p)))
         self.N += Xnew.shape[0]
         return info
+
+    def rollout(self, method, z0, U, Sigma0, sa=None, sb=None):
+        """T-step uncertainty propagation on the device (standardised units): mean[T,Ny], cov[T,Ny,Ny]."""
+        code = METHODS[method] if isinstance(method, str) else int(method)
+        z0 = _f64(z0).reshape(self.d)
+        Nu = self.d - self.Ny
+        U = _f64(U).reshape(-1, max(Nu, 1)) if Nu > 0 else np.zeros((int(np.asarray(U).shape[0]), 1))
+        T = U.shape[0]
+        Sigma0 = _f64(Sigma0).reshape(self.d, self.d)
+        sa = None if sa is None else _f64(sa).reshape(self.Ny)
+        sb = None if sb is None else _f64(sb).reshape(self.Ny)
+        mean, cov = np.zeros((T, self.Ny)), np.zeros((T, self.Ny, self.Ny))
+        self.lib.check(self.lib.dll.gpmpc_rollout(self.h, code, T, _ptr(z0), _ptr(U), _ptr(Sigma0), _ptr(sa), _ptr(sb),
+                                                  _ptr(mean), _ptr(cov)))
+        return mean, cov
 
     def predict_sens(self, Z):
         """mean[B,Ny], var[B,Ny], J[B,Ny,d] = d mean/dz, Hm[B,Ny,d,d] = d2 mean/dz2, dvar[B,Ny,d] = d var/dz."""

@@ -426,6 +426,19 @@ inline void launch_sens(hipStream_t st, int d, const double* XT, const double* Z
 #undef GPMPC_SK
 }
 
+// a17 on the device: input of step t of an uncertainty-propagation roll-out from the output of step t-1
+// (GP.predict_compare's loop gp_class.py:777-804 with GP.predict's re-standardisation :253-261 folded in):
+//   z_t = [sa * mean_{t-1} + sb, u_t],   Sigma_t[:Ny,:Ny] = cov_{t-1}  (the other blocks keep their initial values).
+// One workgroup of 64 threads.
+__global__ void __launch_bounds__(64) rollout_feed_kernel(const double* __restrict__ mean_prev, const double* __restrict__ cov_prev,
+                                                          const double* __restrict__ u_t, const double* __restrict__ sa,
+                                                          const double* __restrict__ sb, double* __restrict__ z,
+                                                          double* __restrict__ Sigma, int Ny, int d) {
+    const int tid = threadIdx.x;
+    for (int e = tid; e < d; e += 64) z[e] = e < Ny ? sa[e] * mean_prev[e] + sb[e] : u_t[e - Ny];
+    for (int e = tid; e < Ny * Ny; e += 64) Sigma[(e / Ny) * d + e % Ny] = cov_prev[e];
+}
+
 // Matrix-vector products with the explicit factors (a5: alpha = L^-T (L^-1 y), optimize.py:353-354,494;
 // beta = K^-1 y, gp_functions.py:383).  HBM-read bound: 4 N^2 bytes for a triangular operand.
 // out[i] = sum_{k < (lower ? i+1 : Np)} A[i][k] x[k]: one wave per row, lanes stride the row (512 B

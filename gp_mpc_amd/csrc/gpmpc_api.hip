@@ -1237,6 +1237,68 @@ extern "C" int gpmpc_mean_jac(gpmpc_gp* h, int B, const double* Z, double* mean,
     return predict_driver(h, GPMPC_ME, B, Z, nullptr, mean, nullptr, J, nullptr);
 }
 
+extern "C" int gpmpc_rollout(gpmpc_gp* h, int method, int T, const double* z0, const double* U, const double* Sigma0,
+                             const double* sa, const double* sb, double* mean, double* cov) {
+    if (!h) return fail(GPMPC_EINVAL, "NULL handle");
+    if (!h->fitted) return fail(GPMPC_ENOTFIT, "model has no factors (call gpmpc_fit or gpmpc_set_factors)");
+    if (method < GPMPC_ME || method > GPMPC_OLD_TA) return fail(GPMPC_EINVAL, "No GP method with code %d", method);
+    const int d = h->d, Ny = h->Ny, Nu = d - Ny;
+    if (T <= 0 || !z0 || !Sigma0 || !mean || !cov || (Nu > 0 && !U)) return fail(GPMPC_EINVAL, "bad T or NULL argument");
+    if (Nu < 0) return fail(GPMPC_EINVAL, "roll-out needs d >= Ny (inputs are [state, control])");
+    HIPCHK(hipSetDevice(h->device));
+    CHK(ensure_scratch(h, 1));
+    const bool moments = method == GPMPC_EM || method == GPMPC_OLD_ME || method == GPMPC_OLD_TA;
+    if (moments && !h->have_invK) {
+        CHK(compute_invK(h->cx(), h->ws));
+        h->have_invK = true;
+    }
+    // device staging: [z | Sigma | sa | sb | U | mean (T) | cov (T) | var | J]
+    const size_t nz = d, nS = (size_t)d * d, nU = (size_t)T * std::max(Nu, 1), nM = (size_t)T * Ny, nC = (size_t)T * Ny * Ny;
+    const size_t total = nz + nS + 2 * Ny + nU + nM + nC + Ny + (size_t)Ny * d;
+    double* buf = nullptr;
+    HIPCHK(hipMalloc(&buf, total * sizeof(double)));
+    double *dz = buf, *dS = dz + nz, *dsa = dS + nS, *dsb = dsa + Ny, *dU = dsb + Ny, *dM = dU + nU, *dC = dM + nM,
+           *dV = dC + nC, *dJ = dV + Ny;
+    std::vector<double> one(Ny, 1.0), zero(Ny, 0.0);
+    auto up = [&](double* dst, const double* src, size_t n) {
+        return hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyHostToDevice, h->stream);
+    };
+    hipError_t e = up(dz, z0, nz);
+    if (e == hipSuccess) e = up(dS, Sigma0, nS);
+    if (e == hipSuccess) e = up(dsa, sa ? sa : one.data(), Ny);
+    if (e == hipSuccess) e = up(dsb, sb ? sb : zero.data(), Ny);
+    if (e == hipSuccess && Nu > 0) e = up(dU, U, (size_t)T * Nu);
+    int rc = GPMPC_OK;
+    if (e != hipSuccess) rc = fail(GPMPC_EHIP, "%s", hipGetErrorString(e));
+    for (int t = 0; t < T && rc == GPMPC_OK; ++t) {
+        if (t > 0)
+            hipLaunchKernelGGL(rollout_feed_kernel, dim3(1), dim3(64), 0, h->stream, dM + (size_t)(t - 1) * Ny,
+                               dC + (size_t)(t - 1) * Ny * Ny, dU + (size_t)t * std::max(Nu, 1), dsa, dsb, dz, dS, Ny, d);
+        double* oM = dM + (size_t)t * Ny;
+        double* oC = dC + (size_t)t * Ny * Ny;
+        if (moments) {
+            rc = predict_moments_chunk(h, method, 1, dz, dS, oM, oC);
+        } else {
+            const bool ta = method == GPMPC_TA;
+            rc = predict_chunk(h, 1, dz, oM, dV, ta ? dJ : nullptr);
+            if (rc == GPMPC_OK)
+                hipLaunchKernelGGL(cov_assemble_kernel, dim3((unsigned)((Ny * Ny + 255) / 256)), dim3(256), 0, h->stream, dV, dJ,
+                                   ta ? dS : (const double*)nullptr, oC, 1, Ny, d);
+        }
+    }
+    if (rc == GPMPC_OK) {
+        e = hipMemcpyAsync(mean, dM, nM * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(cov, dC, nC * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e == hipSuccess) e = hipGetLastError();
+        if (e != hipSuccess) rc = fail(GPMPC_EHIP, "%s", hipGetErrorString(e));
+    } else {
+        hipStreamSynchronize(h->stream);
+    }
+    hipFree(buf);
+    return rc;
+}
+
 extern "C" int gpmpc_predict_sens(gpmpc_gp* h, int B, const double* Z, double* mean, double* var, double* J, double* Hm,
                                   double* dvar) {
     if (!h) return fail(GPMPC_EINVAL, "NULL handle");

@@ -470,21 +470,28 @@ class GP:
         mean = np.zeros((len(methods), Nt + 1, Ny))
         var = np.zeros((len(methods), Nt + 1, Ny))
         covar = np.eye(Nx) * 1e-6                                               # gp_class.py:764
-        keep = self.__gp_method
+        # DIFF: the reference synchronises with the predictor once per step (a Python loop around GP.predict);
+        # here the whole horizon runs on the device (`gpmpc_rollout`) and the result comes back once.
+        for m in methods:
+            if m not in METHODS:
+                raise NameError('No GP method called: ' + str(m))
+        x0 = np.asarray(x0, dtype=np.float64).reshape(Ny)
+        if self.__normalize:
+            z0 = np.concatenate([self.standardize(x0, self.__meanX, self.__stdX),
+                                 self.standardize(u[0], self.__meanU, self.__stdU)])
+            Us = self.standardize(u, self.__meanU, self.__stdU)
+            sa = np.atleast_1d(self.__stdY) / np.atleast_1d(self.__stdX)           # x_s(next) = sa * mean_s + sb
+            sb = (np.atleast_1d(self.__meanY) - np.atleast_1d(self.__meanX)) / np.atleast_1d(self.__stdX)
+        else:
+            z0, Us, sa, sb = np.concatenate([x0, u[0]]), u, None, None
+        covar[:Ny, :Ny] = np.diag(initVar)                                        # gp_class.py:780
         for i, m in enumerate(methods):
-            self.set_method(m)
-            mean_t = np.asarray(x0, dtype=np.float64).reshape(Ny)
-            covar[:Ny, :Ny] = np.diag(initVar)                                  # gp_class.py:780
-            mean[i, 0, :] = mean_t
-            for t in range(1, Nt + 1):
-                mean_t, covar_x = self.predict(mean_t, u[t - 1, :], covar)
-                mean_t = np.array(mean_t).reshape(Ny)
-                mean[i, t, :] = mean_t
-                var[i, t, :] = np.diag(covar_x)
-                if self.__normalize:
-                    var[i, t, :] = self.inverse_variance(var[i, t, :])
-                covar[:Ny, :Ny] = covar_x
-        self.set_method(keep)
+            mean_s, cov = self._h.rollout(m, z0, Us, covar, sa, sb)
+            mean[i, 0, :] = x0
+            mean[i, 1:, :] = self.inverse_mean(mean_s, self.__meanY, self.__stdY) if self.__normalize else mean_s
+            var[i, 1:, :] = np.einsum('tii->ti', cov)
+            if self.__normalize:
+                var[i, 1:, :] = self.inverse_variance(var[i, 1:, :])
         if np.any(var < 0):
             var = var.clip(min=0)
         return mean, var

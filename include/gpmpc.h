@@ -123,6 +123,14 @@ int gpmpc_predict_sens(gpmpc_gp* h, int B, const double* Z, double* mean, double
  * cov[B x Ny x Ny] in standardised units (gp_class.py:262 leaves cov unscaled). */
 int gpmpc_predict(gpmpc_gp* h, int method, int B, const double* Z, const double* Sigma,
                   double* mean, double* cov);
+/* a17: T-step uncertainty propagation entirely on the device (the numeric loop of GP.predict_compare,
+ * gp_class.py:777-804: feed (mean_t, cov_t) back into GP.predict), one synchronisation at the end instead of
+ * one per step.  All quantities in the GP's standardised units: z0[d] first input, U[T x Nu] controls,
+ * Sigma0[d x d] initial input covariance (its [:Ny,:Ny] block is replaced by cov_t every step, the rest kept),
+ * sa/sb[Ny]: x_{t+1} = sa * mean_t + sb maps an output mean to the next state input (re-standardisation of
+ * GP.predict, gp_class.py:253-261; NULL = identity).  Outputs mean[T x Ny], cov[T x Ny x Ny] (host pointers). */
+int gpmpc_rollout(gpmpc_gp* h, int method, int T, const double* z0, const double* U, const double* Sigma0,
+                  const double* sa, const double* sb, double* mean, double* cov);
 /* a14 GP.covar gp_class.py:353-381: covar[Ny x n x n] = sf^2 - V^T V for n new inputs. */
 int gpmpc_covar(gpmpc_gp* h, int n, const double* Xnew, double* covar);
 

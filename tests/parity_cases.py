@@ -361,7 +361,7 @@ def check_sensitivities(lib, g, nprobe=12):
     h.close()
 
 
-def check_gp_class(lib, g, tmp_path):
+def check_gp_class(lib, g, tmp_path, em_rollout=True):
     """The Python `GP` surface (reference gp_class.py) against `OracleGP` on a saved reference model."""
     from gp_mpc_amd.gp import GP
     hyper = dict(hyper=g['hyper'], chol=g['chol'], alpha=g['alpha'], invK=g['invK'])
@@ -409,6 +409,26 @@ def check_gp_class(lib, g, tmp_path):
     mr, vr = gp.rollout(x, U, methods=['TA', 'ME'])
     omr, ovr = og.rollout(x, U, methods=('TA', 'ME'))
     assert np.allclose(mr, omr, rtol=1e-7, atol=1e-9) and np.allclose(vr, np.clip(ovr, 0, None), rtol=1e-5, atol=1e-9 * sf2.max())
+    # the exact-moment roll-out too.  EM covariances on the reference's models are cancellation-limited (~1e-5
+    # absolute here, alpha ~ 1e3) and the feedback amplifies that noise, so the device roll-out (one call,
+    # gpmpc_rollout) is checked against the SAME device predictor driven step by step from the host, as the
+    # reference's loop does (gp_class.py:777-804); single EM steps are compared with the oracle elsewhere.
+    if em_rollout:
+        me, ve = gp.rollout(x, U, methods=['EM'])
+        gp.set_method('EM')
+        covar = np.eye(Nx) * 1e-6
+        covar[:Ny, :Ny] = np.diag(g['hyper'][:, Nx + 1] ** 2)
+        mt = np.asarray(x, dtype=np.float64)
+        for t in range(1, 5):
+            mt, cx = gp.predict(mt, U[t - 1], covar)
+            mt = mt.reshape(Ny)
+            vt = np.diag(cx) * (g['meta']['stdY'] ** 2 if g['normalize'] else 1.0)
+            # (the device maps mean_s -> next x_s in one affine step, the host un-standardises and re-standardises:
+            #  one ulp apart, which EM's cancellation turns into ~1e-2 relative in the variance after 4 steps)
+            assert np.allclose(me[0, t], mt, rtol=1e-7, atol=1e-7 * np.abs(mt).max())
+            assert np.allclose(ve[0, t], np.clip(vt, 0, None), rtol=3e-2, atol=1e-6 * np.abs(vt).max())
+            covar[:Ny, :Ny] = cx
+        gp.set_method('TA')
     # validate on the training inputs themselves
     Xraw = g['X'] * g['meta']['stdZ'] + g['meta']['meanZ'] if g['normalize'] else g['X']
     Yraw = g['Y'] * g['meta']['stdY'] + g['meta']['meanY'] if g['normalize'] else g['Y']

@@ -45,6 +45,17 @@ for method in ('ME', 'TA', 'EM'):
     print(json.dumps({'bench': f'C3 rollout {method}', 'steps': T, 'total_s': dt, 'ms_per_step': dt / T * 1e3,
                       'finite': bool(np.all(np.isfinite(mean_t)) and np.all(np.isfinite(S))),
                       'phases_ms_per_step': {k: v[0] / T for k, v in prof.items() if v[1]}}))
+# the same propagation as ONE device call (gpmpc_rollout: no host round trip per step)
+h.profile_enable(False)
+for method in ('ME', 'TA', 'EM'):
+    z0 = np.concatenate([x0, U[0]])
+    h.rollout(method, z0, U[:T], S0)
+    t0 = time.perf_counter()
+    m, c = h.rollout(method, z0, U[:T], S0)
+    dt = time.perf_counter() - t0
+    print(json.dumps({'bench': f'C3 rollout {method}, one device call', 'steps': T, 'total_s': dt, 'ms_per_step': dt / T * 1e3,
+                      'finite': bool(np.all(np.isfinite(m)) and np.all(np.isfinite(c)))}))
+h.profile_enable(True)
 # C5: 30 nodes per call, value + Jacobian + TA covariance
 Z = p['Z'][:30]
 Sg = p['Sigma'][:30]
