@@ -50,6 +50,7 @@ SIGNATURES = {
     'gpmpc_predict_mean_var': (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp]),
     'gpmpc_mean_jac': (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp]),
     'gpmpc_predict_sens': (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'gpmpc_predict_jac': (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, _vp, _vp]),
     'gpmpc_rollout': (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'gpmpc_predict': (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, _vp]),
     'gpmpc_covar': (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp]),
@@ -246,6 +247,17 @@ class Handle:
                                                  info.ctypes.data_as(ctypes.c_void_p)))
         self.N += Xnew.shape[0]
         return info
+
+    def predict_jac(self, method, Z, Sigma=None):
+        """mean[B,Ny], cov[B,Ny,Ny] ('ME'/'TA') and J[B,Ny,d] = d mean / d z from one pass."""
+        code = METHODS[method] if isinstance(method, str) else int(method)
+        Z = _f64(Z).reshape(-1, self.d)
+        B = Z.shape[0]
+        if Sigma is not None:
+            Sigma = _f64(Sigma).reshape(B, self.d, self.d)
+        mean, cov, J = np.zeros((B, self.Ny)), np.zeros((B, self.Ny, self.Ny)), np.zeros((B, self.Ny, self.d))
+        self.lib.check(self.lib.dll.gpmpc_predict_jac(self.h, code, B, _ptr(Z), _ptr(Sigma), _ptr(mean), _ptr(cov), _ptr(J)))
+        return mean, cov, J
 
     def rollout(self, method, z0, U, Sigma0, sa=None, sb=None):
         """T-step uncertainty propagation on the device (standardised units): mean[T,Ny], cov[T,Ny,Ny]."""

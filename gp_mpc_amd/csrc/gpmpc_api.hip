@@ -1237,6 +1237,13 @@ extern "C" int gpmpc_mean_jac(gpmpc_gp* h, int B, const double* Z, double* mean,
     return predict_driver(h, GPMPC_ME, B, Z, nullptr, mean, nullptr, J, nullptr);
 }
 
+extern "C" int gpmpc_predict_jac(gpmpc_gp* h, int method, int B, const double* Z, const double* Sigma, double* mean,
+                                 double* cov, double* J) {
+    if (method != GPMPC_ME && method != GPMPC_TA) return fail(GPMPC_EINVAL, "gpmpc_predict_jac serves the 'ME' and 'TA' methods");
+    if (!mean || !cov || !J) return fail(GPMPC_EINVAL, "mean/cov/J NULL");
+    return predict_driver(h, method, B, Z, Sigma, mean, nullptr, J, cov);
+}
+
 extern "C" int gpmpc_rollout(gpmpc_gp* h, int method, int T, const double* z0, const double* U, const double* Sigma0,
                              const double* sa, const double* sb, double* mean, double* cov) {
     if (!h) return fail(GPMPC_EINVAL, "NULL handle");

@@ -123,6 +123,10 @@ int gpmpc_predict_sens(gpmpc_gp* h, int B, const double* Z, double* mean, double
  * cov[B x Ny x Ny] in standardised units (gp_class.py:262 leaves cov unscaled). */
 int gpmpc_predict(gpmpc_gp* h, int method, int B, const double* Z, const double* Sigma,
                   double* mean, double* cov);
+/* gpmpc_predict for 'ME' / 'TA' plus J[B x Ny x d] = d mean / d z from the same pass (what one evaluation of an NLP
+ * callback needs: GP.__predict and its jac_x / jac_u, gp_class.py:212-219,239-242). */
+int gpmpc_predict_jac(gpmpc_gp* h, int method, int B, const double* Z, const double* Sigma, double* mean,
+                      double* cov, double* J);
 /* a17: T-step uncertainty propagation entirely on the device (the numeric loop of GP.predict_compare,
  * gp_class.py:777-804: feed (mean_t, cov_t) back into GP.predict), one synchronisation at the end instead of
  * one per step.  All quantities in the GP's standardised units: z0[d] first input, U[T x Nu] controls,

@@ -275,6 +275,8 @@ def check_small_batch_chunks(lib, N=600, d=5, Ny=2):
         mt, ct = h.predict('TA', Z, S)
         oc = go.ta_cov(ov, oJ, S)
         assert np.max(np.abs(ct - oc)) <= 1e-10 * max(1.0, np.abs(oc).max())
+        m3, c3, J3 = h.predict_jac('TA', Z, S)                 # the same in one pass
+        assert np.array_equal(m3, mt) and np.array_equal(c3, ct) and np.array_equal(J3, J)
     h.close()
 
 

@@ -68,6 +68,13 @@ for it in range(50):
 dt = time.perf_counter() - t0
 prof = h.profile_read()
 print(json.dumps({'bench': 'C5 phases', 'phases_ms_per_call': {k: v[0] / 50 for k, v in prof.items() if v[1]}}))
-print(json.dumps({'bench': 'C5 IPOPT-pattern (Nt=30, value+J+TA cov per call)', 'calls': 50, 'ms_per_call': dt / 50 * 1e3,
-                  'node_evals_per_s': 50 * 30 / dt}))
+print(json.dumps({'bench': 'C5 IPOPT-pattern (Nt=30, value+J+TA cov per call; predict + mean_jac)', 'calls': 50,
+                  'ms_per_call': dt / 50 * 1e3, 'node_evals_per_s': 50 * 30 / dt}))
+h.predict_jac('TA', Z, Sg)
+t0 = time.perf_counter()
+for it in range(50):
+    m, c, J = h.predict_jac('TA', Z, Sg)
+dt = time.perf_counter() - t0
+print(json.dumps({'bench': 'C5 IPOPT-pattern (Nt=30, value+J+TA cov per call; one pass, gpmpc_predict_jac)', 'calls': 50,
+                  'ms_per_call': dt / 50 * 1e3, 'node_evals_per_s': 50 * 30 / dt}))
 h.close()
