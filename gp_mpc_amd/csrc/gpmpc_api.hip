@@ -1128,20 +1128,23 @@ static int predict_chunk(gpmpc_gp* h, int B, const double* dZ, double* dMean, do
         else if (B <= 4) hipLaunchKernelGGL((var_small_kernel<4>), grid, dim3(256), 0, cx.stream, h->ws.Inv, h->KsT, h->part, Np, Bp);
         else hipLaunchKernelGGL((var_small_kernel<8>), grid, dim3(256), 0, cx.stream, h->ws.Inv, h->KsT, h->part, Np, Bp);
     } else if (dVar && B <= 64) {
-        // medium batch (an MPC's Nt shooting nodes): tall-skinny tiles, 128 rows x all columns per workgroup,
-        // so that L^-1 is streamed once and the small Ks panel is shared by 8 waves through LDS; every
-        // workgroup takes a row tile and its mirror (balanced triangle).  Measured at N=8192, Ny=6, B=30:
-        // 0.54 ms vs 0.69 ms for square 32-tiles and 0.66 ms for a no-LDS direct-fragment streaming kernel
-        // (which re-reads the Ks panel from L2 once per row tile).
+        // medium batch (an MPC's Nt shooting nodes): tall-skinny tiles, a row tile x all columns per workgroup,
+        // so that L^-1 is streamed once and the small Ks panel is shared through LDS; every workgroup takes a
+        // row tile and its mirror (balanced triangle).  (A no-LDS direct-fragment streaming kernel, which
+        // re-reads the Ks panel from L2 once per row tile, was slower: 0.66 ms at N=8192, Ny=6, B=30.)
         PhaseTimer t(h, GPMPC_PH_VARGEMM);
         GemmP p = gemm_base(cx);
         p.A = h->ws.Inv; p.lda = Np; p.sA = (long)Np * Np; p.a_mc = 0; p.kflags = KA_LE_M;
         p.B = h->KsT; p.ldb = Np; p.sB = (long)Bp * Np; p.b_nc = 0;
         p.M = Np; p.N = Bp; p.K = Np;
         p.epi = EPI_COLSUMSQ; p.part = h->part; p.ldpart = Bp;
-        tilesM = (Np + 127) / 128;
+        // up to 32 columns: 32-row tiles (2 waves) -- thousands of small workgroups hide the HBM latency of the
+        // L^-1 stream better than 128-row tiles (measured at N = 8192, Ny = 6, B = 30: 0.46 against 0.52 ms;
+        // 64 rows 0.53, 16 rows 0.56, 32 rows with BK = 64 0.60)
+        const int tm_rows = Bp <= 32 ? 32 : 128;
+        tilesM = (Np + tm_rows - 1) / tm_rows;
         p.sPart = (long)tilesM * Bp;
-        if (Bp <= 32) launch_gemm_cfg<128, 32, 32, 8, 1>(p, Ny, cx.stream, 1 << 30, 2);
+        if (Bp <= 32) launch_gemm_cfg<32, 32, 32, 2, 1>(p, Ny, cx.stream, 1 << 30, 2);
         else launch_gemm_cfg<128, 64, 16, 4, 2>(p, Ny, cx.stream, 1 << 30, 2);
     } else if (dVar) {
         PhaseTimer t(h, GPMPC_PH_VARGEMM);
