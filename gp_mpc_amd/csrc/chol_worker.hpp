@@ -106,12 +106,12 @@ __global__ void __launch_bounds__(WORKER_THREADS) chol_worker_kernel(double* Kma
     if (tid == 0) flag_store(progress + 256, (int)((wall_clock64() / 100) & 0x3fffffff));   // start time, us
 #endif
     const int ntiles = (nb - 1) * nb / 2 - 1;    // resident tiles: (i, j), 1 <= j <= i, without (1,1)
-    // per-thread BYTE offsets inside a 64 x 64 tile of an [ld]-strided matrix: csub[r] = the thread's
-    // r-th accumulator element (sub-tile row crow(lane, r), column lane & 15), toff = its first copy element
-    unsigned csub[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-        csub[r] = 8u * (unsigned)((16 * wr + crow(lane, r, crow_mode)) * (int)ld + 32 * wc + (lane & 15));
+    // per-thread BYTE offsets inside a 64 x 64 tile of an [ld]-strided matrix: csub = the thread's first
+    // accumulator element (sub-tile row crow(lane, 0), column lane & 15), toff = its first copy element
+    // (crow(lane, r) is linear in r with a uniform step -- 4 rows in the gfx950 f64 map -- so element r sits
+    //  r * cstep rows below element 0: one offset register, the step goes into the uniform base pointer)
+    const long cstep = (long)(crow(0, 1, crow_mode) - crow(0, 0, crow_mode)) * ld;
+    const unsigned csub = 8u * (unsigned)((16 * wr + crow(lane, 0, crow_mode)) * (int)ld + 32 * wc + (lane & 15));
     const unsigned toff = 8u * (unsigned)((tid >> 6) * (int)ld + (tid & 63));
 
     // my tiles: (ti[n], tj[n]) in LDS (workgroup-uniform; ti < 0 = none / finished), the tiles themselves in
@@ -140,8 +140,8 @@ __global__ void __launch_bounds__(WORKER_THREADS) chol_worker_kernel(double* Kma
             const double* src = Kb + (long)(64 * i) * ld + 64 * j;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                C[n][0][r] = at_byte(src, csub[r]);
-                C[n][1][r] = at_byte(src, csub[r] + 128u);
+                C[n][0][r] = at_byte(src + r * cstep, csub);
+                C[n][1][r] = at_byte(src + r * cstep, csub + 128u);
             }
         }
     }
@@ -164,8 +164,8 @@ __global__ void __launch_bounds__(WORKER_THREADS) chol_worker_kernel(double* Kma
             double* dst = Lb + (long)(64 * i) * ld;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                at_byte(dst, csub[r]) = acc[0][r];
-                at_byte(dst, csub[r] + 128u) = acc[1][r];
+                at_byte(dst + r * cstep, csub) = acc[0][r];
+                at_byte(dst + r * cstep, csub + 128u) = acc[1][r];
             }
             GPMPC_DRAIN_VM();
             __syncthreads();
@@ -195,8 +195,8 @@ __global__ void __launch_bounds__(WORKER_THREADS) chol_worker_kernel(double* Kma
             double* dst = Lb + (long)(64 * i) * ld + 64 * k;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                at_byte(dst, csub[r]) = acc[0][r];
-                at_byte(dst, csub[r] + 128u) = acc[1][r];
+                at_byte(dst + r * cstep, csub) = acc[0][r];
+                at_byte(dst + r * cstep, csub + 128u) = acc[1][r];
             }
             GPMPC_DRAIN_VM();
             __syncthreads();                           // (also: everybody is done with A and B)
@@ -229,8 +229,8 @@ __global__ void __launch_bounds__(WORKER_THREADS) chol_worker_kernel(double* Kma
             lds_mm_tile(A, 16 * wr, B, 32 * wc, lane, C[n], -1.0);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                at_byte(dst, csub[r]) = C[n][0][r];
-                at_byte(dst, csub[r] + 128u) = C[n][1][r];
+                at_byte(dst + r * cstep, csub) = C[n][0][r];
+                at_byte(dst + r * cstep, csub + 128u) = C[n][1][r];
             }
             wg_publish(&tdone[2 * k + (j == k + 2 ? 1 : 0)], 1);
             if (tid == 0) ti[n] = -1;
@@ -275,8 +275,8 @@ __global__ void __launch_bounds__(WORKER_THREADS) chol_worker_kernel(double* Kma
             double* dst = Kb + (long)(64 * i) * ld + 64 * j;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                at_byte(dst, csub[r]) = C[n][0][r];
-                at_byte(dst, csub[r] + 128u) = C[n][1][r];
+                at_byte(dst + r * cstep, csub) = C[n][0][r];
+                at_byte(dst + r * cstep, csub + 128u) = C[n][1][r];
             }
         }
     }
