@@ -146,7 +146,7 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': 'C2: single-output SE-ARD GP, K build + Cholesky + 10k mean+var predictions per step',
                        'N': N, 'd': d, 'Ny': 1, 'B': B, 'parallelism': f'independent GP per GPU x{world}'},
-            'roofline': {'kernel': 'gemm_f64_kernel<128,128> (variance GEMM + column sum of squares)',
+            'roofline': {'kernel': 'gemm_f64_dma_kernel<2,4,2,4> 128x128 tile (variance GEMM + column sum of squares)',
                          'bound': 'mfma', 'achieved': achieved, 'peak': FP64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': achieved / FP64_MFMA_PEAK_TFLOPS, 'traffic': traffic,
                          'avg_launch_ms': gemm_ms / max(gemm_n, 1), 'launches': gemm_n,

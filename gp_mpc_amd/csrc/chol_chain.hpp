@@ -33,13 +33,6 @@ __host__ __device__ inline int chain_colready_index(int nb, int k) { return 1 + 
 __host__ __device__ inline int chain_pan1_index(int nb, int k) { return 1 + nb + k; }
 __host__ __device__ inline int chain_ready_index(int nb) { return 1 + 7 * nb + 512; }   // counter; the flag is the next word
 
-#ifdef GPMPC_EMULATED
-#define GPMPC_DYN_SMEM() ((double*)::emu::dyn_smem())
-#else
-extern __shared__ __attribute__((aligned(16))) double gpmpc_dyn_smem[];
-#define GPMPC_DYN_SMEM() (gpmpc_dyn_smem)
-#endif
-
 // Gate for the side queue: one tiny workgroup per matrix that returns once the chain kernel has
 // published its first leaf, i.e. once every chain workgroup is resident.  Without it a batch of bulk
 // workgroups could fill the LDS of all CUs while polling and keep the chain from ever being placed.

@@ -409,19 +409,4 @@ inline void launch_gemm_cfg(GemmP p, int batch, hipStream_t stream, int resident
         hipLaunchKernelGGL((gemm_f64_kernel<BM, BN, BK, WGM, WGN, true, true>), grid, block, 0, stream, p);
 }
 
-// Returns the tile edge used (the caller of EPI_COLSUMSQ sizes `part` with it).
-inline int launch_gemm(const GemmP& p, int batch, hipStream_t stream, int force_tile = 0) {
-    const int tile = force_tile ? force_tile : gemm_pick_tile(p, batch);
-    if (tile == 128) {
-        launch_gemm_cfg<128, 128, 16, 2, 4>(p, batch, stream, 512);
-    } else if (tile == 64) {
-        launch_gemm_cfg<64, 64, 16, 2, 2>(p, batch, stream, 1024);
-    } else if (p.K % 32 == 0) {
-        launch_gemm_cfg<32, 32, 32, 2, 2>(p, batch, stream, 1024);
-    } else {
-        launch_gemm_cfg<32, 32, 16, 2, 2>(p, batch, stream, 1024);
-    }
-    return tile;
-}
-
 }  // namespace gpmpc

@@ -15,7 +15,7 @@
 #include "chol_chain.hpp"
 #include "chol_worker.hpp"
 #include "em_kernels.hpp"
-#include "gemm_f64.hpp"
+#include "gemm_f64_dma.hpp"
 #include "gp_kernels.hpp"
 #include "leaf64.hpp"
 
@@ -1533,7 +1533,8 @@ extern "C" int gpmpc_dgemm(int device, int transa, int transb, int M, int N, int
     p.B = dB; p.ldb = colsB; p.b_nc = transb ? 0 : 1;
     p.C = dC; p.ldc = N;
     p.M = M; p.N = N; p.K = Kp; p.alpha = alpha; p.beta = beta;
-    launch_gemm(p, 1, cx.stream);
+    // GPMPC_DGEMM_TILE=128|64|32 pins the tile (tests reach the large-tile kernels with small matrices)
+    launch_gemm(p, 1, cx.stream, getenv("GPMPC_DGEMM_TILE") ? atoi(getenv("GPMPC_DGEMM_TILE")) : 0);
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(c.data(), dC, c.size() * sizeof(double), hipMemcpyDeviceToHost));

@@ -11,6 +11,14 @@
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
+// the one dynamic LDS array of the library (chain / worker kernels, DMA-staged GEMM)
+#ifdef GPMPC_EMULATED
+#define GPMPC_DYN_SMEM() ((double*)::emu::dyn_smem())
+#else
+extern __shared__ __attribute__((aligned(16))) double gpmpc_dyn_smem[];
+#define GPMPC_DYN_SMEM() (gpmpc_dyn_smem)
+#endif
+
 namespace gpmpc {
 
 __device__ __forceinline__ d4 mfma16(double a, double b, d4 c) {

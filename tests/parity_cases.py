@@ -44,6 +44,24 @@ def check_dgemm(lib, sizes=((70, 33, 50), (128, 128, 64), (200, 130, 96)), seed=
                 assert np.abs(C - ref).max() <= 1e-12 * K, (M, N, K, ta, tb)
 
 
+def check_dgemm_large_tile(lib, seed=5):
+    """128 x 128 tile kernels (DMA-staged for K-contiguous operands, register-staged otherwise) on ragged shapes."""
+    import os
+    rng = np.random.default_rng(seed)
+    os.environ['GPMPC_DGEMM_TILE'] = '128'
+    try:
+        for (M, N, K) in ((128, 128, 16), (200, 130, 96), (257, 300, 48), (90, 513, 160)):
+            for ta, tb in ((False, True), (False, False), (True, True)):
+                A = rng.standard_normal((K, M) if ta else (M, K))
+                B = rng.standard_normal((N, K) if tb else (K, N))
+                C0 = rng.standard_normal((M, N))
+                ref = 1.3 * (A.T if ta else A) @ (B.T if tb else B) + 0.4 * C0
+                C = lib.dgemm(A, B, C0, alpha=1.3, beta=0.4, transa=ta, transb=tb)
+                assert np.abs(C - ref).max() <= 1e-12 * K, (M, N, K, ta, tb)
+    finally:
+        del os.environ['GPMPC_DGEMM_TILE']
+
+
 def check_cholesky(lib, sizes=(64, 100, 192, 256), seed=1):
     rng = np.random.default_rng(seed)
     for n in sizes:

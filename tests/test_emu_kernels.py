@@ -27,6 +27,10 @@ def test_emu_dgemm(emu):
     pc.check_dgemm(emu)
 
 
+def test_emu_dgemm_large_tile(emu):
+    pc.check_dgemm_large_tile(emu)
+
+
 def test_emu_cholesky(emu):
     pc.check_cholesky(emu)
 

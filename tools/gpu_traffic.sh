@@ -10,6 +10,6 @@ con=sqlite3.connect("$R/gpurun_out/pmc_t/p_results.db")
 rows=con.execute("select kernel_name, grid_size_x, workgroup_size_x, value, dispatch_id from counters_collection where counter_name='FETCH_SIZE'").fetchall()
 acc={}
 for n,gx,wx,v,d in rows:
-    if 'gemm_f64_kernel<128' in n and gx//wx>2000: acc[d]=acc.get(d,0)+v
+    if 'gemm_f64_dma_kernel' in n and gx//wx>2000: acc[d]=acc.get(d,0)+v
 print('variance GEMM FETCH_SIZE per launch: %.3f GB raw (x2 corrected %.3f GB), launches %d' % (sum(acc.values())/len(acc)/1e6*1.024, 2*sum(acc.values())/len(acc)/1e6*1.024, len(acc)))
 PY
