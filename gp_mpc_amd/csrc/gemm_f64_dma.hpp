@@ -26,8 +26,6 @@
 
 namespace gpmpc {
 
-constexpr int DMA_SLAB_BYTES = 2 * 128 * 128;   // one K slab of both operands
-
 #ifdef GPMPC_EMULATED
 struct dma_rsrc_t { const char* base; unsigned bytes; };
 inline dma_rsrc_t dma_make_rsrc(const void* base, unsigned bytes) { return dma_rsrc_t{(const char*)base, bytes}; }
@@ -72,14 +70,19 @@ __device__ __forceinline__ void dma_barrier() {
 #endif
 
 // WPS: waves per SIMD the register allocation must allow (workgroups per CU x waves per workgroup / 4)
-template <int WGM, int WGN, int STAGES, int WPS>
+// AMC / BNC: operand stored with M (resp. N) contiguous instead of K, as in GemmP::a_mc / b_nc
+template <int BM, int BN, int WGM, int WGN, int STAGES, int WPS, bool AMC, bool BNC>
 __global__ void __launch_bounds__(64 * WGM * WGN, WPS) gemm_f64_dma_kernel(GemmP p) {
-    constexpr int BM = 128, BN = 128, BK = 16;
+    constexpr int BK = 16;
     constexpr int NW = WGM * WGN;
     constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 16, TN = WN / 16;
-    constexpr int LPW = 32 / NW;                       // wave loads (1 KB each) per wave per slab
-    static_assert(32 % NW == 0 && STAGES >= 2 && STAGES <= 5, "bad configuration");
+    constexpr int LA = BM / 8, LB = BN / 8;            // wave loads (1 KB each) per slab image
+    constexpr int LPW = (LA + LB) / NW;                // ... per wave
+    constexpr int IMG_A = BM * 128, SLAB = (BM + BN) * 128;
+    constexpr int RBA = BM * 8, RBB = BN * 8;          // M/N-contiguous images: bytes per K row
+    static_assert((LA + LB) % NW == 0 && STAGES >= 2 && STAGES <= 5, "bad configuration");
     char* smem = (char*)GPMPC_DYN_SMEM();
+    int* slot = reinterpret_cast<int*>(smem + STAGES * SLAB);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -87,18 +90,43 @@ __global__ void __launch_bounds__(64 * WGM * WGN, WPS) gemm_f64_dma_kernel(GemmP
     const int tilesM = (p.M + BM - 1) / BM, tilesN = (p.N + BN - 1) / BN;
     const int tme = (int)blockIdx.x / p.npad, tne = (int)blockIdx.x % p.npad;
     if (tme >= p.tilesMe || tne >= p.tilesNe) return;
+    if (p.wait_flag) {
+        if (!wg_wait2(p.wait_flag + (long)blockIdx.z * p.sFlags, 1, nullptr, 0, p.err + (long)blockIdx.z * p.sFlags,
+                      p.spin_limit, slot))
+            return;
+    }
 
     const int z1 = p.zdiv > 0 ? (int)blockIdx.z % p.zdiv : (int)blockIdx.z;
     const int z2 = p.zdiv > 0 ? (int)blockIdx.z / p.zdiv : 0;
     const double* __restrict__ A = p.A + (long)z1 * p.sA + (long)z2 * p.sA2;
     const double* __restrict__ B = p.B + (long)z1 * p.sB + (long)z2 * p.sB2;
-    const dma_rsrc_t rsA = dma_make_rsrc(A, (unsigned)((long)p.M * p.lda * 8));
-    const dma_rsrc_t rsB = dma_make_rsrc(B, (unsigned)((long)p.N * p.ldb * 8));
+    const dma_rsrc_t rsA = dma_make_rsrc(A, (unsigned)((long)(AMC ? p.K : p.M) * p.lda * 8));
+    const dma_rsrc_t rsB = dma_make_rsrc(B, (unsigned)((long)(BNC ? p.K : p.N) * p.ldb * 8));
     const int fr = lane & 15, fq = lane >> 4;
-    // fragment read offsets inside a slab image: pieces q and 4 + q of the lane's row
+    // Fragment read offsets inside a slab image.  The four matrix instructions of a slab half h use, in lane group q,
+    // K index 8h + 2q + e (e = 0, 1) of BOTH operands.
+    //   K-contiguous image: 16-byte piece c of row r at r*128 + ((c ^ ((r>>1)&7)) << 4); one ds_read_b128 fetches
+    //     (e = 0, e = 1); tile i is 2048 bytes further; h flips bit 6 of the offset.
+    //   M/N-contiguous image: K row k at k*RB, element m at ((m ^ (16 * ((k>>1)&1))) * 8: K rows 2q of the four
+    //     lane groups alternate between the two 128-byte bank halves; one ds_read_b64 per (h, e) at +(8h+e)*RB.
     const unsigned sw = (unsigned)((fr >> 1) & 7);
-    const unsigned fa0 = (unsigned)((wm * WM + fr) * 128) + (((unsigned)fq ^ sw) << 4), fa1 = fa0 ^ 64u;
-    const unsigned fb0 = (unsigned)(16384 + (wn * WN + fr) * 128) + (((unsigned)fq ^ sw) << 4), fb1 = fb0 ^ 64u;
+    unsigned fa[AMC ? TM : 2], fb[BNC ? TN : 2];
+    if (AMC) {
+#pragma unroll
+        for (int i = 0; i < (AMC ? TM : 0); ++i)
+            fa[i] = (unsigned)(2 * fq * RBA + (((wm * WM + 16 * i + fr) ^ (16 * (fq & 1))) << 3));
+    } else {
+        fa[0] = (unsigned)((wm * WM + fr) * 128) + (((unsigned)fq ^ sw) << 4);
+        fa[1] = fa[0] ^ 64u;
+    }
+    if (BNC) {
+#pragma unroll
+        for (int j = 0; j < (BNC ? TN : 0); ++j)
+            fb[j] = (unsigned)(IMG_A + 2 * fq * RBB + (((wn * WN + 16 * j + fr) ^ (16 * (fq & 1))) << 3));
+    } else {
+        fb[0] = (unsigned)(IMG_A + (wn * WN + fr) * 128) + (((unsigned)fq ^ sw) << 4);
+        fb[1] = fb[0] ^ 64u;
+    }
 
     for (int pass = 0; pass < 2; ++pass) {
         int tm = (p.kflags & KA_LE_M) ? tilesM - 1 - tme : tme;     // heavy tiles first
@@ -116,6 +144,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN, WPS) gemm_f64_dma_kernel(GemmP
         }
         const int m0 = tm * BM, n0 = tn * BN;
         if (p.lower && n0 > m0 + BM - 1) continue;
+        if (p.skip00 && tm == 0 && tn == 0) continue;
 
         int klo = 0, khi = p.K;
         if (p.kflags & KA_LE_M) khi = min(khi, m0 + BM);
@@ -126,24 +155,38 @@ __global__ void __launch_bounds__(64 * WGM * WGN, WPS) gemm_f64_dma_kernel(GemmP
         khi = min(p.K, (khi + BK - 1) / BK * BK);
         const int nk = khi > klo ? (khi - klo) / BK : 0;
 
-        // this lane's source offsets for its LPW pieces of a slab; rows beyond the operand are clamped (their
-        // products land in rows / columns that are never stored, the column sums mask them)
+        // This lane's source offsets for its LPW pieces of a slab (the slab's K offset rides in the scalar offset).
+        // Rows (K-contiguous) or columns (M/N-contiguous) beyond the operand are clamped: what they fetch only
+        // reaches rows / columns of the product that are never stored (the column sums mask them).
         unsigned vo[LPW];
 #pragma unroll
         for (int i = 0; i < LPW; ++i) {
-            const int j = wave + NW * i;                           // 0..15: A rows 8j.., 16..31: B rows 8(j-16)..
-            const int row = 8 * (j & 15) + (lane >> 3);
-            const unsigned piece = (unsigned)(lane & 7) ^ (unsigned)((row >> 1) & 7);
-            const long grow = (j < 16) ? (long)min(m0 + row, p.M - 1) * p.lda : (long)min(n0 + row, p.N - 1) * p.ldb;
-            vo[i] = (unsigned)(grow * 8) + (piece << 4);
+            const int j = wave + NW * i;                           // [0, LA): piece j of the A image, else of the B image
+            const bool isA = j < LA;
+            const int jj = isA ? j : j - LA;
+            if (isA ? AMC : BNC) {
+                const int rb = isA ? RBA : RBB;
+                const int byte = 1024 * jj + 16 * lane, k = byte / rb, pos = (byte % rb) >> 4;
+                const int piece = pos ^ (8 * ((k >> 1) & 1));
+                const long ldx = isA ? p.lda : p.ldb;
+                const long col = min((long)(isA ? m0 : n0) + 2 * piece, ldx - 2);     // stay inside the K row
+                vo[i] = (unsigned)(((long)k * ldx + col) * 8);
+            } else {
+                const int row = 8 * jj + (lane >> 3);
+                const unsigned piece = (unsigned)(lane & 7) ^ (unsigned)((row >> 1) & 7);
+                const long grow = isA ? (long)min(m0 + row, p.M - 1) * p.lda : (long)min(n0 + row, p.N - 1) * p.ldb;
+                vo[i] = (unsigned)(grow * 8) + (piece << 4);
+            }
         }
+        const unsigned kstepA = AMC ? (unsigned)(p.lda * 8) : 8u, kstepB = BNC ? (unsigned)(p.ldb * 8) : 8u;
         auto request = [&](int t) {                               // slab t of this tile -> ring image t % STAGES
-            char* img = smem + (t % STAGES) * DMA_SLAB_BYTES;
-            const unsigned so = (unsigned)(klo + t * BK) * 8u;
+            char* img = smem + (t % STAGES) * SLAB;
+            const unsigned k0 = (unsigned)(klo + t * BK);
 #pragma unroll
             for (int i = 0; i < LPW; ++i) {
                 const int j = wave + NW * i;
-                dma_load16(j < 16 ? rsA : rsB, img + 1024 * j, vo[i], so);
+                if (j < LA) dma_load16(rsA, img + 1024 * j, vo[i], k0 * kstepA);
+                else dma_load16(rsB, img + 1024 * j, vo[i], k0 * kstepB);
             }
         };
 
@@ -154,14 +197,28 @@ __global__ void __launch_bounds__(64 * WGM * WGN, WPS) gemm_f64_dma_kernel(GemmP
             for (int j = 0; j < TN; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
 
         auto multiply = [&](int t) {
-            const char* img = smem + (t % STAGES) * DMA_SLAB_BYTES;
+            const char* img = smem + (t % STAGES) * SLAB;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 double2 a[TM], b[TN];
 #pragma unroll
-                for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const double2*>(img + (h ? fa1 : fa0) + i * 2048);
+                for (int i = 0; i < TM; ++i) {
+                    if (AMC) {
+                        a[i].x = *reinterpret_cast<const double*>(img + fa[AMC ? i : 0] + (8 * h) * RBA);
+                        a[i].y = *reinterpret_cast<const double*>(img + fa[AMC ? i : 0] + (8 * h + 1) * RBA);
+                    } else {
+                        a[i] = *reinterpret_cast<const double2*>(img + fa[AMC ? 0 : h] + i * 2048);
+                    }
+                }
 #pragma unroll
-                for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const double2*>(img + (h ? fb1 : fb0) + j * 2048);
+                for (int j = 0; j < TN; ++j) {
+                    if (BNC) {
+                        b[j].x = *reinterpret_cast<const double*>(img + fb[BNC ? j : 0] + (8 * h) * RBB);
+                        b[j].y = *reinterpret_cast<const double*>(img + fb[BNC ? j : 0] + (8 * h + 1) * RBB);
+                    } else {
+                        b[j] = *reinterpret_cast<const double2*>(img + fb[BNC ? 0 : h] + j * 2048);
+                    }
+                }
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -234,21 +291,34 @@ __global__ void __launch_bounds__(64 * WGM * WGN, WPS) gemm_f64_dma_kernel(GemmP
                 p.part[(long)blockIdx.z * p.sPart + (long)tm * p.ldpart + n0 + tid] = t;
             }
         }
+        if (p.done_flags && tm == 1 && tn <= 1) wg_publish(p.done_flags + (long)blockIdx.z * p.sFlags + tn, 1);
         __syncthreads();  // LDS (red) is reused by the next pass
     }
 }
 
 // true if gemm_f64_dma_kernel can run this product
 inline bool gemm_dma_supported(const GemmP& p) {
-    return !p.a_mc && !p.b_nc && !p.wait_flag && !p.skip00 && !p.done_flags && !p.remap && p.K % 16 == 0 &&
-           p.lda % 2 == 0 && p.ldb % 2 == 0 && ((unsigned long)p.A & 15) == 0 && ((unsigned long)p.B & 15) == 0 &&
-           (p.sA % 2 == 0) && (p.sB % 2 == 0) && (p.sA2 % 2 == 0) && (p.sB2 % 2 == 0) &&
-           (long)p.M * p.lda * 8 < (1L << 32) && (long)p.N * p.ldb * 8 < (1L << 32);
+    const long rowsA = p.a_mc ? p.K : p.M, rowsB = p.b_nc ? p.K : p.N;
+    return !p.remap && p.K % 16 == 0 && p.lda % 2 == 0 && p.ldb % 2 == 0 && ((unsigned long)p.A & 15) == 0 &&
+           ((unsigned long)p.B & 15) == 0 && (p.sA % 2 == 0) && (p.sB % 2 == 0) && (p.sA2 % 2 == 0) && (p.sB2 % 2 == 0) &&
+           rowsA * p.lda * 8 < (1L << 32) && rowsB * p.ldb * 8 < (1L << 32);
 }
 
-template <int WGM, int WGN, int STAGES, int WPS>
+template <int BM, int BN, int WGM, int WGN, int STAGES, int WPS, bool AMC, bool BNC>
+inline void launch_gemm_dma_kernel(const GemmP& p, dim3 grid, hipStream_t stream) {
+    constexpr int lds = STAGES * (BM + BN) * 128 + 16;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_dma_kernel<BM, BN, WGM, WGN, STAGES, WPS, AMC, BNC>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_f64_dma_kernel<BM, BN, WGM, WGN, STAGES, WPS, AMC, BNC>), grid, dim3(64 * WGM * WGN), lds,
+                       stream, p);
+}
+
+template <int BM, int BN, int WGM, int WGN, int STAGES, int WPS>
 inline void launch_gemm_dma(GemmP p, int batch, hipStream_t stream, int resident, int min_pair_blocks = 512) {
-    constexpr int BM = 128, BN = 128;
     const int tilesM = (p.M + BM - 1) / BM, tilesN = (p.N + BN - 1) / BN;
     p.pair = PAIR_NONE;
     p.tilesMe = tilesM;
@@ -265,24 +335,24 @@ inline void launch_gemm_dma(GemmP p, int batch, hipStream_t stream, int resident
         }
     }
     p.npad = p.tilesNe;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_dma_kernel<WGM, WGN, STAGES, WPS>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, STAGES * DMA_SLAB_BYTES);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((gemm_f64_dma_kernel<WGM, WGN, STAGES, WPS>), dim3(p.tilesMe * p.npad, 1, batch), dim3(64 * WGM * WGN),
-                       STAGES * DMA_SLAB_BYTES, stream, p);
+    const dim3 grid(p.tilesMe * p.npad, 1, batch);
+    if (!p.a_mc && !p.b_nc) launch_gemm_dma_kernel<BM, BN, WGM, WGN, STAGES, WPS, false, false>(p, grid, stream);
+    else if (!p.a_mc && p.b_nc) launch_gemm_dma_kernel<BM, BN, WGM, WGN, STAGES, WPS, false, true>(p, grid, stream);
+    else if (p.a_mc && !p.b_nc) launch_gemm_dma_kernel<BM, BN, WGM, WGN, STAGES, WPS, true, false>(p, grid, stream);
+    else launch_gemm_dma_kernel<BM, BN, WGM, WGN, STAGES, WPS, true, true>(p, grid, stream);
 }
 
 // Returns the tile edge used (the caller of EPI_COLSUMSQ sizes `part` with it).
 inline int launch_gemm(const GemmP& p, int batch, hipStream_t stream, int force_tile = 0) {
     const int tile = force_tile ? force_tile : gemm_pick_tile(p, batch);
-    static const bool use_dma = !(getenv("GPMPC_GEMM_DMA") && atoi(getenv("GPMPC_GEMM_DMA")) == 0);
-    if (tile == 128 && use_dma && gemm_dma_supported(p)) {
-        launch_gemm_dma<2, 4, 2, 4>(p, batch, stream, 512);
+    // GPMPC_GEMM_DMA: bit 0 the 128 x 128 tile, bit 1 the 64 x 64 tile through the DMA-staged kernel (default both)
+    static const int use_dma = getenv("GPMPC_GEMM_DMA") ? atoi(getenv("GPMPC_GEMM_DMA")) : 3;
+    if (tile == 128 && (use_dma & 1) && gemm_dma_supported(p)) {
+        launch_gemm_dma<128, 128, 2, 4, 2, 4>(p, batch, stream, 512);
     } else if (tile == 128) {
         launch_gemm_cfg<128, 128, 16, 2, 4>(p, batch, stream, 512);
+    } else if (tile == 64 && (use_dma & 2) && gemm_dma_supported(p)) {
+        launch_gemm_dma<64, 64, 2, 2, 2, 4>(p, batch, stream, 1024);
     } else if (tile == 64) {
         launch_gemm_cfg<64, 64, 16, 2, 2>(p, batch, stream, 1024);
     } else if (p.K % 32 == 0) {

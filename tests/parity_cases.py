@@ -45,19 +45,21 @@ def check_dgemm(lib, sizes=((70, 33, 50), (128, 128, 64), (200, 130, 96)), seed=
 
 
 def check_dgemm_large_tile(lib, seed=5):
-    """128 x 128 tile kernels (DMA-staged for K-contiguous operands, register-staged otherwise) on ragged shapes."""
+    """The 128 x 128 and 64 x 64 tile kernels (DMA-staged operand tiles) in all four operand orientations on
+    ragged shapes; GPMPC_DGEMM_TILE pins the tile so that small matrices reach them."""
     import os
     rng = np.random.default_rng(seed)
-    os.environ['GPMPC_DGEMM_TILE'] = '128'
     try:
-        for (M, N, K) in ((128, 128, 16), (200, 130, 96), (257, 300, 48), (90, 513, 160)):
-            for ta, tb in ((False, True), (False, False), (True, True)):
-                A = rng.standard_normal((K, M) if ta else (M, K))
-                B = rng.standard_normal((N, K) if tb else (K, N))
-                C0 = rng.standard_normal((M, N))
-                ref = 1.3 * (A.T if ta else A) @ (B.T if tb else B) + 0.4 * C0
-                C = lib.dgemm(A, B, C0, alpha=1.3, beta=0.4, transa=ta, transb=tb)
-                assert np.abs(C - ref).max() <= 1e-12 * K, (M, N, K, ta, tb)
+        for tile in ('128', '64'):
+            os.environ['GPMPC_DGEMM_TILE'] = tile
+            for (M, N, K) in ((128, 128, 16), (200, 130, 96), (257, 300, 48), (90, 513, 160)):
+                for ta, tb in ((False, True), (False, False), (True, True), (True, False)):
+                    A = rng.standard_normal((K, M) if ta else (M, K))
+                    B = rng.standard_normal((N, K) if tb else (K, N))
+                    C0 = rng.standard_normal((M, N))
+                    ref = 1.3 * (A.T if ta else A) @ (B.T if tb else B) + 0.4 * C0
+                    C = lib.dgemm(A, B, C0, alpha=1.3, beta=0.4, transa=ta, transb=tb)
+                    assert np.abs(C - ref).max() <= 1e-12 * K, (tile, M, N, K, ta, tb)
     finally:
         del os.environ['GPMPC_DGEMM_TILE']
 
