@@ -9,11 +9,16 @@
 //   * K^-1 = invL^T invL                                                         (a6, optimize.py:490)
 //   * predictive variance  sum_i (invL Ks)_ij^2                                  (a9, gp_functions.py:122-126)
 //
-// Design for MI355X (measurements: tools/ubench/mfma_f64_bench.hip, profiles/):
-//   * v_mfma_f64_16x16x4_f64 holds a SIMD's matrix pipe for 64 cycles, but ONE wave can only issue
-//     one every ~142 cycles and two waves one every ~104: the pipe saturates only with >= 4 waves per
-//     SIMD.  So the large tile (128 x 128) is worked by 8 waves (512 threads, <= 128 VGPRs: two
-//     workgroups = 16 waves per CU), the small tiles by 4 waves with 4-5 workgroups per CU.
+// This is the register-staged kernel; the DMA-staged kernel of gemm_f64_dma.hpp (same GemmP contract, operand
+// tiles loaded straight into LDS) has replaced it for the 128 x 128 and 64 x 64 tiles wherever its preconditions
+// hold (gemm_dma_supported), and launch_gemm lives there.  This one remains for the 32-row tiles, the skinny
+// variance products and as the fallback.
+//
+// Design for MI355X (measurements: tools/ubench/mfma_issue_bench.hip, profiles/):
+//   * v_mfma_f64_16x16x4_f64 holds a SIMD's matrix pipe for 64 cycles and one wave per SIMD can keep it busy
+//     with a clean instruction stream; every other instruction of the same wave costs pipe time, so the staging
+//     work is spread over many waves: the large tile (128 x 128) is worked by 8 waves (512 threads, <= 128
+//     VGPRs: two workgroups = 16 waves per CU), the small tiles by 4 waves with 4-5 workgroups per CU.
 //   * operand tiles go global -> registers -> LDS with a one-tile software pipeline (loads of tile t+1
 //     in flight while tile t feeds the matrix pipe, one barrier per K step).  LDS holds each operand in
 //     MFMA-fragment order [k/4][row][k%4]: the 64 lanes of a fragment read fetch 64 consecutive

@@ -41,7 +41,7 @@ int main(int argc, char** argv) {
         hipMemcpy(r0.data(), part, r0.size() * 8, hipMemcpyDeviceToHost);
         v.part = part2;
 #define VAR(WM, WN, S, WPS) { hipMemset(part2, 0, r1.size() * 8); \
-        float t = timeit([&] { launch_gemm_dma<WM, WN, S, WPS>(v, 1, 0, 0); }); \
+        float t = timeit([&] { launch_gemm_dma<128, 128, WM, WN, S, WPS>(v, 1, 0, 0); }); \
         hipMemcpy(r1.data(), part2, r1.size() * 8, hipMemcpyDeviceToHost); \
         double e = 0, m = 0; for (size_t i = 0; i < r0.size(); ++i) { e = fmax(e, fabs(r0[i] - r1[i])); m = fmax(m, fabs(r0[i])); } \
         printf("%s dma %dx%d stages %d wps %d : %7.3f ms %6.2f TF   rel err %.2e\n", tri ? "tri  " : "dense", WM, WN, S, WPS, t, fl / t * 1e-9, e / m); }
