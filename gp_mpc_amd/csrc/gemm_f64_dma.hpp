@@ -230,6 +230,10 @@ __global__ void __launch_bounds__(64 * WGM * WGN, WPS) gemm_f64_dma_kernel(GemmP
             }
         };
 
+        // Lower-triangular A: inside the diagonal block the slabs whose K offset lies beyond this wave's last row
+        // multiply exact zeros; the wave sits them out (it still requests its pieces and meets the barriers) and
+        // the matrix pipe time goes to the waves that have work.
+        const int kskip = (p.kflags & KA_LE_M) ? (m0 + (wm + 1) * WM - klo + BK - 1) / BK : (1 << 30);
         // prologue: STAGES - 1 slabs requested (requests past the end are skipped: the tail waits for everything)
 #pragma unroll
         for (int t = 0; t < STAGES - 1; ++t)
@@ -239,12 +243,12 @@ __global__ void __launch_bounds__(64 * WGM * WGN, WPS) gemm_f64_dma_kernel(GemmP
             dma_wait<LPW * (STAGES - 2)>();                       // slab kt has landed (this wave's pieces)
             dma_barrier();                                        // ... everybody's, and image (kt - 1) is free
             request(kt + STAGES - 1);
-            multiply(kt);
+            if (kt < kskip) multiply(kt);
         }
         for (; kt < nk; ++kt) {
             dma_wait<0>();
             dma_barrier();
-            multiply(kt);
+            if (kt < kskip) multiply(kt);
         }
         dma_barrier();                                            // all fragment reads done: LDS reusable
 

@@ -21,7 +21,7 @@ template <class F> float timeit(F f, int reps = 5) {
 int main(int argc, char** argv) {
     const int N = argc > 1 ? atoi(argv[1]) : 4096, B = argc > 2 ? atoi(argv[2]) : 10112;
     std::vector<double> hA((size_t)N * N, 0.0), hB((size_t)B * N);
-    for (int i = 0; i < N; ++i) for (int j = 0; j < N; ++j) hA[(size_t)i * N + j] = ((i * 7 + j * 13) % 101 - 50) * 1e-3;
+    for (int i = 0; i < N; ++i) for (int j = 0; j <= i; ++j) hA[(size_t)i * N + j] = ((i * 7 + j * 13) % 101 - 50) * 1e-3;   // lower triangular
     for (size_t i = 0; i < hB.size(); ++i) hB[i] = ((i * 31) % 97 - 48) * 1e-2;
     double *A, *Bm, *part, *part2;
     const int tiles = (N + 127) / 128;
@@ -46,13 +46,10 @@ int main(int argc, char** argv) {
         double e = 0, m = 0; for (size_t i = 0; i < r0.size(); ++i) { e = fmax(e, fabs(r0[i] - r1[i])); m = fmax(m, fabs(r0[i])); } \
         printf("%s dma %dx%d stages %d wps %d : %7.3f ms %6.2f TF   rel err %.2e\n", tri ? "tri  " : "dense", WM, WN, S, WPS, t, fl / t * 1e-9, e / m); }
         VAR(2, 4, 2, 4)
-        VAR(2, 4, 3, 2)
-        VAR(2, 4, 4, 2)
+        VAR(4, 2, 2, 4)
         VAR(2, 2, 2, 2)
-        VAR(2, 2, 3, 1)
-        VAR(2, 2, 4, 1)
-        VAR(4, 4, 3, 4)
-        VAR(4, 4, 4, 4)
+        VAR(4, 1, 2, 2)
+        VAR(8, 1, 2, 4)
     }
     return 0;
 }
