@@ -30,54 +30,36 @@
 // grid (NW, 1, batch), 512 threads, dynamic LDS WORKER_LDS_BYTES.
 #pragma once
 #include "chol_chain.hpp"
+#include "lds_dma.hpp"
 
 namespace gpmpc {
 
 constexpr int WORKER_MAXT = 9;
 constexpr int WORKER_THREADS = 512;
-constexpr int WORKER_EPT = 4096 / WORKER_THREADS;   // elements of a 64 x 64 block per thread
-constexpr int WORKER_LDS_BYTES = 90000;   // two 64 x 65 operand blocks (66.6 KB); > 80 KB keeps one worker per CU
+// LDS: two operand pairs of the trailing update (2 x 2 x 32 KB, DMA images); the two padded 64 x 65 blocks of the
+// panel / hand-off products alias the first of them; then the slot table.  > 80 KB also keeps one worker per CU.
+constexpr int WORKER_PAIR_BYTES = 2 * 64 * 64 * 8;
+constexpr int WORKER_LDS_BYTES = 2 * WORKER_PAIR_BYTES + 256;
 
-// acc[c] += sgn * A(16 rows at ar, 64 deep) * B(16 rows at br + 16 c, 64 deep)^T, c = 0, 1; operands in LDS
-__device__ __forceinline__ void lds_mm_tile(const double* A, int ar, const double* B, int br, int lane, d4* acc, double sgn) {
-    const int fr = lane & 15, fk = lane >> 4;
-#pragma unroll 4
-    for (int k0 = 0; k0 < 64; k0 += 4) {
-        const double a = sgn * A[(ar + fr) * LS + k0 + fk];
-        acc[0] = mfma16(a, B[(br + fr) * LS + k0 + fk], acc[0]);
-        acc[1] = mfma16(a, B[(br + 16 + fr) * LS + k0 + fk], acc[1]);
-    }
-}
-
-// a 64 x 64 block between global memory, WORKER_EPT registers per thread, and LDS.  Addresses are a
-// workgroup-uniform base plus ONE per-thread unsigned 32-bit BYTE offset (8 (row * ld + col) of the thread's
-// first element) so that the accesses can take the SGPR-base form and the addresses cost one register.
+// Global addresses are a workgroup-uniform base plus ONE per-thread unsigned 32-bit BYTE offset, so that the
+// accesses can take the SGPR-base form and the addresses cost one register.
 __device__ __forceinline__ const double& at_byte(const double* base, unsigned byte_off) {
     return *(const double*)((const char*)base + byte_off);
 }
 __device__ __forceinline__ double& at_byte(double* base, unsigned byte_off) { return *(double*)((char*)base + byte_off); }
 
-// (the thread's i-th element sits 8 i rows below its first: a uniform pointer step, one offset register)
-__device__ __forceinline__ void block_to_regs(double* r, const double* __restrict__ src, unsigned toff0, long ld) {
-#pragma unroll
-    for (int i = 0; i < WORKER_EPT; ++i) r[i] = at_byte(src + (long)(WORKER_THREADS / 64) * i * ld, toff0);
-}
-__device__ __forceinline__ void regs_to_lds(double* dst, const double* r, int tid) {
-#pragma unroll
-    for (int i = 0; i < WORKER_EPT; ++i) {
-        const int idx = tid + WORKER_THREADS * i, rr = idx >> 6, cc = idx & 63;
-        dst[rr * LS + cc] = r[i];
-    }
-}
-
 __global__ void __launch_bounds__(WORKER_THREADS) chol_worker_kernel(double* Kmat, double* L, const double* Inv, long ld,
                                                                      long sBatch, int nb_all, int* flags, long sFlags,
                                                                      int crow_mode, int spin_limit, int kb, int ksteps,
-                                                                     int* ready) {
+                                                                     int* ready, long long* trace) {
+    // optional time stamps (100 MHz wall clock) for tools/worker_trace.py: [launch][worker][step][4] from entry 4096 on
+#ifdef GPMPC_EMULATED
+#define WORKER_STAMP(i) ((void)0)
+#else
+#define WORKER_STAMP(i) do { if (trace && threadIdx.x == 0) trace[4096 + ((((kb ? 1L : 0L) * 256 + blockIdx.x) * 64 + (kb + k)) * 4) + (i)] = wall_clock64(); } while (0)
+#endif
     double* smem = GPMPC_DYN_SMEM();
-    double* A = smem;
-    double* B = A + 64 * LS;
-    int* slot = (int*)(B + 64 * LS);
+    int* slot = (int*)((char*)smem + 2 * WORKER_PAIR_BYTES);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;                 // this wave's 16 x 32 piece: rows 16 wr, columns 32 wc
     const int w = blockIdx.x, NW = gridDim.x;
@@ -106,13 +88,22 @@ __global__ void __launch_bounds__(WORKER_THREADS) chol_worker_kernel(double* Kma
     if (tid == 0) flag_store(progress + 256, (int)((wall_clock64() / 100) & 0x3fffffff));   // start time, us
 #endif
     const int ntiles = (nb - 1) * nb / 2 - 1;    // resident tiles: (i, j), 1 <= j <= i, without (1,1)
-    // per-thread BYTE offsets inside a 64 x 64 tile of an [ld]-strided matrix: csub = the thread's first
-    // accumulator element (sub-tile row crow(lane, 0), column lane & 15), toff = its first copy element
+    // per-thread BYTE offset inside a 64 x 64 tile of an [ld]-strided matrix: csub = the thread's first
+    // accumulator element (sub-tile row crow(lane, 0), column lane & 15)
     // (crow(lane, r) is linear in r with a uniform step -- 4 rows in the gfx950 f64 map -- so element r sits
     //  r * cstep rows below element 0: one offset register, the step goes into the uniform base pointer)
     const long cstep = (long)(crow(0, 1, crow_mode) - crow(0, 0, crow_mode)) * ld;
     const unsigned csub = 8u * (unsigned)((16 * wr + crow(lane, 0, crow_mode)) * (int)ld + 32 * wc + (lane & 15));
-    const unsigned toff = 8u * (unsigned)((tid >> 6) * (int)ld + (tid & 63));
+    // every product takes its operands by DMA (lds_dma.hpp): a 64 x 64 block becomes four 16-column slab images of
+    // [64 rows][128 B], 16-byte piece c of row r stored at position c ^ ((r >> 1) & 7) (the layout of
+    // gemm_f64_dma.hpp: one conflict-free ds_read_b128 per fragment and K pair).  Wave v < 4 loads rows 8v .. 8v+7 and
+    // 8v+32 .. 8v+39 of every slab: dvo = this lane's source byte offset inside the block, fa / fb = fragment read offsets.
+    const int swave = __builtin_amdgcn_readfirstlane(wave);
+    const int drow = 8 * (wave & 3) + (lane >> 3);
+    const unsigned dvo = 8u * (unsigned)(drow * (int)ld) + ((unsigned)((lane & 7) ^ ((drow >> 1) & 7)) << 4);
+    const unsigned fsw = (unsigned)(((lane & 15) >> 1) & 7), fq = (unsigned)(lane >> 4);
+    const unsigned fa0 = (unsigned)((16 * wr + (lane & 15)) * 128) + ((fq ^ fsw) << 4), fa1 = fa0 ^ 64u;
+    const unsigned fb0 = (unsigned)(32768 + (32 * wc + (lane & 15)) * 128) + ((fq ^ fsw) << 4), fb1 = fb0 ^ 64u;
 
     // my tiles: (ti[n], tj[n]) in LDS (workgroup-uniform; ti < 0 = none / finished), the tiles themselves in
     // registers C[n].  The slot index is a run-time value: the code that touches a tile is
@@ -148,19 +139,72 @@ __global__ void __launch_bounds__(WORKER_THREADS) chol_worker_kernel(double* Kma
 
     int k = 0;
     for (; k + 2 < nb && k < ksteps; ++k) {
+        WORKER_STAMP(0);
+        // operand pair of tile (i, j) for this step: blocks L(i,k) and L(j,k) -> pair image `pp` (0 / 1) by DMA,
+        // 8 loads per wave; `update`: c -= L(i,k) L(j,k)^T from a landed pair image
+        // Issued by ONE wave per SIMD (waves 0-3, two row groups each): the other four go straight on to their
+        // matrix instructions, so the ~150 scalar instructions of a request do not idle the matrix pipes.
+        auto request_blocks = [&](const double* pa, const double* pb, int pp, bool with_a) {
+            if (swave >= 4) return;
+            char* img = (char*)smem + pp * WORKER_PAIR_BYTES + 1024 * swave;
+            const unsigned half = (unsigned)(32 * ld * 8);        // rows 8 (wave + 4) .. : 32 rows further down
+            if (with_a) {
+                const dma_rsrc_t ra = dma_make_rsrc(pa, (unsigned)(64 * ld * 8));
+#pragma unroll
+                for (int sl = 0; sl < 4; ++sl) {
+                    dma_load16(ra, img + 8192 * sl, dvo, 128u * sl);
+                    dma_load16(ra, img + 8192 * sl + 4096, dvo, 128u * sl + half);
+                }
+            }
+            const dma_rsrc_t rb = dma_make_rsrc(pb, (unsigned)(64 * ld * 8));
+#pragma unroll
+            for (int sl = 0; sl < 4; ++sl) {
+                dma_load16(rb, img + 32768 + 8192 * sl, dvo, 128u * sl);
+                dma_load16(rb, img + 32768 + 8192 * sl + 4096, dvo, 128u * sl + half);
+            }
+        };
+        auto request = [&](int i, int j, int pp) {
+            request_blocks(Lb + (long)(64 * i) * ld + 64 * k, Lb + (long)(64 * j) * ld + 64 * k, pp, true);
+        };
+        // c0, c1 += sgn * A B^T on this wave's 16 x 32 piece, operands from the landed pair image pp
+        auto product = [&](int pp, d4& c0, d4& c1, bool negate) {
+            const char* img = (const char*)smem + pp * WORKER_PAIR_BYTES;
+#pragma unroll 1
+            for (int sl = 0; sl < 4; ++sl)             // (fully unrolled, the 24 fragment loads are hoisted and spill)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    double2 a = *reinterpret_cast<const double2*>(img + 8192 * sl + (h ? fa1 : fa0));
+                    const double2 b0 = *reinterpret_cast<const double2*>(img + 8192 * sl + (h ? fb1 : fb0));
+                    const double2 b1 = *reinterpret_cast<const double2*>(img + 8192 * sl + 2048 + (h ? fb1 : fb0));
+                    if (negate) { a.x = -a.x; a.y = -a.y; }
+                    c0 = mfma16(a.x, b0.x, c0);
+                    c1 = mfma16(a.x, b1.x, c1);
+                    c0 = mfma16(a.y, b0.y, c0);
+                    c1 = mfma16(a.y, b1.y, c1);
+                }
+        };
+        auto update = [&](int pp, d4& c0, d4& c1) { product(pp, c0, c1, true); };
+        // a resident tile (this wave's two accumulators) as the A operand of pair image 0, in the slab layout
+        auto tile_to_image = [&](const d4& c0, const d4& c1) {
+            char* img = (char*)smem;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * wr + crow(lane, r, crow_mode), cc = lane & 15;
+                const unsigned o = (unsigned)(row * 128) + ((unsigned)((cc >> 1) ^ ((row >> 1) & 7)) << 4) + 8u * (cc & 1);
+                *reinterpret_cast<double*>(img + 8192 * (2 * wc) + o) = c0[r];
+                *reinterpret_cast<double*>(img + 8192 * (2 * wc + 1) + o) = c1[r];
+            }
+        };
         // ---- 1. panel tiles of column k.  Column 0 never receives an update, so its tiles are not kept in
         //         registers: at k = 0 worker w takes rows 2 + w, 2 + w + NW, ... straight from K.
         for (int i = 2 + w; k == 0 && i < nb; i += NW) {
             if (tid == 0) flag_store(progress, 1 + 4 * k + 1);
             if (!wg_wait2(&leafdone[0], 1, nullptr, 0, err, spin_limit, slot, 2000000 + w)) return;
-            double ra[WORKER_EPT], rb[WORKER_EPT];
-            block_to_regs(ra, Kb + (long)(64 * i) * ld, toff, ld);
-            block_to_regs(rb, Ib, toff, ld);                                        // inv_00
-            regs_to_lds(A, ra, tid);
-            regs_to_lds(B, rb, tid);
+            request_blocks(Kb + (long)(64 * i) * ld, Ib, 0, true);                  // A(i,0), inv_00
+            dma_wait<0>();
             __syncthreads();
             d4 acc[2] = {d4{0.0, 0.0, 0.0, 0.0}, d4{0.0, 0.0, 0.0, 0.0}};
-            lds_mm_tile(A, 16 * wr, B, 32 * wc, lane, acc, 1.0);
+            product(0, acc[0], acc[1], false);
             double* dst = Lb + (long)(64 * i) * ld;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -184,14 +228,12 @@ __global__ void __launch_bounds__(WORKER_THREADS) chol_worker_kernel(double* Kma
             if (i < 0 || j != k) continue;             // (workgroup-uniform)
             if (tid == 0) flag_store(progress, 1 + 4 * k + 1);
             if (!wg_wait2(&leafdone[k], 1, nullptr, 0, err, spin_limit, slot, 2000000 + 1000 * k + w)) return;
-            double rb[WORKER_EPT];
-            block_to_regs(rb, Ib + (long)(64 * k) * ld + 64 * k, toff, ld);        // inv_kk (zeros above the diagonal)
-            lds_put16(A, 16 * wr, 32 * wc, C[n][0], 1.0, lane, crow_mode);
-            lds_put16(A, 16 * wr, 32 * wc + 16, C[n][1], 1.0, lane, crow_mode);
-            regs_to_lds(B, rb, tid);
-            __syncthreads();
+            request_blocks(nullptr, Ib + (long)(64 * k) * ld + 64 * k, 0, false);   // inv_kk (zeros above the diagonal)
+            tile_to_image(C[n][0], C[n][1]);
+            dma_wait<0>();
+            __syncthreads();                           // (also waits for the LDS stores of tile_to_image)
             d4 acc[2] = {d4{0.0, 0.0, 0.0, 0.0}, d4{0.0, 0.0, 0.0, 0.0}};
-            lds_mm_tile(A, 16 * wr, B, 32 * wc, lane, acc, 1.0);
+            product(0, acc[0], acc[1], false);
             double* dst = Lb + (long)(64 * i) * ld + 64 * k;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -219,14 +261,11 @@ __global__ void __launch_bounds__(WORKER_THREADS) chol_worker_kernel(double* Kma
             if (tid == 0) flag_store(progress, 1 + 4 * k + 2);
             if (!wg_wait2(&row2done[k], 1, j == k + 1 ? &pan1[k] : nullptr, 1, err, spin_limit, slot, 3000000 + 1000 * k + w))
                 return;
-            double ra[WORKER_EPT], rb[WORKER_EPT];
-            block_to_regs(ra, Lb + (long)(64 * (k + 2)) * ld + 64 * k, toff, ld);
-            block_to_regs(rb, Lb + (long)(64 * j) * ld + 64 * k, toff, ld);
-            regs_to_lds(A, ra, tid);
-            regs_to_lds(B, rb, tid);
+            request(k + 2, j, 0);
+            dma_wait<0>();
             __syncthreads();
             double* dst = Kb + (long)(64 * (k + 2)) * ld + 64 * j;
-            lds_mm_tile(A, 16 * wr, B, 32 * wc, lane, C[n], -1.0);
+            update(0, C[n][0], C[n][1]);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 at_byte(dst + r * cstep, csub) = C[n][0][r];
@@ -238,33 +277,58 @@ __global__ void __launch_bounds__(WORKER_THREADS) chol_worker_kernel(double* Kma
         }
         // ---- 3. all other live tiles, software-pipelined: operands of the next tile travel global -> registers
         //         while the MFMAs of the current one run from LDS
-        int cur = -1;
-        for (int n = WORKER_MAXT - 1; n >= 0; --n)
-            if (__builtin_amdgcn_readfirstlane(ti[n]) >= 0 && __builtin_amdgcn_readfirstlane(tj[n]) > k) cur = n;
-        if (cur < 0) continue;
+        WORKER_STAMP(1);
+        // live tiles of this step, once: coordinates in scalar registers, membership as a bit mask (looking the next
+        // tile up in the LDS table between two tiles cost ~0.7 us per tile: 16 dependent LDS round trips)
+        int li[WORKER_MAXT], lj[WORKER_MAXT];
+        unsigned live = 0;
+#pragma unroll
+        for (int n = 0; n < WORKER_MAXT; ++n) {
+            li[n] = __builtin_amdgcn_readfirstlane(ti[n]);
+            lj[n] = __builtin_amdgcn_readfirstlane(tj[n]);
+            if (li[n] >= 0 && lj[n] > k) live |= 1u << n;
+        }
+        if (live == 0) continue;
+        int cur = __builtin_ctz(live);
+        auto coords = [&](int m, int& ci, int& cj) {   // li[m], lj[m] for a run-time m (scalar selects)
+            ci = li[0]; cj = lj[0];
+#pragma unroll
+            for (int q = 1; q < WORKER_MAXT; ++q)
+                if (q == m) { ci = li[q]; cj = lj[q]; }
+        };
         if (tid == 0) flag_store(progress, 1 + 4 * k + 3);
         if (!wg_wait2(&colready[k], 1, &pan1[k], 1, err, spin_limit, slot, 4000000 + 1000 * k + w)) return;
-        double ra[WORKER_EPT], rb[WORKER_EPT];
-        block_to_regs(ra, Lb + (long)(64 * __builtin_amdgcn_readfirstlane(ti[cur])) * ld + 64 * k, toff, ld);
-        block_to_regs(rb, Lb + (long)(64 * __builtin_amdgcn_readfirstlane(tj[cur])) * ld + 64 * k, toff, ld);
+        WORKER_STAMP(2);
+        {
+            int ci, cj;
+            coords(cur, ci, cj);
+            request(ci, cj, 0);
+        }
+        int pp = 0;
 #pragma unroll
         for (int n = 0; n < WORKER_MAXT; ++n) {
             if (n != cur) continue;                    // (slots before the first / between live tiles)
-            regs_to_lds(A, ra, tid);
-            regs_to_lds(B, rb, tid);
-            __syncthreads();
-            int nxt = -1;
-            for (int m = WORKER_MAXT - 1; m > n; --m)
-                if (__builtin_amdgcn_readfirstlane(ti[m]) >= 0 && __builtin_amdgcn_readfirstlane(tj[m]) > k) nxt = m;
+            const unsigned rest = live & ~((2u << n) - 1u);
+            const int nxt = rest ? __builtin_ctz(rest) : -1;
+            dma_wait<0>();                             // this wave's pieces of the current pair have landed
+            dma_barrier();                             // ... everybody's; the other pair image is free
             if (nxt >= 0) {
-                block_to_regs(ra, Lb + (long)(64 * __builtin_amdgcn_readfirstlane(ti[nxt])) * ld + 64 * k, toff, ld);
-                block_to_regs(rb, Lb + (long)(64 * __builtin_amdgcn_readfirstlane(tj[nxt])) * ld + 64 * k, toff, ld);
+                int ci, cj;
+                coords(nxt, ci, cj);
+                request(ci, cj, pp ^ 1);
             }
-            lds_mm_tile(A, 16 * wr, B, 32 * wc, lane, C[n], -1.0);
-            __syncthreads();                           // A, B free again
+            update(pp, C[n][0], C[n][1]);
+            pp ^= 1;
             cur = nxt;
+#ifndef GPMPC_EMULATED
+            if (trace && threadIdx.x == 0 && blockIdx.x < 8 && kb == 0)      // per-tile stamps of the first 8 workers
+                trace[135168 + ((long)blockIdx.x * 64 + k) * 10 + n] = wall_clock64();
+#endif
         }
+        __syncthreads();                               // the pair images alias A and B of the next step
+        WORKER_STAMP(3);
     }
+#undef WORKER_STAMP
     // a launch that stops before the last step hands its live tiles back through K: the next launch (from block
     // kb + ksteps on, with fewer workers -- the freed CUs take the inverse pipeline) reloads them
     if (k + 2 < nb) {

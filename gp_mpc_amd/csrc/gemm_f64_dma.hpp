@@ -23,51 +23,10 @@
 // DMA builtin every LDS read is preceded by vmcnt(0), which drains the ring (measured in the assembly output).
 #pragma once
 #include "gemm_f64.hpp"
+#include "lds_dma.hpp"
 
 namespace gpmpc {
 
-#ifdef GPMPC_EMULATED
-struct dma_rsrc_t { const char* base; unsigned bytes; };
-inline dma_rsrc_t dma_make_rsrc(const void* base, unsigned bytes) { return dma_rsrc_t{(const char*)base, bytes}; }
-// wave-uniform LDS destination + 16 * lane
-inline void dma_load16(const dma_rsrc_t& r, char* lds_wave_base, unsigned voff, unsigned soff) {
-    const unsigned long o = (unsigned long)voff + soff;
-    char* dst = lds_wave_base + 16 * (threadIdx.x & 63);
-    if (o + 16 > r.bytes) { for (int i = 0; i < 16; ++i) dst[i] = 0; return; }
-    for (int i = 0; i < 16; ++i) dst[i] = r.base[o + i];
-}
-template <int N> inline void dma_wait() {}
-inline void dma_barrier() { __syncthreads(); }
-#else
-typedef int dma_rsrc_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ dma_rsrc_t dma_make_rsrc(const void* base, unsigned bytes) {
-    const unsigned long b = (unsigned long)base;
-    dma_rsrc_t r;
-    r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)b);
-    r.y = __builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32));   // stride 0, no swizzle
-    r.z = __builtin_amdgcn_readfirstlane((int)bytes);
-    r.w = 0x00020000;
-    return r;
-}
-__device__ __forceinline__ void dma_load16(dma_rsrc_t r, char* lds_wave_base, unsigned voff, unsigned soff) {
-    const unsigned dst = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)lds_wave_base;
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "s"(__builtin_amdgcn_readfirstlane(dst)), "v"(voff), "s"(r), "s"(soff)
-                 : "memory");
-}
-// at most N of this wave's DMA loads still in flight
-template <int N> __device__ __forceinline__ void dma_wait() {
-    static_assert(N >= 0 && N < 64, "vmcnt range");
-    __builtin_amdgcn_s_waitcnt((N & 15) | ((N >> 4) << 14) | 0x0f70);
-}
-__device__ __forceinline__ void dma_barrier() {
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-}
-#endif
 
 // WPS: waves per SIMD the register allocation must allow (workgroups per CU x waves per workgroup / 4)
 // AMC / BNC: operand stored with M (resp. N) contiguous instead of K, as in GemmP::a_mc / b_nc

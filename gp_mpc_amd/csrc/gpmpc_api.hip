@@ -410,16 +410,16 @@ static bool factor_chain(const Ctx& cx, Workspace& ws, int spin_limit) {
     if (use_workers && !split) {
         hipLaunchKernelGGL(chol_worker_kernel, dim3(NW, 1, ws.batch), dim3(WORKER_THREADS), WORKER_LDS_BYTES, cx.side, ws.K, ws.L,
                            (const double*)ws.Inv, ld, sM, nb, ws.flags, (long)nf, cx.crow_mode, spin_limit, 0, nb,
-                           (int*)nullptr);
+                           (int*)nullptr, g_chain_trace);
     } else if (use_workers) {
         int* ready = ws.flags + chain_ready_index(nb);      // arrival counter + flag of the second launch
         hipLaunchKernelGGL(chol_worker_kernel, dim3(NW, 1, ws.batch), dim3(WORKER_THREADS), WORKER_LDS_BYTES, cx.side, ws.K, ws.L,
                            (const double*)ws.Inv, ld, sM, nb, ws.flags, (long)nf, cx.crow_mode, spin_limit, 0, kb2,
-                           (int*)nullptr);
+                           (int*)nullptr, g_chain_trace);
         hipEventRecord(cx.seg[cx.n_seg - 2], cx.side);      // first launch finished: L(:, < kb2) is final
         hipLaunchKernelGGL(chol_worker_kernel, dim3(NW2, 1, ws.batch), dim3(WORKER_THREADS), WORKER_LDS_BYTES, cx.side, ws.K,
                            ws.L, (const double*)ws.Inv, ld, sM, nb, ws.flags, (long)nf, cx.crow_mode, spin_limit, kb2, nb,
-                           ready);
+                           ready, g_chain_trace);
         // the left half of the inverse and the first product of the root, on the CUs the second launch leaves
         // free -- but not before that launch is resident (its workgroups need whole CUs)
         hipStreamWaitEvent(cx.aux, cx.seg[cx.n_seg - 2], 0);
@@ -774,7 +774,7 @@ static int factor_with_jitter(gpmpc_gp* h, Workspace& ws, const double* hyper_ho
         HIPCHK(hipMemcpyAsync(info.data(), ws.info, nb * sizeof(int), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
         if (g_chain_trace && h->chain_mode) {
-            const size_t cnt = std::min<size_t>(1 << 20, (size_t)nb * (ws.Np / 64) * 8);
+            const size_t cnt = 1 << 20;    // chain stamps first, worker stamps from entry 4096 on (chol_worker.hpp)
             std::vector<long long> tr(cnt);
             HIPCHK(hipMemcpy(tr.data(), g_chain_trace, cnt * sizeof(long long), hipMemcpyDeviceToHost));
             if (FILE* f = fopen(getenv("GPMPC_CHAIN_TRACE"), "wb")) { fwrite(tr.data(), sizeof(long long), cnt, f); fclose(f); }

@@ -42,6 +42,12 @@ __global__ void __launch_bounds__(256, 4) k(double* __restrict__ out, const doub
 #define STEP(j, aa, bb) c[j] = MFMA(aa, bb, c[j]); asm volatile("s_nop 1"); __builtin_amdgcn_sched_barrier(0);
             STEP(0, a0, b0) STEP(1, a0, b1) STEP(2, a1, b0) STEP(3, a1, b1) STEP(4, a2, b0) STEP(5, a2, b1) STEP(6, a3, b0) STEP(7, a3, b1)
 #undef STEP
+        } else if (V == 6) {   // 2 accumulators (the tile-owner worker's wave piece), back to back
+            c[0] = MFMA(a0, b0, c[0]); c[1] = MFMA(a0, b1, c[1]); c[0] = MFMA(a1, b0, c[0]); c[1] = MFMA(a1, b1, c[1]);
+            c[0] = MFMA(a2, b0, c[0]); c[1] = MFMA(a2, b1, c[1]); c[0] = MFMA(a3, b0, c[0]); c[1] = MFMA(a3, b1, c[1]);
+        } else if (V == 7) {   // 1 accumulator
+            c[0] = MFMA(a0, b0, c[0]); c[0] = MFMA(a0, b1, c[0]); c[0] = MFMA(a1, b0, c[0]); c[0] = MFMA(a1, b1, c[0]);
+            c[0] = MFMA(a2, b0, c[0]); c[0] = MFMA(a2, b1, c[0]); c[0] = MFMA(a3, b0, c[0]); c[0] = MFMA(a3, b1, c[0]);
         } else if (V == 5) {   // as 1 with s_setprio 3 held for the whole loop
             if (i == 0) __builtin_amdgcn_s_setprio(3);
             c[0] = MFMA(a0, b0, c[0]); c[1] = MFMA(a0, b1, c[1]); c[2] = MFMA(a1, b0, c[2]); c[3] = MFMA(a1, b1, c[3]);
@@ -81,5 +87,7 @@ int main() {
     run<3>("V3 = V1 + an LDS operand fetch after every 2nd MFMA", out, in, p.multiProcessorCount);
     run<4>("V4 = V1 + s_nop 1 after every MFMA", out, in, p.multiProcessorCount);
     run<5>("V5 = V1 at s_setprio 3", out, in, p.multiProcessorCount);
+    run<6>("V6 2 acc, back to back", out, in, p.multiProcessorCount);
+    run<7>("V7 1 acc, back to back", out, in, p.multiProcessorCount);
     return 0;
 }
