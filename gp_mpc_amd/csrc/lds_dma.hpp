@@ -20,6 +20,9 @@ inline void dma_load16(const dma_rsrc_t& r, char* lds_wave_base, unsigned voff, 
     if (o + 16 > r.bytes) { for (int i = 0; i < 16; ++i) dst[i] = 0; return; }
     for (int i = 0; i < 16; ++i) dst[i] = r.base[o + i];
 }
+inline void dma_load16_relaxed(const dma_rsrc_t& r, char* lds_wave_base, unsigned voff, unsigned soff) {
+    dma_load16(r, lds_wave_base, voff, soff);
+}
 template <int N> inline void dma_wait() {}
 inline void dma_barrier() { __syncthreads(); }
 #else
@@ -40,6 +43,16 @@ __device__ __forceinline__ void dma_load16(dma_rsrc_t r, char* lds_wave_base, un
                  : "=&s"(keep)
                  : "s"(__builtin_amdgcn_readfirstlane(dst)), "v"(voff), "s"(r), "s"(soff)
                  : "memory");
+}
+// The same load without the compiler-level memory barrier, for loads interleaved with the matrix instructions of a
+// loop whose LDS reads must stay free to move (they touch a different LDS image; the s_barrier / counted wait that
+// order the image's reuse are themselves compiler barriers).
+__device__ __forceinline__ void dma_load16_relaxed(dma_rsrc_t r, char* lds_wave_base, unsigned voff, unsigned soff) {
+    const unsigned dst = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)lds_wave_base;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "s"(__builtin_amdgcn_readfirstlane(dst)), "v"(voff), "s"(r), "s"(soff));
 }
 // at most N of this wave's DMA loads still in flight
 template <int N> __device__ __forceinline__ void dma_wait() {

@@ -42,12 +42,24 @@ __global__ void __launch_bounds__(512) k(const double* __restrict__ L0, long ld,
             if (cold == 2 && n == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             dma_wait<0>();
             if (!(ABL & 4)) dma_barrier();
-            if (t + 1 < T) request(t + 1, pp ^ 1);
+            if (!(ABL & 16) && t + 1 < T) request(t + 1, pp ^ 1);
             const char* img = smem + pp * 65536;
+            dma_rsrc_t nra, nrb;
+            const bool more = (ABL & 16) && t + 1 < T;
+            if (more) {
+                const int i = (blockIdx.x * 7 + (t + 1) * 3) % nblk, j = (blockIdx.x * 5 + t + 1) % nblk;
+                const double* Ln = L0 + (cold ? (long)(((t + 1) / 9) % 64) * 64 * nblk * ld : 0);
+                nra = dma_make_rsrc(Ln + (long)(64 * i) * ld, (unsigned)(64 * ld * 8));
+                nrb = dma_make_rsrc(Ln + (long)(64 * j) * ld, (unsigned)(64 * ld * 8));
+            }
 #pragma unroll 1
             for (int sl = 0; sl < 4; ++sl)
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
+                    if (more) {                      // piece q = 2 sl + h of the next pair: one DMA per four MFMAs
+                        const int q = 2 * sl + h;
+                        dma_load16_relaxed(q < 4 ? nra : nrb, smem + (pp ^ 1) * 65536 + (q >> 2) * 32768 + 8192 * (q & 3) + 1024 * wave, dvo, 128u * (q & 3));
+                    }
                     double2 a, b0, b1;
                     if (ABL & 2) { a = double2{1.0 + lane, 2.0}; b0 = double2{3.0, 1.0 + sl}; b1 = double2{0.5 * h, 1.5}; }
                     else {
@@ -89,6 +101,8 @@ int main() {
     double *L, *out;
     hipMalloc(&L, (size_t)64 * 64 * nblk * ld * 8); hipMalloc(&out, 256 * 512 * 8);    // 64 panel columns of 132 MB (ld = N)
     hipMemset(L, 0, (size_t)64 * 64 * nblk * ld * 8);
+    run<16, 9>("interleaved requests", L, ld, nblk, out, 224, 0);
+    run<16, 9>("interleaved requests, fresh column + acquire fence", L, ld, nblk, out, 224, 2);
     run<0, 9>("full, fresh panel column every 9 tiles", L, ld, nblk, out, 224, 1);
     run<0, 9>("full, fresh column + acquire fence", L, ld, nblk, out, 224, 2);
     run<8, 9>("no MFMAs, fresh column + acquire fence", L, ld, nblk, out, 224, 2);
