@@ -1,12 +1,14 @@
-// fp64 GEMM, 128 x 128 tile, with operand tiles streamed HBM/L2 -> LDS by the DMA path of the load unit
-// (buffer_load_dwordx4 ... lds): no staging registers, no LDS store instructions and no VALU work in the K loop.
+// fp64 GEMM (128 x 128 and 64 x 64 tiles) with operand tiles streamed HBM/L2 -> LDS by the DMA path of the load
+// unit (buffer_load_dwordx4 ... lds, lds_dma.hpp): no staging registers, no LDS store instructions and no VALU work
+// in the K loop.
 //
-// Same contract as gemm_f64_kernel (gemm_f64.hpp, GemmP) for the K-contiguous / K-contiguous case
-//     C = alpha * A B + beta * C,   A(m,k) = A[m*lda + k],  B(k,n) = B[n*ldb + k]
-// including the triangular K ranges and the fused column-sum-of-squares epilogue of the predictive variance
-// (a9, gp_functions.py:122-126).  Not supported here (the launcher keeps the register-staged kernel for them):
-// transposed operands, the chain hand-off flags, K not a multiple of 16, operands of 4 GB or more.
+// Same contract as gemm_f64_kernel (gemm_f64.hpp, GemmP):  C = alpha * A B + beta * C  with either operand stored
+// K-contiguous or M/N-contiguous, the triangular K ranges, the `lower` output mask, the chain hand-off flags and the
+// fused column-sum-of-squares epilogue of the predictive variance (a9, gp_functions.py:122-126).  Preconditions
+// (gemm_dma_supported; the launcher keeps the register-staged kernel otherwise): K a multiple of 16, 16-byte
+// aligned operands with even leading dimensions, each operand below 4 GB.
 //
+// K-contiguous operand, A(m,k) = A[m*lda + k]:
 // LDS image of one K slab (16 doubles = 128 bytes per row): [128 rows of A][128 rows of B], row r at byte 128 r,
 // and inside a row the eight 16-byte pieces are permuted, piece c stored at position c ^ ((r >> 1) & 7).  A DMA
 // load writes wave-uniform base + 16 lane, so one wave instruction fills 8 consecutive rows (1 KB) and the
@@ -16,6 +18,10 @@
 // together hit 16 different bank groups (rows r, r+1 differ in bit 5 of the bank index, pairs of rows in the
 // permuted piece position).  Which K index a lane group holds in a given instruction does not matter for the
 // product as long as A and B fragments agree, which they do by construction.
+// M/N-contiguous operand, A(m,k) = A[k*lda + m]: the image is [16 K rows][tile width], every other pair of K rows with
+// its two 16-element halves swapped (element m at m ^ 16: the four lane groups of a ds_read_b64 fragment read then
+// alternate between the two 128-byte bank halves); one wave instruction fills 1 KB of consecutive K rows.
+// A lower-triangular A: inside the diagonal block, a wave whose rows all lie above a slab's K range skips that slab.
 //
 // Pipeline: STAGES slab images form a ring; slab t + STAGES - 1 is requested right after the barrier of step t
 // (its image was last read in step t - 1), the wait in front of the barrier of step t is a COUNTED s_waitcnt
