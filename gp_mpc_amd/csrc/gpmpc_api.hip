@@ -389,9 +389,11 @@ static bool factor_chain(const Ctx& cx, Workspace& ws, int spin_limit) {
     while (2 * s_top < Np) s_top *= 2;
     const int kb2 = s_top / 64;                             // first block of the second launch
     const int nb2 = nb - kb2, ntiles2 = (nb2 - 1) * nb2 / 2 - 1;
-    int NW2 = std::max(1, cx.workers * 3 / 8);              // 96 of 256 CUs: <= 6 tiles per worker at Np = 4096
+    static const int nw2_env = getenv("GPMPC_NW2") ? atoi(getenv("GPMPC_NW2")) : 0;   // (tuning aid)
+    int NW2 = nw2_env > 0 ? nw2_env : std::max(1, cx.workers * 3 / 8);              // 96 of 256 CUs: <= 6 tiles per worker at Np = 4096
                                                             // (measured: 64 / 96 / 128 / 160 / 192 workers ->
-                                                            //  2.44 / 2.40 / 2.43 / 2.53 / 2.61 ms)
+                                                            //  2.44 / 2.40 / 2.43 / 2.53 / 2.61 ms; with the
+                                                            //  DMA-staged workers 64 .. 160 are within 1 %)
     if (NW2 > ntiles2) NW2 = std::max(1, ntiles2);
     static const bool split_ok = !(getenv("GPMPC_WORKER_SPLIT") && atoi(getenv("GPMPC_WORKER_SPLIT")) == 0);
     const bool split = use_workers && split_ok && cx.aux && cx.seg && s_top >= SEGR && nb2 >= 3 &&
