@@ -366,9 +366,11 @@ inline int gemm_pick_tile(const GemmP& p, int batch) {
         const long b = (long)((p.M + t - 1) / t) * ((p.N + t - 1) / t) * batch;
         return p.lower ? (b + 1) / 2 : b;
     };
+    static const int t128 = getenv("GPMPC_T128") ? atoi(getenv("GPMPC_T128")) : 512;
+    static const int t64 = getenv("GPMPC_T64") ? atoi(getenv("GPMPC_T64")) : 512;
     if (p.N <= 32 || p.M <= 32) return 32;     // skinny products (a handful of prediction points)
-    if (blocks(128) >= 512) return 128;
-    if (blocks(64) >= 512) return 64;
+    if (blocks(128) >= t128) return 128;
+    if (blocks(64) >= t64) return 64;
     return 32;
 }
 
