@@ -58,6 +58,7 @@ SIGNATURES = {
     'gpmpc_kernel_matrix': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp,
                                            ctypes.c_double, _vp]),
     'gpmpc_cholesky': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _vp, _vp, _ip]),
+    'gpmpc_set_tuning': (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int]),
     'gpmpc_dgemm': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                    ctypes.c_int, ctypes.c_double, _vp, ctypes.c_int, _vp, ctypes.c_int,
                                    ctypes.c_double, _vp, ctypes.c_int]),
@@ -124,6 +125,10 @@ class GpmpcLib:
         tf = ctypes.c_double(0.0)
         self.check(self.dll.gpmpc_mfma_selftest(device, ctypes.byref(layout), ctypes.byref(tf)))
         return layout.value, tf.value
+
+    def set_tuning(self, name, value):
+        """Diagnostic knob, e.g. set_tuning('gemm_tile', 64) pins the GEMM tile (0 = automatic)."""
+        self.check(self.dll.gpmpc_set_tuning(name.encode(), int(value)))
 
     # -- low-level dense ops
     def cholesky(self, A, device=0, want_inverse=False):

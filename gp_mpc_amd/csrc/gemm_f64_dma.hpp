@@ -312,8 +312,10 @@ inline void launch_gemm_dma(GemmP p, int batch, hipStream_t stream, int resident
 }
 
 // Returns the tile edge used (the caller of EPI_COLSUMSQ sizes `part` with it).
+inline int g_gemm_force_tile = 0;   // gpmpc_set_tuning("gemm_tile", ...): tests reach the large tiles with small matrices
+
 inline int launch_gemm(const GemmP& p, int batch, hipStream_t stream, int force_tile = 0) {
-    const int tile = force_tile ? force_tile : gemm_pick_tile(p, batch);
+    const int tile = force_tile ? force_tile : g_gemm_force_tile ? g_gemm_force_tile : gemm_pick_tile(p, batch);
     // GPMPC_GEMM_DMA: bit 0 the 128 x 128 tile, bit 1 the 64 x 64 tile through the DMA-staged kernel (default both)
     static const int use_dma = getenv("GPMPC_GEMM_DMA") ? atoi(getenv("GPMPC_GEMM_DMA")) : 3;
     if (tile == 128 && (use_dma & 1) && gemm_dma_supported(p)) {

@@ -1545,6 +1545,16 @@ extern "C" int gpmpc_dgemm(int device, int transa, int transb, int M, int N, int
     return GPMPC_OK;
 }
 
+extern "C" int gpmpc_set_tuning(const char* name, int value) {
+    if (!name) return fail(GPMPC_EINVAL, "NULL name");
+    if (std::strcmp(name, "gemm_tile") == 0) {
+        if (value != 0 && value != 32 && value != 64 && value != 128) return fail(GPMPC_EINVAL, "gemm_tile must be 0, 32, 64 or 128");
+        g_gemm_force_tile = value;
+        return GPMPC_OK;
+    }
+    return fail(GPMPC_EINVAL, "unknown tuning knob '%s'", name);
+}
+
 extern "C" int gpmpc_kernel_matrix(int device, int n1, int n2, int d, const double* X, const double* Z, const double* ell,
                                    double sf2, double* out) {
     if (n1 <= 0 || n2 <= 0 || d <= 0 || !X || !Z || !ell || !out) return fail(GPMPC_EINVAL, "bad arguments");

@@ -159,6 +159,11 @@ int gpmpc_cholesky(int device, int n, double* A, double* Ainv, int* info);
 int gpmpc_dgemm(int device, int transa, int transb, int M, int N, int K, double alpha,
                 const double* A, int lda, const double* B, int ldb, double beta, double* C, int ldc);
 
+/* Diagnostic knob for tests and tuning runs (no reference counterpart): `name` = "gemm_tile", value 0 (automatic),
+ * 32, 64 or 128 pins the tile of every GEMM launch of the process, so that small problems reach the large-tile
+ * kernels.  Returns GPMPC_EINVAL for an unknown name or value. */
+int gpmpc_set_tuning(const char* name, int value);
+
 #ifdef __cplusplus
 }
 #endif

@@ -64,6 +64,19 @@ def check_dgemm_large_tile(lib, seed=5):
         del os.environ['GPMPC_DGEMM_TILE']
 
 
+def check_forced_tiles(lib, tank):
+    """The large-tile GEMM kernels (DMA-staged) with everything the factorisation asks of them -- triangular K ranges,
+    lower-only output, transposed operands, batched nodes of the inverse tree -- on problems small enough for the
+    emulator: pin the tile and run the Cholesky / inverse and a model fit with K^-1."""
+    try:
+        for tile in (64, 128):
+            lib.set_tuning('gemm_tile', tile)
+            check_cholesky(lib, sizes=(192, 320))
+            check_model_fixture(lib, tank, tolL=1e-10, tol_nll=1e-10)
+    finally:
+        lib.set_tuning('gemm_tile', 0)
+
+
 def check_cholesky(lib, sizes=(64, 100, 192, 256), seed=1):
     rng = np.random.default_rng(seed)
     for n in sizes:

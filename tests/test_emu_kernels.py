@@ -31,6 +31,10 @@ def test_emu_dgemm_large_tile(emu):
     pc.check_dgemm_large_tile(emu)
 
 
+def test_emu_forced_tiles(emu, tank):
+    pc.check_forced_tiles(emu, tank)
+
+
 def test_emu_cholesky(emu):
     pc.check_cholesky(emu)
 

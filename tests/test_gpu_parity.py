@@ -30,6 +30,10 @@ def test_dgemm_large_tile(lib):
     pc.check_dgemm_large_tile(lib)
 
 
+def test_forced_tiles(lib, tank):
+    pc.check_forced_tiles(lib, tank)
+
+
 def test_dgemm(lib):
     pc.check_dgemm(lib, sizes=((70, 33, 50), (128, 128, 64), (200, 130, 96), (1000, 900, 512), (2048, 2048, 256)))
 
