@@ -1121,8 +1121,12 @@ static int predict_chunk(gpmpc_gp* h, int B, const double* dZ, double* dMean, do
                         h->ccpart, nch);
     }
     int tilesM = 0;
-    if (dVar && B <= 8) {
-        PhaseTimer t(h, GPMPC_PH_VARGEMM);   // small batch: stream L^-1 once (HBM-bound), no MFMA padding waste
+    // One point: a dedicated kernel streams L^-1 once at 5.6 TB/s (C3 size).  Measured at N = 8192, Ny = 6
+    // (tools/bench_smallb.py), its multi-column versions fall off quickly (B = 2 / 4 / 8: 0.41 / 0.52 / 0.82 ms)
+    // while the DMA-staged GEMM below does any B <= 32 in 0.30-0.32 ms: GPMPC_VARSMALL_MAX (default 1) is the switch.
+    static const int varsmall_max = getenv("GPMPC_VARSMALL_MAX") ? atoi(getenv("GPMPC_VARSMALL_MAX")) : 1;
+    if (dVar && B <= varsmall_max && B <= 8) {
+        PhaseTimer t(h, GPMPC_PH_VARGEMM);   // stream L^-1 once (HBM-bound), no MFMA padding waste
         tilesM = Np / 32;
         const dim3 grid(tilesM, Ny);
         if (B == 1) hipLaunchKernelGGL((var_small_kernel<1>), grid, dim3(256), 0, cx.stream, h->ws.Inv, h->KsT, h->part, Np, Bp);
@@ -1130,23 +1134,28 @@ static int predict_chunk(gpmpc_gp* h, int B, const double* dZ, double* dMean, do
         else if (B <= 4) hipLaunchKernelGGL((var_small_kernel<4>), grid, dim3(256), 0, cx.stream, h->ws.Inv, h->KsT, h->part, Np, Bp);
         else hipLaunchKernelGGL((var_small_kernel<8>), grid, dim3(256), 0, cx.stream, h->ws.Inv, h->KsT, h->part, Np, Bp);
     } else if (dVar && B <= 64) {
-        // medium batch (an MPC's Nt shooting nodes): tall-skinny tiles, a row tile x all columns per workgroup,
-        // so that L^-1 is streamed once and the small Ks panel is shared through LDS; every workgroup takes a
-        // row tile and its mirror (balanced triangle).  (A no-LDS direct-fragment streaming kernel, which
-        // re-reads the Ks panel from L2 once per row tile, was slower: 0.66 ms at N=8192, Ny=6, B=30.)
+        // small batch (an MPC's Nt shooting nodes): tall-skinny tiles, a row tile x all columns per workgroup,
+        // so that L^-1 is streamed once and the small Ks panel is shared through LDS.  The stream is what matters:
+        // the DMA-staged kernel with a THREE-image ring and 64-row tiles (several workgroups per CU, each with two
+        // slabs in flight) reaches 5.0 TB/s of L^-1 at N = 8192, Ny = 6, B <= 32 (0.32 ms; four / five images 0.33 /
+        // 0.34, 32-row tiles 0.39, 128-row tiles 0.40) where the register-staged 32-row kernel managed 3.5 TB/s
+        // (0.46 ms; 128 rows 0.52, 64 rows 0.53, 16 rows 0.56).  33-64 columns: 64 x 64 tiles, 0.54 against 0.70 ms.
+        // (A no-LDS direct-fragment streaming kernel, which re-reads the Ks panel from L2 once per row tile, was
+        //  slower still: 0.66 ms at B = 30.)  GPMPC_SMALLB_DMA=0 selects the register-staged kernels.
         PhaseTimer t(h, GPMPC_PH_VARGEMM);
         GemmP p = gemm_base(cx);
         p.A = h->ws.Inv; p.lda = Np; p.sA = (long)Np * Np; p.a_mc = 0; p.kflags = KA_LE_M;
         p.B = h->KsT; p.ldb = Np; p.sB = (long)Bp * Np; p.b_nc = 0;
         p.M = Np; p.N = Bp; p.K = Np;
         p.epi = EPI_COLSUMSQ; p.part = h->part; p.ldpart = Bp;
-        // up to 32 columns: 32-row tiles (2 waves) -- thousands of small workgroups hide the HBM latency of the
-        // L^-1 stream better than 128-row tiles (measured at N = 8192, Ny = 6, B = 30: 0.46 against 0.52 ms;
-        // 64 rows 0.53, 16 rows 0.56, 32 rows with BK = 64 0.60)
-        const int tm_rows = Bp <= 32 ? 32 : 128;
+        static const bool smallb_dma = !(getenv("GPMPC_SMALLB_DMA") && atoi(getenv("GPMPC_SMALLB_DMA")) == 0);
+        const bool dma = smallb_dma && gemm_dma_supported(p);
+        const int tm_rows = dma ? 64 : Bp <= 32 ? 32 : 128;
         tilesM = (Np + tm_rows - 1) / tm_rows;
         p.sPart = (long)tilesM * Bp;
-        if (Bp <= 32) launch_gemm_cfg<32, 32, 32, 2, 1>(p, Ny, cx.stream, 1 << 30, 2);
+        if (dma && Bp <= 32) launch_gemm_dma<64, 32, 4, 1, 3, 4>(p, Ny, cx.stream, 1 << 30, 2);
+        else if (dma) launch_gemm_dma<64, 64, 2, 2, 3, 4>(p, Ny, cx.stream, 1 << 30, 2);
+        else if (Bp <= 32) launch_gemm_cfg<32, 32, 32, 2, 1>(p, Ny, cx.stream, 1 << 30, 2);
         else launch_gemm_cfg<128, 64, 16, 4, 2>(p, Ny, cx.stream, 1 << 30, 2);
     } else if (dVar) {
         PhaseTimer t(h, GPMPC_PH_VARGEMM);
