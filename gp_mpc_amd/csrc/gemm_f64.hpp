@@ -369,7 +369,16 @@ inline int gemm_pick_tile(const GemmP& p, int batch) {
     static const int t128 = getenv("GPMPC_T128") ? atoi(getenv("GPMPC_T128")) : 512;
     static const int t64 = getenv("GPMPC_T64") ? atoi(getenv("GPMPC_T64")) : 512;
     if (p.N <= 32 || p.M <= 32) return 32;     // skinny products (a handful of prediction points)
-    if (blocks(128) >= t128) return 128;
+    // A triangular operand makes the heaviest tile K / 128 slabs long while the average is half that: unless the
+    // average work per workgroup slot (512 of them) reaches the heaviest tile, the heaviest tiles alone set the time
+    // and smaller tiles balance better (N = 8192, Ny = 6, B = 256 variance product: 2.42 ms with 128-row tiles, 1.74 with 64).
+    bool balanced = true;
+    if (p.kflags == KA_LE_M || p.kflags == KA_GE_M || p.kflags == KB_LE_N || p.kflags == KB_GE_N) {
+        const bool onM = p.kflags == KA_LE_M || p.kflags == KA_GE_M;
+        const long tT = ((onM ? p.M : p.N) + 127) / 128, tO = ((onM ? p.N : p.M) + 127) / 128;
+        balanced = (double)(tO * batch) * (tT + 1) / 2.0 / 512.0 >= 1.0 || tT <= 2;   // (average per slot) / (heaviest tile)
+    }
+    if (blocks(128) >= t128 && balanced) return 128;
     if (blocks(64) >= t64) return 64;
     return 32;
 }
