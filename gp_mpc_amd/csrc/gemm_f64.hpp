@@ -367,7 +367,7 @@ inline int gemm_pick_tile(const GemmP& p, int batch) {
         return p.lower ? (b + 1) / 2 : b;
     };
     static const int t128 = getenv("GPMPC_T128") ? atoi(getenv("GPMPC_T128")) : 512;
-    static const int t64 = getenv("GPMPC_T64") ? atoi(getenv("GPMPC_T64")) : 512;
+    static const int t64 = getenv("GPMPC_T64") ? atoi(getenv("GPMPC_T64")) : 256;   // (256 instead of 512: -14 us on the C2 inverse tail with the DMA-staged 64-row kernel)
     if (p.N <= 32 || p.M <= 32) return 32;     // skinny products (a handful of prediction points)
     // A triangular operand makes the heaviest tile K / 128 slabs long while the average is half that: unless the
     // average work per workgroup slot (512 of them) reaches the heaviest tile, the heaviest tiles alone set the time
