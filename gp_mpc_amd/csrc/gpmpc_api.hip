@@ -8,6 +8,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -530,6 +531,9 @@ struct gpmpc_gp {
     int device = 0, N = 0, Np = 0, d = 0, Ny = 0;
     hipStream_t own_stream = nullptr, stream = nullptr, side_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_info = nullptr;       // "the factorisation's status words are on the host" (factor_with_jitter)
+    int* pin = nullptr;                 // pinned host buffer for them
+    size_t pin_ints = 0;
     hipStream_t aux_stream = nullptr;
     std::vector<hipEvent_t> seg_events;
     int chain_mode = 1;      // 1: chained factorisation (falls back to 0 after a hand-off time-out)
@@ -689,6 +693,8 @@ int gpmpc_destroy(gpmpc_gp* h) {
     for (int ph = 0; ph < GPMPC_PH_COUNT; ++ph)
         for (auto& pr : h->prof.ev[ph]) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     for (auto e : h->prof.pool) hipEventDestroy(e);
+    if (h->ev_info) hipEventDestroy(h->ev_info);
+    if (h->pin) hipHostFree(h->pin);
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
     if (h->ev_join) hipEventDestroy(h->ev_join);
     for (auto e : h->seg_events) hipEventDestroy(e);
@@ -764,26 +770,48 @@ static void gram_and_factor(gpmpc_gp* h, Workspace& ws) {
 
 // Runs gram+Cholesky with the reference's one-shot jitter rule (optimize.py:345-350).
 // info_out[b]: 0 ok, 1 jitter applied, <0: -(first bad pivot) after jitter.
-static int factor_with_jitter(gpmpc_gp* h, Workspace& ws, const double* hyper_host, int* info_out) {
+// `post` enqueues the work that consumes the factors (alpha, K^-1, the NLL terms).  It goes into the stream right
+// after the copies of the status words and BEFORE the host waits for them -- the host waits on an event recorded
+// between the two -- so the host's round trip (wake up, inspect, return to the caller, next launches: ~50 us)
+// overlaps with that work instead of leaving the device idle.  If the attempt turns out to have failed (jitter rule,
+// hand-off time-out) the next attempt overwrites what `post` produced.
+static int factor_with_jitter(gpmpc_gp* h, Workspace& ws, const double* hyper_host, int* info_out,
+                              const std::function<void()>& post = std::function<void()>()) {
     const int nb = ws.batch;
     std::vector<double> jit(nb, 0.0);
     std::vector<int> info(nb, 0), res(nb, 0);
+    const size_t nflag = (size_t)nb * chain_flag_count(ws.Np / 64);
+    if (!h->ev_info) HIPCHK(hipEventCreateWithFlags(&h->ev_info, hipEventDisableTiming));
+    if (h->pin_ints < nb + nflag) {
+        if (h->pin) hipHostFree(h->pin);
+        h->pin = nullptr;
+        HIPCHK(hipHostMalloc((void**)&h->pin, (nb + nflag) * sizeof(int), hipHostMallocDefault));
+        h->pin_ints = nb + nflag;
+    }
+    int* pin_info = h->pin;
+    int* cerr = h->pin + nb;
     HIPCHK(hipMemcpyAsync(ws.hyper, hyper_host, (size_t)nb * (h->d + 2) * sizeof(double), hipMemcpyHostToDevice, h->stream));
     for (int attempt = 0; attempt < 2; ++attempt) {
         HIPCHK(hipMemcpyAsync(ws.jitter, jit.data(), nb * sizeof(double), hipMemcpyHostToDevice, h->stream));
         gram_and_factor(h, ws);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(info.data(), ws.info, nb * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
+        const bool check_chain = h->chain_mode && h->side_stream && ws.Np >= 128;
+        HIPCHK(hipMemcpyAsync(pin_info, ws.info, nb * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        if (check_chain) HIPCHK(hipMemcpyAsync(cerr, ws.flags, nflag * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipEventRecord(h->ev_info, h->stream));
+        static const bool post_early = !(getenv("GPMPC_POST_EARLY") && atoi(getenv("GPMPC_POST_EARLY")) == 0);
+        if (post && post_early) post();
+        HIPCHK(hipEventSynchronize(h->ev_info));
+        if (post && !post_early) post();
+        for (int b = 0; b < nb; ++b) info[b] = pin_info[b];
         if (g_chain_trace && h->chain_mode) {
+            HIPCHK(hipStreamSynchronize(h->stream));
             const size_t cnt = 1 << 20;    // chain stamps first, worker stamps from entry 4096 on (chol_worker.hpp)
             std::vector<long long> tr(cnt);
             HIPCHK(hipMemcpy(tr.data(), g_chain_trace, cnt * sizeof(long long), hipMemcpyDeviceToHost));
             if (FILE* f = fopen(getenv("GPMPC_CHAIN_TRACE"), "wb")) { fwrite(tr.data(), sizeof(long long), cnt, f); fclose(f); }
         }
-        if (h->chain_mode && h->side_stream && ws.Np >= 128) {   // did a hand-off of the chained factorisation time out?
-            std::vector<int> cerr((size_t)nb * chain_flag_count(ws.Np / 64));
-            HIPCHK(hipMemcpy(cerr.data(), ws.flags, cerr.size() * sizeof(int), hipMemcpyDeviceToHost));
+        if (check_chain) {   // did a hand-off of the chained factorisation time out?
             int bad = 0;
             for (int b = 0; b < nb; ++b)
                 if (cerr[(size_t)b * chain_flag_count(ws.Np / 64)] != 0) bad = cerr[(size_t)b * chain_flag_count(ws.Np / 64)];
@@ -808,10 +836,14 @@ static int factor_with_jitter(gpmpc_gp* h, Workspace& ws, const double* hyper_ho
                     }
                 }
                 h->chain_mode = 0;
+                HIPCHK(hipStreamSynchronize(h->stream));
                 HIPCHK(hipStreamSynchronize(h->side_stream));
                 gram_and_factor(h, ws);
-                HIPCHK(hipMemcpyAsync(info.data(), ws.info, nb * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-                HIPCHK(hipStreamSynchronize(h->stream));
+                HIPCHK(hipMemcpyAsync(pin_info, ws.info, nb * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+                HIPCHK(hipEventRecord(h->ev_info, h->stream));
+                if (post) post();
+                HIPCHK(hipEventSynchronize(h->ev_info));
+                for (int b = 0; b < nb; ++b) info[b] = pin_info[b];
             }
         }
         bool any = false;
@@ -844,16 +876,19 @@ extern "C" int gpmpc_fit(gpmpc_gp* h, const double* hyper, int want_invK, int* i
     h->fitted = false;
     h->have_invK = false;
     h->have_beta = false;
-    CHK(factor_with_jitter(h, h->ws, hyper, info));
-    {
-        PhaseTimer t(h, GPMPC_PH_SOLVE);
-        solve_alpha(h->cx(), h->ws, h->Y, h->Np);
-    }
-    if (want_invK) {
-        PhaseTimer t(h, GPMPC_PH_INVK);
-        CHK(compute_invK(h->cx(), h->ws));
-        h->have_invK = true;
-    }
+    int post_rc = GPMPC_OK;
+    CHK(factor_with_jitter(h, h->ws, hyper, info, [&]() {
+        {
+            PhaseTimer t(h, GPMPC_PH_SOLVE);
+            solve_alpha(h->cx(), h->ws, h->Y, h->Np);
+        }
+        if (want_invK) {
+            PhaseTimer t(h, GPMPC_PH_INVK);
+            post_rc = compute_invK(h->cx(), h->ws);
+        }
+    }));
+    CHK(post_rc);
+    if (want_invK) h->have_invK = true;
     HIPCHK(hipGetLastError());
     h->hyper.assign(hyper, hyper + (size_t)h->Ny * (h->d + 2));
     h->fitted = true;
@@ -1451,35 +1486,37 @@ extern "C" int gpmpc_nll(gpmpc_gp* h, int a, const double* hyper_row, double* nl
     }
     Workspace& ws = h->tws;
     int info = 0;
-    CHK(factor_with_jitter(h, ws, hyper_row, &info));
-    if (jitter_out) *jitter_out = info;
     const Ctx cx = h->cx();
-    {
-        PhaseTimer t(h, GPMPC_PH_SOLVE);
-        solve_alpha(cx, ws, h->Y + (size_t)a * Np, Np);
-    }
-    {
-        PhaseTimer t(h, GPMPC_PH_NLL);
-        hipLaunchKernelGGL(nll_reduce_kernel, dim3(1), dim3(256), 0, cx.stream, ws.L, ws.w, ws.nll, h->N, Np);
-    }
-    if (grad) {
+    if (grad) CHK(ws_need_invK(ws));
+    // everything that follows the factorisation is enqueued before the host waits for `info` (factor_with_jitter)
+    CHK(factor_with_jitter(h, ws, hyper_row, &info, [&]() {
         {
-            PhaseTimer t(h, GPMPC_PH_INVK);
-            CHK(ws_need_invK(ws));
-            GemmP p = gemm_base(cx);  // lower triangle of K^-1 = L^-T L^-1 is all the gradient pass reads
-            p.A = ws.Inv; p.lda = Np; p.sA = ws.mat(); p.a_mc = 1;
-            p.B = ws.Inv; p.ldb = Np; p.sB = ws.mat(); p.b_nc = 1;
-            p.kflags = KA_GE_M | KB_GE_N;
-            p.C = ws.InvK; p.ldc = Np; p.sC = ws.mat();
-            p.M = Np; p.N = Np; p.K = Np; p.lower = 1;
-            launch_gemm(p, 1, cx.stream);
+            PhaseTimer t(h, GPMPC_PH_SOLVE);
+            solve_alpha(cx, ws, h->Y + (size_t)a * Np, Np);
         }
-        PhaseTimer t(h, GPMPC_PH_NLL);
-        hipLaunchKernelGGL(nll_grad_kernel, dim3(Np / 64, Np / 64), dim3(256), 0, cx.stream, h->XT, ws.hyper, ws.InvK,
-                           ws.alpha, h->gradPartial, h->N, Np, d);
-        hipLaunchKernelGGL(nll_grad_finish_kernel, dim3(1), dim3(64), 0, cx.stream, h->gradPartial, ws.hyper,
-                           h->gradOut, Np, d);
-    }
+        {
+            PhaseTimer t(h, GPMPC_PH_NLL);
+            hipLaunchKernelGGL(nll_reduce_kernel, dim3(1), dim3(256), 0, cx.stream, ws.L, ws.w, ws.nll, h->N, Np);
+        }
+        if (grad) {
+            {
+                PhaseTimer t(h, GPMPC_PH_INVK);
+                GemmP p = gemm_base(cx);  // lower triangle of K^-1 = L^-T L^-1 is all the gradient pass reads
+                p.A = ws.Inv; p.lda = Np; p.sA = ws.mat(); p.a_mc = 1;
+                p.B = ws.Inv; p.ldb = Np; p.sB = ws.mat(); p.b_nc = 1;
+                p.kflags = KA_GE_M | KB_GE_N;
+                p.C = ws.InvK; p.ldc = Np; p.sC = ws.mat();
+                p.M = Np; p.N = Np; p.K = Np; p.lower = 1;
+                launch_gemm(p, 1, cx.stream);
+            }
+            PhaseTimer t(h, GPMPC_PH_NLL);
+            hipLaunchKernelGGL(nll_grad_kernel, dim3(Np / 64, Np / 64), dim3(256), 0, cx.stream, h->XT, ws.hyper, ws.InvK,
+                               ws.alpha, h->gradPartial, h->N, Np, d);
+            hipLaunchKernelGGL(nll_grad_finish_kernel, dim3(1), dim3(64), 0, cx.stream, h->gradPartial, ws.hyper,
+                               h->gradOut, Np, d);
+        }
+    }));
+    if (jitter_out) *jitter_out = info;
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(nll, ws.nll, sizeof(double), hipMemcpyDeviceToHost, h->stream));
     if (grad) HIPCHK(hipMemcpyAsync(grad, h->gradOut, (d + 2) * sizeof(double), hipMemcpyDeviceToHost, h->stream));

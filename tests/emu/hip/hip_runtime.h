@@ -99,6 +99,9 @@ template <class T> inline hipError_t hipMalloc(T** p, size_t bytes) {
     return hipSuccess;
 }
 inline hipError_t hipFree(void* p) { emu::drain(); std::free(p); return hipSuccess; }
+enum { hipHostMallocDefault = 0 };
+inline hipError_t hipHostMalloc(void** p, size_t bytes, unsigned) { *p = std::calloc(bytes ? bytes : 1, 1); return *p ? hipSuccess : (hipError_t)2; }
+inline hipError_t hipHostFree(void* p) { emu::drain(); std::free(p); return hipSuccess; }
 inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { emu::drain(); std::memcpy(d, s, n); return hipSuccess; }
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { emu::drain(); std::memcpy(d, s, n); return hipSuccess; }
 inline hipError_t hipMemcpy2DAsync(void* d, size_t dpitch, const void* s, size_t spitch, size_t width, size_t height,
