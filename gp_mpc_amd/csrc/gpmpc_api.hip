@@ -399,6 +399,19 @@ static bool factor_chain(const Ctx& cx, Workspace& ws, int spin_limit) {
     static const bool split_ok = !(getenv("GPMPC_WORKER_SPLIT") && atoi(getenv("GPMPC_WORKER_SPLIT")) == 0);
     const bool split = use_workers && split_ok && cx.aux && cx.seg && s_top >= SEGR && nb2 >= 3 &&
                        (ntiles2 + NW2 - 1) / NW2 <= WORKER_MAXT;
+    // Third launch: the second one is cut once more where the left child of the right half's top node ends (block
+    // kb3), so that this child's inverse and the node's first product also run behind a worker launch instead of
+    // after the chain.
+    const int RH = Np - s_top;
+    int s2 = 64;
+    while (2 * s2 < RH) s2 *= 2;
+    const int kb3 = (s_top + s2) / 64, nb3 = nb - kb3, ntiles3 = (nb3 - 1) * nb3 / 2 - 1;
+    static const int nw3_env = getenv("GPMPC_NW3") ? atoi(getenv("GPMPC_NW3")) : -1;       // 0 disables the third launch
+    int NW3 = nw3_env >= 0 ? nw3_env : std::max(1, cx.workers / 8);
+    if (ntiles3 > 0 && NW3 > ntiles3) NW3 = ntiles3;
+    const long wo_root = ws.hw() * ws.hw(), wo_top2 = wo_root + (long)RH * s_top;
+    const bool split3 = split && NW3 > 0 && nb3 >= 3 && s2 >= SEGR && RH - s2 >= 64 && cx.n_seg >= 3 &&
+                        (ntiles3 + NW3 - 1) / NW3 <= WORKER_MAXT && wo_top2 + (long)(RH - s2) * s2 <= ws.wstride();
     // inverse pipelined segment by segment behind the chain: next to GEMM launches only
     const bool pipelined = !use_workers && cx.aux && cx.seg && Np >= 4 * SEGR;
     int seg_done = 0;
@@ -408,7 +421,7 @@ static bool factor_chain(const Ctx& cx, Workspace& ws, int spin_limit) {
     static const bool verbose = getenv("GPMPC_VERBOSE") != nullptr;
     if (verbose)
         fprintf(stderr, "gpmpc: factor Np=%d batch=%d: chain kernel + %s, inverse %s\n", Np, ws.batch,
-                split ? "tile-owner workers in two launches" : use_workers ? "tile-owner workers" : "GEMM launches",
+                split3 ? "tile-owner workers in three launches" : split ? "tile-owner workers in two launches" : use_workers ? "tile-owner workers" : "GEMM launches",
                 split ? "left half behind the second launch" : pipelined ? "pipelined" : "at the end");
     if (use_workers && !split) {
         hipLaunchKernelGGL(chol_worker_kernel, dim3(NW, 1, ws.batch), dim3(WORKER_THREADS), WORKER_LDS_BYTES, cx.side, ws.K, ws.L,
@@ -421,15 +434,28 @@ static bool factor_chain(const Ctx& cx, Workspace& ws, int spin_limit) {
                            (int*)nullptr, g_chain_trace);
         hipEventRecord(cx.seg[cx.n_seg - 2], cx.side);      // first launch finished: L(:, < kb2) is final
         hipLaunchKernelGGL(chol_worker_kernel, dim3(NW2, 1, ws.batch), dim3(WORKER_THREADS), WORKER_LDS_BYTES, cx.side, ws.K,
-                           ws.L, (const double*)ws.Inv, ld, sM, nb, ws.flags, (long)nf, cx.crow_mode, spin_limit, kb2, nb,
-                           ready, g_chain_trace);
+                           ws.L, (const double*)ws.Inv, ld, sM, nb, ws.flags, (long)nf, cx.crow_mode, spin_limit, kb2,
+                           split3 ? kb3 - kb2 : nb, ready, g_chain_trace);
+        if (split3) {
+            hipEventRecord(cx.seg[cx.n_seg - 3], cx.side);  // second launch finished: L(:, < kb3) is final
+            hipLaunchKernelGGL(chol_worker_kernel, dim3(NW3, 1, ws.batch), dim3(WORKER_THREADS), WORKER_LDS_BYTES, cx.side, ws.K,
+                               ws.L, (const double*)ws.Inv, ld, sM, nb, ws.flags, (long)nf, cx.crow_mode, spin_limit, kb3, nb,
+                               ready + 2, g_chain_trace);
+        }
         // the left half of the inverse and the first product of the root, on the CUs the second launch leaves
         // free -- but not before that launch is resident (its workgroups need whole CUs)
         hipStreamWaitEvent(cx.aux, cx.seg[cx.n_seg - 2], 0);
         hipLaunchKernelGGL(flag_gate_kernel, dim3(ws.batch), dim3(64), 0, cx.aux, ws.flags, (long)nf, chain_ready_index(nb) + 1, 1,
                            -1, 0, spin_limit);
         trtri_range(cx, ws, cx.aux, 0, s_top);
-        trtri_node_w(cx, ws, cx.aux, 0, s_top, Np - s_top, ws.hw() * ws.hw());
+        trtri_node_w(cx, ws, cx.aux, 0, s_top, Np - s_top, wo_root);
+        if (split3) {                                       // behind the third launch, once it is resident
+            hipStreamWaitEvent(cx.aux, cx.seg[cx.n_seg - 3], 0);
+            hipLaunchKernelGGL(flag_gate_kernel, dim3(ws.batch), dim3(64), 0, cx.aux, ws.flags, (long)nf, chain_ready_index(nb) + 3, 1,
+                               -1, 0, spin_limit);
+            trtri_range(cx, ws, cx.aux, s_top, s2);
+            trtri_node_w(cx, ws, cx.aux, s_top, s2, RH - s2, wo_top2);
+        }
     } else {
         hipLaunchKernelGGL(chain_gate_kernel, dim3(ws.batch), dim3(64), 0, cx.side, ws.flags, (long)nf, spin_limit);
         int* leafdone = ws.flags + 1;
@@ -475,8 +501,13 @@ static bool factor_chain(const Ctx& cx, Workspace& ws, int spin_limit) {
     if (split) {                                            // right half and the second product of the root
         hipEventRecord(cx.seg[cx.n_seg - 1], cx.aux);
         hipStreamWaitEvent(cx.stream, cx.seg[cx.n_seg - 1], 0);
-        trtri_range(cx, ws, cx.stream, s_top, Np - s_top);
-        trtri_node_inv(cx, ws, cx.stream, 0, s_top, Np - s_top, ws.hw() * ws.hw());
+        if (split3) {                                       // last quarter, second product of the right half's top node
+            trtri_range(cx, ws, cx.stream, s_top + s2, RH - s2);
+            trtri_node_inv(cx, ws, cx.stream, s_top, s2, RH - s2, wo_top2);
+        } else {
+            trtri_range(cx, ws, cx.stream, s_top, Np - s_top);
+        }
+        trtri_node_inv(cx, ws, cx.stream, 0, s_top, Np - s_top, wo_root);
         return true;
     }
     if (!pipelined) { trtri_levels(cx, ws); return true; }
@@ -1596,6 +1627,18 @@ extern "C" int gpmpc_set_tuning(const char* name, int value) {
     if (std::strcmp(name, "gemm_tile") == 0) {
         if (value != 0 && value != 32 && value != 64 && value != 128) return fail(GPMPC_EINVAL, "gemm_tile must be 0, 32, 64 or 128");
         g_gemm_force_tile = value;
+        return GPMPC_OK;
+    }
+    if (std::strcmp(name, "cu_count") == 0) {           // pretend device 0 has fewer compute units (worker counts follow)
+        CHK(ensure_device(0));
+        static int real = g_cu_count[0];
+#ifndef GPMPC_EMULATED
+        if (value < 8 || value > real) return fail(GPMPC_EINVAL, "cu_count must be in [8, %d]", real);
+#else
+        if (value < 8 || value > 64) return fail(GPMPC_EINVAL, "cu_count must be in [8, 64]");
+        (void)real;
+#endif
+        g_cu_count[0] = value;
         return GPMPC_OK;
     }
     return fail(GPMPC_EINVAL, "unknown tuning knob '%s'", name);

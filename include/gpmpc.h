@@ -159,9 +159,11 @@ int gpmpc_cholesky(int device, int n, double* A, double* Ainv, int* info);
 int gpmpc_dgemm(int device, int transa, int transb, int M, int N, int K, double alpha,
                 const double* A, int lda, const double* B, int ldb, double beta, double* C, int ldc);
 
-/* Diagnostic knob for tests and tuning runs (no reference counterpart): `name` = "gemm_tile", value 0 (automatic),
- * 32, 64 or 128 pins the tile of every GEMM launch of the process, so that small problems reach the large-tile
- * kernels.  Returns GPMPC_EINVAL for an unknown name or value. */
+/* Diagnostic knobs for tests and tuning runs (no reference counterpart).  "gemm_tile": 0 (automatic), 32, 64 or 128
+ * pins the tile of every GEMM launch of the process, so that small problems reach the large-tile kernels.
+ * "cu_count": the number of compute units of device 0 the persistent-kernel factorisation plans with (at most the
+ * real count on a GPU; the emulated build accepts up to 64 so that the multi-launch worker schedules can be
+ * exercised).  Returns GPMPC_EINVAL for an unknown name or value. */
 int gpmpc_set_tuning(const char* name, int value);
 
 #ifdef __cplusplus

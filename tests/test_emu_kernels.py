@@ -67,6 +67,16 @@ def test_emu_tile_owner_workers(emu):
     pc.check_synthetic(emu, N=700, d=3, Ny=1, B=10, sn=0.1, strict_rel=True)
 
 
+def test_emu_three_worker_launches(emu):
+    # Np = 960 with 14 emulated workers: blocks 0-7, 8-11 and 12-14 as three worker launches, the inverse of the
+    # left half behind the second and of the third quarter behind the third (factor_chain, split3)
+    emu.set_tuning('cu_count', 16)
+    try:
+        pc.check_synthetic(emu, N=950, d=3, Ny=1, B=10, sn=0.1, strict_rel=True)
+    finally:
+        emu.set_tuning('cu_count', 8)
+
+
 def test_emu_jitter_rule(emu, train_small):
     pc.check_jitter_rule(emu, train_small)
 
