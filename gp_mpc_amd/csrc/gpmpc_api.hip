@@ -409,9 +409,24 @@ static bool factor_chain(const Ctx& cx, Workspace& ws, int spin_limit) {
     static const int nw3_env = getenv("GPMPC_NW3") ? atoi(getenv("GPMPC_NW3")) : -1;       // 0 disables the third launch
     int NW3 = nw3_env >= 0 ? nw3_env : std::max(1, cx.workers / 8);
     if (ntiles3 > 0 && NW3 > ntiles3) NW3 = ntiles3;
-    const long wo_root = ws.hw() * ws.hw(), wo_top2 = wo_root + (long)RH * s_top;
-    const bool split3 = split && NW3 > 0 && nb3 >= 3 && s2 >= SEGR && RH - s2 >= 64 && cx.n_seg >= 3 &&
-                        (ntiles3 + NW3 - 1) / NW3 <= WORKER_MAXT && wo_top2 + (long)(RH - s2) * s2 <= ws.wstride();
+    // W buffers of the three-launch schedule (all in the node-slot part of ws.W): Wt = rows [0, s2) of the root's
+    // first product W = L21 inv11 (s2 x s_top), Wc = [X | W2] (h3 x (s_top + s2)) with W2 the first product of the
+    // right half's top node and X = W_bottom - W2 Wt.  Since inv21 of that node is -I22 W2, the bottom rows of the
+    // root's inv21 = -inv22 W are -I22 (W_bottom - W2 Wt): after the chain ONE product -I22 [X | W2] fills rows
+    // >= s_top + s2 of L^-1 left of the last diagonal block, everything else having been formed behind the launches.
+    const int h3 = RH - s2;
+    const long wo_root = ws.hw() * ws.hw(), wo_c = wo_root + (long)s2 * s_top;
+    const bool split3 = split && NW3 > 0 && nb3 >= 3 && s2 >= SEGR && h3 >= 64 && cx.n_seg >= 3 &&
+                        (ntiles3 + NW3 - 1) / NW3 <= WORKER_MAXT && wo_c + (long)h3 * (s_top + s2) <= ws.wstride();
+    auto product = [&](hipStream_t st, const double* A, long lda, int kfl, const double* B, long ldb, double* C, long ldc,
+                       int M, int N, int K, double alpha, double beta) {   // C = alpha A B + beta C, A K-contiguous, B N-contiguous
+        GemmP g = gemm_base(cx);
+        g.A = A; g.lda = lda; g.sA = 0; g.a_mc = 0;
+        g.B = B; g.ldb = ldb; g.sB = 0; g.b_nc = 1;
+        g.C = C; g.ldc = ldc; g.sC = 0;
+        g.kflags = kfl; g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.beta = beta;
+        launch_gemm(g, 1, st);
+    };
     // inverse pipelined segment by segment behind the chain: next to GEMM launches only
     const bool pipelined = !use_workers && cx.aux && cx.seg && Np >= 4 * SEGR;
     int seg_done = 0;
@@ -448,13 +463,25 @@ static bool factor_chain(const Ctx& cx, Workspace& ws, int spin_limit) {
         hipLaunchKernelGGL(flag_gate_kernel, dim3(ws.batch), dim3(64), 0, cx.aux, ws.flags, (long)nf, chain_ready_index(nb) + 1, 1,
                            -1, 0, spin_limit);
         trtri_range(cx, ws, cx.aux, 0, s_top);
-        trtri_node_w(cx, ws, cx.aux, 0, s_top, Np - s_top, wo_root);
-        if (split3) {                                       // behind the third launch, once it is resident
+        if (!split3) {
+            trtri_node_w(cx, ws, cx.aux, 0, s_top, Np - s_top, wo_root);
+        } else {
+            double* Wt = ws.W + wo_root;
+            double* Wc = ws.W + wo_c;
+            const long ldwc = s_top + s2;
+            // W = L21 inv11, top rows to Wt, bottom rows into the X part of Wc
+            product(cx.aux, ws.L + (long)s_top * ld, ld, KB_GE_N, ws.Inv, ld, Wt, s_top, s2, s_top, s_top, 1.0, 0.0);
+            product(cx.aux, ws.L + (long)(s_top + s2) * ld, ld, KB_GE_N, ws.Inv, ld, Wc, ldwc, h3, s_top, s_top, 1.0, 0.0);
+            // behind the third launch, once it is resident: the third quarter's inverse I11', W2, X and the rows of
+            // the root's inv21 that only need I11'
             hipStreamWaitEvent(cx.aux, cx.seg[cx.n_seg - 3], 0);
             hipLaunchKernelGGL(flag_gate_kernel, dim3(ws.batch), dim3(64), 0, cx.aux, ws.flags, (long)nf, chain_ready_index(nb) + 3, 1,
                                -1, 0, spin_limit);
             trtri_range(cx, ws, cx.aux, s_top, s2);
-            trtri_node_w(cx, ws, cx.aux, s_top, s2, RH - s2, wo_top2);
+            const double* I11 = ws.Inv + (long)s_top * ld + s_top;
+            product(cx.aux, ws.L + (long)(s_top + s2) * ld + s_top, ld, KB_GE_N, I11, ld, Wc + s_top, ldwc, h3, s2, s2, 1.0, 0.0);   // W2
+            product(cx.aux, Wc + s_top, ldwc, 0, Wt, s_top, Wc, ldwc, h3, s_top, s2, -1.0, 1.0);                               // X
+            product(cx.aux, I11, ld, KA_LE_M, Wt, s_top, ws.Inv + (long)s_top * ld, ld, s2, s_top, s2, -1.0, 0.0);
         }
     } else {
         hipLaunchKernelGGL(chain_gate_kernel, dim3(ws.batch), dim3(64), 0, cx.side, ws.flags, (long)nf, spin_limit);
@@ -501,13 +528,14 @@ static bool factor_chain(const Ctx& cx, Workspace& ws, int spin_limit) {
     if (split) {                                            // right half and the second product of the root
         hipEventRecord(cx.seg[cx.n_seg - 1], cx.aux);
         hipStreamWaitEvent(cx.stream, cx.seg[cx.n_seg - 1], 0);
-        if (split3) {                                       // last quarter, second product of the right half's top node
-            trtri_range(cx, ws, cx.stream, s_top + s2, RH - s2);
-            trtri_node_inv(cx, ws, cx.stream, s_top, s2, RH - s2, wo_top2);
+        if (split3) {                                       // last quarter's inverse I22, then -I22 [X | W2]
+            trtri_range(cx, ws, cx.stream, s_top + s2, h3);
+            product(cx.stream, ws.Inv + (long)(s_top + s2) * ld + s_top + s2, ld, KA_LE_M, ws.W + wo_c, s_top + s2,
+                    ws.Inv + (long)(s_top + s2) * ld, ld, h3, s_top + s2, h3, -1.0, 0.0);
         } else {
             trtri_range(cx, ws, cx.stream, s_top, Np - s_top);
+            trtri_node_inv(cx, ws, cx.stream, 0, s_top, Np - s_top, wo_root);
         }
-        trtri_node_inv(cx, ws, cx.stream, 0, s_top, Np - s_top, wo_root);
         return true;
     }
     if (!pipelined) { trtri_levels(cx, ws); return true; }
