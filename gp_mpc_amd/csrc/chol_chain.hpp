@@ -27,8 +27,8 @@ constexpr int CHAIN_LDS_BYTES = 150000;
 // flag layout per matrix (ints): [0] error, [1 .. nb] leafdone, [1+nb .. 2nb] pan1, [1+2nb .. 1+4nb) tdone[k][2],
 // and for the tile-owner workers (chol_worker.hpp): [1+4nb .. 1+5nb) pancount, [1+5nb .. 1+6nb) row2done,
 // [1+6nb .. 1+7nb) colready, [1+7nb .. 1+7nb+512) progress / start time of worker w (diagnostics),
-// [1+7nb+512 .. +4) arrival counter and "all resident" flag of the second and of the third worker launch
-__host__ __device__ inline int chain_flag_count(int nb) { return 1 + 7 * nb + 512 + 4; }
+// [1+7nb+512 .. +8) arrival counter and "all resident" flag of the second, third and fourth worker launch
+__host__ __device__ inline int chain_flag_count(int nb) { return 1 + 7 * nb + 512 + 8; }
 __host__ __device__ inline int chain_colready_index(int nb, int k) { return 1 + 6 * nb + k; }
 __host__ __device__ inline int chain_pan1_index(int nb, int k) { return 1 + nb + k; }
 __host__ __device__ inline int chain_ready_index(int nb) { return 1 + 7 * nb + 512; }   // counter; the flag is the next word

@@ -383,41 +383,57 @@ static bool factor_chain(const Ctx& cx, Workspace& ws, int spin_limit) {
     int NW = ws.batch == 1 ? cx.workers - cx.workers / 8 : 0;
     if (NW > ntiles) NW = ntiles;
     const bool use_workers = NW >= 1 && nb >= 3 && (ntiles + NW - 1) / NW <= WORKER_MAXT;
-    // Worker split: after the first half of the steps three quarters of the tiles are finished.  A second,
-    // smaller worker launch takes over the rest and the CUs it does not need run the part of the inverse that
-    // is computable by then (rows of the first half, W products), gated by flags as next to GEMM launches.
+    // Worker launches and the row-panel schedule of the inverse.  The workers run as up to three launches
+    // (GPMPC_MAX_LAUNCHES), cut where the tree of the triangular inverse has its nodes on the right spine (Np = 4096:
+    // blocks 0-31, 32-47, 48-63 with 224 / 96 / 32 workers: after half of the steps three quarters of the tiles are
+    // finished, and so on; a fourth launch for blocks 56-63 was measured slower, 2.33 against 2.11 ms).  A launch i that has finished leaves rows P_i = [r_i, r_i+1) of L final, and the CUs the NEXT launch does
+    // not need run -- behind a gate that waits until that launch is resident, its workgroups need whole CUs -- the
+    // part of L^-1 that is computable by then.  With S_j = (L[P_j, <r] L^-1[<r, <r]) for a later panel P_j, kept as a
+    // matrix of its own and grown panel by panel,
+    //     I_i = (L[P_i, P_i])^-1 (level-batched, trtri_range),    L^-1[P_i, <r_i] = -I_i S_i,
+    //     W_j = L[P_j, P_i] I_i,   S_j <- [S_j - W_j S_i | W_j]                                    for every j > i,
+    // so that after the chain only the LAST panel's own inverse and ONE product -I S remain.
+    // (History, N = 4096, factor time: two launches 2.22-2.24 ms, three 2.11; pieces gated on the chain's progress by
+    //  polling kernels instead of launch boundaries were slower)
     int s_top = 64;                                         // rows of the left child of the inverse tree's root
     while (2 * s_top < Np) s_top *= 2;
-    const int kb2 = s_top / 64;                             // first block of the second launch
-    const int nb2 = nb - kb2, ntiles2 = (nb2 - 1) * nb2 / 2 - 1;
-    static const int nw2_env = getenv("GPMPC_NW2") ? atoi(getenv("GPMPC_NW2")) : 0;   // (tuning aid)
-    int NW2 = nw2_env > 0 ? nw2_env : std::max(1, cx.workers * 3 / 8);              // 96 of 256 CUs: <= 6 tiles per worker at Np = 4096
-                                                            // (measured: 64 / 96 / 128 / 160 / 192 workers ->
-                                                            //  2.44 / 2.40 / 2.43 / 2.53 / 2.61 ms; with the
-                                                            //  DMA-staged workers 64 .. 160 are within 1 %)
-    if (NW2 > ntiles2) NW2 = std::max(1, ntiles2);
     static const bool split_ok = !(getenv("GPMPC_WORKER_SPLIT") && atoi(getenv("GPMPC_WORKER_SPLIT")) == 0);
-    const bool split = use_workers && split_ok && cx.aux && cx.seg && s_top >= SEGR && nb2 >= 3 &&
-                       (ntiles2 + NW2 - 1) / NW2 <= WORKER_MAXT;
-    // Third launch: the second one is cut once more where the left child of the right half's top node ends (block
-    // kb3), so that this child's inverse and the node's first product also run behind a worker launch instead of
-    // after the chain.
-    const int RH = Np - s_top;
-    int s2 = 64;
-    while (2 * s2 < RH) s2 *= 2;
-    const int kb3 = (s_top + s2) / 64, nb3 = nb - kb3, ntiles3 = (nb3 - 1) * nb3 / 2 - 1;
-    static const int nw3_env = getenv("GPMPC_NW3") ? atoi(getenv("GPMPC_NW3")) : -1;       // 0 disables the third launch
-    int NW3 = nw3_env >= 0 ? nw3_env : std::max(1, cx.workers / 8);
-    if (ntiles3 > 0 && NW3 > ntiles3) NW3 = ntiles3;
-    // W buffers of the three-launch schedule (all in the node-slot part of ws.W): Wt = rows [0, s2) of the root's
-    // first product W = L21 inv11 (s2 x s_top), Wc = [X | W2] (h3 x (s_top + s2)) with W2 the first product of the
-    // right half's top node and X = W_bottom - W2 Wt.  Since inv21 of that node is -I22 W2, the bottom rows of the
-    // root's inv21 = -inv22 W are -I22 (W_bottom - W2 Wt): after the chain ONE product -I22 [X | W2] fills rows
-    // >= s_top + s2 of L^-1 left of the last diagonal block, everything else having been formed behind the launches.
-    const int h3 = RH - s2;
-    const long wo_root = ws.hw() * ws.hw(), wo_c = wo_root + (long)s2 * s_top;
-    const bool split3 = split && NW3 > 0 && nb3 >= 3 && s2 >= SEGR && h3 >= 64 && cx.n_seg >= 3 &&
-                        (ntiles3 + NW3 - 1) / NW3 <= WORKER_MAXT && wo_c + (long)h3 * (s_top + s2) <= ws.wstride();
+    static const int max_launches = getenv("GPMPC_MAX_LAUNCHES") ? atoi(getenv("GPMPC_MAX_LAUNCHES")) : 3;
+    static const int nw2_env = getenv("GPMPC_NW2") ? atoi(getenv("GPMPC_NW2")) : 0;   // (tuning aids)
+    static const int nw3_env = getenv("GPMPC_NW3") ? atoi(getenv("GPMPC_NW3")) : 0;
+    static const int nw4_env = getenv("GPMPC_NW4") ? atoi(getenv("GPMPC_NW4")) : 0;
+    // second launch: 96 of 256 CUs, <= 6 tiles per worker at Np = 4096 (measured: 64 / 96 / 128 / 160 / 192 workers ->
+    // 2.44 / 2.40 / 2.43 / 2.53 / 2.61 ms; with the DMA-staged workers 64 .. 160 are within 1 %)
+    const int nw_rule[4] = {NW, nw2_env > 0 ? nw2_env : std::max(1, cx.workers * 3 / 8),
+                            nw3_env > 0 ? nw3_env : std::max(1, cx.workers / 8), nw4_env > 0 ? nw4_env : std::max(1, cx.workers / 16)};
+    int r[6] = {0, Np, Np, Np, Np, Np}, nws[5] = {NW, 0, 0, 0, 0};   // panel starts r[0..L], r[L] = Np; workers per launch
+    int L = 1;
+    long wofs[5] = {0, 0, 0, 0, 0};                         // S_j of panel j (1 <= j < L) inside ws.W, ld = r[j]
+    if (use_workers && split_ok && cx.aux && cx.seg) {
+        long wo = ws.hw() * ws.hw();
+        int start = s_top;
+        while (L < 4 && L < max_launches && L + 1 <= cx.n_seg - 1) {
+            const int a = start - r[L - 1];                 // rows of the panel the new cut closes
+            const int nbr = (Np - start) / 64, nt = (nbr - 1) * nbr / 2 - 1;
+            int nw = nw_rule[L];
+            if (nt > 0 && nw > nt) nw = nt;
+            if (a < SEGR || nbr < 3 || nt < 1 || (nt + nw - 1) / nw > WORKER_MAXT) break;
+            r[L] = start; nws[L] = nw; ++L;
+            int nxt = 64;                                   // next cut: the left child of what remains
+            while (2 * nxt < Np - start) nxt *= 2;
+            start += nxt;
+            if (start >= Np) break;
+        }
+        r[L] = Np;
+        // storage of S_j: panels 1 .. L-2 a_j x r_j, the last panel (Np - r[L-1]) x r[L-1]; drop cuts that do not fit
+        for (;;) {
+            long need = wo;
+            for (int jj = 1; jj < L; ++jj) { wofs[jj] = need; need += (long)(r[jj + 1] - r[jj]) * r[jj]; }
+            if (L == 1 || need <= ws.wstride()) break;
+            --L; r[L] = Np;
+        }
+    }
+    const bool split = L >= 2;
     auto product = [&](hipStream_t st, const double* A, long lda, int kfl, const double* B, long ldb, double* C, long ldc,
                        int M, int N, int K, double alpha, double beta) {   // C = alpha A B + beta C, A K-contiguous, B N-contiguous
         GemmP g = gemm_base(cx);
@@ -435,53 +451,32 @@ static bool factor_chain(const Ctx& cx, Workspace& ws, int spin_limit) {
                        use_workers ? 1 : 0);
     static const bool verbose = getenv("GPMPC_VERBOSE") != nullptr;
     if (verbose)
-        fprintf(stderr, "gpmpc: factor Np=%d batch=%d: chain kernel + %s, inverse %s\n", Np, ws.batch,
-                split3 ? "tile-owner workers in three launches" : split ? "tile-owner workers in two launches" : use_workers ? "tile-owner workers" : "GEMM launches",
-                split ? "left half behind the second launch" : pipelined ? "pipelined" : "at the end");
-    if (use_workers && !split) {
-        hipLaunchKernelGGL(chol_worker_kernel, dim3(NW, 1, ws.batch), dim3(WORKER_THREADS), WORKER_LDS_BYTES, cx.side, ws.K, ws.L,
-                           (const double*)ws.Inv, ld, sM, nb, ws.flags, (long)nf, cx.crow_mode, spin_limit, 0, nb,
-                           (int*)nullptr, g_chain_trace);
-    } else if (use_workers) {
-        int* ready = ws.flags + chain_ready_index(nb);      // arrival counter + flag of the second launch
-        hipLaunchKernelGGL(chol_worker_kernel, dim3(NW, 1, ws.batch), dim3(WORKER_THREADS), WORKER_LDS_BYTES, cx.side, ws.K, ws.L,
-                           (const double*)ws.Inv, ld, sM, nb, ws.flags, (long)nf, cx.crow_mode, spin_limit, 0, kb2,
-                           (int*)nullptr, g_chain_trace);
-        hipEventRecord(cx.seg[cx.n_seg - 2], cx.side);      // first launch finished: L(:, < kb2) is final
-        hipLaunchKernelGGL(chol_worker_kernel, dim3(NW2, 1, ws.batch), dim3(WORKER_THREADS), WORKER_LDS_BYTES, cx.side, ws.K,
-                           ws.L, (const double*)ws.Inv, ld, sM, nb, ws.flags, (long)nf, cx.crow_mode, spin_limit, kb2,
-                           split3 ? kb3 - kb2 : nb, ready, g_chain_trace);
-        if (split3) {
-            hipEventRecord(cx.seg[cx.n_seg - 3], cx.side);  // second launch finished: L(:, < kb3) is final
-            hipLaunchKernelGGL(chol_worker_kernel, dim3(NW3, 1, ws.batch), dim3(WORKER_THREADS), WORKER_LDS_BYTES, cx.side, ws.K,
-                               ws.L, (const double*)ws.Inv, ld, sM, nb, ws.flags, (long)nf, cx.crow_mode, spin_limit, kb3, nb,
-                               ready + 2, g_chain_trace);
-        }
-        // the left half of the inverse and the first product of the root, on the CUs the second launch leaves
-        // free -- but not before that launch is resident (its workgroups need whole CUs)
-        hipStreamWaitEvent(cx.aux, cx.seg[cx.n_seg - 2], 0);
-        hipLaunchKernelGGL(flag_gate_kernel, dim3(ws.batch), dim3(64), 0, cx.aux, ws.flags, (long)nf, chain_ready_index(nb) + 1, 1,
-                           -1, 0, spin_limit);
-        trtri_range(cx, ws, cx.aux, 0, s_top);
-        if (!split3) {
-            trtri_node_w(cx, ws, cx.aux, 0, s_top, Np - s_top, wo_root);
-        } else {
-            double* Wt = ws.W + wo_root;
-            double* Wc = ws.W + wo_c;
-            const long ldwc = s_top + s2;
-            // W = L21 inv11, top rows to Wt, bottom rows into the X part of Wc
-            product(cx.aux, ws.L + (long)s_top * ld, ld, KB_GE_N, ws.Inv, ld, Wt, s_top, s2, s_top, s_top, 1.0, 0.0);
-            product(cx.aux, ws.L + (long)(s_top + s2) * ld, ld, KB_GE_N, ws.Inv, ld, Wc, ldwc, h3, s_top, s_top, 1.0, 0.0);
-            // behind the third launch, once it is resident: the third quarter's inverse I11', W2, X and the rows of
-            // the root's inv21 that only need I11'
-            hipStreamWaitEvent(cx.aux, cx.seg[cx.n_seg - 3], 0);
-            hipLaunchKernelGGL(flag_gate_kernel, dim3(ws.batch), dim3(64), 0, cx.aux, ws.flags, (long)nf, chain_ready_index(nb) + 3, 1,
-                               -1, 0, spin_limit);
-            trtri_range(cx, ws, cx.aux, s_top, s2);
-            const double* I11 = ws.Inv + (long)s_top * ld + s_top;
-            product(cx.aux, ws.L + (long)(s_top + s2) * ld + s_top, ld, KB_GE_N, I11, ld, Wc + s_top, ldwc, h3, s2, s2, 1.0, 0.0);   // W2
-            product(cx.aux, Wc + s_top, ldwc, 0, Wt, s_top, Wc, ldwc, h3, s_top, s2, -1.0, 1.0);                               // X
-            product(cx.aux, I11, ld, KA_LE_M, Wt, s_top, ws.Inv + (long)s_top * ld, ld, s2, s_top, s2, -1.0, 0.0);
+        fprintf(stderr, "gpmpc: factor Np=%d batch=%d: chain kernel + %s (%d launch%s), inverse %s\n", Np, ws.batch,
+                use_workers ? "tile-owner workers" : "GEMM launches", use_workers ? L : 0, L == 1 ? "" : "es",
+                split ? "by row panels behind the worker launches" : pipelined ? "pipelined" : "at the end");
+    if (use_workers) {
+        for (int i = 0; i < L; ++i) {
+            int* ready = i ? ws.flags + chain_ready_index(nb) + 2 * (i - 1) : nullptr;   // arrival counter + flag of launch i
+            hipLaunchKernelGGL(chol_worker_kernel, dim3(nws[i], 1, ws.batch), dim3(WORKER_THREADS), WORKER_LDS_BYTES, cx.side,
+                               ws.K, ws.L, (const double*)ws.Inv, ld, sM, nb, ws.flags, (long)nf, cx.crow_mode, spin_limit,
+                               r[i] / 64, i + 1 < L ? (r[i + 1] - r[i]) / 64 : nb, ready, g_chain_trace);
+            if (i + 1 == L) break;
+            // launch i finished: rows P_i of L are final.  Behind launch i + 1, once it is resident:
+            hipEventRecord(cx.seg[i], cx.side);
+            hipStreamWaitEvent(cx.aux, cx.seg[i], 0);
+            hipLaunchKernelGGL(flag_gate_kernel, dim3(ws.batch), dim3(64), 0, cx.aux, ws.flags, (long)nf,
+                               chain_ready_index(nb) + 2 * i + 1, 1, -1, 0, spin_limit);
+            const int ri = r[i], a = r[i + 1] - r[i];
+            trtri_range(cx, ws, cx.aux, ri, a);                                    // I_i
+            const double* Ii = ws.Inv + (long)ri * ld + ri;
+            const double* Si = i ? ws.W + wofs[i] : nullptr;                       // a x ri
+            for (int jj = i + 1; jj < L; ++jj) {
+                const int rj = r[jj], hj = r[jj + 1] - r[jj];
+                double* Sj = ws.W + wofs[jj];
+                product(cx.aux, ws.L + (long)rj * ld + ri, ld, KB_GE_N, Ii, ld, Sj + ri, rj, hj, a, a, 1.0, 0.0);        // W_j
+                if (i) product(cx.aux, Sj + ri, rj, 0, Si, ri, Sj, rj, hj, ri, a, -1.0, 1.0);                            // S_j -= W_j S_i
+            }
+            if (i) product(cx.aux, Ii, ld, KA_LE_M, Si, ri, ws.Inv + (long)ri * ld, ld, a, ri, a, -1.0, 0.0);             // L^-1[P_i, <r_i]
         }
     } else {
         hipLaunchKernelGGL(chain_gate_kernel, dim3(ws.batch), dim3(64), 0, cx.side, ws.flags, (long)nf, spin_limit);
@@ -525,17 +520,13 @@ static bool factor_chain(const Ctx& cx, Workspace& ws, int spin_limit) {
     }
     hipEventRecord(cx.join, cx.side);
     hipStreamWaitEvent(cx.stream, cx.join, 0);
-    if (split) {                                            // right half and the second product of the root
+    if (split) {                                            // the last panel: its own inverse, then -I S
         hipEventRecord(cx.seg[cx.n_seg - 1], cx.aux);
         hipStreamWaitEvent(cx.stream, cx.seg[cx.n_seg - 1], 0);
-        if (split3) {                                       // last quarter's inverse I22, then -I22 [X | W2]
-            trtri_range(cx, ws, cx.stream, s_top + s2, h3);
-            product(cx.stream, ws.Inv + (long)(s_top + s2) * ld + s_top + s2, ld, KA_LE_M, ws.W + wo_c, s_top + s2,
-                    ws.Inv + (long)(s_top + s2) * ld, ld, h3, s_top + s2, h3, -1.0, 0.0);
-        } else {
-            trtri_range(cx, ws, cx.stream, s_top, Np - s_top);
-            trtri_node_inv(cx, ws, cx.stream, 0, s_top, Np - s_top, wo_root);
-        }
+        const int rl = r[L - 1], h = Np - rl;
+        trtri_range(cx, ws, cx.stream, rl, h);
+        product(cx.stream, ws.Inv + (long)rl * ld + rl, ld, KA_LE_M, ws.W + wofs[L - 1], rl, ws.Inv + (long)rl * ld, ld,
+                h, rl, h, -1.0, 0.0);
         return true;
     }
     if (!pipelined) { trtri_levels(cx, ws); return true; }
