@@ -411,7 +411,8 @@ static bool factor_chain(const Ctx& cx, Workspace& ws, int spin_limit) {
     long wofs[5] = {0, 0, 0, 0, 0};                         // S_j of panel j (1 <= j < L) inside ws.W, ld = r[j]
     if (use_workers && split_ok && cx.aux && cx.seg) {
         long wo = ws.hw() * ws.hw();
-        int start = s_top;
+        static const int cut1 = getenv("GPMPC_CUT1") ? atoi(getenv("GPMPC_CUT1")) : 0;   // (tuning aid: block of the first cut)
+        int start = (cut1 > 0 && 64 * cut1 < Np) ? 64 * cut1 : s_top;
         while (L < 4 && L < max_launches && L + 1 <= cx.n_seg - 1) {
             const int a = start - r[L - 1];                 // rows of the panel the new cut closes
             const int nbr = (Np - start) / 64, nt = (nbr - 1) * nbr / 2 - 1;
@@ -421,6 +422,8 @@ static bool factor_chain(const Ctx& cx, Workspace& ws, int spin_limit) {
             r[L] = start; nws[L] = nw; ++L;
             int nxt = 64;                                   // next cut: the left child of what remains
             while (2 * nxt < Np - start) nxt *= 2;
+            static const int cut2 = getenv("GPMPC_CUT2") ? atoi(getenv("GPMPC_CUT2")) : 0;   // (tuning aid: block of the second cut)
+            if (L == 2 && cut2 > 0 && 64 * cut2 > start && 64 * cut2 < Np) nxt = 64 * cut2 - start;
             start += nxt;
             if (start >= Np) break;
         }
