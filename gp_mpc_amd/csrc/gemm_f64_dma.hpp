@@ -316,8 +316,9 @@ inline int g_gemm_force_tile = 0;   // gpmpc_set_tuning("gemm_tile", ...): tests
 
 inline int launch_gemm(const GemmP& p, int batch, hipStream_t stream, int force_tile = 0) {
     const int tile = force_tile ? force_tile : g_gemm_force_tile ? g_gemm_force_tile : gemm_pick_tile(p, batch);
-    // GPMPC_GEMM_DMA: bit 0 the 128 x 128 tile, bit 1 the 64 x 64 tile through the DMA-staged kernel (default both)
-    static const int use_dma = getenv("GPMPC_GEMM_DMA") ? atoi(getenv("GPMPC_GEMM_DMA")) : 3;
+    // GPMPC_GEMM_DMA: bit 0 the 128 x 128 tile, bit 1 the 64 x 64 tile, bit 2 the 32 x 32 tile (four-image ring: the
+    // latency-bound small products of the inverse tree, -18 us on the C2 fit) through the DMA-staged kernel; default all
+    static const int use_dma = getenv("GPMPC_GEMM_DMA") ? atoi(getenv("GPMPC_GEMM_DMA")) : 7;
     if (tile == 128 && (use_dma & 1) && gemm_dma_supported(p)) {
         launch_gemm_dma<128, 128, 2, 4, 2, 4>(p, batch, stream, 512);
     } else if (tile == 128) {
@@ -326,6 +327,8 @@ inline int launch_gemm(const GemmP& p, int batch, hipStream_t stream, int force_
         launch_gemm_dma<64, 64, 2, 2, 2, 4>(p, batch, stream, 1024);
     } else if (tile == 64) {
         launch_gemm_cfg<64, 64, 16, 2, 2>(p, batch, stream, 1024);
+    } else if ((use_dma & 4) && gemm_dma_supported(p)) {
+        launch_gemm_dma<32, 32, 2, 1, 4, 4>(p, batch, stream, 1024);
     } else if (p.K % 32 == 0) {
         launch_gemm_cfg<32, 32, 32, 2, 2>(p, batch, stream, 1024);
     } else {
