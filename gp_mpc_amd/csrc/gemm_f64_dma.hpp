@@ -324,7 +324,12 @@ inline int launch_gemm(const GemmP& p, int batch, hipStream_t stream, int force_
     } else if (tile == 128) {
         launch_gemm_cfg<128, 128, 16, 2, 4>(p, batch, stream, 512);
     } else if (tile == 64 && (use_dma & 2) && gemm_dma_supported(p)) {
-        launch_gemm_dma<64, 64, 2, 2, 2, 4>(p, batch, stream, 1024);
+        // long K (the products of the inverse tree): three slab images; short K (the K = 64 updates of the flagged
+        // factorisation, bound by their C traffic): two, so that more workgroups fit a CU  (C2 fit -15 us with three,
+        // C3 fit +8 ms with three everywhere)
+        static const int st64 = getenv("GPMPC_T64_STAGES") ? atoi(getenv("GPMPC_T64_STAGES")) : 0;
+        if (st64 == 3 || (st64 == 0 && p.K >= 256)) launch_gemm_dma<64, 64, 2, 2, 3, 4>(p, batch, stream, 1024);
+        else launch_gemm_dma<64, 64, 2, 2, 2, 4>(p, batch, stream, 1024);
     } else if (tile == 64) {
         launch_gemm_cfg<64, 64, 16, 2, 2>(p, batch, stream, 1024);
     } else if ((use_dma & 4) && gemm_dma_supported(p)) {
