@@ -120,10 +120,15 @@ __global__ void __launch_bounds__(256) chol_chain_kernel(const double* Kmat, dou
         const int bad = leaf_body(S, T, U, Dr, 1, 15, crow_mode, pf);
         CHAIN_STAMP(1);
         if (tid == 0 && bad >= 0) atomicCAS(&info[blockIdx.z], 0, 64 * k + bad + 1);
-        for (int idx = tid; idx < 4096; idx += 256) {
-            const int rr = idx >> 6, cc = idx & 63;
-            Lb[o + (long)rr * ld + cc] = (cc <= rr) ? S[rr * LS + cc] : 0.0;
-            Ib[o + (long)rr * ld + cc] = (cc <= rr) ? T[rr * LS + cc] : 0.0;
+        for (int idx = tid; idx < 2048; idx += 256) {     // two columns per thread: 16-byte global stores
+            const int rr = idx >> 5, cc = (idx & 31) * 2;
+            double2 l, v;
+            l.x = (cc <= rr) ? S[rr * LS + cc] : 0.0;
+            l.y = (cc + 1 <= rr) ? S[rr * LS + cc + 1] : 0.0;
+            v.x = (cc <= rr) ? T[rr * LS + cc] : 0.0;
+            v.y = (cc + 1 <= rr) ? T[rr * LS + cc + 1] : 0.0;
+            *reinterpret_cast<double2*>(&Lb[o + (long)rr * ld + cc]) = l;
+            *reinterpret_cast<double2*>(&Ib[o + (long)rr * ld + cc]) = v;
         }
         // merge_publish (tile-owner workers, which have slack): leafdone[k] goes out together with pan1[k]
         // a few microseconds later, saving one L2 write-back per step on this critical path
@@ -167,9 +172,16 @@ __global__ void __launch_bounds__(256) chol_chain_kernel(const double* Kmat, dou
         for (int tj = 0; tj < 4; ++tj) lds_put16(U, 16 * wave, 16 * tj, acc[tj], 1.0, lane, crow_mode);
         __syncthreads();
 #pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int idx = tid + 256 * i, rr = idx >> 5, cc = (idx & 31) * 2;
+            double2 u;
+            u.x = U[rr * LS + cc];
+            u.y = U[rr * LS + cc + 1];
+            *reinterpret_cast<double2*>(&Lb[o10 + (long)rr * ld + cc]) = u;
+        }
+#pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int idx = tid + 256 * i, rr = idx >> 6, cc = idx & 63;
-            Lb[o10 + (long)rr * ld + cc] = U[rr * LS + cc];
             S[rr * LS + cc] = ps[i];                                              // next diagonal block
         }
         CHAIN_STAMP(5);
