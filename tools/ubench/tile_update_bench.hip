@@ -42,7 +42,18 @@ __global__ void __launch_bounds__(512) k(const double* __restrict__ L0, long ld,
             if (cold == 2 && n == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             dma_wait<0>();
             if (!(ABL & 4)) dma_barrier();
-            if (!(ABL & 16) && t + 1 < T) request(t + 1, pp ^ 1);
+            if (!(ABL & 16) && !(ABL & 32) && t + 1 < T) request(t + 1, pp ^ 1);
+            double2 stage[8];
+            const bool rs = (ABL & 32) && t + 1 < T;
+            if (rs) {      // register staging: this thread's 8 pieces of 16 bytes of the next pair (piece = wave-load index)
+                const int i = (blockIdx.x * 7 + (t + 1) * 3) % nblk, j = (blockIdx.x * 5 + t + 1) % nblk;
+                const double* Ln = L0 + (cold ? (long)(((t + 1) / 9) % 64) * 64 * nblk * ld : 0);
+                const char* pa = (const char*)(Ln + (long)(64 * i) * ld);
+                const char* pb = (const char*)(Ln + (long)(64 * j) * ld);
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    stage[q] = *reinterpret_cast<const double2*>((q < 4 ? pa : pb) + dvo + 128u * (q & 3));
+            }
             const char* img = smem + pp * 65536;
             dma_rsrc_t nra, nrb;
             const bool more = (ABL & 16) && t + 1 < T;
@@ -75,6 +86,12 @@ __global__ void __launch_bounds__(512) k(const double* __restrict__ L0, long ld,
                         C[n][1] = mfma16(a.y, b1.y, C[n][1]);
                     } else { C[n][0][0] += a.x * b0.x; C[n][1][0] += a.y * b1.y; }
                 }
+            if (rs) {
+                char* img = smem + (pp ^ 1) * 65536 + 1024 * wave + 16 * lane;
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    *reinterpret_cast<double2*>(img + (q >> 2) * 32768 + 8192 * (q & 3)) = stage[q];
+            }
             pp ^= 1;
         }
     }
@@ -101,6 +118,8 @@ int main() {
     double *L, *out;
     hipMalloc(&L, (size_t)64 * 64 * nblk * ld * 8); hipMalloc(&out, 256 * 512 * 8);    // 64 panel columns of 132 MB (ld = N)
     hipMemset(L, 0, (size_t)64 * 64 * nblk * ld * 8);
+    run<32, 9>("register-staged (16-byte loads, ds_write_b128)", L, ld, nblk, out, 224, 0);
+    run<32, 9>("register-staged, fresh column + acquire fence", L, ld, nblk, out, 224, 2);
     run<16, 9>("interleaved requests", L, ld, nblk, out, 224, 0);
     run<16, 9>("interleaved requests, fresh column + acquire fence", L, ld, nblk, out, 224, 2);
     run<0, 9>("full, fresh panel column every 9 tiles", L, ld, nblk, out, 224, 1);
