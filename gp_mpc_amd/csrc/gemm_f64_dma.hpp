@@ -303,7 +303,12 @@ inline void launch_gemm_dma(GemmP p, int batch, hipStream_t stream, int resident
             p.tilesNe = (tilesN + 1) / 2;
         }
     }
-    p.npad = p.tilesNe;
+    // XCD-consistent column residues: from 16 tile columns on, the grid width is padded to a multiple of 8 (consecutive
+    // workgroups go round-robin to the 8 XCDs, so every XCD then keeps seeing the same B panels in its own L2).  With
+    // the register-staged kernel this cost 1-3 % (gemm_f64.hpp); with the DMA-staged one it gains 0.5 % on the
+    // variance GEMM and on the step.  GPMPC_PAD_MIN=<tiles> moves the threshold.
+    static const int pad_min = getenv("GPMPC_PAD_MIN") ? atoi(getenv("GPMPC_PAD_MIN")) : 16;
+    p.npad = (p.tilesNe >= pad_min) ? ((p.tilesNe + 7) & ~7) : p.tilesNe;
     const dim3 grid(p.tilesMe * p.npad, 1, batch);
     if (!p.a_mc && !p.b_nc) launch_gemm_dma_kernel<BM, BN, WGM, WGN, STAGES, WPS, false, false>(p, grid, stream);
     else if (!p.a_mc && p.b_nc) launch_gemm_dma_kernel<BM, BN, WGM, WGN, STAGES, WPS, false, true>(p, grid, stream);
