@@ -248,9 +248,12 @@ class Handle:
         Xnew = _f64(Xnew).reshape(-1, self.d)
         Ynew = _f64(Ynew).reshape(Xnew.shape[0], self.Ny)
         info = np.zeros(self.Ny, dtype=np.int32)
-        self.lib.check(self.lib.dll.gpmpc_append(self.h, Xnew.shape[0], _ptr(Xnew), _ptr(Ynew),
-                                                 info.ctypes.data_as(ctypes.c_void_p)))
-        self.N += Xnew.shape[0]
+        rc = self.lib.dll.gpmpc_append(self.h, Xnew.shape[0], _ptr(Xnew), _ptr(Ynew), info.ctypes.data_as(ctypes.c_void_p))
+        n = ctypes.c_int(0)                 # the library is the authority on the size, whether the call succeeded or not
+        self.lib.dll.gpmpc_get_size(self.h, ctypes.byref(n), None, None)
+        self.N = n.value
+        self.info = info
+        self.lib.check(rc)
         return info
 
     def predict_jac(self, method, Z, Sigma=None):

@@ -196,6 +196,10 @@ static int ws_alloc(Workspace& ws, int batch, int Np, int d) {
     HIPCHK(hipMemset(ws.Inv, 0, mb));
     HIPCHK(hipMemset(ws.alpha, 0, (size_t)batch * Np * sizeof(double)));
     HIPCHK(hipMemset(ws.w, 0, (size_t)batch * Np * sizeof(double)));
+    // only factor_with_jitter writes these; gpmpc_set_factors -> gpmpc_append reads jitter without a fit in between
+    HIPCHK(hipMemset(ws.jitter, 0, (size_t)batch * sizeof(double)));
+    HIPCHK(hipMemset(ws.nll, 0, (size_t)batch * sizeof(double)));
+    HIPCHK(hipMemset(ws.info, 0, (size_t)batch * sizeof(int)));
     return GPMPC_OK;
 }
 
@@ -687,14 +691,11 @@ int gpmpc_mfma_selftest(int device, int* layout_out, double* tflops_out) {
     return mfma_selftest(device, layout_out, tflops_out);
 }
 
-int gpmpc_create(int device, int N, int d, int Ny, const double* X, const double* Y, gpmpc_gp** out) {
-    if (!out) return fail(GPMPC_EINVAL, "out is NULL");
-    *out = nullptr;
-    if (N <= 0 || d <= 0 || Ny <= 0 || !X || !Y) return fail(GPMPC_EINVAL, "bad N/d/Ny or NULL data");
-    if (d > DMAX) return fail(GPMPC_EINVAL, "input dimension d=%d exceeds the built-in maximum %d", d, DMAX);
-    CHK(ensure_device(device));
-    gpmpc_gp* h = new gpmpc_gp();
-    h->device = device; h->N = N; h->d = d; h->Ny = Ny; h->Np = round_up(N, 64);
+int gpmpc_destroy(gpmpc_gp* h);
+}  // extern "C"
+
+static int create_impl(gpmpc_gp* h, const double* X, const double* Y) {
+    const int device = h->device, N = h->N, d = h->d, Ny = h->Ny;
     h->crow_mode = g_crow_mode[device];
     HIPCHK(hipStreamCreate(&h->own_stream));
     h->stream = h->own_stream;
@@ -705,8 +706,12 @@ int gpmpc_create(int device, int N, int d, int Ny, const double* X, const double
     // the persistent kernels ask for more than the default 64 KB of dynamic LDS (per device: set for every handle)
     HIPCHK(hipFuncSetAttribute((const void*)chol_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CHAIN_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)chol_worker_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WORKER_LDS_BYTES));
-    h->seg_events.resize(std::max(3, round_up(N, 64) / SEGR + 2));
-    for (auto& e : h->seg_events) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    const size_t nseg = std::max(3, round_up(N, 64) / SEGR + 2);
+    for (size_t i = 0; i < nseg; ++i) {
+        hipEvent_t e;
+        HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        h->seg_events.push_back(e);
+    }
     if (getenv("GPMPC_CHAIN_TRACE") && !g_chain_trace) {
         HIPCHK(hipMalloc(&g_chain_trace, (size_t)(1 << 20) * sizeof(long long)));
         HIPCHK(hipMemset(g_chain_trace, 0, (size_t)(1 << 20) * sizeof(long long)));
@@ -726,9 +731,28 @@ int gpmpc_create(int device, int N, int d, int Ny, const double* X, const double
     HIPCHK(hipMalloc(&h->Y, yt.size() * sizeof(double)));
     HIPCHK(hipMemcpy(h->XT, xt.data(), xt.size() * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->Y, yt.data(), yt.size() * sizeof(double), hipMemcpyHostToDevice));
-    int rc = ws_alloc(h->ws, Ny, Np, d);
-    if (rc != GPMPC_OK) { gpmpc_destroy(h); return rc; }
+    CHK(ws_alloc(h->ws, Ny, Np, d));
     h->hyper.assign((size_t)Ny * (d + 2), 0.0);
+    return GPMPC_OK;
+}
+
+extern "C" {
+
+int gpmpc_create(int device, int N, int d, int Ny, const double* X, const double* Y, gpmpc_gp** out) {
+    if (!out) return fail(GPMPC_EINVAL, "out is NULL");
+    *out = nullptr;
+    if (N <= 0 || d <= 0 || Ny <= 0 || !X || !Y) return fail(GPMPC_EINVAL, "bad N/d/Ny or NULL data");
+    if (d > DMAX) return fail(GPMPC_EINVAL, "input dimension d=%d exceeds the built-in maximum %d", d, DMAX);
+    CHK(ensure_device(device));
+    gpmpc_gp* h = new gpmpc_gp();
+    h->device = device; h->N = N; h->d = d; h->Ny = Ny; h->Np = round_up(N, 64);
+    const int rc = create_impl(h, X, Y);
+    if (rc != GPMPC_OK) {                       // every early exit releases what was created so far
+        const std::string keep = g_err;
+        gpmpc_destroy(h);
+        g_err = keep;
+        return rc;
+    }
     *out = h;
     return GPMPC_OK;
 }
@@ -958,9 +982,10 @@ extern "C" int gpmpc_fit(gpmpc_gp* h, const double* hyper, int want_invK, int* i
 static void free_predict_scratch(gpmpc_gp* h) {
     hipFree(h->Z); hipFree(h->Sigma); hipFree(h->KsT); hipFree(h->part); hipFree(h->meanT);
     hipFree(h->mean); hipFree(h->var); hipFree(h->J); hipFree(h->cov); hipFree(h->UT);
-    hipFree(h->sensH); hipFree(h->sensV); hipFree(h->em); hipFree(h->beta); hipFree(h->gradPartial); hipFree(h->ccpart);
+    hipFree(h->sensH); hipFree(h->sensV); hipFree(h->em); hipFree(h->beta); hipFree(h->gradPartial); hipFree(h->gradOut);
+    hipFree(h->ccpart);
     h->Z = h->Sigma = h->KsT = h->part = h->meanT = h->mean = h->var = h->J = h->cov = h->UT = nullptr;
-    h->sensH = h->sensV = h->em = h->beta = h->gradPartial = h->ccpart = nullptr;
+    h->sensH = h->sensV = h->em = h->beta = h->gradPartial = h->gradOut = h->ccpart = nullptr;
     h->Bcap = 0;
     h->emBytes = 0;
     h->have_beta = false;
@@ -1013,9 +1038,39 @@ extern "C" int gpmpc_append(gpmpc_gp* h, int n, const double* Xnew, const double
         }
     };
     if (!strip) {                                           // too many new rows for the update to pay: plain refit
-        install();
-        std::vector<double> hy = h->hyper;
-        return gpmpc_fit(h, hy.data(), 0, info);
+        // the handle takes the new data set for the duration of the fit; if K turns out not to be positive definite
+        // the old model (data, factors, K^-1 state) is put back, as the header promises
+        double *XT0 = h->XT, *Y0 = h->Y;
+        Workspace ws0 = h->ws;
+        const bool invK0 = h->have_invK;
+        const std::vector<double> hy = h->hyper;
+        free_predict_scratch(h);
+        h->XT = XT1; h->Y = Y1; h->ws = ws1;
+        h->N = N1; h->Np = Np1;
+        const size_t need = Np1 / SEGR + 2;
+        while (h->seg_events.size() < need) {
+            hipEvent_t e;
+            hipEventCreateWithFlags(&e, hipEventDisableTiming);
+            h->seg_events.push_back(e);
+        }
+        rc = gpmpc_fit(h, hy.data(), 0, info);
+        if (rc == GPMPC_OK) {
+            hipFree(XT0); hipFree(Y0);
+            ws_free(ws0);
+            return GPMPC_OK;
+        }
+        const std::string keep = g_err;
+        hipStreamSynchronize(h->stream);
+        ws_free(h->ws);
+        hipFree(XT1); hipFree(Y1);
+        h->XT = XT0; h->Y = Y0; h->ws = ws0;
+        h->N = N0; h->Np = Np0;
+        h->hyper = hy;
+        h->fitted = true;
+        h->have_invK = invK0;
+        h->have_beta = false;
+        g_err = keep;
+        return rc;
     }
     const Ctx cx = h->cx();
     const long ld = Np1, sM = ws1.mat(), sW = ws1.wstride();

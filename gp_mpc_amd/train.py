@@ -54,9 +54,11 @@ def default_init(X, y):
 
 
 def lhs_starts(n, lb, ub, seed):
-    """Seeded Latin hypercube in log space inside [lb, ub] (lower bounds floored at 1e-2 for ell)."""
+    """Seeded Latin hypercube in log space inside [lb, ub].  A non-positive lower bound (the numpy path's
+    ell >= -1, optimize.py:437) is replaced by the IPOPT path's 1e-2 (optimize.py:210) for the purpose of drawing
+    starts: log-uniform draws down to 1e-10 would put most starts where K = sf^2 I."""
     rng = np.random.default_rng(seed)
-    lo = np.log(np.maximum(lb, 1e-10))
+    lo = np.log(np.where(lb > 0, lb, 1e-2))
     hi = np.log(ub)
     dim = len(lb)
     u = (rng.permuted(np.tile(np.arange(n), (dim, 1)), axis=1).T + rng.random((n, dim))) / n
@@ -90,6 +92,7 @@ def train_gp(handle, X, Y, multistart=1, hyper_init=None, optimizer_opts=None,
     """Train all Ny outputs of the model behind `handle` (a `gp_mpc_amd._lib.Handle` holding X, Y)
     and fit it at the optimum.  Returns the reference's `opt` dictionary keys plus diagnostics."""
     from scipy.optimize import minimize
+    from ._lib import GpmpcError
 
     N, Nx = X.shape
     Ny = Y.shape[1]
@@ -132,8 +135,9 @@ def train_gp(handle, X, Y, multistart=1, hyper_init=None, optimizer_opts=None,
                                options=options, bounds=bounds, tol=1e-12)
                 local[r, 0] = res.fun
                 local[r, 1:] = res.x
-            except np.linalg.LinAlgError:
-                pass                                         # this start ran into a non-SPD K twice
+            except (np.linalg.LinAlgError, GpmpcError):
+                pass    # this start ran into a non-SPD K twice, or the optimiser stepped onto an unusable point
+                        # (ell = 0, NaN): the restart counts as failed (inf) and every rank still reaches the gather
         if dist:
             gathered = _all_gather_rows(dist, local, world)   # [world, multistart, Nx+3]
             owner = np.arange(multistart) % world

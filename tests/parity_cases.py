@@ -368,6 +368,55 @@ def check_append(lib, N0, n, d=4, Ny=2, sn=0.1, seed=5):
     h.close()
 
 
+def check_append_after_set_factors(lib, N0=300, n=10, d=4, Ny=2, seed=8):
+    """load_model path followed by update_data_all (gp_class.py:58-66, :474-550): `gpmpc_set_factors` never runs the
+    jitter rule, so the strip update must find a defined (zero) jitter on the device.  Compared with a full refit."""
+    p = go.synthetic_problem(N0 + n, d, Ny, 12, seed=seed, sn=0.1)
+    X, Y, H, Z = p['X'], p['Y'], p['hyper'], p['Z']
+    o0 = go.fit(X[:N0], Y[:N0], H, want_invK=False)
+    h = Handle(lib, X[:N0], Y[:N0])
+    h.set_factors(H, o0['chol'], o0['alpha'])
+    assert np.all(h.append(X[N0:], Y[N0:]) == 0) and h.N == N0 + n
+    f = h.get_factors()
+    o = go.fit(X, Y, H, want_invK=False)
+    for a in range(Ny):
+        assert relF(f['chol'][a], o['chol'][a]) <= 1e-10
+    mean, var = h.predict_mean_var(Z)
+    om, ov, _ = go.mean_var_jac(Z, X, H, o['alpha'], o['chol'], False)
+    assert np.max(np.abs(mean - om) / mean_scale(X, Z, H, o['alpha'])) <= 1e-10
+    assert np.max(np.abs(var - ov) / H[:, d] ** 2) <= 1e-10
+    h.close()
+
+
+def check_append_rollback(lib, seed=4):
+    """gpmpc_append on GPMPC_ENOTPD leaves the model unchanged (include/gpmpc.h), on the strip path and on the refit
+    path: appending exact duplicates with sf^2 = 1e12 >> jitter makes the extended K singular."""
+    rng = np.random.default_rng(seed)
+    for N0 in (40, 300):                      # 40: fewer than 64 old points -> refit path; 300: strip path
+        X = rng.standard_normal((N0, 2)) * 3
+        Y = rng.standard_normal((N0, 1))
+        H = np.array([[0.05, 0.05, 1e6, 1e-12]])
+        h = Handle(lib, X, Y)
+        assert np.all(h.fit(H) == 0)
+        f0 = h.get_factors()
+        Z = rng.standard_normal((5, 2))
+        m0, v0 = h.predict_mean_var(Z)
+        try:
+            h.append(X[:8], Y[:8])
+            raised = False
+        except NotPositiveDefinite:
+            raised = True
+        assert raised and h.N == N0 and np.all(h.info < 0)
+        f1 = h.get_factors()                  # sized by the library's N: a stale size would overrun these buffers
+        assert np.array_equal(f0['chol'], f1['chol']) and np.array_equal(f0['alpha'], f1['alpha'])
+        m1, v1 = h.predict_mean_var(Z)
+        assert np.array_equal(m0, m1) and np.array_equal(v0, v1)
+        # and the handle still takes a good append afterwards
+        Xn = rng.standard_normal((3, 2)) * 3 + 20.0
+        assert np.all(h.append(Xn, rng.standard_normal((3, 1))) == 0) and h.N == N0 + 3
+        h.close()
+
+
 def check_sensitivities(lib, g, nprobe=12):
     """gpmpc_predict_sens (second-order outputs for a casadi Callback) against the oracle's
     closed forms, which tests/test_oracle.py pins by finite differences of the first-order functions."""

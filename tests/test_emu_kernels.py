@@ -106,6 +106,11 @@ def test_emu_append(emu):
     pc.check_append(emu, N0=40, n=30, Ny=1)  # fewer than 64 old points: refit path
 
 
+def test_emu_append_after_set_factors_and_rollback(emu):
+    pc.check_append_after_set_factors(emu)
+    pc.check_append_rollback(emu)
+
+
 def test_emu_sensitivities(emu, tank, car):
     pc.check_sensitivities(emu, tank)
     pc.check_sensitivities(emu, car, nprobe=5)

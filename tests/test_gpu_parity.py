@@ -126,6 +126,12 @@ def test_append(lib):
     pc.check_append(lib, N0=2000, n=90, d=6, Ny=1, sn=1e-2)
 
 
+def test_append_after_set_factors_and_rollback(lib):
+    pc.check_append_after_set_factors(lib)
+    pc.check_append_after_set_factors(lib, N0=2000, n=90, d=6, Ny=1)
+    pc.check_append_rollback(lib)
+
+
 def test_sensitivities(lib, tank, car):
     pc.check_sensitivities(lib, tank)
     pc.check_sensitivities(lib, car, nprobe=20)
