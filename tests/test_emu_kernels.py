@@ -141,3 +141,22 @@ def test_emu_training(emu, train_small):
 
 def test_emu_edge_cases(emu):
     pc.check_edge_cases(emu)
+
+
+def test_emu_config_patterns(emu, car):
+    """Toy-size runs of the C3 / C4 / C5 bodies the GPU tier executes at full size (tests/test_gpu_configs.py)."""
+    import numpy as np
+    import gp_oracle as go
+    from gp_mpc_amd._lib import Handle
+    Ny, d, T = 3, 5, 6
+    p = go.synthetic_problem(150, d, Ny, T, seed=12, sn=0.1)
+    h = Handle(emu, p['X'], p['Y'])
+    assert np.all(h.fit(p['hyper'], want_invK=True) == 0)
+    pc.check_rollout_vs_host_loop(h, p, Ny=Ny, d=d, T=T)
+    f = h.get_factors()
+    pc.check_callback_pattern(h, p['X'], p['hyper'], f['alpha'], f['chol'], p['Z'][:6], p['Sigma'][:6], repeats=1)
+    h.close()
+    pc.check_rollout_vs_oracle(emu, N=120, Ny=3, d=5, T=8)
+    q = go.synthetic_problem(90, 3, 1, 1, seed=4, sn=1e-2)
+    pc.check_random_restarts(emu, q['X'], q['Y'], multistart=4, maxiter=3, min_finite=2)
+    # (check_two_handles_two_threads is GPU-only: the fiber emulator keeps its scheduler state in globals)

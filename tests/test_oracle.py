@@ -240,3 +240,181 @@ def test_sensitivities_match_finite_differences(tank):
     E = np.zeros((d, d)); E[1, 2] = 1.0
     c1 = go.ta_cov(var[:1], J[:1], (S + E)[None])[0]
     assert np.allclose(c1 - cov0[0], dcS[:, :, 1, 2], rtol=1e-12, atol=1e-14)
+
+
+# ---------------------------------------------------------------------------------------------
+# Stronger pins for the CasADi-only functions (a9-a12).  Everything below is built on functions that
+# ARE pinned to the reference's numpy code: `cov_se_ard` (bit-exact vs GP.covSEard / calc_cov_matrix)
+# and the Cholesky-based variance of GP.covar.
+# ---------------------------------------------------------------------------------------------
+def _pinned_mean_var(Zq, X, H, alpha, chol):
+    """mean_a(z) = covSEard(X, z)^T alpha_a and var_a(z) = sf2 - |L^-1 ks|^2 exactly as the reference's numeric
+    code evaluates them (gp_class.py:314-350 kernel, :377-380 variance), for complex or real z."""
+    from scipy.linalg import solve_triangular
+    d = X.shape[1]
+    Ny = H.shape[0]
+    mean = np.zeros((len(Zq), Ny), dtype=Zq.dtype)
+    var = np.zeros((len(Zq), Ny), dtype=Zq.dtype)
+    for a in range(Ny):
+        sf2 = H[a, d] ** 2
+        dist = 0
+        for i in range(d):                      # calc_cov_matrix / covSEard operation order, complex-safe
+            x1 = X[:, i].reshape(-1, 1)
+            x2 = Zq[:, i].reshape(-1, 1)
+            dist = ((x1 ** 2).sum(1).reshape(-1, 1) + (x2 ** 2).sum(1) - 2 * (x1 @ x2.T)) / H[a, i] ** 2 + dist
+        ks = sf2 * np.exp(-.5 * dist)
+        mean[:, a] = ks.T @ alpha[a]
+        v = solve_triangular(chol[a].astype(Zq.dtype), ks, lower=True)
+        var[:, a] = sf2 - np.sum(v * v, axis=0)
+    return mean, var
+
+
+def test_mean_jacobian_and_sensitivities_by_complex_step(tank):
+    """a9's J (CasADi AD in the reference, gp_functions.py:146-147) and the second-order closed forms: the pinned
+    mean / variance are analytic in z, so Im f(z + i h e_p) / h is their derivative to rounding -- a pin at 1e-12
+    instead of the 1e-4 of central differences."""
+    g = tank
+    X, H = g['X'], g['hyper']
+    d = X.shape[1]
+    o = go.fit(X, g['Y'], H, want_invK=False)
+    Z = g['Z'][:4]
+    mean, var, J = go.mean_var_jac(Z, X, H, o['alpha'], o['chol'])
+    Hm, dvar = go.mean_var_sens(Z, X, H, o['alpha'], o['chol'])
+    h = 1e-30
+    ms = np.abs(go.cov_se_ard_direct(X, Z, H[0, :d], 1.0)).T @ np.abs(o['alpha'][0])     # size of the sum's terms
+    for p in range(d):
+        Zc = Z.astype(complex)
+        Zc[:, p] += 1j * h
+        mc, vc = _pinned_mean_var(Zc, X, H, o['alpha'], o['chol'])
+        assert np.max(np.abs(mc.real - mean)) <= 1e-9 * ms.max()
+        assert np.max(np.abs(mc.imag / h - J[:, :, p])) <= 1e-11 * np.abs(J).max() + 1e-12 * ms.max()
+        assert np.max(np.abs(vc.imag / h - dvar[:, :, p])) <= 1e-9 * np.abs(dvar).max()
+    # Hessian of the mean: complex step through the analytic Jacobian (same formula, complex arithmetic)
+    for p in range(d):
+        for b in range(len(Z)):
+            zc = Z[b].astype(complex)
+            zc[p] += 1j * h
+            for a in range(H.shape[0]):
+                ell2 = H[a, :d] ** 2
+                ks = H[a, d] ** 2 * np.exp(-.5 * np.sum((X - zc) ** 2 / ell2, axis=1))
+                Jc = ((ks * o['alpha'][a])[:, None] * (X - zc) / ell2).sum(axis=0)
+                assert np.max(np.abs(Jc.imag / h - Hm[b, a, :, p])) <= 1e-11 * np.abs(Hm[b, a]).max()
+
+
+def _gauss_hermite_moments(mu, Sigma, X, H, alpha, chol, n=64):
+    """E[mean(z)], Cov[mean(z)] + diag(E[var(z)]) under z ~ N(mu, Sigma) by tensor Gauss-Hermite quadrature of the
+    PINNED predictor (d <= 2)."""
+    d = len(mu)
+    t, w = np.polynomial.hermite_e.hermegauss(n)        # weight exp(-t^2/2)
+    w = w / np.sqrt(2 * np.pi)
+    A = np.linalg.cholesky(Sigma)
+    grids = np.meshgrid(*([t] * d), indexing='ij')
+    T = np.stack([g.ravel() for g in grids], axis=1)
+    W = np.ones(len(T))
+    for k in range(d):
+        W = W * w[np.stack([g.ravel() for g in np.meshgrid(*([np.arange(n)] * d), indexing='ij')], axis=1)[:, k]]
+    Zq = mu + T @ A.T
+    m, v = _pinned_mean_var(Zq, X, H, alpha, chol)
+    Em = W @ m
+    Ev = W @ v
+    C = (m * W[:, None]).T @ m - np.outer(Em, Em) + np.diag(Ev)
+    return Em, C
+
+
+@pytest.mark.parametrize('d', [1, 2])
+def test_exact_moment_vs_gauss_hermite_quadrature(d):
+    """a11 `gp_exact_moment` (gp_functions.py:344-418): mean, variances AND the cross-covariance between outputs
+    against quadrature of the pinned ME predictor, to 1e-9 (this replaces a 2 % Monte-Carlo check)."""
+    Ny = 2
+    p = go.synthetic_problem(40, d, Ny, 4, seed=11 + d, sn=0.1)
+    X, Y, H = p['X'], p['Y'], p['hyper']
+    H[:, :d] = [[1.3, 0.9][:d], [0.8, 1.6][:d]]
+    H[:, d] = [1.2, 0.7]
+    f = go.fit(X, Y, H)
+    for (mu, Sigma) in ((np.array([0.3, -0.4][:d]), np.array([[0.09, 0.03], [0.03, 0.16]])[:d, :d]),
+                        (np.array([-1.1, 0.6][:d]), np.array([[0.5, -0.2], [-0.2, 0.3]])[:d, :d])):
+        em_mean, em_cov = go.exact_moment(f['invK'], X, Y, H, mu, Sigma)
+        q_mean, q_cov = _gauss_hermite_moments(mu, Sigma, X, H, f['alpha'], f['chol'], n=80)
+        q2_mean, q2_cov = _gauss_hermite_moments(mu, Sigma, X, H, f['alpha'], f['chol'], n=64)
+        assert np.max(np.abs(q_mean - q2_mean)) <= 1e-12 and np.max(np.abs(q_cov - q2_cov)) <= 1e-11   # converged
+        assert np.max(np.abs(em_mean - q_mean)) <= 1e-9 * max(1.0, np.abs(q_mean).max())
+        assert np.max(np.abs(em_cov - q_cov)) <= 1e-9 * (H[:, d] ** 2).max(), (em_cov, q_cov)
+        assert abs(em_cov[0, 1]) > 1e-4          # the cross-covariance is not trivially zero in this set-up
+
+
+def _old_ta_scalar_loops(invK, X, Y, H, z, S):
+    """`gp_taylor_approx(diag=True)` gp_functions.py:259-340 evaluated entry by entry with explicit loops and CasADi's
+    indexing semantics spelt out (an evaluation independent of the vectorised `go.old_ta`):
+      * `v[e]` on the N x Nx matrix v is linear (column-major) element e, i.e. v[e, 0]           (:327-328)
+      * `var` has Nx entries and is filled output by output, so `var[d]` with d > a is still 0     (:283,:320,:331)
+      * covar_temp keeps only its [0, 0] entry = inputcovar[a, a]                                   (:334-335)"""
+    Ny = len(invK)
+    N, Nx = X.shape
+    v = X - z.reshape(1, Nx)
+    var = [0.0] * Nx
+    d_mean = [0.0] * Ny
+    mean = [0.0] * Ny
+    cov = np.zeros((Ny, Ny))
+    dd = [[0.0] * Ny for _ in range(Ny)]
+    for a in range(Ny):
+        w = [1.0 / H[a, k] ** 2 for k in range(Nx)]
+        sf2 = H[a, Nx] ** 2
+        ks = [sf2 * np.exp(-0.5 * sum((X[i, k] - z[k]) ** 2 / H[a, k] ** 2 for k in range(Nx))) for i in range(N)]
+        alpha = [sum(invK[a][i, j] * Y[j, a] for j in range(N)) for i in range(N)]
+        invKks = [sum(invK[a][i, j] * ks[j] for j in range(N)) for i in range(N)]
+        mean[a] = sum(ks[i] * alpha[i] for i in range(N))
+        var[a] = sf2 - sum(ks[i] * invKks[i] for i in range(N))
+        d_mean[a] = sum(w[a] * v[i, a] * ks[i] * alpha[i] for i in range(N))
+        for d in range(Ny):
+            for e in range(Ny):
+                ve = v[e, 0]                      # v[e]: linear index
+                vd = v[d, 0]                      # v[d]
+                t1a = [sum(v[i, d] * ks[i] * invK[a][i, j] for i in range(N)) for j in range(N)]
+                t1b = sum(t1a[j] * ve * ks[j] for j in range(N))
+                t2 = sum(vd * ve * ks[i] * invKks[i] for i in range(N))
+                dd[d][e] = -2 * w[d] * w[e] * (t1b + t2)
+                if d == e:
+                    dd[d][e] += 2 * w[d] * (sf2 - var[d])
+        cov[a, a] = var[a] + S[a, a] * (0.5 * dd[0][0] + d_mean[0] * d_mean[0])    # trace(covar_temp @ (...))
+    return np.array(mean), cov
+
+
+def test_old_ta_with_input_covariance():
+    """a12 'old_TA' with Sigma != 0: the whole dd_var block, which the Sigma = 0 test never reaches."""
+    p = go.synthetic_problem(30, 4, 3, 3, seed=9, sn=0.1)
+    X, Y, H = p['X'], p['Y'], p['hyper']
+    H[:, :4] = [[1.2, 0.9, 1.5, 1.1], [0.8, 1.4, 1.1, 0.7], [1.0, 1.3, 0.6, 1.9]]
+    f = go.fit(X, Y, H)
+    from scipy.linalg import solve_triangular
+    for b in range(3):
+        z = p['Z'][b]
+        S = p['Sigma'][b] * 200
+        m, c = go.old_ta(f['invK'], X, Y, H, z, S)
+        m2, c2 = _old_ta_scalar_loops(f['invK'], X, Y, H, z, S)
+        assert np.allclose(m, m2, rtol=1e-12, atol=1e-13)
+        assert np.allclose(c, c2, rtol=1e-10, atol=1e-13)
+        assert np.all(np.abs(np.diag(c) - np.diag(go.old_me(f['invK'], X, Y, H, z)[1])) > 1e-8)   # the Sigma term is live
+    # building blocks of :325-331 against derivatives of the pinned variance: -2 w_d (v_d * ks)^T K^-1 ks = d var_a/dz_d
+    z = p['Z'][0]
+    for a in range(3):
+        ell2 = H[a, :4] ** 2
+        ks = go.cov_se_ard_direct(X, z, H[a, :4], H[a, 4] ** 2)[:, 0]
+        for dd_ in range(4):
+            t1a = ((X[:, dd_] - z[dd_]) * ks) @ f['invK'][a]
+            zc = z.astype(complex)
+            zc[dd_] += 1e-30j
+            kc = H[a, 4] ** 2 * np.exp(-.5 * np.sum((X - zc) ** 2 / ell2, axis=1))
+            vc = solve_triangular(f['chol'][a].astype(complex), kc, lower=True)
+            dvar = (-(vc * vc).sum()).imag / 1e-30
+            assert abs(-2 / ell2[dd_] * (t1a @ ks) - dvar) <= 1e-8 * max(1.0, abs(dvar))
+
+
+def test_em_rollout_is_stable_on_well_conditioned_model():
+    """The EM roll-out of OracleGP (the comparison target of the device roll-out in the GPU tier) on a model where
+    K^-1 cancellation does not dominate: repeated runs agree and the covariance stays symmetric PSD."""
+    p = go.synthetic_problem(60, 3, 2, 2, seed=5, sn=0.1)
+    gp = go.OracleGP(p['X'], p['Y'], p['hyper'], gp_method='EM')
+    U = np.tile(np.array([[0.2]]), (6, 1))
+    m1, v1 = gp.rollout(np.array([0.1, -0.2]), U, methods=('EM', 'TA'))
+    assert np.all(np.isfinite(m1)) and np.all(v1 >= 0)
+    assert np.allclose(m1[0, 1], m1[1, 1], rtol=0, atol=2e-2)     # EM ~ TA after one step (Sigma_x = sn^2 I = 0.01 I)
