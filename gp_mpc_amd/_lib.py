@@ -20,6 +20,7 @@ HEADER = os.path.abspath(os.path.join(HERE, '..', 'include', 'gpmpc.h'))
 
 OK, EINVAL, EHIP, ENOTFIT, ENOTPD, ENOMEM = 0, -1, -2, -3, -4, -5
 METHODS = {'ME': 0, 'TA': 1, 'EM': 2, 'old_ME': 3, 'old_TA': 4}
+MEAN_FUNCS = {'zero': 0, 'const': 1, 'linear': 2, 'polynomial': 3}     # gp_functions.py:25-69
 PTR_HOST, PTR_DEVICE = 0, 1
 PHASES = ['gram', 'factor', 'solve', 'invK', 'crosscov', 'vargemm', 'finish', 'em', 'nll']
 
@@ -38,6 +39,8 @@ SIGNATURES = {
                                     ctypes.POINTER(_vp)]),
     'gpmpc_destroy': (ctypes.c_int, [_vp]),
     'gpmpc_get_size': (ctypes.c_int, [_vp, _ip, _ip, _ip]),
+    'gpmpc_set_mean_func': (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int]),
+    'gpmpc_hyper_width': (ctypes.c_int, [_vp, _ip]),
     'gpmpc_set_pointer_mode': (ctypes.c_int, [_vp, ctypes.c_int]),
     'gpmpc_set_stream': (ctypes.c_int, [_vp, _vp]),
     'gpmpc_synchronize': (ctypes.c_int, [_vp]),
@@ -171,6 +174,7 @@ class Handle:
         lib.check(lib.dll.gpmpc_create(device, self.N, self.d, self.Ny, _ptr(X), _ptr(Y), ctypes.byref(h)))
         self.h = h
         self.device_mode = False
+        self.nh = self.d + 2                 # entries of a hyper row: [ell.., sf, sn] + mean-function parameters
 
     def close(self):
         if getattr(self, 'h', None):
@@ -182,6 +186,16 @@ class Handle:
             self.close()
         except Exception:
             pass
+
+    def set_mean_func(self, mean_func='zero', add_to_prediction=False):
+        """Prior mean function 'zero' | 'const' | 'linear' | 'polynomial' (gp_functions.py:25-69); hyper rows grow by
+        its parameters.  add_to_prediction: build_gp(meanFunc=...) semantics, see include/gpmpc.h."""
+        if mean_func not in MEAN_FUNCS:
+            raise NameError('No mean function called: ' + str(mean_func))          # gp_functions.py:67
+        self.lib.check(self.lib.dll.gpmpc_set_mean_func(self.h, MEAN_FUNCS[mean_func], int(add_to_prediction)))
+        w = ctypes.c_int(0)
+        self.lib.check(self.lib.dll.gpmpc_hyper_width(self.h, ctypes.byref(w)))
+        self.nh = w.value
 
     def set_pointer_mode(self, device: bool):
         self.lib.check(self.lib.dll.gpmpc_set_pointer_mode(self.h, PTR_DEVICE if device else PTR_HOST))
@@ -205,7 +219,7 @@ class Handle:
         return out
 
     def fit(self, hyper, want_invK=False):
-        hyper = _f64(hyper).reshape(self.Ny, self.d + 2)
+        hyper = _f64(hyper).reshape(self.Ny, self.nh)
         info = np.zeros(self.Ny, dtype=np.int32)
         rc = self.lib.dll.gpmpc_fit(self.h, _ptr(hyper), int(want_invK), info.ctypes.data_as(ctypes.c_void_p))
         self.info = info
@@ -214,7 +228,7 @@ class Handle:
 
     def get_factors(self, chol=True, alpha=True, invK=False):
         N, Ny = self.N, self.Ny
-        hyper = np.zeros((Ny, self.d + 2))
+        hyper = np.zeros((Ny, self.nh))
         L = np.zeros((Ny, N, N)) if chol else None
         al = np.zeros((Ny, N)) if alpha else None
         iK = np.zeros((Ny, N, N)) if invK else None
@@ -222,7 +236,7 @@ class Handle:
         return dict(hyper=hyper, chol=L, alpha=al, invK=iK)
 
     def set_factors(self, hyper, chol, alpha=None, invK=None):
-        hyper = _f64(hyper).reshape(self.Ny, self.d + 2)
+        hyper = _f64(hyper).reshape(self.Ny, self.nh)
         chol = _f64(chol).reshape(self.Ny, self.N, self.N)
         alpha = None if alpha is None else _f64(alpha).reshape(self.Ny, self.N)
         invK = None if invK is None else _f64(invK).reshape(self.Ny, self.N, self.N)
@@ -311,9 +325,9 @@ class Handle:
         return out
 
     def nll(self, a, hyper_row, want_grad=False):
-        hyper_row = _f64(hyper_row).reshape(self.d + 2)
+        hyper_row = _f64(hyper_row).reshape(self.nh)
         val = ctypes.c_double(0.0)
-        grad = np.zeros(self.d + 2) if want_grad else None
+        grad = np.zeros(self.nh) if want_grad else None
         jit = ctypes.c_int(0)
         self.lib.check(self.lib.dll.gpmpc_nll(self.h, int(a), _ptr(hyper_row), ctypes.byref(val), _ptr(grad),
                                               ctypes.byref(jit)))

@@ -426,6 +426,80 @@ inline void launch_sens(hipStream_t st, int d, const double* XT, const double* Z
 #undef GPMPC_SK
 }
 
+// ---- prior mean functions (gp_functions.py:25-69): m(x) = 0 | c | a^T x + c | a^T x^2 + b^T x + c ----------------
+// Parameter row (what follows sn in a hyper row, gp_functions.py:52-62): const [c]; linear [a_1..a_d, c];
+// polynomial [a_1..a_d, b_1..b_d, c].  MEAN_* mirror GPMPC_MEAN_* of include/gpmpc.h.
+constexpr int MEAN_ZERO = 0, MEAN_CONST = 1, MEAN_LINEAR = 2, MEAN_POLY = 3;
+constexpr int MPW = 2 * DMAX + 1;   // stride of a mean-parameter row on the device
+__host__ __device__ inline int mean_param_count(int kind, int d) {
+    return kind == MEAN_CONST ? 1 : kind == MEAN_LINEAR ? d + 1 : kind == MEAN_POLY ? 2 * d + 1 : 0;
+}
+// m(x) for a point whose coordinates are x[k * stride], k < d
+__device__ __forceinline__ double mean_eval(int kind, const double* __restrict__ mp, const double* __restrict__ x,
+                                            long stride, int d) {
+    if (kind == MEAN_CONST) return mp[0];
+    double s = 0.0;
+    if (kind == MEAN_LINEAR) {
+        for (int k = 0; k < d; ++k) s += mp[k] * x[k * stride];
+        return s + mp[d];
+    }
+    for (int k = 0; k < d; ++k) {
+        const double xv = x[k * stride];
+        s += mp[k] * (xv * xv) + mp[d + k] * xv;
+    }
+    return s + mp[2 * d];
+}
+
+// Yc[a][i] = Y[a][i] - m_a(x_i): the vector alpha and the NLL are formed from (optimize.py:75,285,494).
+// grid (Np/256, batch), 256 threads.  mpar: [batch][MPW].
+__global__ void __launch_bounds__(256) mean_resid_kernel(const double* __restrict__ XT, const double* __restrict__ Y,
+                                                         const double* __restrict__ mpar, double* __restrict__ Yc,
+                                                         int kind, int N, int Np, int d, long sy) {
+    const int i = blockIdx.x * 256 + threadIdx.x, a = blockIdx.y;
+    if (i >= Np) return;
+    double v = 0.0;
+    if (i < N) v = Y[(long)a * sy + i] - mean_eval(kind, mpar + (long)a * MPW, XT + i, Np, d);
+    Yc[(long)a * Np + i] = v;
+}
+
+// d NLL / d (mean parameters) = -alpha^T dm/dtheta (from NLL = 1/2 (y-m)^T K^-1 (y-m) + ...):
+// const: -sum alpha; linear a_k: -sum alpha_i x_ik; polynomial a_k: -sum alpha_i x_ik^2, b_k: -sum alpha_i x_ik.
+// One workgroup, one wave per parameter in turn, fixed order.  out[count].
+__global__ void __launch_bounds__(256) mean_grad_kernel(const double* __restrict__ XT, const double* __restrict__ alpha,
+                                                        double* __restrict__ out, int kind, int N, int Np, int d) {
+    const int count = mean_param_count(kind, d), lane = threadIdx.x & 63;
+    for (int e = threadIdx.x >> 6; e < count; e += 4) {
+        const bool is_c = e == count - 1;
+        const int k = (kind == MEAN_POLY && e >= d) ? e - d : e;
+        const bool sq = kind == MEAN_POLY && e < d;
+        double s = 0.0;
+        for (int i = lane; i < N; i += 64) {
+            const double xv = is_c ? 1.0 : XT[(long)k * Np + i];
+            s += alpha[i] * (sq ? xv * xv : xv);
+        }
+        s = wave_sum(s);
+        if (lane == 0) out[e] = -s;
+    }
+}
+
+// build_gp with meanFunc (gp_functions.py:131,135): mean_a(z) += m_a(z); its derivatives follow: J_a += a (+ 2 a z
+// + b), Hm_a += diag(2 a).  One thread per (point, output).  Any of mean / J / Hm may be NULL.
+__global__ void __launch_bounds__(256) mean_add_kernel(const double* __restrict__ Z, const double* __restrict__ mpar,
+                                                       double* __restrict__ mean, double* __restrict__ J,
+                                                       double* __restrict__ Hm, int kind, int B, int Ny, int d) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long)B * Ny) return;
+    const int a = (int)(e % Ny);
+    const long b = e / Ny;
+    const double* mp = mpar + (long)a * MPW;
+    const double* z = Z + b * d;
+    if (mean) mean[e] += mean_eval(kind, mp, z, 1, d);
+    if (J && kind >= MEAN_LINEAR)
+        for (int k = 0; k < d; ++k) J[e * d + k] += kind == MEAN_LINEAR ? mp[k] : 2.0 * mp[k] * z[k] + mp[d + k];
+    if (Hm && kind == MEAN_POLY)
+        for (int k = 0; k < d; ++k) Hm[(e * d + k) * d + k] += 2.0 * mp[k];
+}
+
 // a17 on the device: input of step t of an uncertainty-propagation roll-out from the output of step t-1
 // (GP.predict_compare's loop gp_class.py:777-804 with GP.predict's re-standardisation :253-261 folded in):
 //   z_t = [sa * mean_{t-1} + sb, u_t],   Sigma_t[:Ny,:Ny] = cov_{t-1}  (the other blocks keep their initial values).

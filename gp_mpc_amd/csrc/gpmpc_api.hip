@@ -607,7 +607,16 @@ struct gpmpc_gp {
     Workspace tws;                       // training workspace, batch = 1 (lazy)
     double* gradPartial = nullptr;
     double* gradOut = nullptr;
-    std::vector<double> hyper;           // host copy [Ny][d+2]
+    std::vector<double> hyper;           // host copy [Ny][nh()]: [ell.., sf, sn, mean parameters]
+    // prior mean function (gp_functions.py:25-69): kind GPMPC_MEAN_*, its parameters per output on the device,
+    // and the residual targets y - m(X) that alpha and the NLL are formed from
+    int mean_kind = 0;
+    bool mean_add = false;               // add m(z) to the predicted mean (build_gp's meanFunc argument)
+    double* mpar = nullptr;              // [Ny][MPW]
+    double* Yc = nullptr;                // [Ny][Np]
+    double *tmpar = nullptr, *tYc = nullptr;   // the same for the single-output training workspace
+    int nh() const { return d + 2 + mean_param_count(mean_kind, d); }
+    const double* y_model() const { return mean_kind ? Yc : Y; }
     // predict scratch
     int Bcap = 0;
     double *Z = nullptr, *Sigma = nullptr, *KsT = nullptr, *part = nullptr, *meanT = nullptr;
@@ -662,6 +671,31 @@ static int prof_collect(gpmpc_gp* h) {
         }
         h->prof.ev[ph].clear();
     }
+    return GPMPC_OK;
+}
+
+// ---- prior mean function plumbing ------------------------------------------------------------------------------
+// Splits host hyper rows [rows][nh] into the kernel part [rows][d+2] (what the SE-ARD kernels read) and uploads the
+// mean parameters to `mpar_dev` ([rows][MPW]); then forms Yc = Y - m(X) for `rows` outputs starting at Y.
+static int upload_mean_and_residual(gpmpc_gp* h, const double* hyper_rows, int rows, std::vector<double>& kernel_part,
+                                    double** mpar_dev, const double* Y, double** Yc_dev) {
+    const int d = h->d, nh = h->nh(), cnt = mean_param_count(h->mean_kind, d);
+    kernel_part.resize((size_t)rows * (d + 2));
+    for (int a = 0; a < rows; ++a) std::memcpy(&kernel_part[(size_t)a * (d + 2)], hyper_rows + (size_t)a * nh, (d + 2) * sizeof(double));
+    if (!h->mean_kind) return GPMPC_OK;
+    std::vector<double> mp((size_t)rows * MPW, 0.0);
+    for (int a = 0; a < rows; ++a)
+        for (int k = 0; k < cnt; ++k) {
+            const double v = hyper_rows[(size_t)a * nh + d + 2 + k];
+            if (!(v == v)) return fail(GPMPC_EINVAL, "mean-function parameter %d of row %d is NaN", k, a);
+            mp[(size_t)a * MPW + k] = v;
+        }
+    if (!*mpar_dev) HIPCHK(hipMalloc(mpar_dev, (size_t)rows * MPW * sizeof(double)));
+    if (!*Yc_dev) HIPCHK(hipMalloc(Yc_dev, (size_t)rows * h->Np * sizeof(double)));
+    HIPCHK(hipStreamSynchronize(h->stream));     // `mp` is a stack-lifetime source: the copy below must not outlive it
+    HIPCHK(hipMemcpy(*mpar_dev, mp.data(), mp.size() * sizeof(double), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(mean_resid_kernel, dim3((h->Np + 255) / 256, rows), dim3(256), 0, h->stream, h->XT, Y, *mpar_dev, *Yc_dev,
+                       h->mean_kind, h->N, h->Np, d, (long)h->Np);
     return GPMPC_OK;
 }
 
@@ -764,6 +798,7 @@ int gpmpc_destroy(gpmpc_gp* h) {
     ws_free(h->ws);
     ws_free(h->tws);
     hipFree(h->XT); hipFree(h->Y); hipFree(h->gradPartial); hipFree(h->gradOut);
+    hipFree(h->mpar); hipFree(h->Yc); hipFree(h->tmpar); hipFree(h->tYc);
     hipFree(h->Z); hipFree(h->Sigma); hipFree(h->KsT); hipFree(h->part); hipFree(h->meanT);
     hipFree(h->mean); hipFree(h->var); hipFree(h->J); hipFree(h->cov); hipFree(h->em);
     hipFree(h->beta); hipFree(h->UT); hipFree(h->sensH); hipFree(h->sensV); hipFree(h->ccpart);
@@ -787,6 +822,26 @@ int gpmpc_get_size(const gpmpc_gp* h, int* N, int* d, int* Ny) {
     if (N) *N = h->N;
     if (d) *d = h->d;
     if (Ny) *Ny = h->Ny;
+    return GPMPC_OK;
+}
+
+int gpmpc_set_mean_func(gpmpc_gp* h, int kind, int add_to_prediction) {
+    if (!h) return fail(GPMPC_EINVAL, "NULL handle");
+    if (kind < GPMPC_MEAN_ZERO || kind > GPMPC_MEAN_POLYNOMIAL) return fail(GPMPC_EINVAL, "No mean function with code %d", kind);
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->mean_kind = kind;
+    h->mean_add = add_to_prediction != 0;
+    h->hyper.assign((size_t)h->Ny * h->nh(), 0.0);     // rows change width: the model has to be fitted / loaded again
+    h->fitted = false;
+    h->have_invK = false;
+    h->have_beta = false;
+    return GPMPC_OK;
+}
+
+int gpmpc_hyper_width(const gpmpc_gp* h, int* width) {
+    if (!h || !width) return fail(GPMPC_EINVAL, "NULL handle/width");
+    *width = h->nh();
     return GPMPC_OK;
 }
 
@@ -944,9 +999,10 @@ static int factor_with_jitter(gpmpc_gp* h, Workspace& ws, const double* hyper_ho
 extern "C" int gpmpc_fit(gpmpc_gp* h, const double* hyper, int want_invK, int* info) {
     if (!h || !hyper) return fail(GPMPC_EINVAL, "NULL handle/hyper");
     HIPCHK(hipSetDevice(h->device));
+    const int nh = h->nh();
     for (int a = 0; a < h->Ny; ++a)
         for (int k = 0; k < h->d + 2; ++k) {
-            const double v = hyper[(size_t)a * (h->d + 2) + k];
+            const double v = hyper[(size_t)a * nh + k];
             if (!(v == v) || (k < h->d && v == 0.0) || (k == h->d && v == 0.0))
                 return fail(GPMPC_EINVAL, "hyper[%d][%d] = %g is not a usable SE-ARD parameter", a, k, v);
         }
@@ -954,10 +1010,12 @@ extern "C" int gpmpc_fit(gpmpc_gp* h, const double* hyper, int want_invK, int* i
     h->have_invK = false;
     h->have_beta = false;
     int post_rc = GPMPC_OK;
-    CHK(factor_with_jitter(h, h->ws, hyper, info, [&]() {
+    std::vector<double> kpart;           // [Ny][d+2]; y - m(X) goes to h->Yc (optimize.py:285,494)
+    CHK(upload_mean_and_residual(h, hyper, h->Ny, kpart, &h->mpar, h->Y, &h->Yc));
+    CHK(factor_with_jitter(h, h->ws, kpart.data(), info, [&]() {
         {
             PhaseTimer t(h, GPMPC_PH_SOLVE);
-            solve_alpha(h->cx(), h->ws, h->Y, h->Np);
+            solve_alpha(h->cx(), h->ws, h->y_model(), h->Np);
         }
         if (want_invK) {
             PhaseTimer t(h, GPMPC_PH_INVK);
@@ -967,7 +1025,7 @@ extern "C" int gpmpc_fit(gpmpc_gp* h, const double* hyper, int want_invK, int* i
     CHK(post_rc);
     if (want_invK) h->have_invK = true;
     HIPCHK(hipGetLastError());
-    h->hyper.assign(hyper, hyper + (size_t)h->Ny * (h->d + 2));
+    h->hyper.assign(hyper, hyper + (size_t)h->Ny * nh);
     h->fitted = true;
     return GPMPC_OK;
 }
@@ -983,13 +1041,21 @@ static void free_predict_scratch(gpmpc_gp* h) {
     hipFree(h->Z); hipFree(h->Sigma); hipFree(h->KsT); hipFree(h->part); hipFree(h->meanT);
     hipFree(h->mean); hipFree(h->var); hipFree(h->J); hipFree(h->cov); hipFree(h->UT);
     hipFree(h->sensH); hipFree(h->sensV); hipFree(h->em); hipFree(h->beta); hipFree(h->gradPartial); hipFree(h->gradOut);
-    hipFree(h->ccpart);
+    hipFree(h->ccpart); hipFree(h->Yc); hipFree(h->tYc);
+    h->Yc = h->tYc = nullptr;
     h->Z = h->Sigma = h->KsT = h->part = h->meanT = h->mean = h->var = h->J = h->cov = h->UT = nullptr;
     h->sensH = h->sensV = h->em = h->beta = h->gradPartial = h->gradOut = h->ccpart = nullptr;
     h->Bcap = 0;
     h->emBytes = 0;
     h->have_beta = false;
     ws_free(h->tws);
+}
+
+// y - m(X) of the model's current data and stored mean parameters (after the data changed)
+static int refresh_residual(gpmpc_gp* h) {
+    if (!h->mean_kind) return GPMPC_OK;
+    std::vector<double> unused;
+    return upload_mean_and_residual(h, h->hyper.data(), h->Ny, unused, &h->mpar, h->Y, &h->Yc);
 }
 
 extern "C" int gpmpc_append(gpmpc_gp* h, int n, const double* Xnew, const double* Ynew, int* info) {
@@ -1069,6 +1135,7 @@ extern "C" int gpmpc_append(gpmpc_gp* h, int n, const double* Xnew, const double
         h->fitted = true;
         h->have_invK = invK0;
         h->have_beta = false;
+        refresh_residual(h);
         g_err = keep;
         return rc;
     }
@@ -1130,7 +1197,8 @@ extern "C" int gpmpc_append(gpmpc_gp* h, int n, const double* Xnew, const double
         return fail(GPMPC_ENOTPD, "the extended K is not positive definite with the stored hyper-parameters and jitter");
     }
     install();
-    solve_alpha(h->cx(), h->ws, h->Y, h->Np);
+    CHK(refresh_residual(h));
+    solve_alpha(h->cx(), h->ws, h->y_model(), h->Np);
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipGetLastError());
     return GPMPC_OK;
@@ -1193,8 +1261,10 @@ extern "C" int gpmpc_set_factors(gpmpc_gp* h, const double* hyper, const double*
     h->fitted = false;
     h->have_invK = false;
     h->have_beta = false;
-    h->hyper.assign(hyper, hyper + (size_t)h->Ny * (h->d + 2));
-    HIPCHK(hipMemcpy(h->ws.hyper, hyper, h->hyper.size() * sizeof(double), hipMemcpyHostToDevice));
+    h->hyper.assign(hyper, hyper + (size_t)h->Ny * h->nh());
+    std::vector<double> kpart;
+    CHK(upload_mean_and_residual(h, hyper, h->Ny, kpart, &h->mpar, h->Y, &h->Yc));
+    HIPCHK(hipMemcpy(h->ws.hyper, kpart.data(), kpart.size() * sizeof(double), hipMemcpyHostToDevice));
     CHK(import_mats(h, chol, h->ws.L, true));
     factor_blocked(h->cx(), h->ws, false);  // L^-1 from the stored L
     if (alpha) {
@@ -1202,7 +1272,7 @@ extern "C" int gpmpc_set_factors(gpmpc_gp* h, const double* hyper, const double*
         for (int a = 0; a < h->Ny; ++a) std::memcpy(tmp.data() + (size_t)a * h->Np, alpha + (size_t)a * h->N, h->N * sizeof(double));
         HIPCHK(hipMemcpy(h->ws.alpha, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice));
     } else {
-        solve_alpha(h->cx(), h->ws, h->Y, h->Np);
+        solve_alpha(h->cx(), h->ws, h->y_model(), h->Np);
     }
     if (invK) {
         CHK(ws_need_invK(h->ws));
@@ -1316,6 +1386,9 @@ static int predict_chunk(gpmpc_gp* h, int B, const double* dZ, double* dMean, do
         PhaseTimer t(h, GPMPC_PH_FINISH);
         hipLaunchKernelGGL(var_finish_kernel, dim3(B), dim3(256), 0, cx.stream, h->part, h->meanT,
                            h->ws.hyper, dMean, dVar, B, Bp, Ny, h->d, tilesM);
+        if (h->mean_kind && h->mean_add && (dMean || dJ))   // build_gp(meanFunc=...): mean += m(z), gp_functions.py:131,135
+            hipLaunchKernelGGL(mean_add_kernel, dim3((unsigned)(((long)B * Ny + 255) / 256)), dim3(256), 0, cx.stream, dZ, h->mpar,
+                               dMean, dJ, (double*)nullptr, h->mean_kind, B, Ny, h->d);
     }
     HIPCHK(hipGetLastError());
     return GPMPC_OK;
@@ -1330,6 +1403,8 @@ static int predict_driver(gpmpc_gp* h, int method, int B, const double* Z, const
     if (!h) return fail(GPMPC_EINVAL, "NULL handle");
     if (!h->fitted) return fail(GPMPC_ENOTFIT, "model has no factors (call gpmpc_fit or gpmpc_set_factors)");
     if (B <= 0 || !Z) return fail(GPMPC_EINVAL, "bad B or NULL Z");
+    if (method == GPMPC_OLD_TA && h->mean_kind)   // gp_functions.py:311: m(inputmean) has Nx entries there, Y[:, a] - m(...) does not conform
+        return fail(GPMPC_EINVAL, "'old_TA' with a non-zero mean function raises in the reference (gp_functions.py:309-311); not served");
     const bool need_sigma = (method == GPMPC_TA || method == GPMPC_EM || method == GPMPC_OLD_TA);
     if (cov && need_sigma && !Sigma) return fail(GPMPC_EINVAL, "this method needs the input covariance Sigma");
     HIPCHK(hipSetDevice(h->device));
@@ -1409,6 +1484,8 @@ extern "C" int gpmpc_rollout(gpmpc_gp* h, int method, int T, const double* z0, c
     const int d = h->d, Ny = h->Ny, Nu = d - Ny;
     if (T <= 0 || !z0 || !Sigma0 || !mean || !cov || (Nu > 0 && !U)) return fail(GPMPC_EINVAL, "bad T or NULL argument");
     if (Nu < 0) return fail(GPMPC_EINVAL, "roll-out needs d >= Ny (inputs are [state, control])");
+    if (method == GPMPC_OLD_TA && h->mean_kind)
+        return fail(GPMPC_EINVAL, "'old_TA' with a non-zero mean function raises in the reference (gp_functions.py:309-311); not served");
     HIPCHK(hipSetDevice(h->device));
     CHK(ensure_scratch(h, 1));
     const bool moments = method == GPMPC_EM || method == GPMPC_OLD_ME || method == GPMPC_OLD_TA;
@@ -1507,6 +1584,9 @@ extern "C" int gpmpc_predict_sens(gpmpc_gp* h, int B, const double* Z, double* m
             p.M = Bp; p.N = Np; p.K = Np;
             launch_gemm(p, Ny, cx.stream);
             launch_sens(cx.stream, d, h->XT, dZ, h->ws.hyper, h->ws.alpha, h->KsT, h->UT, oH, oV, h->N, Np, nb, Bp, Ny);
+            if (h->mean_kind == GPMPC_MEAN_POLYNOMIAL && h->mean_add)
+                hipLaunchKernelGGL(mean_add_kernel, dim3((unsigned)(((long)nb * Ny + 255) / 256)), dim3(256), 0, cx.stream, dZ,
+                                   h->mpar, (double*)nullptr, (double*)nullptr, oH, h->mean_kind, nb, Ny, d);
         }
         if (host) {
             if (mean) HIPCHK(hipMemcpyAsync(mean + (size_t)b0 * Ny, h->mean, (size_t)nb * Ny * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -1568,7 +1648,7 @@ extern "C" int gpmpc_covar(gpmpc_gp* h, int n, const double* Xnew, double* covar
     hipFree(C);
     std::vector<double> out((size_t)Ny * n * n);
     for (int a = 0; a < Ny; ++a) {
-        const double sf = h->hyper[(size_t)a * (d + 2) + d];
+        const double sf = h->hyper[(size_t)a * h->nh() + d];
         for (int i = 0; i < n; ++i)
             for (int j = 0; j < n; ++j) out[((size_t)a * n + i) * n + j] = sf * sf + tmp[((size_t)a * Bp + i) * Bp + j];
     }
@@ -1590,17 +1670,22 @@ extern "C" int gpmpc_nll(gpmpc_gp* h, int a, const double* hyper_row, double* nl
     if (!h->tws.K) {
         CHK(ws_alloc(h->tws, 1, Np, d));
         HIPCHK(hipMalloc(&h->gradPartial, (size_t)(Np / 64) * (Np / 64) * (DMAX + 2) * sizeof(double)));
-        HIPCHK(hipMalloc(&h->gradOut, (DMAX + 2) * sizeof(double)));
+        HIPCHK(hipMalloc(&h->gradOut, (DMAX + 2 + MPW) * sizeof(double)));
     }
     Workspace& ws = h->tws;
     int info = 0;
     const Ctx cx = h->cx();
     if (grad) CHK(ws_need_invK(ws));
+    // prior mean: the objective is evaluated on y - m(X) (calc_NLL optimize.py:43,75,96)
+    std::vector<double> kpart;
+    CHK(upload_mean_and_residual(h, hyper_row, 1, kpart, &h->tmpar, h->Y + (size_t)a * Np, &h->tYc));
+    const double* ytrain = h->mean_kind ? h->tYc : h->Y + (size_t)a * Np;
+    const int nmean = mean_param_count(h->mean_kind, d);
     // everything that follows the factorisation is enqueued before the host waits for `info` (factor_with_jitter)
     CHK(factor_with_jitter(h, ws, hyper_row, &info, [&]() {
         {
             PhaseTimer t(h, GPMPC_PH_SOLVE);
-            solve_alpha(cx, ws, h->Y + (size_t)a * Np, Np);
+            solve_alpha(cx, ws, ytrain, Np);
         }
         {
             PhaseTimer t(h, GPMPC_PH_NLL);
@@ -1622,12 +1707,15 @@ extern "C" int gpmpc_nll(gpmpc_gp* h, int a, const double* hyper_row, double* nl
                                ws.alpha, h->gradPartial, h->N, Np, d);
             hipLaunchKernelGGL(nll_grad_finish_kernel, dim3(1), dim3(64), 0, cx.stream, h->gradPartial, ws.hyper,
                                h->gradOut, Np, d);
+            if (nmean)
+                hipLaunchKernelGGL(mean_grad_kernel, dim3(1), dim3(256), 0, cx.stream, h->XT, ws.alpha, h->gradOut + d + 2,
+                                   h->mean_kind, h->N, Np, d);
         }
     }));
     if (jitter_out) *jitter_out = info;
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(nll, ws.nll, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    if (grad) HIPCHK(hipMemcpyAsync(grad, h->gradOut, (d + 2) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (grad) HIPCHK(hipMemcpyAsync(grad, h->gradOut, (d + 2 + nmean) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return GPMPC_OK;
 }

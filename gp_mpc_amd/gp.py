@@ -36,11 +36,14 @@ class GP:
     def __init__(self, X, Y, mean_func="zero", gp_method="TA",
                  optimizer_opts=None, hyper=None, normalize=True, multistart=1,
                  xlb=None, xub=None, ulb=None, uub=None, meta=None,
-                 optimize_nummeric=True, device=0, lib=None):
+                 optimize_nummeric=True, device=0, lib=None, predict_adds_mean=False):
         """Initialize and optimize GP model (gp_class.py:21-75).
 
-        Extra arguments: `device` (GPU ordinal) and `lib` (a loaded `GpmpcLib`; default: the
-        in-tree libgpmpc_hip.so, raising if it is missing)."""
+        Extra arguments: `device` (GPU ordinal), `lib` (a loaded `GpmpcLib`; default: the in-tree
+        libgpmpc_hip.so, raising if it is missing) and `predict_adds_mean`: the reference builds its predictor
+        WITHOUT the mean function (`build_gp(...)` is called with its default meanFunc='zero', gp_class.py:68-71),
+        so a model trained with mean_func != 'zero' predicts ks^T alpha only; that is the default here too.
+        True gives build_gp(..., meanFunc=mean_func) (gp_functions.py:131,135): mean(z) = ks^T alpha + m(z)."""
         self._lib = lib if lib is not None else _lib.get_lib()
         self._device = device
         X = np.array(X, dtype=np.float64).copy()
@@ -54,6 +57,7 @@ class GP:
         self.__gp_method = gp_method
         self.__mean_func = mean_func
         self.__normalize = normalize
+        self._predict_adds_mean = bool(predict_adds_mean)
         self._h = None
         self._check_mean_func(mean_func)
 
@@ -83,6 +87,7 @@ class GP:
             self.__hyper_noise_variance = self.__hyper[:, self.__Nx + 1] ** 2
             self.__hyper_mean = self.__hyper[:, (self.__Nx + 1):]
             self._new_handle()
+            self._h.set_mean_func(mean_func, self._predict_adds_mean)
             self._h.set_factors(self.__hyper, np.array(hyper['chol'], dtype=np.float64),
                                 None if hyper.get('alpha') is None else np.array(hyper['alpha'], dtype=np.float64),
                                 None if hyper.get('invK') is None else np.array(hyper['invK'], dtype=np.float64))
@@ -93,9 +98,6 @@ class GP:
     def _check_mean_func(mean_func):
         if mean_func not in ('zero', 'const', 'linear', 'polynomial'):
             raise NameError('No mean function called: ' + str(mean_func))      # gp_functions.py:67
-        if mean_func != 'zero':
-            # the reference's own default training path supports only the zero mean (optimize.py:377-379)
-            raise NotImplementedError("mean_func='%s': only the zero prior mean is on the HIP path" % mean_func)
 
     def _new_handle(self):
         if self._h is not None:
@@ -104,6 +106,7 @@ class GP:
 
     def _refit(self, want_invK=False):
         self._new_handle()
+        self._h.set_mean_func(self.__mean_func, self._predict_adds_mean)
         self._h.fit(self.__hyper, want_invK=want_invK)
 
     @property
@@ -151,7 +154,8 @@ class GP:
         self._new_handle()
         opt = train_gp(self._h, self.__X, self.__Y, multistart=multistart, hyper_init=hyp_init,
                        optimizer_opts=opts, numpy_path_conventions=optimize_nummeric,
-                       random_restarts=random_restarts, seed=seed, gradient=gradient)
+                       random_restarts=random_restarts, seed=seed, gradient=gradient,
+                       mean_func=mean_func, predict_adds_mean=self._predict_adds_mean)
         self.__hyper = opt['hyper']
         self.__lam_x = opt['lam_x']
         self.__hyper_length_scales = self.__hyper[:, :self.__Nx]

@@ -44,6 +44,23 @@ def bounds_ipopt_path(Nx):
     return lb, ub
 
 
+MEAN_PARAMS = {'zero': lambda Nx: 0, 'const': lambda Nx: 1, 'linear': lambda Nx: Nx + 1,
+               'polynomial': lambda Nx: 2 * Nx + 1}          # h_m, optimize.py:136-145
+
+
+def mean_param_bounds(lb, ub, mean_func, h_m, meanF):
+    """Mean-parameter box of train_gp, optimize.py:221-229, written into the last h_m entries of lb / ub."""
+    if mean_func == 'const':
+        lb[-1], ub[-1] = -1e2, 1e2
+    elif mean_func != 'zero':
+        lb[-1] = meanF / 10 - 1e-8
+        ub[-1] = meanF * 10 + 1e-8
+        if lb[-1] > ub[-1]:                 # DIFF: a negative output mean makes the reference's box empty
+            lb[-1], ub[-1] = ub[-1], lb[-1]
+        lb[-h_m:-1] = -1e-2
+        ub[-h_m:-1] = 1e-2
+
+
 def default_init(X, y):
     Nx = X.shape[1]
     h = np.zeros(Nx + 2)
@@ -88,9 +105,17 @@ def _all_gather_rows(dist, local, world, device=None):
 
 def train_gp(handle, X, Y, multistart=1, hyper_init=None, optimizer_opts=None,
              numpy_path_conventions=True, random_restarts=False, seed=1234, gradient='analytic',
-             method='SLSQP'):
+             method='SLSQP', mean_func='zero', predict_adds_mean=False):
     """Train all Ny outputs of the model behind `handle` (a `gp_mpc_amd._lib.Handle` holding X, Y)
-    and fit it at the optimum.  Returns the reference's `opt` dictionary keys plus diagnostics."""
+    and fit it at the optimum.  Returns the reference's `opt` dictionary keys plus diagnostics.
+
+    mean_func (gp_functions.py:25-69): on the IPOPT-path conventions the h_m mean parameters are optimised together
+    with the kernel's, inside the box of optimize.py:221-229, on the objective of `calc_NLL` (y - m(X) in place of y).
+    On the numpy-path conventions the reference's objective `calc_NLL_numpy` ignores them (optimize.py:377-379) and
+    its `bounds` array is assembled before their box is written (:443 vs :451-458): they stay at their initial value
+    0, which is what this driver returns as well (hyper rows are padded with h_m zeros)."""
+    if mean_func not in MEAN_PARAMS:
+        raise NameError('No mean function called: ' + str(mean_func))
     from scipy.optimize import minimize
     from ._lib import GpmpcError
 
@@ -99,23 +124,36 @@ def train_gp(handle, X, Y, multistart=1, hyper_init=None, optimizer_opts=None,
     options = {'disp': False, 'maxiter': 10000}
     if optimizer_opts is not None:
         options.update(optimizer_opts)
-    lb, ub = bounds_numpy_path(Nx) if numpy_path_conventions else bounds_ipopt_path(Nx)
-    bounds = np.stack([lb, ub], axis=1)
+    h_m = MEAN_PARAMS[mean_func](Nx)
+    opt_mean = h_m > 0 and not numpy_path_conventions        # are the mean parameters decision variables?
+    handle.set_mean_func(mean_func if opt_mean else 'zero', predict_adds_mean)
+    nv = Nx + 2 + (h_m if opt_mean else 0)
+    lbk, ubk = bounds_numpy_path(Nx) if numpy_path_conventions else bounds_ipopt_path(Nx)
 
     dist = _dist()
     rank = dist.get_rank() if dist else 0
     world = dist.get_world_size() if dist else 1
 
-    hyp_opt = np.zeros((Ny, Nx + 2))
+    hyp_opt = np.zeros((Ny, Nx + 2 + h_m))
     all_obj = np.zeros((Ny, multistart))
     n_eval = 0
     for a in range(Ny):
+        lb = np.concatenate([lbk, np.full(nv - Nx - 2, -np.inf)])
+        ub = np.concatenate([ubk, np.full(nv - Nx - 2, np.inf)])
+        if opt_mean:
+            mean_param_bounds(lb, ub, mean_func, h_m, np.mean(Y[:, a]))
+        bounds = np.stack([lb, ub], axis=1)
         if random_restarts:
-            starts = lhs_starts(multistart, lb, ub, seed + a)
+            starts = np.zeros((multistart, nv))
+            starts[:, :Nx + 2] = lhs_starts(multistart, lbk, ubk, seed + a)
             if hyper_init is not None:
-                starts[0] = hyper_init[a]
+                starts[0] = np.asarray(hyper_init[a], dtype=np.float64)[:nv]
         else:
-            h0 = default_init(X, Y[:, a]) if hyper_init is None else np.asarray(hyper_init[a], dtype=np.float64)
+            if hyper_init is None:
+                h0 = np.zeros(nv)                               # optimize.py:215-219: mean parameters start at 0
+                h0[:Nx + 2] = default_init(X, Y[:, a])
+            else:
+                h0 = np.asarray(hyper_init[a], dtype=np.float64)[:nv]
             starts = np.tile(h0, (multistart, 1))            # optimize.py:462-466: identical restarts
 
         def fun(h):
@@ -126,7 +164,7 @@ def train_gp(handle, X, Y, multistart=1, hyper_init=None, optimizer_opts=None,
                 return v, g
             return handle.nll(a, h)
 
-        local = np.full((multistart, Nx + 3), np.inf)
+        local = np.full((multistart, nv + 1), np.inf)
         for r in range(multistart):
             if r % world != rank:
                 continue
@@ -145,8 +183,9 @@ def train_gp(handle, X, Y, multistart=1, hyper_init=None, optimizer_opts=None,
         if not np.isfinite(local[:, 0]).any():
             raise np.linalg.LinAlgError('every restart failed for output %d' % a)
         best = int(np.argmin(local[:, 0]))                    # optimize.py:474
-        hyp_opt[a] = local[best, 1:]
+        hyp_opt[a, :nv] = local[best, 1:]
         all_obj[a] = local[:, 0]
 
-    info = handle.fit(hyp_opt, want_invK=True)               # optimize.py:476-494 at theta*
+    handle.set_mean_func(mean_func, predict_adds_mean)
+    info = handle.fit(hyp_opt, want_invK=True)               # optimize.py:476-494 / :264-285 at theta*
     return dict(hyper=hyp_opt, lam_x=0, obj=all_obj, info=info, n_eval=n_eval, rank=rank, world=world)

@@ -43,6 +43,13 @@ extern "C" {
 #define GPMPC_OLD_ME 3 /* 'old_ME' gp_class.py:225-229: gp()                               */
 #define GPMPC_OLD_TA 4 /* 'old_TA' gp_class.py:230-235: gp_taylor_approx(diag=True)        */
 
+/* prior mean functions: the strings of get_mean_function, gp_functions.py:25-69.  With a mean function set, a hyper
+ * row is [ell_1..ell_d, sf, sn, mean parameters] (train_gp optimize.py:136-151): */
+#define GPMPC_MEAN_ZERO 0       /* 'zero'        m(x) = 0                        no parameters          */
+#define GPMPC_MEAN_CONST 1      /* 'const'       m(x) = c                        [c]                    */
+#define GPMPC_MEAN_LINEAR 2     /* 'linear'      m(x) = a^T x + c                [a_1..a_d, c]          */
+#define GPMPC_MEAN_POLYNOMIAL 3 /* 'polynomial'  m(x) = a^T x^2 + b^T x + c      [a_1..a_d, b_1..b_d, c] */
+
 #define GPMPC_PTR_HOST 0
 #define GPMPC_PTR_DEVICE 1
 
@@ -76,6 +83,16 @@ int gpmpc_create(int device, int N, int d, int Ny, const double* X, const double
 int gpmpc_destroy(gpmpc_gp* h);
 /* (N, d, Ny); GP.get_size gp_class.py:266-274 derives (N, Ny, Nu = d - Ny) from these. */
 int gpmpc_get_size(const gpmpc_gp* h, int* N, int* d, int* Ny);
+/* Prior mean function of the model (get_mean_function gp_functions.py:25-69; train_gp optimize.py:100-294 is the
+ * reference path that trains with one).  alpha and the NLL are then formed from y - m(X) (optimize.py:75,96,285), and
+ * every hyper array of this API -- gpmpc_fit, gpmpc_get_factors, gpmpc_set_factors, gpmpc_nll (and its gradient) -- has
+ * rows of gpmpc_hyper_width() = d + 2 + #parameters entries.  add_to_prediction != 0 adds m(z) to the predicted mean and
+ * its derivatives, i.e. build_gp(..., meanFunc=kind) gp_functions.py:131,135; 0 reproduces GP.__init__, which calls
+ * build_gp WITHOUT meanFunc (gp_class.py:68-71), so the reference's GP object predicts ks^T alpha only.  'EM' and
+ * 'old_ME' ignore the mean function like the reference (gp_functions.py:383,232); 'old_TA' with one is refused (the
+ * reference raises there, gp_functions.py:309-311).  Changing the kind discards the factors. */
+int gpmpc_set_mean_func(gpmpc_gp* h, int kind, int add_to_prediction);
+int gpmpc_hyper_width(const gpmpc_gp* h, int* width);
 int gpmpc_set_pointer_mode(gpmpc_gp* h, int mode);
 int gpmpc_set_stream(gpmpc_gp* h, void* hip_stream); /* NULL restores the handle's own stream */
 int gpmpc_synchronize(gpmpc_gp* h);
@@ -87,9 +104,9 @@ int gpmpc_profile_read(gpmpc_gp* h, int phase, double* total_ms, long* launches,
  * rule (optimize.py:345-350, :483-488; gp_class.py:524-529): info[a] = 0 ok, 1 = 1e-8*I was added
  * once, and the call returns GPMPC_ENOTPD (info[a] = -(first bad pivot index, 1-based)) if that
  * also fails.  alpha = K^-1 y (optimize.py:494), and if want_invK: K^-1 (optimize.py:489-490).
- * hyper is [Ny x (d+2)]; info may be NULL. */
+ * hyper is [Ny x gpmpc_hyper_width()] (= d+2 for the zero mean); info may be NULL. */
 int gpmpc_fit(gpmpc_gp* h, const double* hyper, int want_invK, int* info);
-/* Export in the reference's save_model layout (gp_class.py:693-704): hyper[Ny x (d+2)],
+/* Export in the reference's save_model layout (gp_class.py:693-704): hyper[Ny x gpmpc_hyper_width()],
  * chol[Ny x N x N] (lower, zeros above), alpha[Ny x N], invK[Ny x N x N]; any pointer may be NULL. */
 int gpmpc_get_factors(gpmpc_gp* h, double* hyper, double* chol, double* alpha, double* invK);
 /* Append n training points and update L, L^-1, alpha with the EXISTING hyper-parameters: the result of
@@ -139,8 +156,9 @@ int gpmpc_rollout(gpmpc_gp* h, int method, int T, const double* z0, const double
 int gpmpc_covar(gpmpc_gp* h, int n, const double* Xnew, double* covar);
 
 /* ---- training objective: a7 (+ gradient) ------------------------------------------------- */
-/* NLL of output `a` at hyper_row[d+2] (calc_NLL_numpy optimize.py:322-356: 0.5 y^T alpha +
- * sum log|L_ii|, jitter rule included); grad[d+2] (may be NULL) is dNLL/dhyper, Rasmussen &
+/* NLL of output `a` at hyper_row[gpmpc_hyper_width()] (calc_NLL_numpy optimize.py:322-356: 0.5 y^T alpha +
+ * sum log|L_ii|, jitter rule included; with a mean function calc_NLL optimize.py:22-97 without its unused
+ * hyper-priors); grad[gpmpc_hyper_width()] (may be NULL) is dNLL/dhyper, Rasmussen &
  * Williams eq. 5.9 -- the reference has no analytic gradient (optimize.py:371-375).
  * jitter_out (may be NULL) reports whether the jitter branch was taken. */
 int gpmpc_nll(gpmpc_gp* h, int a, const double* hyper_row, double* nll, double* grad, int* jitter_out);

@@ -185,6 +185,110 @@ def nll_grad(hyper, X, y):
 
 
 # --------------------------------------------------------------------------
+# f4  prior mean functions
+# --------------------------------------------------------------------------
+def mean_param_count(func, Nx):
+    """h_m of optimize.py:136-145."""
+    if func == 'zero':
+        return 0
+    if func == 'const':
+        return 1
+    if func == 'linear':
+        return Nx + 1
+    if func == 'polynomial':
+        return 2 * Nx + 1
+    raise NameError('No mean function called: ' + func)        # gp_functions.py:67 / optimize.py:145
+
+
+def mean_function(hyper_row, X, func='zero'):
+    """`get_mean_function` gp_functions.py:25-69 evaluated on the rows of X[n, Nx] (the reference hands it X.T and
+    indexes columns): the parameters are the LAST entries of the hyper row --
+    const: a = hyp[-1]; linear: a = hyp[-Nx-1:-1], b = hyp[-1]; polynomial: a = hyp[-2Nx-1:-Nx-1], b = hyp[-Nx-1:-1],
+    c = hyp[-1], m(x) = a^T x^2 + b^T x + c."""
+    X = np.atleast_2d(np.asarray(X, dtype=np.float64))
+    n, Nx = X.shape
+    hyp = np.asarray(hyper_row, dtype=np.float64)
+    if func == 'zero':
+        return np.zeros(n)
+    if func == 'const':
+        return np.full(n, hyp[-1])
+    if func == 'linear':
+        return X @ hyp[-Nx - 1:-1] + hyp[-1]
+    if func == 'polynomial':
+        return (X ** 2) @ hyp[-2 * Nx - 1:-Nx - 1] + X @ hyp[-Nx - 1:-1] + hyp[-1]
+    raise NameError('No mean function called: ' + func)
+
+
+def nll_mean(hyper, X, y, func='zero'):
+    """`calc_NLL` optimize.py:22-97 with prior=None (:157): NLL(Y - m(X), alpha, log det) :95-97, i.e. the pinned
+    `calc_NLL_numpy` objective on the residual y - m(X) (alpha itself is formed from the residual, :75)."""
+    D = X.shape[1]
+    return nll(np.asarray(hyper)[:D + 2], X, y - mean_function(hyper, X, func))
+
+
+def nll_mean_grad(hyper, X, y, func='zero'):
+    """Gradient of `nll_mean` w.r.t. the whole row: the kernel part as `nll_grad` on the residual, the mean part
+    -alpha^T dm/dtheta (no reference function: CasADi AD inside IPOPT, optimize.py:168-194)."""
+    D = X.shape[1]
+    hyper = np.asarray(hyper, dtype=np.float64)
+    r = y - mean_function(hyper, X, func)
+    v, g = nll_grad(hyper[:D + 2], X, r)
+    f = fit_output(X, r, hyper[:D + 2], want_invK=False)
+    al = f['alpha']
+    if func == 'const':
+        gm = np.array([-al.sum()])
+    elif func == 'linear':
+        gm = np.concatenate([-(X.T @ al), [-al.sum()]])
+    elif func == 'polynomial':
+        gm = np.concatenate([-((X ** 2).T @ al), -(X.T @ al), [-al.sum()]])
+    else:
+        gm = np.zeros(0)
+    return v, np.concatenate([g, gm])
+
+
+def fit_mean(X, Y, hyper, func='zero', want_invK=True):
+    """train_gp's recomputation at the optimum with a mean function, optimize.py:264-285: K, L, invK from the kernel
+    part; alpha = K^-1 (y - m(X))."""
+    N, Ny = Y.shape
+    D = X.shape[1]
+    R = np.stack([Y[:, a] - mean_function(hyper[a], X, func) for a in range(Ny)], axis=1)
+    return fit(X, R, np.asarray(hyper)[:, :D + 2], want_invK)
+
+
+def mean_func_jac(hyper_row, Z, func='zero'):
+    """d m / d z at the rows of Z (what CasADi's jacobian of build_gp's mean adds, gp_functions.py:131,146-147)."""
+    Z = np.atleast_2d(np.asarray(Z, dtype=np.float64))
+    n, Nx = Z.shape
+    hyp = np.asarray(hyper_row, dtype=np.float64)
+    if func == 'linear':
+        return np.tile(hyp[-Nx - 1:-1], (n, 1))
+    if func == 'polynomial':
+        return 2 * Z * hyp[-2 * Nx - 1:-Nx - 1] + hyp[-Nx - 1:-1]
+    return np.zeros((n, Nx))
+
+
+def train_bounds_mean(Nx, func, meanF, numpy_path=False):
+    """Box bounds of the IPOPT path with a mean function, optimize.py:204-229 (numpy path :434-458 sets the same
+    mean-parameter bounds AFTER `bounds` was assembled :443, so SLSQP never sees them)."""
+    h_m = mean_param_count(func, Nx)
+    lb = -np.inf * np.ones(Nx + 2 + h_m)
+    ub = np.inf * np.ones(Nx + 2 + h_m)
+    lb[:Nx], ub[:Nx] = (1 - 2, 2e2) if numpy_path else (1e-2, 1e2)
+    lb[Nx], ub[Nx] = 1e-8, 1e2
+    lb[Nx + 1], ub[Nx + 1] = 10 ** -10, 10 ** -2
+    if numpy_path:
+        return lb, ub
+    if func == 'const':
+        lb[-1], ub[-1] = -1e2, 1e2
+    elif func != 'zero':
+        lb[-1] = meanF / 10 - 1e-8
+        ub[-1] = meanF * 10 + 1e-8
+        lb[-h_m:-1] = -1e-2
+        ub[-h_m:-1] = 1e-2
+    return lb, ub
+
+
+# --------------------------------------------------------------------------
 # a8  multistart training
 # --------------------------------------------------------------------------
 def train_bounds(Nx):
@@ -242,7 +346,7 @@ def train(X, Y, multistart=1, hyper_init=None, optimizer_opts=None):
 # --------------------------------------------------------------------------
 # a9 / a10  mean, variance, mean Jacobian, TA covariance
 # --------------------------------------------------------------------------
-def mean_var_jac(Z, X, hyper, alpha, chol, want_jac=True):
+def mean_var_jac(Z, X, hyper, alpha, chol, want_jac=True, mean_func='zero'):
     """a9: `build_gp` gp_functions.py:72-149, zero mean, batched over rows of
     Z[B,d].  ks_i direct form :114-117; mean = ks^T alpha :119-120,135;
     v = L^-1 ks :122-123,133; var = sf^2 - v^T v :125-126,136 (kss = sf^2, no
@@ -259,7 +363,7 @@ def mean_var_jac(Z, X, hyper, alpha, chol, want_jac=True):
         ell = hyper[a, :d]
         sf2 = hyper[a, d] ** 2
         ks = cov_se_ard_direct(X, Z, ell, sf2)          # [N, B]
-        mean[:, a] = ks.T @ alpha[a]
+        mean[:, a] = ks.T @ alpha[a] + mean_function(hyper[a], Z, mean_func)     # :119-120,131,135
         v = solve_triangular(chol[a], ks, lower=True)
         var[:, a] = sf2 - np.sum(v * v, axis=0)
         if want_jac:
@@ -267,6 +371,7 @@ def mean_var_jac(Z, X, hyper, alpha, chol, want_jac=True):
             for dd in range(d):
                 diff = X[:, dd:dd + 1] - Z[None, :, dd]  # [N, B]
                 J[:, a, dd] = np.sum(w * diff, axis=0) / ell[dd] ** 2
+            J[:, a, :] += mean_func_jac(hyper[a], Z, mean_func)
     return mean, var, J
 
 

@@ -827,3 +827,100 @@ def check_two_handles_two_threads(lib, N, d=6, B=256, reps=6):
     for hh in handles:
         hh.close()
     assert not errs, errs
+
+
+def check_mean_functions(lib, N=150, d=3, Ny=2, seed=31):
+    """f4: prior mean functions 'const' / 'linear' / 'polynomial' (gp_functions.py:25-69) through fit, NLL (+ gradient),
+    prediction with and without m(z) (build_gp's meanFunc argument vs GP.__init__'s call), data update, training."""
+    from gp_mpc_amd._lib import GpmpcError, EINVAL
+    from gp_mpc_amd.gp import GP
+    p = go.synthetic_problem(N, d, Ny, 9, seed=seed, sn=0.1)
+    X, Y, Hk, Z, S = p['X'], p['Y'], p['hyper'], p['Z'], p['Sigma']
+    Y = Y + 0.4 + 0.3 * X[:, :1]                       # something for a mean function to explain
+    rng = np.random.default_rng(seed)
+    h0 = Handle(lib, X, Y)
+    h0.fit(Hk, want_invK=True)
+    em0 = h0.predict('EM', Z[:3], S[:3] * 20)
+    h0.close()
+    for func in ('const', 'linear', 'polynomial'):
+        hm = go.mean_param_count(func, d)
+        H = np.hstack([Hk, rng.uniform(-0.3, 0.3, (Ny, hm))])
+        o = go.fit_mean(X, Y, H, func)
+        h = Handle(lib, X, Y)
+        h.set_mean_func(func, False)
+        assert h.nh == d + 2 + hm
+        assert np.all(h.fit(H) == 0)
+        f = h.get_factors()
+        assert np.array_equal(f['hyper'], H)
+        for a in range(Ny):
+            assert relF(f['chol'][a], o['chol'][a]) <= 1e-10 and relF(f['alpha'][a], o['alpha'][a]) <= 1e-9
+            v, g = h.nll(a, H[a], want_grad=True)
+            ov, og = go.nll_mean_grad(H[a], X, Y[:, a], func)
+            assert abs(v - go.nll_mean(H[a], X, Y[:, a], func)) / (abs(ov) + N) <= 1e-10
+            assert np.max(np.abs(g - og) / (np.abs(og) + 1e-3 * np.abs(og).max())) <= 1e-6, (func, g, og)
+        # GP.__init__'s predictor (build_gp without meanFunc): ks^T alpha only
+        ms = mean_scale(X, Z, Hk, o['alpha'])
+        mean, var = h.predict_mean_var(Z)
+        om, ov_, oJ = go.mean_var_jac(Z, X, Hk, o['alpha'], o['chol'])
+        assert np.max(np.abs(mean - om) / ms) <= 1e-10 and np.max(np.abs(var - ov_)) <= 1e-10
+        # build_gp(meanFunc=func): + m(z), Jacobian + dm/dz, TA covariance through that Jacobian
+        h.set_mean_func(func, True)
+        h.fit(H)
+        mean, cov, J = h.predict_jac('TA', Z, S)
+        om, ov_, oJ = go.mean_var_jac(Z, X, H, o['alpha'], o['chol'], mean_func=func)
+        assert np.max(np.abs(mean - om) / (ms + 1.0)) <= 1e-10
+        assert np.max(np.abs(J - oJ)) <= 1e-10 * max(1.0, np.abs(oJ).max())
+        assert np.max(np.abs(cov - go.ta_cov(ov_, oJ, S))) <= 1e-10
+        m1, v1, J1, Hm, dvar = h.predict_sens(Z[:2])
+        oH, odv = go.mean_var_sens(Z[:2], X, Hk, o['alpha'], o['chol'])
+        if func == 'polynomial':
+            for a in range(Ny):
+                oH[:, a] += np.diag(2 * H[a, d + 2:d + 2 + d])
+        assert np.max(np.abs(Hm - oH)) <= 1e-9 * max(1.0, np.abs(oH).max()) and np.max(np.abs(dvar - odv)) <= 1e-9
+        assert np.array_equal(m1, mean[:2]) and np.array_equal(J1, J[:2])
+        # the moment methods ignore the mean function like the reference (beta = K^-1 y, gp_functions.py:383)
+        em = h.predict('EM', Z[:3], S[:3] * 20)
+        assert np.allclose(em[0], em0[0], rtol=0, atol=1e-12) and np.allclose(em[1], em0[1], rtol=0, atol=1e-12)
+        try:
+            h.predict('old_TA', Z[:1], S[:1])
+            assert False
+        except GpmpcError as e:
+            assert e.code == EINVAL
+        # load_model path without alpha: recomputed from y - m(X)
+        h2 = Handle(lib, X, Y)
+        h2.set_mean_func(func, True)
+        h2.set_factors(H, o['chol'])
+        m2, _ = h2.predict_mean_var(Z)
+        assert np.max(np.abs(m2 - om) / (ms + 1.0)) <= 1e-10
+        h2.close()
+        # data update keeps the mean function
+        q = go.synthetic_problem(6, d, Ny, 1, seed=seed + 1, sn=0.1)
+        h.append(q['X'], q['Y'])
+        X2, Y2 = np.vstack([X, q['X']]), np.vstack([Y, q['Y']])
+        o2 = go.fit_mean(X2, Y2, H, func, want_invK=False)
+        m3, v3 = h.predict_mean_var(Z)
+        om3, ov3, _ = go.mean_var_jac(Z, X2, H, o2['alpha'], o2['chol'], False, mean_func=func)
+        assert np.max(np.abs(m3 - om3) / (ms + 1.0)) <= 1e-9 and np.max(np.abs(v3 - ov3)) <= 1e-10
+        h.close()
+    # training, IPOPT-path conventions (train_gp optimize.py:100-294): mean parameters are decision variables
+    gp = GP(X[:60], Y[:60], mean_func='const', normalize=False, optimize_nummeric=False, gp_method='ME', lib=lib,
+            optimizer_opts={'maxiter': 40})
+    Ht = gp.train_info['hyper']
+    assert Ht.shape == (Ny, d + 3)
+    for a in range(Ny):
+        h_init = np.concatenate([np.std(X[:60], 0), [np.std(Y[:60, a]), 1e-5, 0.0]])
+        assert go.nll_mean(Ht[a], X[:60], Y[:60, a], 'const') < go.nll_mean(h_init, X[:60], Y[:60, a], 'const')
+        assert -1e2 <= Ht[a, -1] <= 1e2 and abs(Ht[a, -1]) > 1e-3           # the constant moved off its start
+    assert gp.get_hyper_parameters()['mean'].shape == (Ny, 2)                # off-by-one slice: [sn, c], gp_class.py:142
+    gp.close()
+    # numpy-path conventions: calc_NLL_numpy ignores the mean parameters, they stay 0 (optimize.py:377-379)
+    gp = GP(X[:40], Y[:40], mean_func='linear', normalize=False, optimize_nummeric=True, gp_method='ME', lib=lib,
+            optimizer_opts={'maxiter': 15})
+    Hn = gp.train_info['hyper']
+    assert Hn.shape == (Ny, d + 2 + d + 1) and np.all(Hn[:, d + 2:] == 0.0)
+    gp.close()
+    try:
+        GP(X[:10], Y[:10], mean_func='cubic', lib=lib)
+        assert False
+    except NameError:
+        pass

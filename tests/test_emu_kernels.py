@@ -160,3 +160,7 @@ def test_emu_config_patterns(emu, car):
     q = go.synthetic_problem(90, 3, 1, 1, seed=4, sn=1e-2)
     pc.check_random_restarts(emu, q['X'], q['Y'], multistart=4, maxiter=3, min_finite=2)
     # (check_two_handles_two_threads is GPU-only: the fiber emulator keeps its scheduler state in globals)
+
+
+def test_emu_mean_functions(emu):
+    pc.check_mean_functions(emu)
