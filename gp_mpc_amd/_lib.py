@@ -55,6 +55,7 @@ SIGNATURES = {
     'gpmpc_predict_sens': (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp, _vp, _vp, _vp]),
     'gpmpc_predict_jac': (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, _vp, _vp]),
     'gpmpc_rollout': (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'gpmpc_rollout_feedback': (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'gpmpc_predict': (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, _vp]),
     'gpmpc_covar': (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp]),
     'gpmpc_nll': (ctypes.c_int, [_vp, ctypes.c_int, _vp, _dp, _vp, _ip]),
@@ -295,6 +296,20 @@ class Handle:
         self.lib.check(self.lib.dll.gpmpc_rollout(self.h, code, T, _ptr(z0), _ptr(U), _ptr(Sigma0), _ptr(sa), _ptr(sb),
                                                   _ptr(mean), _ptr(cov)))
         return mean, cov
+
+    def rollout_feedback(self, method, T, z0, Sigma0, Kz, k0, Kc, sa=None, sb=None):
+        """Roll-out with state feedback u_t = Kz mean_{t-1} + k0 (include/gpmpc.h): mean[T,Ny], cov[T,Ny,Ny], U[T,Nu]."""
+        code = METHODS[method] if isinstance(method, str) else int(method)
+        Nu = self.d - self.Ny
+        z0 = _f64(z0).reshape(self.d)
+        Sigma0 = _f64(Sigma0).reshape(self.d, self.d)
+        Kz, k0, Kc = _f64(Kz).reshape(Nu, self.Ny), _f64(k0).reshape(Nu), _f64(Kc).reshape(Nu, self.Ny)
+        sa = None if sa is None else _f64(sa).reshape(self.Ny)
+        sb = None if sb is None else _f64(sb).reshape(self.Ny)
+        mean, cov, U = np.zeros((T, self.Ny)), np.zeros((T, self.Ny, self.Ny)), np.zeros((T, Nu))
+        self.lib.check(self.lib.dll.gpmpc_rollout_feedback(self.h, code, int(T), _ptr(z0), _ptr(Sigma0), _ptr(sa), _ptr(sb),
+                                                           _ptr(Kz), _ptr(k0), _ptr(Kc), _ptr(mean), _ptr(cov), _ptr(U)))
+        return mean, cov, U
 
     def predict_sens(self, Z):
         """mean[B,Ny], var[B,Ny], J[B,Ny,d] = d mean/dz, Hm[B,Ny,d,d] = d2 mean/dz2, dvar[B,Ny,d] = d var/dz."""

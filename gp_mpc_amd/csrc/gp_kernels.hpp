@@ -507,10 +507,44 @@ __global__ void __launch_bounds__(256) mean_add_kernel(const double* __restrict_
 __global__ void __launch_bounds__(64) rollout_feed_kernel(const double* __restrict__ mean_prev, const double* __restrict__ cov_prev,
                                                           const double* __restrict__ u_t, const double* __restrict__ sa,
                                                           const double* __restrict__ sb, double* __restrict__ z,
-                                                          double* __restrict__ Sigma, int Ny, int d) {
-    const int tid = threadIdx.x;
-    for (int e = tid; e < d; e += 64) z[e] = e < Ny ? sa[e] * mean_prev[e] + sb[e] : u_t[e - Ny];
+                                                          double* __restrict__ Sigma, int Ny, int d,
+                                                          const double* __restrict__ Kz = nullptr,
+                                                          const double* __restrict__ k0 = nullptr,
+                                                          const double* __restrict__ Kc = nullptr,
+                                                          double* __restrict__ u_out = nullptr) {
+    // Kz != NULL: state feedback (gp_class.py:789-790,797-803): u_t = Kz mean_{t-1} + k0 (the gain with GP.predict's
+    // standardisation folded in) and the input covariance [[C, C Kc^T], [Kc C, Kc C Kc^T]] with C = cov_{t-1}.
+    const int tid = threadIdx.x, Nu = d - Ny;
+    for (int e = tid; e < d; e += 64) {
+        double v;
+        if (e < Ny) v = sa[e] * mean_prev[e] + sb[e];
+        else if (Kz) {
+            v = k0[e - Ny];
+            for (int c = 0; c < Ny; ++c) v += Kz[(e - Ny) * Ny + c] * mean_prev[c];
+            if (u_out) u_out[e - Ny] = v;
+        } else v = u_t[e - Ny];
+        z[e] = v;
+    }
     for (int e = tid; e < Ny * Ny; e += 64) Sigma[(e / Ny) * d + e % Ny] = cov_prev[e];
+    if (Kc) {
+        for (int e = tid; e < Ny * Nu; e += 64) {           // cov_xu = C Kc^T  [Ny x Nu]
+            const int r = e / Nu, q = e % Nu;
+            double v = 0.0;
+            for (int c = 0; c < Ny; ++c) v += cov_prev[r * Ny + c] * Kc[q * Ny + c];
+            Sigma[r * d + Ny + q] = v;
+            Sigma[(Ny + q) * d + r] = v;
+        }
+        for (int e = tid; e < Nu * Nu; e += 64) {           // covar_u = Kc C Kc^T
+            const int p = e / Nu, q = e % Nu;
+            double v = 0.0;
+            for (int r = 0; r < Ny; ++r) {
+                double t = 0.0;
+                for (int c = 0; c < Ny; ++c) t += cov_prev[r * Ny + c] * Kc[q * Ny + c];
+                v += Kc[p * Ny + r] * t;
+            }
+            Sigma[(Ny + p) * d + Ny + q] = v;
+        }
+    }
 }
 
 // Matrix-vector products with the explicit factors (a5: alpha = L^-T (L^-1 y), optimize.py:353-354,494;

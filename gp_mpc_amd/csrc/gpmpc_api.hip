@@ -1476,14 +1476,18 @@ extern "C" int gpmpc_predict_jac(gpmpc_gp* h, int method, int B, const double* Z
     return predict_driver(h, method, B, Z, Sigma, mean, nullptr, J, cov);
 }
 
-extern "C" int gpmpc_rollout(gpmpc_gp* h, int method, int T, const double* z0, const double* U, const double* Sigma0,
-                             const double* sa, const double* sb, double* mean, double* cov) {
+// T-step propagation; U given (open loop) or generated on the device from the state-feedback law (Kz, k0, Kc).
+static int rollout_impl(gpmpc_gp* h, int method, int T, const double* z0, const double* U, const double* Sigma0,
+                        const double* sa, const double* sb, const double* Kz, const double* k0, const double* Kc,
+                        double* mean, double* cov, double* Uout) {
     if (!h) return fail(GPMPC_EINVAL, "NULL handle");
     if (!h->fitted) return fail(GPMPC_ENOTFIT, "model has no factors (call gpmpc_fit or gpmpc_set_factors)");
     if (method < GPMPC_ME || method > GPMPC_OLD_TA) return fail(GPMPC_EINVAL, "No GP method with code %d", method);
     const int d = h->d, Ny = h->Ny, Nu = d - Ny;
-    if (T <= 0 || !z0 || !Sigma0 || !mean || !cov || (Nu > 0 && !U)) return fail(GPMPC_EINVAL, "bad T or NULL argument");
+    const bool fb = Kz != nullptr;
+    if (T <= 0 || !z0 || !Sigma0 || !mean || !cov || (!fb && Nu > 0 && !U)) return fail(GPMPC_EINVAL, "bad T or NULL argument");
     if (Nu < 0) return fail(GPMPC_EINVAL, "roll-out needs d >= Ny (inputs are [state, control])");
+    if (fb && (Nu == 0 || !k0 || !Kc)) return fail(GPMPC_EINVAL, "feedback roll-out needs controls and Kz, k0, Kc");
     if (method == GPMPC_OLD_TA && h->mean_kind)
         return fail(GPMPC_EINVAL, "'old_TA' with a non-zero mean function raises in the reference (gp_functions.py:309-311); not served");
     HIPCHK(hipSetDevice(h->device));
@@ -1493,13 +1497,15 @@ extern "C" int gpmpc_rollout(gpmpc_gp* h, int method, int T, const double* z0, c
         CHK(compute_invK(h->cx(), h->ws));
         h->have_invK = true;
     }
-    // device staging: [z | Sigma | sa | sb | U | mean (T) | cov (T) | var | J]
-    const size_t nz = d, nS = (size_t)d * d, nU = (size_t)T * std::max(Nu, 1), nM = (size_t)T * Ny, nC = (size_t)T * Ny * Ny;
-    const size_t total = nz + nS + 2 * Ny + nU + nM + nC + Ny + (size_t)Ny * d;
+    // device staging: [z | Sigma | sa | sb | U | mean (T) | cov (T) | var | J | Kz | k0 | Kc]
+    const int nu1 = std::max(Nu, 1);
+    const size_t nz = d, nS = (size_t)d * d, nU = (size_t)T * nu1, nM = (size_t)T * Ny, nC = (size_t)T * Ny * Ny;
+    const size_t nK = (size_t)nu1 * Ny;
+    const size_t total = nz + nS + 2 * Ny + nU + nM + nC + Ny + (size_t)Ny * d + 2 * nK + nu1;
     double* buf = nullptr;
     HIPCHK(hipMalloc(&buf, total * sizeof(double)));
     double *dz = buf, *dS = dz + nz, *dsa = dS + nS, *dsb = dsa + Ny, *dU = dsb + Ny, *dM = dU + nU, *dC = dM + nM,
-           *dV = dC + nC, *dJ = dV + Ny;
+           *dV = dC + nC, *dJ = dV + Ny, *dKz = dJ + (size_t)Ny * d, *dk0 = dKz + nK, *dKc = dk0 + nu1;
     std::vector<double> one(Ny, 1.0), zero(Ny, 0.0);
     auto up = [&](double* dst, const double* src, size_t n) {
         return hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyHostToDevice, h->stream);
@@ -1508,13 +1514,19 @@ extern "C" int gpmpc_rollout(gpmpc_gp* h, int method, int T, const double* z0, c
     if (e == hipSuccess) e = up(dS, Sigma0, nS);
     if (e == hipSuccess) e = up(dsa, sa ? sa : one.data(), Ny);
     if (e == hipSuccess) e = up(dsb, sb ? sb : zero.data(), Ny);
-    if (e == hipSuccess && Nu > 0) e = up(dU, U, (size_t)T * Nu);
+    if (e == hipSuccess && !fb && Nu > 0) e = up(dU, U, (size_t)T * Nu);
+    if (e == hipSuccess && fb) e = up(dKz, Kz, nK);
+    if (e == hipSuccess && fb) e = up(dk0, k0, Nu);
+    if (e == hipSuccess && fb) e = up(dKc, Kc, nK);
+    if (e == hipSuccess && fb) e = up(dU, z0 + Ny, Nu);          // the first control comes with z0
     int rc = GPMPC_OK;
     if (e != hipSuccess) rc = fail(GPMPC_EHIP, "%s", hipGetErrorString(e));
     for (int t = 0; t < T && rc == GPMPC_OK; ++t) {
         if (t > 0)
             hipLaunchKernelGGL(rollout_feed_kernel, dim3(1), dim3(64), 0, h->stream, dM + (size_t)(t - 1) * Ny,
-                               dC + (size_t)(t - 1) * Ny * Ny, dU + (size_t)t * std::max(Nu, 1), dsa, dsb, dz, dS, Ny, d);
+                               dC + (size_t)(t - 1) * Ny * Ny, dU + (size_t)t * nu1, dsa, dsb, dz, dS, Ny, d,
+                               fb ? dKz : (const double*)nullptr, fb ? dk0 : (const double*)nullptr,
+                               fb ? dKc : (const double*)nullptr, fb ? dU + (size_t)t * nu1 : (double*)nullptr);
         double* oM = dM + (size_t)t * Ny;
         double* oC = dC + (size_t)t * Ny * Ny;
         if (moments) {
@@ -1530,6 +1542,7 @@ extern "C" int gpmpc_rollout(gpmpc_gp* h, int method, int T, const double* z0, c
     if (rc == GPMPC_OK) {
         e = hipMemcpyAsync(mean, dM, nM * sizeof(double), hipMemcpyDeviceToHost, h->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(cov, dC, nC * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess && Uout && Nu > 0) e = hipMemcpyAsync(Uout, dU, (size_t)T * Nu * sizeof(double), hipMemcpyDeviceToHost, h->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
         if (e == hipSuccess) e = hipGetLastError();
         if (e != hipSuccess) rc = fail(GPMPC_EHIP, "%s", hipGetErrorString(e));
@@ -1538,6 +1551,18 @@ extern "C" int gpmpc_rollout(gpmpc_gp* h, int method, int T, const double* z0, c
     }
     hipFree(buf);
     return rc;
+}
+
+extern "C" int gpmpc_rollout(gpmpc_gp* h, int method, int T, const double* z0, const double* U, const double* Sigma0,
+                             const double* sa, const double* sb, double* mean, double* cov) {
+    return rollout_impl(h, method, T, z0, U, Sigma0, sa, sb, nullptr, nullptr, nullptr, mean, cov, nullptr);
+}
+
+extern "C" int gpmpc_rollout_feedback(gpmpc_gp* h, int method, int T, const double* z0, const double* Sigma0, const double* sa,
+                                      const double* sb, const double* Kz, const double* k0, const double* Kc, double* mean,
+                                      double* cov, double* U_out) {
+    if (!Kz) return fail(GPMPC_EINVAL, "Kz is NULL");
+    return rollout_impl(h, method, T, z0, nullptr, Sigma0, sa, sb, Kz, k0, Kc, mean, cov, U_out);
 }
 
 extern "C" int gpmpc_predict_sens(gpmpc_gp* h, int B, const double* Z, double* mean, double* var, double* J, double* Hm,

@@ -458,14 +458,26 @@ class GP:
         return cls(**input_dict)
 
     # ------------------------------------------------------------------ rollout (numeric part of predict_compare)
-    def rollout(self, x0, u, methods=None, feedback=False):
+    @staticmethod
+    def lqr_gain(A, B, Q, R):
+        """Infinite-horizon discrete LQR gain u = K x, the three lines of mpc_class.lqr (mpc_class.py:972-973) that
+        predict_compare needs: P from the discrete algebraic Riccati equation, K = -(R + B^T P B)^-1 B^T P A."""
+        import scipy.linalg
+        P = np.array(scipy.linalg.solve_discrete_are(A, B, Q, R))
+        return -np.array(scipy.linalg.solve(R + B.T @ P @ B, B.T @ P @ A))
+
+    def rollout(self, x0, u, methods=None, feedback=False, x_ref=None, Q=None, R=None, K=None, return_controls=False):
         """The numeric loop of `predict_compare` (gp_class.py:746-804) without simulator and
         plots: for every method feed (mean_t, cov_t) back into `predict` for Nt = len(u) steps.
         Returns mean[len(methods), Nt+1, Ny] and var[...] (variances un-standardised by stdY^2 and
-        clipped at 0 like :795-796,826-827)."""
-        if feedback:
-            raise NotImplementedError('feedback=True needs the LQR gain of mpc_class.lqr (out of scope)')
-        Nx, Ny = self.__Nx, self.__Ny
+        clipped at 0 like :795-796,826-827).
+
+        feedback=True (gp_class.py:772-803): u_t = K (mean_t - x_ref) with the LQR gain of the model linearised at
+        (x0, u[0]) (`discrete_linearize` + `lqr_gain`; pass K to use a given gain), and the control blocks of the
+        input covariance K C K^T, C K^T.  DIFF: the reference subtracts x_ref (Ny,) from the (Ny x 1) array `predict`
+        returns, which numpy broadcasts to an Ny x Ny matrix from the second step on ("#TODO: Fix feedback",
+        gp_class.py:806); here the law is evaluated on vectors as written in its docstring."""
+        Nx, Ny, Nu = self.__Nx, self.__Ny, self.__Nu
         u = np.atleast_2d(np.asarray(u, dtype=np.float64))
         Nt = u.shape[0]
         initVar = self.__hyper[:, Nx + 1] ** 2
@@ -473,6 +485,7 @@ class GP:
             methods = ['EM', 'TA', 'ME']
         mean = np.zeros((len(methods), Nt + 1, Ny))
         var = np.zeros((len(methods), Nt + 1, Ny))
+        controls = np.zeros((len(methods), Nt, Nu))
         covar = np.eye(Nx) * 1e-6                                               # gp_class.py:764
         # DIFF: the reference synchronises with the predictor once per step (a Python loop around GP.predict);
         # here the whole horizon runs on the device (`gpmpc_rollout`) and the result comes back once.
@@ -480,25 +493,52 @@ class GP:
             if m not in METHODS:
                 raise NameError('No GP method called: ' + str(m))
         x0 = np.asarray(x0, dtype=np.float64).reshape(Ny)
-        if self.__normalize:
-            z0 = np.concatenate([self.standardize(x0, self.__meanX, self.__stdX),
-                                 self.standardize(u[0], self.__meanU, self.__stdU)])
-            Us = self.standardize(u, self.__meanU, self.__stdU)
-            sa = np.atleast_1d(self.__stdY) / np.atleast_1d(self.__stdX)           # x_s(next) = sa * mean_s + sb
-            sb = (np.atleast_1d(self.__meanY) - np.atleast_1d(self.__meanX)) / np.atleast_1d(self.__stdX)
-        else:
-            z0, Us, sa, sb = np.concatenate([x0, u[0]]), u, None, None
-        covar[:Ny, :Ny] = np.diag(initVar)                                        # gp_class.py:780
+        norm = self.__normalize
+        one = np.ones(1)
+        stdX, meanX = (np.atleast_1d(self.__stdX), np.atleast_1d(self.__meanX)) if norm else (one, 0 * one)
+        stdU, meanU = (np.atleast_1d(self.__stdU), np.atleast_1d(self.__meanU)) if norm else (one, 0 * one)
+        stdY, meanY = (np.atleast_1d(self.__stdY), np.atleast_1d(self.__meanY)) if norm else (one, 0 * one)
+        sa = stdY / stdX if norm else None                                        # x_s(next) = sa * mean_s + sb
+        sb = (meanY - meanX) / stdX if norm else None
+        Us = (u - meanU) / stdU
+        if feedback:
+            if x_ref is None:
+                x_ref = np.zeros(Ny)                                              # gp_class.py:770-771
+            x_ref = np.asarray(x_ref, dtype=np.float64).reshape(Ny)
+            Q = np.eye(Ny) if Q is None else np.asarray(Q, dtype=np.float64)      # :765-768
+            R = np.eye(Nu) if R is None else np.asarray(R, dtype=np.float64)
+        keep = self.__gp_method
         for i, m in enumerate(methods):
-            mean_s, cov = self._h.rollout(m, z0, Us, covar, sa, sb)
+            covar[:Ny, :Ny] = np.diag(initVar)                                    # gp_class.py:780 (other blocks persist)
+            if feedback:
+                if K is None:
+                    self.set_method(m)
+                    A, B = self.discrete_linearize(x0, u[0], covar)               # :785-786
+                    Km = self.lqr_gain(A, B, Q, R)
+                else:
+                    Km = np.asarray(K, dtype=np.float64).reshape(Nu, Ny)
+                u1 = Km @ (x0 - x_ref)                                            # :789-790
+                z0 = np.concatenate([(x0 - meanX) / stdX, (u1 - meanU) / stdU])
+                Kz = (Km * stdY[None, :]) / stdU[:, None]
+                k0 = (Km @ (meanY * np.ones(Ny) - x_ref) - meanU) / stdU
+                mean_s, cov, U_s = self._h.rollout_feedback(m, Nt, z0, covar, Kz, k0, Km, sa, sb)
+                controls[i] = U_s * stdU + meanU
+                covar[:Ny, Ny:] = cov[-1] @ Km.T                                  # what :798-803 leave behind for the
+                covar[Ny:, :Ny] = covar[:Ny, Ny:].T                               # next method (covar is never reset)
+                covar[Ny:, Ny:] = Km @ cov[-1] @ Km.T
+            else:
+                z0 = np.concatenate([(x0 - meanX) / stdX, Us[0]])
+                mean_s, cov = self._h.rollout(m, z0, Us, covar, sa, sb)
+                controls[i] = u
             mean[i, 0, :] = x0
-            mean[i, 1:, :] = self.inverse_mean(mean_s, self.__meanY, self.__stdY) if self.__normalize else mean_s
+            mean[i, 1:, :] = self.inverse_mean(mean_s, self.__meanY, self.__stdY) if norm else mean_s
             var[i, 1:, :] = np.einsum('tii->ti', cov)
-            if self.__normalize:
+            if norm:
                 var[i, 1:, :] = self.inverse_variance(var[i, 1:, :])
+        self.__gp_method = keep
         if np.any(var < 0):
             var = var.clip(min=0)
-        return mean, var
+        return (mean, var, controls) if return_controls else (mean, var)
 
     def predict_compare(self, *args, **kwargs):
         raise NotImplementedError('predict_compare is the plotting front-end of the rollout loop '

@@ -152,6 +152,16 @@ int gpmpc_predict_jac(gpmpc_gp* h, int method, int B, const double* Z, const dou
  * GP.predict, gp_class.py:253-261; NULL = identity).  Outputs mean[T x Ny], cov[T x Ny x Ny] (host pointers). */
 int gpmpc_rollout(gpmpc_gp* h, int method, int T, const double* z0, const double* U, const double* Sigma0,
                   const double* sa, const double* sb, double* mean, double* cov);
+/* The same loop with the reference's state feedback (predict_compare(feedback=True), gp_class.py:772-803):
+ * u_t = K (mean_{t-1} - x_ref) and the input covariance [[C, C K^T], [K C, K C K^T]], C = cov_{t-1}.  The caller
+ * supplies the gain as data (the reference computes K with mpc_class.lqr from discrete_linearize at (x0, u_0)):
+ * Kz[Nu x Ny], k0[Nu]: u_t in the GP's input units as an affine function of the STANDARDISED output mean
+ * (u_t = Kz mean_{t-1} + k0: GP.predict's un-/re-standardisation folded in); Kc[Nu x Ny]: the gain applied to the
+ * covariance blocks (the reference applies the raw K to the standardised cov, :798-799).  z0 = [x_0, u_0] carries
+ * the first control.  U_out[T x Nu] (may be NULL) returns the controls that were applied. */
+int gpmpc_rollout_feedback(gpmpc_gp* h, int method, int T, const double* z0, const double* Sigma0, const double* sa,
+                           const double* sb, const double* Kz, const double* k0, const double* Kc, double* mean,
+                           double* cov, double* U_out);
 /* a14 GP.covar gp_class.py:353-381: covar[Ny x n x n] = sf^2 - V^T V for n new inputs. */
 int gpmpc_covar(gpmpc_gp* h, int n, const double* Xnew, double* covar);
 

@@ -660,10 +660,14 @@ class OracleGP:
         NLP = np.sum(0.5 * np.log(2 * np.pi * var) + (Y_test - mean) ** 2 / (2 * var), axis=0)
         return loss / np.std(Y_test, 0), NLP / N
 
-    def rollout(self, x0, U, methods=('EM', 'TA', 'ME')):
-        """a17: the numeric loop of `predict_compare` gp_class.py:777-804,
-        feedback=False: covar = eye(d)*1e-6 with the state block diag(sn^2),
-        feed (mean_t, cov_t) back; variances un-standardised by stdY^2."""
+    def rollout(self, x0, U, methods=('EM', 'TA', 'ME'), feedback=False, x_ref=None, Q=None, R=None, K=None):
+        """a17: the numeric loop of `predict_compare` gp_class.py:777-804: covar = eye(d)*1e-6 with the state block
+        diag(sn^2), feed (mean_t, cov_t) back; variances un-standardised by stdY^2.
+        feedback=True (:772-803): K from `lqr` (mpc_class.py:972-973) of `discrete_linearize` at (x0, u[0]) unless
+        given, u_t = K (mean_t - x_ref) evaluated on VECTORS (the reference's `mean_t - x_ref` mixes an (Ny x 1) array
+        with an (Ny,) one, :790 -- its own "#TODO: Fix feedback"), control blocks of covar from K and cov_t, and
+        -- literally as the reference -- `covar` is never reset between methods."""
+        import scipy.linalg
         Nx, Ny = self.Nx, self.Ny
         U = np.atleast_2d(np.asarray(U, dtype=np.float64))
         Nt = U.shape[0]
@@ -671,19 +675,41 @@ class OracleGP:
         mean = np.zeros((len(methods), Nt + 1, Ny))
         var = np.zeros((len(methods), Nt + 1, Ny))
         covar = np.eye(Nx) * 1e-6
+        if Q is None:
+            Q = np.eye(Ny)
+        if R is None:
+            R = np.eye(Nx - Ny)
+        if x_ref is None and feedback:
+            x_ref = np.zeros(Ny)
         keep = self.gp_method
+        self.controls = np.zeros((len(methods), Nt, Nx - Ny))
         for i, m in enumerate(methods):
             self.set_method(m)
             mean_t = np.asarray(x0, dtype=np.float64).reshape(Ny)
             covar[:Ny, :Ny] = np.diag(initVar)
             mean[i, 0, :] = mean_t
+            if feedback:
+                if K is None:
+                    A, B = self.discrete_linearize(mean_t, U[0], covar)
+                    P = np.array(scipy.linalg.solve_discrete_are(A, B, Q, R))
+                    Km = -np.array(scipy.linalg.solve(R + B.T @ P @ B, B.T @ P @ A))
+                else:
+                    Km = np.asarray(K, dtype=np.float64)
             for t in range(1, Nt + 1):
-                mean_t, covar_x = self.predict(mean_t, U[t - 1], covar)
+                u_t = Km @ (mean_t - x_ref) if feedback else U[t - 1]
+                self.controls[i, t - 1] = u_t
+                mean_t, covar_x = self.predict(mean_t, u_t, covar)
                 mean_t = mean_t.reshape(Ny)
                 mean[i, t, :] = mean_t
                 var[i, t, :] = np.diag(covar_x)
                 if self.normalize:
                     var[i, t, :] = var[i, t, :] * self.meta['stdY'] ** 2
+                if feedback:
+                    covar_u = Km @ covar_x @ Km.T
+                    cov_xu = covar_x @ Km.T
+                    covar[Ny:, Ny:] = covar_u
+                    covar[Ny:, :Ny] = cov_xu.T
+                    covar[:Ny, Ny:] = cov_xu
                 covar[:Ny, :Ny] = covar_x
         self.set_method(keep)
         return mean, var

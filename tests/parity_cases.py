@@ -924,3 +924,45 @@ def check_mean_functions(lib, N=150, d=3, Ny=2, seed=31):
         assert False
     except NameError:
         pass
+
+
+def check_feedback_rollout(lib, g, T=5):
+    """a17 with feedback=True (gp_class.py:772-803): LQR gain from the model's own linearisation, u_t = K (mean_t -
+    x_ref), control blocks of the input covariance; `GP.rollout` -> `gpmpc_rollout_feedback` against OracleGP.rollout,
+    on a saved reference model (standardised, ME / TA) and on a well-conditioned synthetic one (all three methods)."""
+    from gp_mpc_amd.gp import GP
+    hyper = dict(hyper=g['hyper'], chol=g['chol'], alpha=g['alpha'], invK=g['invK'])
+    kw = dict(normalize=g['normalize'], lib=lib)
+    if g['normalize']:
+        kw.update(meta=g['meta'], xlb=g['xlb'], xub=g['xub'], ulb=g['ulb'], uub=g['uub'])
+    gp = GP(g['X'], g['Y'], hyper=hyper, gp_method='TA', **kw)
+    og = go.OracleGP(g['X'], g['Y'], g['hyper'], g['chol'], g['alpha'], g['invK'], normalize=g['normalize'],
+                     meta=g.get('meta'), gp_method='TA')
+    N, Ny, Nu = gp.get_size()
+    x = g['meta']['meanX'] + 0.3 * g['meta']['stdX'] if g['normalize'] else g['X'][3, :Ny]
+    u = g['meta']['meanU'] - 0.2 * g['meta']['stdU'] if g['normalize'] else g['X'][3, Ny:]
+    x_ref = x * 0.9
+    U = np.tile(u, (T, 1))
+    rng = np.random.default_rng(2)
+    Kgain = 0.05 * rng.standard_normal((Nu, Ny))
+    for Kin in (Kgain, None):                 # a given gain, and the LQR gain of the linearised model
+        m, v, c = gp.rollout(x, U, methods=['TA', 'ME'], feedback=True, x_ref=x_ref, K=Kin, return_controls=True)
+        om, ov = og.rollout(x, U, methods=('TA', 'ME'), feedback=True, x_ref=x_ref, K=Kin)
+        sc = max(1.0, np.abs(om).max())
+        assert np.allclose(c, og.controls, rtol=1e-7, atol=1e-8 * max(1.0, np.abs(og.controls).max())), np.abs(c - og.controls).max()
+        assert np.allclose(m, om, rtol=1e-7, atol=1e-8 * sc), np.abs(m - om).max()
+        assert np.allclose(v, np.clip(ov, 0, None), rtol=1e-5, atol=1e-9 * max(1.0, np.abs(ov).max())), np.abs(v - ov).max()
+    gp.close()
+    p = go.synthetic_problem(120, 5, 3, T, seed=21, sn=0.1)
+    o = go.fit(p['X'], p['Y'], p['hyper'])
+    gp = GP(p['X'], p['Y'], hyper=dict(hyper=p['hyper'], chol=o['chol'], alpha=o['alpha'], invK=o['invK']),
+            normalize=False, gp_method='EM', lib=lib)
+    og = go.OracleGP(p['X'], p['Y'], p['hyper'], o['chol'], o['alpha'], o['invK'], gp_method='EM')
+    x0, U = p['Z'][0, :3], p['Z'][:T, 3:] * 0.3
+    m, v, c = gp.rollout(x0, U, methods=['EM', 'TA', 'ME'], feedback=True, Q=np.eye(3) * 2.0, R=np.eye(2) * 0.5,
+                         return_controls=True)
+    om, ov = og.rollout(x0, U, methods=('EM', 'TA', 'ME'), feedback=True, Q=np.eye(3) * 2.0, R=np.eye(2) * 0.5)
+    assert np.max(np.abs(c - og.controls)) <= 1e-8 * max(1.0, np.abs(og.controls).max())
+    assert np.max(np.abs(m - om)) <= 1e-8 * max(1.0, np.abs(om).max()) and np.max(np.abs(v - np.clip(ov, 0, None))) <= 1e-8
+    assert np.max(np.abs(c[0] - U)) > 1e-3          # the controls really come from the feedback law, not from U
+    gp.close()

@@ -164,3 +164,7 @@ def test_emu_config_patterns(emu, car):
 
 def test_emu_mean_functions(emu):
     pc.check_mean_functions(emu)
+
+
+def test_emu_feedback_rollout(emu, tank):
+    pc.check_feedback_rollout(emu, tank)

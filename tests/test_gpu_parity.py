@@ -145,6 +145,10 @@ def test_training(lib, train_small):
     pc.check_training(lib, train_small)
 
 
+def test_feedback_rollout(lib, tank):
+    pc.check_feedback_rollout(lib, tank, T=8)
+
+
 def test_mean_functions(lib):
     pc.check_mean_functions(lib)
     pc.check_mean_functions(lib, N=700, d=6, Ny=3, seed=5)
