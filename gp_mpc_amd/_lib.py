@@ -53,6 +53,7 @@ SIGNATURES = {
     'gpmpc_predict_mean_var': (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp]),
     'gpmpc_mean_jac': (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp]),
     'gpmpc_predict_sens': (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'gpmpc_predict_em_sens': (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'gpmpc_predict_jac': (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, _vp, _vp]),
     'gpmpc_rollout': (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'gpmpc_rollout_feedback': (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -321,6 +322,16 @@ class Handle:
         self.lib.check(self.lib.dll.gpmpc_predict_sens(self.h, B, _ptr(Z), _ptr(mean), _ptr(var), _ptr(J), _ptr(Hm),
                                                        _ptr(dvar)))
         return mean, var, J, Hm, dvar
+
+    def predict_em_sens(self, Z, Sigma):
+        """'EM' value and Jacobians: mean[B,Ny], cov[B,Ny,Ny], dmean_dz[B,Ny,d], dmean_dS[B,Ny,d,d],
+        dcov_dz[B,Ny,Ny,d], dcov_dS[B,Ny,Ny,d,d]."""
+        Z = _f64(Z).reshape(-1, self.d)
+        B, d, Ny = Z.shape[0], self.d, self.Ny
+        Sigma = _f64(Sigma).reshape(B, d, d)
+        out = [np.zeros(sh) for sh in ((B, Ny), (B, Ny, Ny), (B, Ny, d), (B, Ny, d, d), (B, Ny, Ny, d), (B, Ny, Ny, d, d))]
+        self.lib.check(self.lib.dll.gpmpc_predict_em_sens(self.h, B, _ptr(Z), _ptr(Sigma), *[_ptr(o) for o in out]))
+        return tuple(out)
 
     def predict(self, method, Z, Sigma=None):
         code = METHODS[method] if isinstance(method, str) else int(method)

@@ -295,6 +295,330 @@ __global__ void __launch_bounds__(64) em_finish_kernel(const double* __restrict_
     cov[((long)b * Ny + bb) * Ny + a] = v;
 }
 
+// ---- derivative outputs of the exact moments ---------------------------------------------------
+// d mean / d(mu, Sigma) and d cov / d(mu, Sigma) of gp_exact_moment (what CasADi's AD hands to IPOPT when 'EM' is the
+// MPC's propagation method, gp_class.py:220-224).  With W = A o Q of an ORDERED output pair (a, c) (rows belong to
+// a, columns to c; W^(c,a) = W^(a,c)^T), v_i = x_i - mu, ij_j = v_j / ell_c^2, per 64-row strip the kernel leaves
+//     s0 = sum_i r_i,   S1 = sum_i r_i v_i,   S2 = sum_i r_i v_i v_i^T,   Xg = sum_i v_i g_i^T,
+//     r_i = sum_j W_ij (row sums),   g_i = sum_j W_ij ij_j,
+// from which em_sens_finish_kernel assembles, for the unordered pair (a >= c), with Lab = 1/ell_a^2 + 1/ell_c^2,
+// G = (Lab Sigma + I)^-1:
+//     z1 = S1^(a,c)/ell_a^2 + S1^(c,a)/ell_c^2                       (column sums of (a,c) are row sums of (c,a))
+//     ZZ = L_a^-1 S2^(a,c) L_a^-1 + L_c^-1 S2^(c,a) L_c^-1 + 2 L_a^-1 Xg^(a,c)     (maha's cross term is not symmetrised)
+//     d(t s)/d mu = t G z1,    d(t s)/d Sigma = t (-1/2 G Lab s0 + 1/2 G ZZ G^T).
+// Same tile scheme as em_pair_kernel (cross terms on the matrix pipe, lean exp on the VALU) but every column tile is
+// visited (row sums need whole rows) and each lane carries 4 x (1 + EMK) extra accumulators.
+constexpr int EM_NSS = 1 + EMK + 2 * EMK * EMK;     // values per (input, ordered pair, strip)
+
+// operands for ORDERED pairs: same layout as em_operands_kernel, pair index po = a * Ny + c
+__global__ void __launch_bounds__(256) em_operands_ordered_kernel(const double* __restrict__ XT, const double* __restrict__ Z,
+                                                                  const double* __restrict__ hyper,
+                                                                  const double* __restrict__ prep, double* __restrict__ ops,
+                                                                  int N, int Np, int d, int Ny, int b0) {
+    const int P = Ny * (Ny + 1) / 2, stride = d * d + 1;
+    const int i = blockIdx.x * 256 + threadIdx.x, po = blockIdx.y, bl = blockIdx.z, b = b0 + bl;
+    if (i >= Np) return;
+    const int a = po / Ny, c = po % Ny, hi = a > c ? a : c, lo = a > c ? c : a;
+    const double* S = prep + ((long)b * (Ny + P) + Ny + hi * (hi + 1) / 2 + lo) * stride;
+    const double* ha = hyper + (long)a * (d + 2);
+    const double* hb = hyper + (long)c * (d + 2);
+    double* o = ops + ((long)bl * Ny * Ny + po) * (2 * EMK + 2) * Np;
+    double v[DMAX], ii[DMAX], ij[DMAX];
+    double lka = 0.0, lkb = 0.0;
+    for (int k = 0; k < d; ++k) {
+        v[k] = (i < N) ? XT[(long)k * Np + i] - Z[(long)b * d + k] : 0.0;
+        ii[k] = v[k] / (ha[k] * ha[k]);
+        ij[k] = v[k] / (hb[k] * hb[k]);
+        lka += v[k] * v[k] / (ha[k] * ha[k]);
+        lkb += v[k] * v[k] / (hb[k] * hb[k]);
+    }
+    double qa = 0.0, qb = 0.0;
+    for (int cc = 0; cc < EMK; ++cc) {
+        double ua = 0.0, ub = 0.0;
+        if (cc < d)
+            for (int k = 0; k < d; ++k) { ua += ii[k] * S[k * d + cc]; ub += ij[k] * S[k * d + cc]; }
+        o[(long)cc * Np + i] = 2.0 * ua;
+        o[(long)(EMK + cc) * Np + i] = (cc < d) ? ij[cc] : 0.0;
+        if (cc < d) { qa += ua * ii[cc]; qb += ub * ij[cc]; }
+    }
+    o[(long)(2 * EMK) * Np + i] = (2.0 * log(ha[d]) - 0.5 * lka) + qa;
+    o[(long)(2 * EMK + 1) * Np + i] = (2.0 * log(hb[d]) - 0.5 * lkb) + qb;
+}
+
+// grid (Np/64, Ny*Ny, Bc), 256 threads.  part[((bl*Ny*Ny + po)*tiles + strip)*EM_NSS + e]
+__global__ void __launch_bounds__(256) em_pair_sens_kernel(const double* __restrict__ ops, const double* __restrict__ beta,
+                                                           const double* __restrict__ invK, const double* __restrict__ XT,
+                                                           const double* __restrict__ Z, double* __restrict__ part, int N,
+                                                           int Np, int Ny, int d, int b0, int crow_mode) {
+    const int ti = blockIdx.x, po = blockIdx.y, bl = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles = Np / 64, a = po / Ny, cb = po % Ny;
+    const bool diag = a == cb;
+    const double* __restrict__ o = ops + ((long)bl * Ny * Ny + po) * (2 * EMK + 2) * Np;
+    const double* __restrict__ Wt = o + (long)EMK * Np;
+    const double* __restrict__ La = o + (long)(2 * EMK) * Np;
+    const double* __restrict__ Lb = o + (long)(2 * EMK + 1) * Np;
+    const double* __restrict__ ba = beta + (long)a * Np;
+    const double* __restrict__ bbv = beta + (long)cb * Np;
+    const double* __restrict__ iK = invK + (long)a * Np * Np;
+    __shared__ double Cs[2][EMK + 2][64];
+    __shared__ double Rw[64][EMK + 1];      // per strip row: r_i, g_i[EMK]
+    __shared__ double Vs[64][EMK];          // per strip row: v_i
+    const int fr = lane & 15, fk = lane >> 4, i0 = ti * 64 + 16 * wave;
+    const double a0 = o[(long)fk * Np + i0 + fr], a1 = o[(long)(4 + fk) * Np + i0 + fr];
+    double la[4], bai[4];
+    int irow[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        irow[r] = i0 + crow(lane, r, crow_mode);
+        la[r] = La[irow[r]];
+        bai[r] = (irow[r] < N) ? ba[irow[r]] : 0.0;
+    }
+    for (int e = tid; e < 64 * EMK; e += 256) {
+        const int rw = e / EMK, k = e % EMK, i = ti * 64 + rw;
+        Vs[rw][k] = (k < d && i < N) ? XT[(long)k * Np + i] - Z[(long)(b0 + bl) * d + k] : 0.0;
+    }
+    double rs[4], gp[4][EMK];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        rs[r] = 0.0;
+#pragma unroll
+        for (int k = 0; k < EMK; ++k) gp[r][k] = 0.0;
+    }
+    double st[3];
+    auto fetch = [&](int jt) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int e = tid + 256 * q, rw = e >> 6, cl = e & 63, j = jt * 64 + cl;
+            double v = 0.0;
+            if (rw < EMK) v = Wt[(long)rw * Np + j];
+            else if (rw == EMK) v = Lb[j];
+            else if (rw == EMK + 1) v = (j < N) ? bbv[j] : 0.0;
+            st[q] = v;
+        }
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int e = tid + 256 * q, rw = e >> 6, cl = e & 63;
+            if (rw < EMK + 2) Cs[buf][rw][cl] = st[q];
+        }
+    };
+    fetch(0);
+    stage(0);
+    __syncthreads();
+    int cur = 0;
+    for (int jt = 0; jt < tiles; ++jt) {
+        if (jt + 1 < tiles) fetch(jt + 1);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int cl = 16 * t + fr, j = jt * 64 + cl;
+            d4 c = d4{0.0, 0.0, 0.0, 0.0};
+            c = mfma16(a0, Cs[cur][fk][cl], c);
+            c = mfma16(a1, Cs[cur][4 + fk][cl], c);
+            const double lbj = Cs[cur][EMK][cl];
+            const double bj = Cs[cur][EMK + 1][cl];
+            double wt[EMK];
+#pragma unroll
+            for (int k = 0; k < EMK; ++k) wt[k] = Cs[cur][k][cl];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double q = exp_lean((la[r] + lbj) + c[r]);
+                double wgt = bai[r] * bj;
+                if (diag) wgt -= iK[(long)irow[r] * Np + j];
+                const double w = (j < N && irow[r] < N) ? wgt * q : 0.0;
+                rs[r] += w;
+#pragma unroll
+                for (int k = 0; k < EMK; ++k) gp[r][k] += w * wt[k];
+            }
+        }
+        if (jt + 1 < tiles) stage(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+    // the 16 lanes with the same lane >> 4 hold the same 4 rows: butterfly over the low 4 lane bits
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int m = 8; m >= 1; m >>= 1) {
+            rs[r] += __shfl_xor(rs[r], m);
+#pragma unroll
+            for (int k = 0; k < EMK; ++k) gp[r][k] += __shfl_xor(gp[r][k], m);
+        }
+        if (fr == 0) {
+            const int rw = irow[r] - ti * 64;
+            Rw[rw][0] = rs[r];
+#pragma unroll
+            for (int k = 0; k < EMK; ++k) Rw[rw][1 + k] = gp[r][k];
+        }
+    }
+    __syncthreads();
+    if (tid < EM_NSS) {        // fixed-order sums over the strip's 64 rows
+        double s = 0.0;
+        if (tid == 0) {
+            for (int rw = 0; rw < 64; ++rw) s += Rw[rw][0];
+        } else if (tid < 1 + EMK) {
+            const int k = tid - 1;
+            for (int rw = 0; rw < 64; ++rw) s += Rw[rw][0] * Vs[rw][k];
+        } else if (tid < 1 + EMK + EMK * EMK) {
+            const int e = tid - 1 - EMK, k = e / EMK, l = e % EMK;
+            for (int rw = 0; rw < 64; ++rw) s += Rw[rw][0] * Vs[rw][k] * Vs[rw][l];
+        } else {
+            const int e = tid - 1 - EMK - EMK * EMK, k = e / EMK, l = e % EMK;
+            for (int rw = 0; rw < 64; ++rw) s += Vs[rw][k] * Rw[rw][1 + l];
+        }
+        part[(((long)bl * Ny * Ny + po) * tiles + ti) * EM_NSS + tid] = s;
+    }
+}
+
+// sums[(bl*Ny*Ny + po)*EM_NSS + e] = sum over strips (fixed order).  grid (Ny*Ny, Bc), 256 threads.
+__global__ void __launch_bounds__(256) em_sens_reduce_kernel(const double* __restrict__ part, double* __restrict__ sums,
+                                                             int Ny, int tiles) {
+    const int po = blockIdx.x, bl = blockIdx.y, e = threadIdx.x;
+    if (e >= EM_NSS) return;
+    const double* p = part + (((long)bl * Ny * Ny + po) * tiles) * EM_NSS + e;
+    double s = 0.0;
+    for (int t = 0; t < tiles; ++t) s += p[(long)t * EM_NSS];
+    sums[((long)bl * Ny * Ny + po) * EM_NSS + e] = s;
+}
+
+// d mean_a / d mu = P_a M1, d mean_a / d Sigma = -1/2 P_a mean_a + 1/2 P_a M2 P_a with M1 = sum_i w_i v_i,
+// M2 = sum_i w_i v_i v_i^T, w_i = beta_ai q_ai, P_a = (Sigma + Lambda_a)^-1 (prep's iR).  grid (Ny, Bc), 256 threads.
+__global__ void __launch_bounds__(256) em_mean_sens_kernel(const double* __restrict__ XT, const double* __restrict__ Z,
+                                                           const double* __restrict__ beta, const double* __restrict__ prep,
+                                                           double* __restrict__ dm_dz, double* __restrict__ dm_dS, int N,
+                                                           int Np, int d, int Ny, int b0) {
+    constexpr int NM = 1 + EMK + EMK * (EMK + 1) / 2;
+    const int a = blockIdx.x, b = b0 + blockIdx.y, tid = threadIdx.x;
+    const int P = Ny * (Ny + 1) / 2, stride = d * d + 1;
+    const double* pr = prep + ((long)b * (Ny + P) + a) * stride;
+    __shared__ double iR[EMK * EMK], mu[EMK], red[4][NM], M[NM], T1[EMK * EMK];
+    for (int e = tid; e < EMK * EMK; e += 256) iR[e] = (e / EMK < d && e % EMK < d) ? pr[(e / EMK) * d + e % EMK] : 0.0;
+    if (tid < EMK) mu[tid] = tid < d ? Z[(long)b * d + tid] : 0.0;
+    __syncthreads();
+    const double c = pr[d * d];
+    double acc[NM];
+#pragma unroll
+    for (int e = 0; e < NM; ++e) acc[e] = 0.0;
+    for (int i = tid; i < N; i += 256) {
+        double v[EMK];
+#pragma unroll
+        for (int k = 0; k < EMK; ++k) v[k] = k < d ? XT[(long)k * Np + i] - mu[k] : 0.0;
+        double qf = 0.0;
+#pragma unroll
+        for (int r = 0; r < EMK; ++r) {
+            double t = 0.0;
+#pragma unroll
+            for (int k = 0; k < EMK; ++k) t += v[k] * iR[k * EMK + r];
+            qf += t * v[r];
+        }
+        const double w = c * exp(-0.5 * qf) * beta[(long)a * Np + i];
+        acc[0] += w;
+        int e = 1 + EMK;
+#pragma unroll
+        for (int k = 0; k < EMK; ++k) {
+            acc[1 + k] += w * v[k];
+#pragma unroll
+            for (int l = 0; l <= k; ++l, ++e) acc[e] += w * v[k] * v[l];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < NM; ++e) {
+        const double t = wave_sum(acc[e]);
+        if ((tid & 63) == 0) red[tid >> 6][e] = t;
+    }
+    __syncthreads();
+    if (tid < NM) M[tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+    __syncthreads();
+    auto m2 = [&](int k, int l) { const int hi = k > l ? k : l, lo = k > l ? l : k; return M[1 + EMK + hi * (hi + 1) / 2 + lo]; };
+    if (tid < d) {                                   // d mean / d mu = P M1
+        double s = 0.0;
+        for (int k = 0; k < d; ++k) s += iR[tid * EMK + k] * M[1 + k];
+        dm_dz[((long)blockIdx.y * Ny + a) * d + tid] = s;
+    }
+    if (tid < d * d) {                               // T1 = P M2
+        const int r = tid / d, q = tid % d;
+        double s = 0.0;
+        for (int k = 0; k < d; ++k) s += iR[r * EMK + k] * m2(k, q);
+        T1[r * EMK + q] = s;
+    }
+    __syncthreads();
+    if (tid < d * d) {
+        const int r = tid / d, q = tid % d;
+        double s = 0.0;
+        for (int k = 0; k < d; ++k) s += T1[r * EMK + k] * iR[k * EMK + q];
+        dm_dS[(((long)blockIdx.y * Ny + a) * d + r) * d + q] = -0.5 * iR[r * EMK + q] * M[0] + 0.5 * s;
+    }
+}
+
+// assembly per (input, unordered pair a >= c).  One thread each; grid (ceil(Bc*P/64)), 64 threads.
+__global__ void __launch_bounds__(64) em_sens_finish_kernel(const double* __restrict__ sums, const double* __restrict__ prep,
+                                                            const double* __restrict__ hyper, const double* __restrict__ Sigma,
+                                                            const double* __restrict__ mean, const double* __restrict__ dm_dz,
+                                                            const double* __restrict__ dm_dS, double* __restrict__ dc_dz,
+                                                            double* __restrict__ dc_dS, int Bc, int Ny, int d, int b0) {
+    const int P = Ny * (Ny + 1) / 2, stride = d * d + 1;
+    const long gid = (long)blockIdx.x * 64 + threadIdx.x;
+    if (gid >= (long)Bc * P) return;
+    const int bl = (int)(gid / P), p = (int)(gid % P), b = b0 + bl;
+    int a = 0;
+    while ((a + 1) * (a + 2) / 2 <= p) ++a;
+    const int c = p - a * (a + 1) / 2;
+    const double* ha = hyper + (long)a * (d + 2);
+    const double* hc = hyper + (long)c * (d + 2);
+    const double* Sg = Sigma + (long)b * d * d;
+    const double t = prep[((long)b * (Ny + P) + Ny + p) * stride + d * d];
+    const double* sa_ = sums + ((long)bl * Ny * Ny + a * Ny + c) * EM_NSS;      // ordered (a, c)
+    const double* sc_ = sums + ((long)bl * Ny * Ny + c * Ny + a) * EM_NSS;      // ordered (c, a)
+    double ila[EMK], ilc[EMK], lab[EMK], A[DMAX * DMAX], G[DMAX * DMAX];
+    for (int k = 0; k < d; ++k) {
+        ila[k] = 1.0 / (ha[k] * ha[k]);
+        ilc[k] = 1.0 / (hc[k] * hc[k]);
+        lab[k] = ila[k] + ilc[k];
+    }
+    // G = (Lab Sigma + I)^-1
+    for (int r = 0; r < d; ++r)
+        for (int q = 0; q < d; ++q) {
+            A[r * d + q] = lab[r] * Sg[r * d + q] + (r == q ? 1.0 : 0.0);
+            G[r * d + q] = (r == q) ? 1.0 : 0.0;
+        }
+    small_solve(A, G, d, d);
+    const double s0 = sa_[0];
+    double z1[EMK], ZZ[EMK * EMK], T1[EMK * EMK];
+    for (int k = 0; k < d; ++k) z1[k] = ila[k] * sa_[1 + k] + ilc[k] * sc_[1 + k];
+    const double* S2a = sa_ + 1 + EMK;
+    const double* S2c = sc_ + 1 + EMK;
+    const double* Xg = sa_ + 1 + EMK + EMK * EMK;
+    for (int k = 0; k < d; ++k)
+        for (int l = 0; l < d; ++l)
+            ZZ[k * EMK + l] = ila[k] * S2a[k * EMK + l] * ila[l] + ilc[k] * S2c[k * EMK + l] * ilc[l] + 2.0 * ila[k] * Xg[k * EMK + l];
+    const double ma = mean[(long)b * Ny + a], mc = mean[(long)b * Ny + c];
+    const double* dza = dm_dz + ((long)bl * Ny + a) * d;
+    const double* dzc = dm_dz + ((long)bl * Ny + c) * d;
+    const double* dSa = dm_dS + ((long)bl * Ny + a) * d * d;
+    const double* dSc = dm_dS + ((long)bl * Ny + c) * d * d;
+    for (int k = 0; k < d; ++k) {
+        double s = 0.0;
+        for (int l = 0; l < d; ++l) s += G[k * d + l] * z1[l];
+        const double v = t * s - mc * dza[k] - ma * dzc[k];
+        dc_dz[(((long)bl * Ny + a) * Ny + c) * d + k] = v;
+        dc_dz[(((long)bl * Ny + c) * Ny + a) * d + k] = v;
+    }
+    for (int k = 0; k < d; ++k)
+        for (int l = 0; l < d; ++l) {
+            double s = 0.0;
+            for (int m = 0; m < d; ++m) s += G[k * d + m] * ZZ[m * EMK + l];
+            T1[k * EMK + l] = s;
+        }
+    for (int k = 0; k < d; ++k)
+        for (int l = 0; l < d; ++l) {
+            double s = 0.0;
+            for (int m = 0; m < d; ++m) s += T1[k * EMK + m] * G[l * d + m];       // (G ZZ G^T)_kl
+            const double v = t * (-0.5 * G[k * d + l] * lab[l] * s0 + 0.5 * s) - mc * dSa[k * d + l] - ma * dSc[k * d + l];
+            dc_dS[((((long)bl * Ny + a) * Ny + c) * d + k) * d + l] = v;
+            dc_dS[((((long)bl * Ny + c) * Ny + a) * d + k) * d + l] = v;
+        }
+}
+
 // ---- legacy methods a12 ------------------------------------------------------------------------------
 // 'old_ME' (gp, gp_functions.py:176-256) and 'old_TA' (gp_taylor_approx(diag=True), :259-340) both start
 // from u = K_a^-1 ks (one GEMM for the whole batch: UT = KsT K^-1).  This kernel turns (ks, u) into the

@@ -1626,6 +1626,94 @@ extern "C" int gpmpc_predict_sens(gpmpc_gp* h, int B, const double* Z, double* m
     return GPMPC_OK;
 }
 
+// ---- 'EM' with derivative outputs: what a casadi Callback for GP.__predict needs when the MPC
+// propagates with exact moments (gp_class.py:220-224): value and Jacobians w.r.t. the input mean and covariance.
+extern "C" int gpmpc_predict_em_sens(gpmpc_gp* h, int B, const double* Z, const double* Sigma, double* mean, double* cov,
+                                     double* dmean_dz, double* dmean_dS, double* dcov_dz, double* dcov_dS) {
+    if (!h) return fail(GPMPC_EINVAL, "NULL handle");
+    if (!h->fitted) return fail(GPMPC_ENOTFIT, "model has no factors (call gpmpc_fit or gpmpc_set_factors)");
+    if (B <= 0 || !Z || !Sigma) return fail(GPMPC_EINVAL, "bad B or NULL Z / Sigma");
+    const int d = h->d, Ny = h->Ny, Np = h->Np, N = h->N;
+    if (d > EMK) return fail(GPMPC_EINVAL, "EM: input dimension d=%d exceeds the MFMA cross-term depth %d", d, EMK);
+    HIPCHK(hipSetDevice(h->device));
+    CHK(ensure_scratch(h, 1));
+    if (!h->have_invK) {
+        PhaseTimer t(h, GPMPC_PH_INVK);
+        CHK(compute_invK(h->cx(), h->ws));
+        h->have_invK = true;
+    }
+    CHK(ensure_beta(h));
+    const Ctx cx = h->cx();
+    const bool host = h->ptr_mode == GPMPC_PTR_HOST;
+    const int P = Ny * (Ny + 1) / 2, PO = Ny * Ny, tiles = Np / 64;
+    const size_t per_in = (size_t)PO * ((size_t)(2 * EMK + 2) * Np + (size_t)tiles * EM_NSS + EM_NSS) * sizeof(double);
+    int Bc = (int)std::max<size_t>(1, std::min<size_t>((size_t)B, ((size_t)512 << 20) / per_in));
+    // one device block: [Z | Sigma | mean | cov | dm_dz | dm_dS | dc_dz | dc_dS | prep | ops | part | sums]
+    const size_t nZ = (size_t)B * d, nS = (size_t)B * d * d, nM = (size_t)B * Ny, nC = (size_t)B * Ny * Ny;
+    const size_t n1 = nM * d, n2 = nM * d * d, n3 = nC * d, n4 = nC * d * d;
+    const size_t nPrep = (size_t)B * (Ny + P) * (d * d + 1);
+    const size_t nOps = (size_t)Bc * PO * (2 * EMK + 2) * Np, nPart = (size_t)Bc * PO * tiles * EM_NSS, nSum = (size_t)Bc * PO * EM_NSS;
+    double* buf = nullptr;
+    HIPCHK(hipMalloc(&buf, (nZ + nS + nM + nC + n1 + n2 + n3 + n4 + nPrep + nOps + nPart + nSum) * sizeof(double)));
+    double *bZ = buf, *bS = bZ + nZ, *bM = bS + nS, *bC = bM + nM, *b1 = bC + nC, *b2 = b1 + n1, *b3 = b2 + n2, *b4 = b3 + n3,
+           *prep = b4 + n4, *ops = prep + nPrep, *part = ops + nOps, *sums = part + nPart;
+    int rc = GPMPC_OK;
+    auto run = [&]() -> int {
+        const double *dZ = Z, *dS = Sigma;
+        if (host) {
+            HIPCHK(hipMemcpyAsync(bZ, Z, nZ * sizeof(double), hipMemcpyHostToDevice, h->stream));
+            HIPCHK(hipMemcpyAsync(bS, Sigma, nS * sizeof(double), hipMemcpyHostToDevice, h->stream));
+            dZ = bZ; dS = bS;
+        }
+        // device-pointer mode writes straight into the caller's arrays; NULL outputs land in the scratch block
+        double* oM = (!host && mean) ? mean : bM;
+        double* oC = (!host && cov) ? cov : bC;
+        double* o1 = (!host && dmean_dz) ? dmean_dz : b1;
+        double* o2 = (!host && dmean_dS) ? dmean_dS : b2;
+        double* o3 = (!host && dcov_dz) ? dcov_dz : b3;
+        double* o4 = (!host && dcov_dS) ? dcov_dS : b4;
+        for (int b0 = 0; b0 < B; b0 += Bc) {
+            const int nb = std::min(Bc, B - b0);
+            CHK(predict_moments_chunk(h, GPMPC_EM, nb, dZ + (size_t)b0 * d, dS + (size_t)b0 * d * d, oM + (size_t)b0 * Ny,
+                                      oC + (size_t)b0 * Ny * Ny));
+            PhaseTimer t(h, GPMPC_PH_EM);
+            if (b0 == 0) {
+                const long items = (long)B * (Ny + P);
+                hipLaunchKernelGGL(em_prep_kernel, dim3((unsigned)((items + 63) / 64)), dim3(64), 0, cx.stream, h->ws.hyper, dS,
+                                   prep, B, Ny, d);
+            }
+            hipLaunchKernelGGL(em_mean_sens_kernel, dim3(Ny, nb), dim3(256), 0, cx.stream, h->XT, dZ, h->beta, prep,
+                               o1 + (size_t)b0 * Ny * d, o2 + (size_t)b0 * Ny * d * d, N, Np, d, Ny, b0);
+            hipLaunchKernelGGL(em_operands_ordered_kernel, dim3((Np + 255) / 256, PO, nb), dim3(256), 0, cx.stream, h->XT, dZ,
+                               h->ws.hyper, prep, ops, N, Np, d, Ny, b0);
+            hipLaunchKernelGGL(em_pair_sens_kernel, dim3(tiles, PO, nb), dim3(256), 0, cx.stream, ops, h->beta, h->ws.InvK, h->XT,
+                               dZ, part, N, Np, Ny, d, b0, cx.crow_mode);
+            hipLaunchKernelGGL(em_sens_reduce_kernel, dim3(PO, nb), dim3(256), 0, cx.stream, part, sums, Ny, tiles);
+            hipLaunchKernelGGL(em_sens_finish_kernel, dim3((unsigned)(((long)nb * P + 63) / 64)), dim3(64), 0, cx.stream, sums, prep,
+                               h->ws.hyper, dS, oM, o1 + (size_t)b0 * Ny * d, o2 + (size_t)b0 * Ny * d * d,
+                               o3 + (size_t)b0 * Ny * Ny * d, o4 + (size_t)b0 * Ny * Ny * d * d, nb, Ny, d, b0);
+            HIPCHK(hipGetLastError());
+        }
+        if (host) {
+            auto down = [&](double* dst, const double* src, size_t n) {
+                return dst ? hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyDeviceToHost, h->stream) : hipSuccess;
+            };
+            HIPCHK(down(mean, bM, nM));
+            HIPCHK(down(cov, bC, nC));
+            HIPCHK(down(dmean_dz, b1, n1));
+            HIPCHK(down(dmean_dS, b2, n2));
+            HIPCHK(down(dcov_dz, b3, n3));
+            HIPCHK(down(dcov_dS, b4, n4));
+        }
+        HIPCHK(hipStreamSynchronize(h->stream));
+        return GPMPC_OK;
+    };
+    rc = run();
+    if (rc != GPMPC_OK) hipStreamSynchronize(h->stream);
+    hipFree(buf);
+    return rc;
+}
+
 extern "C" int gpmpc_predict(gpmpc_gp* h, int method, int B, const double* Z, const double* Sigma, double* mean,
                              double* cov) {
     if (method < GPMPC_ME || method > GPMPC_OLD_TA) return fail(GPMPC_EINVAL, "No GP method with code %d", method);

@@ -222,18 +222,19 @@ class GP:
 
     def predict_derivatives(self, x, u, cov):
         """`predict` plus the exact first derivatives of both outputs with respect to all three inputs,
-        for the 'ME' and 'TA' methods -- what a casadi Callback standing in for `__predict`
-        (gp_class.py:212-219) must provide through `get_jacobian`; the reference gets them from CasADi's
-        AD of build_gp / build_TA_cov (gp_functions.py:114-173).  One device call
-        (`gpmpc_predict_sens`: mean, var, J, d2 mean/dz2, d var/dz), closed-form assembly here.
+        for the 'ME', 'TA' and 'EM' methods -- what a casadi Callback standing in for `__predict`
+        (gp_class.py:212-224) must provide through `get_jacobian`; the reference gets them from CasADi's
+        AD of build_gp / build_TA_cov / gp_exact_moment (gp_functions.py:114-173,344-418).  One device call
+        (`gpmpc_predict_sens`: mean, var, J, d2 mean/dz2, d var/dz, closed-form assembly here; 'EM':
+        `gpmpc_predict_em_sens`, the Jacobians themselves).
 
         Returns (mean[Ny,1], cov[Ny,Ny], D) with D a dict of
-          'dmean_dx' [Ny,Ny], 'dmean_du' [Ny,Nu], 'dmean_dcov' [Ny,Nx,Nx] (zero),
+          'dmean_dx' [Ny,Ny], 'dmean_du' [Ny,Nu], 'dmean_dcov' [Ny,Nx,Nx] (zero for ME / TA),
           'dcov_dx' [Ny,Ny,Ny], 'dcov_du' [Ny,Ny,Nu], 'dcov_dcov' [Ny,Ny,Nx,Nx],
         all with respect to the RAW x, u (the chain rule through the standardisation is applied; cov
         stays in standardised units exactly as `predict` returns it, gp_class.py:262)."""
-        if self.__gp_method not in ('ME', 'TA'):
-            raise NotImplementedError("analytic derivatives exist for 'ME' and 'TA'; use finite differences of "
+        if self.__gp_method not in ('ME', 'TA', 'EM'):
+            raise NotImplementedError("analytic derivatives exist for 'ME', 'TA' and 'EM'; use finite differences of "
                                       "GP.predict for '%s'" % self.__gp_method)
         Ny, Nx, Nu = self.__Ny, self.__Nx, self.__Nu
         x = np.asarray(x, dtype=np.float64).reshape(-1)
@@ -243,22 +244,27 @@ class GP:
             u = self.standardize(u, self.__meanU, self.__stdU)
         z = np.concatenate([x, u]).reshape(1, Nx)
         S = np.asarray(cov, dtype=np.float64).reshape(Nx, Nx)
-        mean, var, J, Hm, dvar = (a[0] for a in self._h.predict_sens(z))
-        c = np.diag(var)
-        dcz = np.zeros((Ny, Ny, Nx))
-        dcz[np.arange(Ny), np.arange(Ny)] = dvar                      # d diag(var) / dz
-        dcS = np.zeros((Ny, Ny, Nx, Nx))
-        if self.__gp_method == 'TA':                                  # cov = diag(var) + J S J^T
-            c = c + J @ S @ J.T
-            dcz += np.einsum('adp,de,ce->acp', Hm, S, J) + np.einsum('ad,de,cep->acp', J, S, Hm)
-            dcS = np.einsum('ad,ce->acde', J, J)
-        dmean = J.copy()
+        if self.__gp_method == 'EM':
+            mean, c, dmean, dmS, dcz, dcS = (a[0] for a in self._h.predict_em_sens(z, S.reshape(1, Nx, Nx)))
+        else:
+            mean, var, J, Hm, dvar = (a[0] for a in self._h.predict_sens(z))
+            c = np.diag(var)
+            dcz = np.zeros((Ny, Ny, Nx))
+            dcz[np.arange(Ny), np.arange(Ny)] = dvar                      # d diag(var) / dz
+            dcS = np.zeros((Ny, Ny, Nx, Nx))
+            dmS = np.zeros((Ny, Nx, Nx))
+            if self.__gp_method == 'TA':                                  # cov = diag(var) + J S J^T
+                c = c + J @ S @ J.T
+                dcz += np.einsum('adp,de,ce->acp', Hm, S, J) + np.einsum('ad,de,cep->acp', J, S, Hm)
+                dcS = np.einsum('ad,ce->acde', J, J)
+            dmean = J.copy()
         if self.__normalize:
             mean = self.inverse_mean(mean, self.__meanY, self.__stdY)
             sz = np.concatenate([np.atleast_1d(self.__stdX), np.atleast_1d(self.__stdU)])
             dmean = dmean * np.atleast_1d(self.__stdY)[:, None] / sz[None, :]
+            dmS = dmS * np.atleast_1d(self.__stdY)[:, None, None]
             dcz = dcz / sz[None, None, :]
-        D = {'dmean_dx': dmean[:, :Ny], 'dmean_du': dmean[:, Ny:], 'dmean_dcov': np.zeros((Ny, Nx, Nx)),
+        D = {'dmean_dx': dmean[:, :Ny], 'dmean_du': dmean[:, Ny:], 'dmean_dcov': dmS,
              'dcov_dx': dcz[:, :, :Ny], 'dcov_du': dcz[:, :, Ny:], 'dcov_dcov': dcS}
         return mean.reshape(Ny, 1), c, D
 

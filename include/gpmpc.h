@@ -135,6 +135,14 @@ int gpmpc_mean_jac(gpmpc_gp* h, int B, const double* Z, double* mean, double* J)
  * (cov = diag(var) + J Sigma J^T).  Any output pointer may be NULL. */
 int gpmpc_predict_sens(gpmpc_gp* h, int B, const double* Z, double* mean, double* var, double* J,
                        double* Hm, double* dvar);
+/* 'EM' (gp_exact_moment gp_functions.py:344-418) with its first derivatives: besides mean[B x Ny] and cov[B x Ny x Ny]
+ * the Jacobians dmean_dz[B x Ny x d], dmean_dS[B x Ny x d x d], dcov_dz[B x Ny x Ny x d], dcov_dS[B x Ny x Ny x d x d]
+ * with respect to the input mean z and the d x d entries of the input covariance (entries independent, as in CasADi's
+ * jacobian(..., covar_s) which the reference relies on inside IPOPT).  Sigma must be symmetric: like gpmpc_predict's
+ * 'EM' value path, which visits each pair (i, j) of training points once, the formulas use Sigma = Sigma^T.  Any output
+ * may be NULL.  d <= 8. */
+int gpmpc_predict_em_sens(gpmpc_gp* h, int B, const double* Z, const double* Sigma, double* mean, double* cov,
+                          double* dmean_dz, double* dmean_dS, double* dcov_dz, double* dcov_dS);
 /* GP.__predict (gp_class.py:212-235) batched over B input distributions:
  * Z[B x d], Sigma[B x d x d] (ignored for ME/old_ME, may be NULL) -> mean[B x Ny],
  * cov[B x Ny x Ny] in standardised units (gp_class.py:262 leaves cov unscaled). */

@@ -493,6 +493,72 @@ def exact_moment(invK, X, Y, hyper, inputmean, inputcov):
     return mean.reshape(Ny), covariance
 
 
+def exact_moment_sens(invK, X, Y, hyper, inputmean, inputcov):
+    """First derivatives of `exact_moment` (gp_functions.py:344-418) with respect to the input mean and the input
+    covariance -- what CasADi's AD of gp_exact_moment hands to IPOPT when 'EM' is the MPC's propagation method
+    (gp_class.py:220-224, mpc_class.py:412-413); there is no reference function.  The d x d entries of the covariance
+    are independent variables (as in `ca.jacobian(..., covar_s)`); formulas are evaluated at a symmetric Sigma.
+    With v_i = x_i - mu, P_a = (Sigma + Lambda_a)^-1, w_i = beta_ai q_ai:
+        d mean_a/d mu    = P_a sum_i w_i v_i
+        d mean_a/d Sigma = -1/2 P_a mean_a + 1/2 P_a (sum_i w_i v_i v_i^T) P_a
+    and with Lab = Lambda_a^-1 + Lambda_b^-1, R = Sigma Lab + I, G = R^-T, z_ij = Lambda_a^-1 v_i + Lambda_b^-1 v_j,
+    W = A o Q (A = beta_a beta_b^T - [a==b] K_a^-1), s = sum W, t = det(R)^-1/2:
+        d(t s)/d mu    = t G sum_ij W_ij z_ij
+        d(t s)/d Sigma = t (-1/2 G Lab s + 1/2 G (sum_ij W_ij [ii_i ii_i^T + ij_j ij_j^T + 2 ii_i ij_j^T]) G^T)
+        cov_ab = t s + [a==b] sf_a^2 - mean_a mean_b  ->  product rule for the last term.
+    Returns dmean_dz[Ny,d], dmean_dS[Ny,d,d], dcov_dz[Ny,Ny,d], dcov_dS[Ny,Ny,d,d].
+    Pinned by complex-step differentiation of a complex-safe transcription of `exact_moment` (tests/test_oracle.py)."""
+    H = np.asarray(hyper, dtype=np.float64)
+    Ny = len(invK)
+    N, d = X.shape
+    mu = np.asarray(inputmean, dtype=np.float64).reshape(d)
+    Sg = np.asarray(inputcov, dtype=np.float64)
+    v = X - mu
+    beta = np.stack([invK[a] @ Y[:, a] for a in range(Ny)], axis=1)
+    mean = np.zeros(Ny)
+    dm_dz = np.zeros((Ny, d))
+    dm_dS = np.zeros((Ny, d, d))
+    lk = np.zeros((N, Ny))
+    for a in range(Ny):
+        lam = H[a, :d] ** 2
+        P = np.linalg.inv(Sg + np.diag(lam))
+        c = H[a, d] ** 2 * np.prod(H[a, :d]) / np.sqrt(abs(np.linalg.det(Sg + np.diag(lam))))
+        w = c * np.exp(-0.5 * np.einsum('ik,kl,il->i', v, P, v)) * beta[:, a]
+        mean[a] = w.sum()
+        dm_dz[a] = P @ (v.T @ w)
+        dm_dS[a] = -0.5 * P * mean[a] + 0.5 * P @ ((v * w[:, None]).T @ v) @ P
+        lk[:, a] = 2 * np.log(H[a, d]) - 0.5 * np.sum(v * v / lam, axis=1)
+    dc_dz = np.zeros((Ny, Ny, d))
+    dc_dS = np.zeros((Ny, Ny, d, d))
+    for a in range(Ny):
+        ila = 1.0 / H[a, :d] ** 2
+        for b in range(a + 1):
+            ilb = 1.0 / H[b, :d] ** 2
+            lab = ila + ilb
+            R = Sg * lab[None, :] + np.eye(d)
+            t = 1.0 / np.sqrt(abs(np.linalg.det(R)))
+            Sm = np.linalg.solve(R, Sg * 0.5)
+            G = np.linalg.inv(R).T
+            ii, ij = v * ila, v * ilb
+            Q = np.exp(lk[:, a][:, None] + lk[:, b][None, :] + maha(ii, -ij, Sm))
+            A = np.outer(beta[:, a], beta[:, b])
+            if a == b:
+                A = A - invK[a]
+            W = A * Q
+            s0 = W.sum()
+            r, c = W.sum(axis=1), W.sum(axis=0)
+            z1 = ila * (v.T @ r) + ilb * (v.T @ c)
+            Xc = (v * ila).T @ W @ (v * ilb)                       # sum_ij W_ij ii_i ij_j^T
+            # `maha` (:421-430) is written a Q a^T + b Q b^T - 2 a Q b^T: its cross term is NOT symmetrised in Q, so
+            # the derivative w.r.t. independent entries of Sigma carries 2 Xc, not Xc + Xc^T
+            ZZ = (ii * r[:, None]).T @ ii + (ij * c[:, None]).T @ ij + 2 * Xc
+            dz = t * (G @ z1) - mean[b] * dm_dz[a] - mean[a] * dm_dz[b]
+            dS = t * (-0.5 * (G * lab[None, :]) * s0 + 0.5 * G @ ZZ @ G.T) - mean[b] * dm_dS[a] - mean[a] * dm_dS[b]
+            dc_dz[a, b] = dc_dz[b, a] = dz
+            dc_dS[a, b] = dc_dS[b, a] = dS
+    return dm_dz, dm_dS, dc_dz, dc_dS
+
+
 # --------------------------------------------------------------------------
 # a12  legacy methods
 # --------------------------------------------------------------------------

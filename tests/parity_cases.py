@@ -551,7 +551,7 @@ def check_gp_class(lib, g, tmp_path, em_rollout=True):
         E[0, 1] = 1e-3
         _, cp = gp.predict(x, u, S + E)
         assert np.allclose((cp - cc) / 1e-3, D['dcov_dcov'][:, :, 0, 1], rtol=1e-9, atol=1e-12 * sf2.max() / 1e-3)
-    gp.set_method('EM')
+    gp.set_method('old_TA')
     try:
         gp.predict_derivatives(x, u, S)
         assert False
@@ -965,4 +965,93 @@ def check_feedback_rollout(lib, g, T=5):
     assert np.max(np.abs(c - og.controls)) <= 1e-8 * max(1.0, np.abs(og.controls).max())
     assert np.max(np.abs(m - om)) <= 1e-8 * max(1.0, np.abs(om).max()) and np.max(np.abs(v - np.clip(ov, 0, None))) <= 1e-8
     assert np.max(np.abs(c[0] - U)) > 1e-3          # the controls really come from the feedback law, not from U
+    gp.close()
+
+
+def check_em_sens(lib, N=150, d=4, Ny=3, B=5, seed=13, tol=1e-9):
+    """f1: value and Jacobians of 'EM' (`gpmpc_predict_em_sens`) against the oracle's closed forms, which
+    tests/test_oracle.py pins by complex-step differentiation of the exact-moment formulas."""
+    p = go.synthetic_problem(N, d, Ny, B, seed=seed, sn=0.1)
+    X, Y, H, Z, S = p['X'], p['Y'], p['hyper'], p['Z'] * 0.5, p['Sigma'] * 40
+    H = H.copy()
+    H[:, :d] *= np.linspace(0.6, 1.3, d)[None, :]
+    h = Handle(lib, X, Y)
+    h.fit(H, want_invK=True)
+    f = h.get_factors(invK=True)
+    mean, cov, dm_dz, dm_dS, dc_dz, dc_dS = h.predict_em_sens(Z, S)
+    m0, c0 = h.predict('EM', Z, S)
+    assert np.array_equal(mean, m0) and np.array_equal(cov, c0)
+    sf2 = (H[:, d] ** 2).max()
+    for b in range(B):
+        o1, o2, o3, o4 = go.exact_moment_sens(f['invK'], X, Y, H, Z[b], S[b])
+        sc = _em_scale(f['invK'], X, Y, H, Z[b], S[b]).max() + sf2          # cancellation scale of the pair sums
+        ell = H[:, :d].min()
+        assert np.max(np.abs(dm_dz[b] - o1)) <= tol * max(1.0, np.abs(o1).max()), (b, np.abs(dm_dz[b] - o1).max())
+        assert np.max(np.abs(dm_dS[b] - o2)) <= tol * max(1.0, np.abs(o2).max()), (b, np.abs(dm_dS[b] - o2).max())
+        assert np.max(np.abs(dc_dz[b] - o3)) <= tol * max(sc / ell, np.abs(o3).max()), (b, np.abs(dc_dz[b] - o3).max(), np.abs(o3).max())
+        assert np.max(np.abs(dc_dS[b] - o4)) <= tol * max(sc / ell ** 2, np.abs(o4).max()), (b, np.abs(dc_dS[b] - o4).max(), np.abs(o4).max())
+    # a direct end-to-end check as well: central differences of the device's own 'EM' value
+    e = 1e-5
+    Zp, Zm = Z[:1].copy(), Z[:1].copy()
+    Zp[0, 1] += e
+    Zm[0, 1] -= e
+    mp, cp = h.predict('EM', Zp, S[:1])
+    mm, cm = h.predict('EM', Zm, S[:1])
+    assert np.allclose((mp - mm)[0] / (2 * e), dm_dz[0][:, 1], rtol=1e-5, atol=1e-6)
+    assert np.allclose((cp - cm)[0] / (2 * e), dc_dz[0][:, :, 1], rtol=1e-4, atol=1e-5)
+    h.close()
+
+
+def check_callback_blocks(lib, N=120, Ny=3, Nu=2, seed=17):
+    """The numeric core of the casadi Callback (gp_mpc_amd/casadi_callback.py::jacobian_blocks): six Jacobian blocks
+    in CasADi's column-major vec layout, for every propagation method, against central differences of `GP.predict`
+    taken in that layout, on a standardised model (so the chain rule through GP.predict's scaling is exercised)."""
+    from gp_mpc_amd.gp import GP
+    from gp_mpc_amd.casadi_callback import jacobian_blocks
+    Nx = Ny + Nu
+    p = go.synthetic_problem(N, Nx, Ny, 2, seed=seed, sn=0.1)
+    rng = np.random.default_rng(seed)
+    meta = dict(meanY=rng.standard_normal(Ny), stdY=rng.uniform(0.5, 2.0, Ny), meanZ=rng.standard_normal(Nx),
+                stdZ=rng.uniform(0.5, 2.0, Nx))
+    meta.update(meanX=meta['meanZ'][:Ny], stdX=meta['stdZ'][:Ny], meanU=meta['meanZ'][Ny:], stdU=meta['stdZ'][Ny:])
+    o = go.fit(p['X'], p['Y'], p['hyper'])
+    gp = GP(p['X'], p['Y'], hyper=dict(hyper=p['hyper'], chol=o['chol'], alpha=o['alpha'], invK=o['invK']), normalize=True,
+            meta=meta, xlb=np.zeros(Ny), xub=np.ones(Ny), ulb=np.zeros(Nu), uub=np.ones(Nu), lib=lib)
+    z = meta['meanZ'] + 0.4 * meta['stdZ'] * rng.standard_normal(Nx)
+    x, u = z[:Ny], z[Ny:]
+    A = rng.standard_normal((Nx, Nx)) * 0.15
+    S = A @ A.T + 1e-3 * np.eye(Nx)
+
+    def both(zv, Sv):
+        m, c = gp.predict(zv[:Ny], zv[Ny:], Sv)
+        return np.concatenate([np.array(m).reshape(-1), np.array(c).reshape(-1, order='F')])
+    for method in ('ME', 'TA', 'EM', 'old_ME'):
+        gp.set_method(method)
+        blocks = jacobian_blocks(gp, x, u, S)
+        shapes = [(Ny, Ny), (Ny, Nu), (Ny, Nx * Nx), (Ny * Ny, Ny), (Ny * Ny, Nu), (Ny * Ny, Nx * Nx)]
+        assert [b.shape for b in blocks] == shapes
+        Jz = np.zeros((Ny + Ny * Ny, Nx))
+        for k in range(Nx):
+            e = np.zeros(Nx)
+            e[k] = 1e-5
+            Jz[:, k] = (both(z + e, S) - both(z - e, S)) / 2e-5
+        # The input covariance is perturbed SYMMETRICALLY, entries (p, q) and (q, p) together -- the only kind of
+        # perturbation an NLP built on a covariance matrix produces, and the only one the device's value path is
+        # defined for (it exploits Sigma = Sigma^T) -- and compared with the sum of the two Jacobian columns.
+        JS = np.zeros((Ny + Ny * Ny, Nx * Nx))
+        fold = lambda Bk: np.stack([Bk[:, pp + Nx * qq] + (Bk[:, qq + Nx * pp] if pp != qq else 0.0)
+                                    for qq in range(Nx) for pp in range(Nx)], axis=1)
+        for qq in range(Nx):
+            for pp in range(Nx):
+                E = np.zeros((Nx, Nx))
+                E[pp, qq] = E[qq, pp] = 1e-5
+                JS[:, pp + Nx * qq] = (both(z, S + E) - both(z, S - E)) / 2e-5
+        ref = [Jz[:Ny, :Ny], Jz[:Ny, Ny:], JS[:Ny], Jz[Ny:, :Ny], Jz[Ny:, Ny:], JS[Ny:]]
+        got = [blocks[0], blocks[1], fold(blocks[2]), blocks[3], blocks[4], fold(blocks[5])]
+        for i, (b, r) in enumerate(zip(got, ref)):
+            assert np.allclose(b, r, rtol=2e-5, atol=2e-6 * max(1.0, np.abs(r).max())), (method, i, np.abs(b - r).max())
+        if method in ('ME', 'TA'):
+            assert np.all(blocks[2] == 0.0)
+        if method == 'EM':
+            assert np.abs(blocks[2]).max() > 1e-4          # the EM mean does depend on Sigma
     gp.close()

@@ -168,3 +168,12 @@ def test_emu_mean_functions(emu):
 
 def test_emu_feedback_rollout(emu, tank):
     pc.check_feedback_rollout(emu, tank)
+
+
+def test_emu_em_sens(emu):
+    pc.check_em_sens(emu, N=100, d=3, Ny=2, B=2)
+    pc.check_em_sens(emu, N=70, d=8, Ny=1, B=1, seed=3)
+
+
+def test_emu_callback_blocks(emu):
+    pc.check_callback_blocks(emu)

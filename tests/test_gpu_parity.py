@@ -145,6 +145,16 @@ def test_training(lib, train_small):
     pc.check_training(lib, train_small)
 
 
+def test_em_sens(lib):
+    pc.check_em_sens(lib)
+    pc.check_em_sens(lib, N=600, d=8, Ny=6, B=3, seed=4)          # C3's output / input dimensions
+
+
+def test_callback_blocks(lib):
+    pc.check_callback_blocks(lib)
+    pc.check_callback_blocks(lib, N=500, Ny=6, Nu=2, seed=3)
+
+
 def test_feedback_rollout(lib, tank):
     pc.check_feedback_rollout(lib, tank, T=8)
 

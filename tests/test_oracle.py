@@ -418,3 +418,64 @@ def test_em_rollout_is_stable_on_well_conditioned_model():
     m1, v1 = gp.rollout(np.array([0.1, -0.2]), U, methods=('EM', 'TA'))
     assert np.all(np.isfinite(m1)) and np.all(v1 >= 0)
     assert np.allclose(m1[0, 1], m1[1, 1], rtol=0, atol=2e-2)     # EM ~ TA after one step (Sigma_x = sn^2 I = 0.01 I)
+
+
+def _exact_moment_complex(invK, X, Y, H, mu, Sigma):
+    """Transcription of go.exact_moment that is analytic in (mu, Sigma): determinants by np.linalg.det instead of
+    |prod diag(R_qr)| (equal for the positive arguments used here).  Only for complex-step differentiation."""
+    Ny, (N, Nx) = len(invK), X.shape
+    lh = np.log(H)
+    v = X - mu.reshape(1, Nx)
+    eye = np.eye(Nx)
+    mean = np.zeros(Ny, dtype=complex)
+    beta = np.stack([invK[a] @ Y[:, a] for a in range(Ny)], axis=1)
+    log_k = np.zeros((N, Ny), dtype=complex)
+    cov = np.zeros((Ny, Ny), dtype=complex)
+    for a in range(Ny):
+        iL = np.diag(np.exp(-2 * lh[a, :Nx]))
+        R = Sigma + np.diag(np.exp(2 * lh[a, :Nx]))
+        iR = iL @ (eye - np.linalg.solve(eye + Sigma @ iL, Sigma @ iL))
+        c = np.exp(2 * lh[a, Nx]) / np.sqrt(np.linalg.det(R)) * np.exp(np.sum(lh[a, :Nx]))
+        mean[a] = np.sum(c * np.exp(-np.sum((v @ iR) * v, axis=1) * 0.5) * beta[:, a])
+        log_k[:, a] = 2 * lh[a, Nx] - np.sum((v / np.exp(lh[a, :Nx])) ** 2, axis=1) * 0.5
+    for a in range(Ny):
+        ii = v / np.exp(2 * lh[a, :Nx])
+        for b in range(a + 1):
+            R = Sigma @ np.diag(np.exp(-2 * lh[a, :Nx]) + np.exp(-2 * lh[b, :Nx])) + eye
+            t = 1.0 / np.sqrt(np.linalg.det(R))
+            ij = v / np.exp(2 * lh[b, :Nx])
+            S = np.linalg.solve(R, Sigma * 0.5)
+            aQ, bQ = ii @ S, (-ij) @ S
+            mh = np.sum(aQ * ii, axis=1)[:, None] + np.sum(bQ * (-ij), axis=1)[None, :] - 2 * aQ @ (-ij).T
+            A = np.outer(beta[:, a], beta[:, b]) - (invK[a] if a == b else 0.0)
+            cov[a, b] = cov[b, a] = t * np.sum(A * np.exp(log_k[:, a][:, None] + log_k[:, b][None, :] + mh))
+        cov[a, a] += np.exp(2 * lh[a, Nx])
+    return mean, cov - np.outer(mean, mean)
+
+
+def test_exact_moment_sensitivities_by_complex_step():
+    """exact_moment_sens (the derivative outputs of 'EM' for a casadi Callback) against complex-step derivatives of
+    the exact-moment formulas, every entry of d/d mu and d/d Sigma (entries of Sigma independent)."""
+    p, f = _well_conditioned(seed=8, N=40, d=3, Ny=2)
+    X, Y, H = p['X'], p['Y'], p['hyper']
+    d, Ny = 3, 2
+    mu = np.array([0.2, -0.3, 0.4])
+    A = np.array([[0.3, 0.0, 0.0], [0.1, 0.25, 0.0], [-0.05, 0.1, 0.2]])
+    Sg = A @ A.T
+    m0, c0 = go.exact_moment(f['invK'], X, Y, H, mu, Sg)
+    mc, cc = _exact_moment_complex(f['invK'], X, Y, H, mu.astype(complex), Sg.astype(complex))
+    assert np.max(np.abs(mc.real - m0)) <= 1e-13 and np.max(np.abs(cc.real - c0)) <= 1e-13   # same function
+    dm_dz, dm_dS, dc_dz, dc_dS = go.exact_moment_sens(f['invK'], X, Y, H, mu, Sg)
+    h = 1e-30
+    for k in range(d):
+        muc = mu.astype(complex)
+        muc[k] += 1j * h
+        mc, cc = _exact_moment_complex(f['invK'], X, Y, H, muc, Sg.astype(complex))
+        assert np.max(np.abs(mc.imag / h - dm_dz[:, k])) <= 1e-11 * max(1.0, np.abs(dm_dz).max())
+        assert np.max(np.abs(cc.imag / h - dc_dz[:, :, k])) <= 1e-11 * max(1.0, np.abs(dc_dz).max())
+        for l in range(d):
+            Sc = Sg.astype(complex)
+            Sc[k, l] += 1j * h
+            mc, cc = _exact_moment_complex(f['invK'], X, Y, H, mu.astype(complex), Sc)
+            assert np.max(np.abs(mc.imag / h - dm_dS[:, k, l])) <= 1e-11 * max(1.0, np.abs(dm_dS).max()), (k, l)
+            assert np.max(np.abs(cc.imag / h - dc_dS[:, :, k, l])) <= 1e-11 * max(1.0, np.abs(dc_dS).max()), (k, l)
