@@ -60,6 +60,11 @@ SIGNATURES = {
     'gpmpc_predict': (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, _vp]),
     'gpmpc_covar': (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp]),
     'gpmpc_nll': (ctypes.c_int, [_vp, ctypes.c_int, _vp, _dp, _vp, _ip]),
+    'gpmpc_train_multistart': (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp, ctypes.c_int, ctypes.c_double, ctypes.c_int,
+                                              ctypes.c_int, _vp, ctypes.c_int, _vp, _vp, _vp, _vp]),
+    'gpmpc_rccl_unique_id': (ctypes.c_int, [ctypes.c_char_p]),
+    'gpmpc_rccl_comm_create': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.POINTER(_vp)]),
+    'gpmpc_rccl_comm_destroy': (ctypes.c_int, [_vp]),
     'gpmpc_kernel_matrix': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp,
                                            ctypes.c_double, _vp]),
     'gpmpc_cholesky': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _vp, _vp, _ip]),
@@ -134,6 +139,20 @@ class GpmpcLib:
     def set_tuning(self, name, value):
         """Diagnostic knob, e.g. set_tuning('gemm_tile', 64) pins the GEMM tile (0 = automatic)."""
         self.check(self.dll.gpmpc_set_tuning(name.encode(), int(value)))
+
+    # -- RCCL bootstrap of the restart shard
+    def rccl_unique_id(self):
+        buf = ctypes.create_string_buffer(128)
+        self.check(self.dll.gpmpc_rccl_unique_id(buf))
+        return buf.raw
+
+    def rccl_comm_create(self, device, world, rank, id128):
+        comm = ctypes.c_void_p()
+        self.check(self.dll.gpmpc_rccl_comm_create(device, world, rank, ctypes.create_string_buffer(id128, 128), ctypes.byref(comm)))
+        return comm
+
+    def rccl_comm_destroy(self, comm):
+        self.check(self.dll.gpmpc_rccl_comm_destroy(comm))
 
     # -- low-level dense ops
     def cholesky(self, A, device=0, want_inverse=False):
@@ -359,6 +378,21 @@ class Handle:
                                               ctypes.byref(jit)))
         self.last_jitter = jit.value
         return (val.value, grad) if want_grad else val.value
+
+    def train_multistart(self, starts, lb, ub, max_iter=0, tol=0.0, rank=0, world=1, comm=None, want_invK=True):
+        """gpmpc_train_multistart: starts[Ny, nstart, nh], lb / ub[Ny, nh] -> dict(hyper, obj, theta, info)."""
+        starts = _f64(starts).reshape(self.Ny, -1, self.nh)
+        nstart = starts.shape[1]
+        lb, ub = _f64(lb).reshape(self.Ny, self.nh), _f64(ub).reshape(self.Ny, self.nh)
+        hyper, obj = np.zeros((self.Ny, self.nh)), np.zeros((self.Ny, nstart))
+        theta = np.zeros((self.Ny, nstart, self.nh))
+        info = np.zeros(self.Ny, dtype=np.int32)
+        rc = self.lib.dll.gpmpc_train_multistart(self.h, nstart, _ptr(starts), _ptr(lb), _ptr(ub), int(max_iter), float(tol),
+                                                 int(rank), int(world), comm, int(want_invK), _ptr(hyper), _ptr(obj),
+                                                 _ptr(theta), info.ctypes.data_as(ctypes.c_void_p))
+        self.info = info
+        self.lib.check(rc)
+        return dict(hyper=hyper, obj=obj, theta=theta, info=info)
 
     # -- raw device-pointer entry points (device pointer mode)
     def predict_mean_var_dev(self, B, z_ptr, mean_ptr, var_ptr):

@@ -19,6 +19,7 @@
 #include "gemm_f64_dma.hpp"
 #include "gp_kernels.hpp"
 #include "leaf64.hpp"
+#include "train_native.hpp"
 
 using namespace gpmpc;
 
@@ -1831,6 +1832,117 @@ extern "C" int gpmpc_nll(gpmpc_gp* h, int a, const double* hyper_row, double* nl
     if (grad) HIPCHK(hipMemcpyAsync(grad, h->gradOut, (d + 2 + nmean) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return GPMPC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// a8 multistart training behind the C ABI (train_gp_numpy optimize.py:359-503 / train_gp :100-294)
+// ------------------------------------------------------------------------------------------------
+extern "C" int gpmpc_rccl_unique_id(char* id128) {
+    if (!id128) return fail(GPMPC_EINVAL, "NULL id buffer");
+    RcclApi& R = rccl_api();
+    if (!R.ok()) return fail(GPMPC_EHIP, "librccl.so could not be loaded: %s", dlerror() ? dlerror() : "missing symbols");
+    RcclId id;
+    const int rc = R.GetUniqueId(&id);
+    if (rc != 0) return fail(GPMPC_EHIP, "ncclGetUniqueId failed: %s", R.GetErrorString ? R.GetErrorString(rc) : "?");
+    std::memcpy(id128, id.internal, 128);
+    return GPMPC_OK;
+}
+
+extern "C" int gpmpc_rccl_comm_create(int device, int world, int rank, const char* id128, void** comm_out) {
+    if (!id128 || !comm_out || world < 1 || rank < 0 || rank >= world) return fail(GPMPC_EINVAL, "bad arguments");
+    *comm_out = nullptr;
+    CHK(ensure_device(device));
+    RcclApi& R = rccl_api();
+    if (!R.ok()) return fail(GPMPC_EHIP, "librccl.so could not be loaded");
+    RcclId id;
+    std::memcpy(id.internal, id128, 128);
+    const int rc = R.CommInitRank(comm_out, world, id, rank);
+    if (rc != 0) return fail(GPMPC_EHIP, "ncclCommInitRank failed: %s", R.GetErrorString ? R.GetErrorString(rc) : "?");
+    return GPMPC_OK;
+}
+
+extern "C" int gpmpc_rccl_comm_destroy(void* comm) {
+    if (!comm) return GPMPC_OK;
+    RcclApi& R = rccl_api();
+    if (!R.ok()) return fail(GPMPC_EHIP, "librccl.so could not be loaded");
+    return R.CommDestroy(comm) == 0 ? GPMPC_OK : fail(GPMPC_EHIP, "ncclCommDestroy failed");
+}
+
+extern "C" int gpmpc_train_multistart(gpmpc_gp* h, int nstart, const double* starts, const double* lb, const double* ub,
+                                      int max_iter, double tol, int rank, int world, void* rccl_comm, int want_invK,
+                                      double* hyper_opt, double* obj, double* theta_all, int* info) {
+    if (!h || nstart <= 0 || !starts || !lb || !ub || !hyper_opt) return fail(GPMPC_EINVAL, "NULL argument or nstart <= 0");
+    if (world < 1 || rank < 0 || rank >= world) return fail(GPMPC_EINVAL, "bad rank %d / world %d", rank, world);
+    HIPCHK(hipSetDevice(h->device));
+    const int Ny = h->Ny, nh = h->nh(), d = h->d, row = nh + 1;
+    const double inf = std::numeric_limits<double>::infinity();
+    if (max_iter <= 0) max_iter = 200;
+    if (!(tol > 0.0)) tol = 1e-8;
+    std::vector<double> table((size_t)Ny * nstart * row, 0.0);   // [a][r][NLL, theta...]; not-owned / failed: +inf
+    int hip_rc = GPMPC_OK;
+    for (int a = 0; a < Ny; ++a) {
+        BoxProblem P;
+        P.n = nh;
+        P.lb.assign(lb + (size_t)a * nh, lb + (size_t)(a + 1) * nh);
+        P.ub.assign(ub + (size_t)a * nh, ub + (size_t)(a + 1) * nh);
+        P.logv.resize(nh);
+        for (int k = 0; k < nh; ++k) {
+            if (!(P.lb[k] <= P.ub[k])) return fail(GPMPC_EINVAL, "empty box for hyper-parameter %d of output %d", k, a);
+            P.logv[k] = k < d + 2 && P.lb[k] > 0.0 && P.ub[k] < inf;
+        }
+        P.eval = [&](const double* th, double* f, double* g) -> bool {
+            const int rc = gpmpc_nll(h, a, th, f, g, nullptr);
+            if (rc == GPMPC_EHIP || rc == GPMPC_ENOMEM) hip_rc = rc;
+            return rc == GPMPC_OK;
+        };
+        for (int r = 0; r < nstart; ++r) {
+            double* out = &table[((size_t)a * nstart + r) * row];
+            out[0] = inf;
+            if (r % world != rank) continue;
+            const BoxResult res = minimize_box_lbfgs(P, starts + ((size_t)a * nstart + r) * nh, max_iter, tol);
+            if (hip_rc != GPMPC_OK) return hip_rc;               // device failure: g_err holds the text
+            std::memcpy(out + 1, res.theta.data(), nh * sizeof(double));
+            if (res.ok) out[0] = res.f;
+        }
+    }
+    if (rccl_comm) {    // one all-gather of the whole table: (1 + nh) doubles per restart (also at world = 1: a self-gather)
+        RcclApi& R = rccl_api();
+        if (!R.ok()) return fail(GPMPC_EHIP, "librccl.so could not be loaded");
+        const size_t cnt = table.size();
+        double *dsend = nullptr, *drecv = nullptr;
+        HIPCHK(hipMalloc(&dsend, cnt * sizeof(double)));
+        HIPCHK(hipMalloc(&drecv, cnt * world * sizeof(double)));
+        HIPCHK(hipMemcpyAsync(dsend, table.data(), cnt * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        const int rc = R.AllGather(dsend, drecv, cnt, RCCL_FLOAT64, rccl_comm, h->stream);
+        std::vector<double> all(cnt * world);
+        if (rc == 0) {
+            HIPCHK(hipMemcpyAsync(all.data(), drecv, all.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+        }
+        hipFree(dsend);
+        hipFree(drecv);
+        if (rc != 0) return fail(GPMPC_EHIP, "ncclAllGather failed: %s", R.GetErrorString ? R.GetErrorString(rc) : "?");
+        for (int a = 0; a < Ny; ++a)
+            for (int r = 0; r < nstart; ++r)
+                std::memcpy(&table[((size_t)a * nstart + r) * row], &all[(size_t)(r % world) * cnt + ((size_t)a * nstart + r) * row],
+                            row * sizeof(double));
+    }
+    const bool merged = world == 1 || rccl_comm != nullptr;
+    bool all_ok = true;
+    for (int a = 0; a < Ny; ++a) {
+        int best = -1;
+        for (int r = 0; r < nstart; ++r) {
+            const double* e = &table[((size_t)a * nstart + r) * row];
+            if (obj) obj[(size_t)a * nstart + r] = e[0];
+            if (theta_all) std::memcpy(theta_all + ((size_t)a * nstart + r) * nh, e + 1, nh * sizeof(double));
+            if (e[0] < inf && (best < 0 || e[0] < table[((size_t)a * nstart + best) * row])) best = r;   // first minimum: np.argmin
+        }
+        if (best >= 0) std::memcpy(hyper_opt + (size_t)a * nh, &table[((size_t)a * nstart + best) * row + 1], nh * sizeof(double));
+        else all_ok = false;
+    }
+    if (!merged) return GPMPC_OK;                               // caller merges the ranks' tables and calls gpmpc_fit
+    if (!all_ok) return fail(GPMPC_ENOTPD, "every restart of an output failed (K not positive definite along the way)");
+    return gpmpc_fit(h, hyper_opt, want_invK, info);            // optimize.py:476-494 at theta*
 }
 
 // ------------------------------------------------------------------------------------------------

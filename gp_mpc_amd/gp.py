@@ -118,7 +118,7 @@ class GP:
     def optimize(self, X=None, Y=None, opts=None, mean_func='zero',
                  xlb=None, xub=None, ulb=None, uub=None,
                  multistart=1, normalize=True, warm_start=False,
-                 optimize_nummeric=True, random_restarts=False, seed=1234, gradient='analytic'):
+                 optimize_nummeric=True, random_restarts=False, seed=1234, gradient='analytic', optimizer='scipy'):
         """Optimize hyper-parameters (gp_class.py:78-142).  DIFF: both of the reference's optimiser
         back-ends (scipy SLSQP with finite differences / CasADi+IPOPT) are replaced by one driver
         (`gp_mpc_amd.train.train_gp`) that evaluates the NLL and its analytic gradient on the GPU;
@@ -155,7 +155,7 @@ class GP:
         opt = train_gp(self._h, self.__X, self.__Y, multistart=multistart, hyper_init=hyp_init,
                        optimizer_opts=opts, numpy_path_conventions=optimize_nummeric,
                        random_restarts=random_restarts, seed=seed, gradient=gradient,
-                       mean_func=mean_func, predict_adds_mean=self._predict_adds_mean)
+                       mean_func=mean_func, predict_adds_mean=self._predict_adds_mean, optimizer=optimizer)
         self.__hyper = opt['hyper']
         self.__lam_x = opt['lam_x']
         self.__hyper_length_scales = self.__hyper[:, :self.__Nx]

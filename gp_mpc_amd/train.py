@@ -105,7 +105,7 @@ def _all_gather_rows(dist, local, world, device=None):
 
 def train_gp(handle, X, Y, multistart=1, hyper_init=None, optimizer_opts=None,
              numpy_path_conventions=True, random_restarts=False, seed=1234, gradient='analytic',
-             method='SLSQP', mean_func='zero', predict_adds_mean=False):
+             method='SLSQP', mean_func='zero', predict_adds_mean=False, optimizer='scipy'):
     """Train all Ny outputs of the model behind `handle` (a `gp_mpc_amd._lib.Handle` holding X, Y)
     and fit it at the optimum.  Returns the reference's `opt` dictionary keys plus diagnostics.
 
@@ -116,6 +116,9 @@ def train_gp(handle, X, Y, multistart=1, hyper_init=None, optimizer_opts=None,
     0, which is what this driver returns as well (hyper rows are padded with h_m zeros)."""
     if mean_func not in MEAN_PARAMS:
         raise NameError('No mean function called: ' + str(mean_func))
+    if optimizer not in ('scipy', 'native'):
+        raise ValueError("optimizer must be 'scipy' (SLSQP on the device objective, the reference's optimiser) or "
+                         "'native' (gpmpc_train_multistart: the whole loop behind the C ABI)")
     from scipy.optimize import minimize
     from ._lib import GpmpcError
 
@@ -137,6 +140,9 @@ def train_gp(handle, X, Y, multistart=1, hyper_init=None, optimizer_opts=None,
     hyp_opt = np.zeros((Ny, Nx + 2 + h_m))
     all_obj = np.zeros((Ny, multistart))
     n_eval = 0
+    if optimizer == 'native':
+        return _train_native(handle, X, Y, multistart, hyper_init, options, lbk, ubk, nv, h_m, opt_mean, mean_func,
+                             predict_adds_mean, random_restarts, seed, dist, rank, world)
     for a in range(Ny):
         lb = np.concatenate([lbk, np.full(nv - Nx - 2, -np.inf)])
         ub = np.concatenate([ubk, np.full(nv - Nx - 2, np.inf)])
@@ -189,3 +195,74 @@ def train_gp(handle, X, Y, multistart=1, hyper_init=None, optimizer_opts=None,
     handle.set_mean_func(mean_func, predict_adds_mean)
     info = handle.fit(hyp_opt, want_invK=True)               # optimize.py:476-494 / :264-285 at theta*
     return dict(hyper=hyp_opt, lam_x=0, obj=all_obj, info=info, n_eval=n_eval, rank=rank, world=world)
+
+
+def _starts_and_bounds(X, Y, a, multistart, hyper_init, lbk, ubk, nv, h_m, opt_mean, mean_func, random_restarts, seed):
+    """Initial points and box of output `a` (the same construction as the scipy path above)."""
+    Nx = X.shape[1]
+    lb = np.concatenate([lbk, np.full(nv - Nx - 2, -np.inf)])
+    ub = np.concatenate([ubk, np.full(nv - Nx - 2, np.inf)])
+    if opt_mean:
+        mean_param_bounds(lb, ub, mean_func, h_m, np.mean(Y[:, a]))
+    if random_restarts:
+        starts = np.zeros((multistart, nv))
+        starts[:, :Nx + 2] = lhs_starts(multistart, lbk, ubk, seed + a)
+        if hyper_init is not None:
+            starts[0] = np.asarray(hyper_init[a], dtype=np.float64)[:nv]
+    else:
+        if hyper_init is None:
+            h0 = np.zeros(nv)
+            h0[:Nx + 2] = default_init(X, Y[:, a])
+        else:
+            h0 = np.asarray(hyper_init[a], dtype=np.float64)[:nv]
+        starts = np.tile(h0, (multistart, 1))
+    return starts, lb, ub
+
+
+def _train_native(handle, X, Y, multistart, hyper_init, options, lbk, ubk, nv, h_m, opt_mean, mean_func, predict_adds_mean,
+                  random_restarts, seed, dist, rank, world):
+    """`gpmpc_train_multistart`: restarts, arg-min and the fit at the optimum in ONE call of the C ABI.  With
+    torch.distributed on the nccl backend the ranks' (NLL, theta) rows travel through an RCCL communicator the library
+    creates itself (its 128-byte id is broadcast through the process group); on gloo (CPU tests) the rows are merged
+    here and the fit is issued afterwards."""
+    Ny, Nx = Y.shape[1], X.shape[1]
+    sb = [_starts_and_bounds(X, Y, a, multistart, hyper_init, lbk, ubk, nv, h_m, opt_mean, mean_func, random_restarts, seed)
+          for a in range(Ny)]
+    starts = np.stack([t[0] for t in sb])
+    lb = np.stack([t[1] for t in sb])
+    ub = np.stack([t[2] for t in sb])
+    max_iter = int(options.get('maxiter', 0))
+    if max_iter >= 10000:
+        max_iter = 0                      # the reference's SLSQP cap (optimize.py:420) is not a meaningful L-BFGS budget
+    tol = float(options.get('tol', 0.0))
+    comm = None
+    if dist and world > 1 and dist.get_backend() == 'nccl':
+        import torch
+        box = [handle.lib.rccl_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        comm = handle.lib.rccl_comm_create(torch.cuda.current_device(), world, rank, box[0])
+    try:
+        res = handle.train_multistart(starts, lb, ub, max_iter=max_iter, tol=tol, rank=rank, world=world, comm=comm)
+    finally:
+        if comm is not None:
+            handle.lib.rccl_comm_destroy(comm)
+    hyp_opt = np.zeros((Ny, Nx + 2 + h_m))
+    if dist and world > 1 and comm is None:                   # gloo: merge the ranks' rows, then fit
+        local = np.concatenate([res['obj'][:, :, None], res['theta']], axis=2)          # [Ny, multistart, 1 + nv]
+        gathered = _all_gather_rows(dist, local, world)                                   # [world, Ny, multistart, 1 + nv]
+        owner = np.arange(multistart) % world
+        merged = gathered[owner, :, np.arange(multistart)].transpose(1, 0, 2)             # [Ny, multistart, 1 + nv]
+        res['obj'] = merged[:, :, 0]
+        for a in range(Ny):
+            if not np.isfinite(merged[a, :, 0]).any():
+                raise np.linalg.LinAlgError('every restart failed for output %d' % a)
+            hyp_opt[a, :nv] = merged[a, int(np.argmin(merged[a, :, 0])), 1:]
+        handle.set_mean_func(mean_func, predict_adds_mean)
+        info = handle.fit(hyp_opt, want_invK=True)
+    else:
+        hyp_opt[:, :nv] = res['hyper']
+        info = res['info']
+        if nv != hyp_opt.shape[1]:        # numpy-path conventions with a mean function: zero mean parameters appended
+            handle.set_mean_func(mean_func, predict_adds_mean)
+            info = handle.fit(hyp_opt, want_invK=True)
+    return dict(hyper=hyp_opt, lam_x=0, obj=res['obj'], info=info, n_eval=-1, rank=rank, world=world)

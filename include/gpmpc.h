@@ -181,6 +181,31 @@ int gpmpc_covar(gpmpc_gp* h, int n, const double* Xnew, double* covar);
  * jitter_out (may be NULL) reports whether the jitter branch was taken. */
 int gpmpc_nll(gpmpc_gp* h, int a, const double* hyper_row, double* nll, double* grad, int* jitter_out);
 
+/* ---- training: a8 ------------------------------------------------------------------------------ */
+/* Multistart hyper-parameter training of all Ny outputs, then the fit at the optimum: train_gp_numpy
+ * optimize.py:359-503 (SLSQP + finite differences) / train_gp :100-294 (IPOPT on CasADi AD), here a projected L-BFGS on
+ * gpmpc_nll and its analytic gradient, positive-bounded parameters in log space.  starts[Ny x nstart x W] (W =
+ * gpmpc_hyper_width): one initial point per restart -- the reference starts every restart from the same point
+ * (optimize.py:462-466, its Latin-hypercube line :218 is commented out); lb, ub[Ny x W]: the box (optimize.py:434-443 or
+ * :204-229; +-HUGE_VAL for none).  For every output the restart with the smallest NLL wins (first minimum, np.argmin
+ * :474), the model is fitted there (:476-494) and hyper_opt[Ny x W], obj[Ny x nstart] (+inf: restart failed),
+ * theta_all[Ny x nstart x W] (may be NULL), info[Ny] (as gpmpc_fit) are returned.  max_iter <= 0 / tol <= 0 select the
+ * defaults (200, 1e-8 on the projected gradient relative to |NLL|).
+ * Restart shard (the only part of the path that shards, north_star): restart r is run by rank r mod world.  With an
+ * RCCL communicator (gpmpc_rccl_comm_create, one rank per GPU) the ranks exchange their (NLL, theta) rows with ONE
+ * ncclAllGather -- (1 + W) doubles per restart -- take the same arg-min and each fits its own copy; nothing else
+ * crosses xGMI.  world > 1 with rccl_comm == NULL: no exchange and no fit; the caller merges the obj / theta_all rows
+ * of the ranks (row r is valid on rank r mod world) and calls gpmpc_fit. */
+int gpmpc_train_multistart(gpmpc_gp* h, int nstart, const double* starts, const double* lb, const double* ub,
+                           int max_iter, double tol, int rank, int world, void* rccl_comm, int want_invK,
+                           double* hyper_opt, double* obj, double* theta_all, int* info);
+/* RCCL bootstrap for the restart shard (librccl is bound at run time).  Rank 0 obtains the 128-byte id and hands it to
+ * the other ranks by any side channel (a file, MPI, torch.distributed's store); every rank then creates its
+ * communicator on its own GPU. */
+int gpmpc_rccl_unique_id(char* id128);
+int gpmpc_rccl_comm_create(int device, int world, int rank, const char* id128, void** comm_out);
+int gpmpc_rccl_comm_destroy(void* comm);
+
 /* ---- low-level dense ops (host pointers), used by the parity tests ------------------------ */
 /* k(X, Z)[n1 x n2] = sf2 exp(-1/2 sum_d (x_d - z_d)^2 / ell_d^2) for X[n1 x d], Z[n2 x d]: GP.covSEard
  * gp_class.py:314-350 (same expanded-form operation order, no FMA contraction). */

@@ -12,6 +12,7 @@ for p in (ROOT, os.path.join(ROOT, 'oracle')):
 
 def main():
     out_dir, multistart = sys.argv[1], int(sys.argv[2])
+    optimizer = sys.argv[3] if len(sys.argv) > 3 else 'scipy'
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     if world > 1:
@@ -23,9 +24,9 @@ def main():
     t = dict(np.load(os.path.join(ROOT, 'tests', 'golden', 'train_small.npz')))
     h = Handle(lib, t['X'], t['Y'])
     opt = train_gp(h, t['X'], t['Y'], multistart=multistart, random_restarts=True, seed=1234,
-                   numpy_path_conventions=False, optimizer_opts={'maxiter': 60})
+                   numpy_path_conventions=False, optimizer_opts={'maxiter': 60}, optimizer=optimizer)
     f = h.get_factors()
-    np.savez(os.path.join(out_dir, f'rank{rank}_of{world}.npz'), hyper=opt['hyper'], obj=opt['obj'],
+    np.savez(os.path.join(out_dir, f'{optimizer}_rank{rank}_of{world}.npz'), hyper=opt['hyper'], obj=opt['obj'],
              chol=f['chol'], alpha=f['alpha'], n_eval=opt['n_eval'])
     if world > 1:
         dist.barrier()

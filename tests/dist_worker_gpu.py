@@ -12,6 +12,7 @@ for p in (ROOT, os.path.join(ROOT, 'oracle')):
 
 def main():
     out_dir, multistart = sys.argv[1], int(sys.argv[2])
+    optimizer = sys.argv[3] if len(sys.argv) > 3 else 'scipy'
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
@@ -26,9 +27,9 @@ def main():
     p = go.synthetic_problem(4096, 6, 1, 1, seed=1234, sn=1e-2)
     h = Handle(get_lib(), p['X'], p['Y'], device=local)
     opt = train_gp(h, p['X'], p['Y'], multistart=multistart, random_restarts=True, seed=1234,
-                   numpy_path_conventions=False, optimizer_opts={'maxiter': 3})
+                   numpy_path_conventions=False, optimizer_opts={'maxiter': 3}, optimizer=optimizer)
     f = h.get_factors(chol=False)
-    np.savez(os.path.join(out_dir, f'gpu_rank{rank}_of{world}.npz'), hyper=opt['hyper'], obj=opt['obj'],
+    np.savez(os.path.join(out_dir, f'gpu_{optimizer}_rank{rank}_of{world}.npz'), hyper=opt['hyper'], obj=opt['obj'],
              alpha=f['alpha'], n_eval=opt['n_eval'])
     if world > 1:
         dist.barrier()

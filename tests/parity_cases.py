@@ -1055,3 +1055,41 @@ def check_callback_blocks(lib, N=120, Ny=3, Nu=2, seed=17):
         if method == 'EM':
             assert np.abs(blocks[2]).max() > 1e-4          # the EM mean does depend on Sigma
     gp.close()
+
+
+def check_training_native(lib, t):
+    """a8 behind the C ABI (`gpmpc_train_multistart`): from the reference's initial point inside the reference's box
+    (both conventions) the native projected L-BFGS must reach an NLL at least as good as `train_gp_numpy`'s SLSQP
+    optimum frozen in train_small.npz, report obj == device NLL at theta*, and leave the model fitted there."""
+    from gp_mpc_amd.train import train_gp
+    X, Y = t['X'], t['Y']
+    Ny, d = Y.shape[1], X.shape[1]
+    for numpy_path in (True, False):
+        h = Handle(lib, X, Y)
+        opt = train_gp(h, X, Y, multistart=2, numpy_path_conventions=numpy_path, optimizer='native')
+        H = opt['hyper']
+        for a in range(Ny):
+            ours = go.nll(H[a], X, Y[:, a])
+            assert ours <= t['nll'][a] + 1e-6 * abs(t['nll'][a]), (numpy_path, a, ours, t['nll'][a])
+            K = go.gram(X, H[a, :d], H[a, d] ** 2, H[a, d + 1] ** 2)
+            tol = max(1e-10, 50 * np.finfo(float).eps * np.linalg.cond(K))      # y^T K^-1 y is cond-limited
+            assert abs(opt['obj'][a].min() - ours) <= tol * (abs(ours) + len(X)), (opt['obj'][a].min(), ours, tol)
+            assert opt['obj'][a, 0] == opt['obj'][a, 1]                  # identical starts -> identical restarts
+        assert np.allclose(H[0], t['hyper'][0], rtol=5e-2)               # output 0 has a sharp optimum
+        f = h.get_factors()
+        o = go.fit(X, Y, H, want_invK=False)
+        for a in range(Ny):
+            assert relF(f['chol'][a], o['chol'][a]) <= 1e-9
+        h.close()
+    # with a mean function on the IPOPT-path conventions, and the error path: an empty box is refused
+    h = Handle(lib, X, Y)
+    opt = train_gp(h, X, Y, multistart=1, numpy_path_conventions=False, optimizer='native', mean_func='const')
+    for a in range(Ny):
+        assert go.nll_mean(opt['hyper'][a], X, Y[:, a], 'const') <= t['nll'][a] + 1e-6 * abs(t['nll'][a])
+    from gp_mpc_amd._lib import GpmpcError, EINVAL
+    try:
+        h.train_multistart(np.ones((Ny, 1, h.nh)), np.ones((Ny, h.nh)), np.zeros((Ny, h.nh)))
+        assert False
+    except GpmpcError as e:
+        assert e.code == EINVAL
+    h.close()

@@ -177,3 +177,7 @@ def test_emu_em_sens(emu):
 
 def test_emu_callback_blocks(emu):
     pc.check_callback_blocks(emu)
+
+
+def test_emu_training_native(emu, train_small):
+    pc.check_training_native(emu, train_small)

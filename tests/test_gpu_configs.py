@@ -83,24 +83,59 @@ def test_c4_random_restarts_world1(lib):
     pc.check_random_restarts(lib, p['X'], p['Y'], multistart=16, maxiter=3)
 
 
-def test_c4_restart_shard_rccl_two_gpus(lib, tmp_path):
-    """The RCCL branch of the restart shard (train.py `_all_gather_rows`, backend nccl): two processes, one GPU each,
-    must reproduce the single-process result bitwise.  Skipped on a one-GPU box."""
+@pytest.mark.parametrize('optimizer', ['scipy', 'native'])
+def test_c4_restart_shard_rccl_two_gpus(lib, tmp_path, optimizer):
+    """The RCCL branches of the restart shard -- train.py `_all_gather_rows` on backend nccl ('scipy') and the
+    library's own ncclAllGather inside `gpmpc_train_multistart` ('native'): two processes, one GPU each, must
+    reproduce the single-process result bitwise.  Skipped on a one-GPU box."""
     if lib.device_count() < 2:
         pytest.skip('needs two GPUs (the driver runs the scaling bench on an 8-GPU node)')
     env = dict(os.environ, MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY='0')
     outs = {}
     for world, port in ((1, 29621), (2, 29622)):
-        procs = [subprocess.Popen([sys.executable, os.path.join(HERE, 'dist_worker_gpu.py'), str(tmp_path), '8'],
+        procs = [subprocess.Popen([sys.executable, os.path.join(HERE, 'dist_worker_gpu.py'), str(tmp_path), '8', optimizer],
                                   env=dict(env, MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(r), LOCAL_RANK=str(r)))
                  for r in range(world)]
         for pr in procs:
             assert pr.wait(timeout=900) == 0
-        outs[world] = [np.load(tmp_path / f'gpu_rank{r}_of{world}.npz') for r in range(world)]
+        outs[world] = [np.load(tmp_path / f'gpu_{optimizer}_rank{r}_of{world}.npz') for r in range(world)]
     one, (r0, r1) = outs[1][0], outs[2]
     for k in ('hyper', 'obj', 'alpha'):
         assert np.array_equal(one[k], r0[k]) and np.array_equal(r0[k], r1[k]), k
-    assert int(r0['n_eval']) + int(r1['n_eval']) == int(one['n_eval'])
+    if optimizer == 'scipy':
+        assert int(r0['n_eval']) + int(r1['n_eval']) == int(one['n_eval'])
+
+
+def test_c4_native_training_with_rccl_self_gather(lib):
+    """`gpmpc_train_multistart` at C4 size on one GPU with a world = 1 RCCL communicator: the (NLL, theta) table goes
+    through ncclAllGather (a self-gather), so librccl's run-time binding and the exchange code execute on every box;
+    the result must equal the run without a communicator bitwise, and NLL* the oracle's value at theta*."""
+    from gp_mpc_amd._lib import Handle
+    from gp_mpc_amd.train import lhs_starts, bounds_ipopt_path
+    p = go.synthetic_problem(4096, 6, 1, 1, seed=1234, sn=1e-2)
+    X, Y = p['X'], p['Y']
+    N, d = X.shape
+    lb, ub = bounds_ipopt_path(d)
+    starts = lhs_starts(8, lb, ub, 1234)[None]
+    res = []
+    for use_comm in (False, True):
+        h = Handle(lib, X, Y)
+        comm = lib.rccl_comm_create(0, 1, 0, lib.rccl_unique_id()) if use_comm else None
+        try:
+            res.append(h.train_multistart(starts, lb[None], ub[None], max_iter=4, comm=comm))
+        finally:
+            if comm is not None:
+                lib.rccl_comm_destroy(comm)
+        if use_comm:
+            th = res[-1]['hyper'][0]
+            best = float(np.min(res[-1]['obj'][0]))
+            ref = go.nll(th, X, Y[:, 0])
+            tol = max(1e-10, 50 * np.finfo(float).eps * N * (th[d] ** 2 + th[d + 1] ** 2) / th[d + 1] ** 2)
+            assert abs(best - ref) <= tol * (abs(ref) + N), (best, ref, tol)
+            assert abs(h.nll(0, th) - best) <= 1e-12 * (abs(best) + N)
+        h.close()
+    for k in ('hyper', 'obj', 'theta'):
+        assert np.array_equal(res[0][k], res[1][k]), k
 
 
 def test_two_handles_two_threads(lib):

@@ -164,6 +164,10 @@ def test_mean_functions(lib):
     pc.check_mean_functions(lib, N=700, d=6, Ny=3, seed=5)
 
 
+def test_training_native(lib, train_small):
+    pc.check_training_native(lib, train_small)
+
+
 def test_edge_cases(lib):
     pc.check_edge_cases(lib)
 
