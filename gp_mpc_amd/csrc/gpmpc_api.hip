@@ -1856,6 +1856,8 @@ extern "C" int gpmpc_rccl_comm_create(int device, int world, int rank, const cha
     if (!R.ok()) return fail(GPMPC_EHIP, "librccl.so could not be loaded");
     RcclId id;
     std::memcpy(id.internal, id128, 128);
+    HIPCHK(hipDeviceSynchronize());
+    (void)hipGetLastError();      // RCCL treats a stale "last error" of this thread (e.g. hipErrorNotReady of an event query) as its own
     const int rc = R.CommInitRank(comm_out, world, id, rank);
     if (rc != 0) return fail(GPMPC_EHIP, "ncclCommInitRank failed: %s", R.GetErrorString ? R.GetErrorString(rc) : "?");
     return GPMPC_OK;
@@ -1913,6 +1915,7 @@ extern "C" int gpmpc_train_multistart(gpmpc_gp* h, int nstart, const double* sta
         HIPCHK(hipMalloc(&dsend, cnt * sizeof(double)));
         HIPCHK(hipMalloc(&drecv, cnt * world * sizeof(double)));
         HIPCHK(hipMemcpyAsync(dsend, table.data(), cnt * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        (void)hipGetLastError();
         const int rc = R.AllGather(dsend, drecv, cnt, RCCL_FLOAT64, rccl_comm, h->stream);
         std::vector<double> all(cnt * world);
         if (rc == 0) {

@@ -13,6 +13,7 @@
 #include <cmath>
 #include <functional>
 #include <limits>
+#include <string>
 #include <vector>
 
 namespace gpmpc {
@@ -162,8 +163,25 @@ struct RcclApi {
 inline RcclApi& rccl_api() {
     static RcclApi api = [] {
         RcclApi a;
-        for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
-            a.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        // RCCL must belong to the ROCm tree whose HIP / HSA runtime is live in this process: a process that imported
+        // PyTorch first runs on the copies bundled in torch/lib, one that loaded this library first on /opt/rocm, and an
+        // RCCL from the other tree opens a second, uninitialised HSA runtime ("no ROCm-capable device is detected").
+        // So: the librccl next to the libamdhip64 that hipGetDeviceCount resolves to, with local symbol scope.
+        std::vector<std::string> names;
+        Dl_info di;
+        if (dladdr((void*)&hipGetDeviceCount, &di) && di.dli_fname) {
+            std::string dir(di.dli_fname);
+            const size_t slash = dir.rfind('/');
+            if (slash != std::string::npos) {
+                dir.resize(slash);
+                names.push_back(dir + "/librccl.so");
+                names.push_back(dir + "/librccl.so.1");
+            }
+        }
+        names.push_back("librccl.so.1");
+        names.push_back("librccl.so");
+        for (const std::string& name : names) {
+            a.lib = dlopen(name.c_str(), RTLD_NOW | RTLD_LOCAL);
             if (a.lib) break;
         }
         if (a.lib) {
