@@ -8,12 +8,19 @@ in HBM (device pointer mode).  `value` = predictions/s over whole steps (fit inc
 ranks.  With --gpus N every rank runs its own model / test batch on its own GPU (independent GP
 objects shard trivially, no data-path collective): weak scaling.
 
+--config C3 (secondary, same JSON shape; the default and the headline stay C2): BASELINE.json configs[2] --
+6-output GP, N=8192, d=8: one STEP = fit of all outputs with K^-1 + a 30-step uncertainty propagation with each
+of 'ME', 'TA', 'EM' (gpmpc_rollout); `value` = propagation steps/s over whole steps (fit included).
+
 Extra objects on the JSON line:
   roofline     -- the dominant kernel (variance GEMM V = L^-1 Ks with fused column sums of squares):
                   algorithmic flops per launch N(N+1) B / HIP-event time of that launch, vs the fp64
                   MFMA peak (78.6 TFLOP/s spec; the rate of a pure MFMA loop measured at library load is reported beside it).
+  cholesky     -- the factorisation alone against the same peak: N^3/3 flops / HIP-event time of the persistent
+                  chain kernel, which ends with the last leaf, i.e. when L is complete (the fused L^-1 is extra).
   cpu_baseline -- the oracle's reference-formulation CPU path (numpy/LAPACK, same box, rank 0, N=1):
-                  one full fit + 1000 of the 10 000 predictions (prediction time scaled x10).
+                  one full fit + 1000 of the 10 000 predictions (prediction time scaled x10); `fair` = the same
+                  with triangular solves instead of the reference's general LU solves; BLAS threads / version.
 """
 import argparse
 import json
@@ -41,18 +48,42 @@ def cpu_baseline(p, B):
     t0 = time.perf_counter()
     K = go.gram(X, H[0, :d], H[0, d] ** 2, H[0, d + 1] ** 2)
     L, _ = go.chol_jitter(K)
+    t_kl = time.perf_counter() - t0
+    t0 = time.perf_counter()
     alpha = go.alpha_from_chol(L, Y[:, 0])
-    t_fit = time.perf_counter() - t0
+    t_fit = t_kl + (time.perf_counter() - t0)
     t0 = time.perf_counter()
     ks = go.cov_se_ard(X, Z[:nsub], H[0, :d], H[0, d] ** 2)
     mean = ks.T @ alpha
     v = np.linalg.solve(L, ks)
     var = H[0, d] ** 2 - np.sum(v * v, axis=0)
     t_pred = (time.perf_counter() - t0) * (B / nsub)
-    return dict(value=B / (t_fit + t_pred), unit='predictions/s', cores=os.cpu_count(), kind='port',
+    # fair CPU variant: same K and Cholesky, triangular solves where the reference uses general LU
+    from scipy.linalg import solve_triangular
+    t0 = time.perf_counter()
+    alpha2 = solve_triangular(L, solve_triangular(L, Y[:, 0], lower=True), lower=True, trans='T')
+    t_fit_fair = t_kl + (time.perf_counter() - t0)
+    t0 = time.perf_counter()
+    ks2 = go.cov_se_ard(X, Z[:nsub], H[0, :d], H[0, d] ** 2)
+    v2 = solve_triangular(L, ks2, lower=True)
+    var2 = H[0, d] ** 2 - np.sum(v2 * v2, axis=0)
+    mean2 = ks2.T @ alpha2
+    t_pred_fair = (time.perf_counter() - t0) * (B / nsub)
+    blas = {}
+    try:
+        from threadpoolctl import threadpool_info
+        for lib_ in threadpool_info():
+            if lib_.get('user_api') == 'blas':
+                blas = {'blas': lib_.get('internal_api'), 'version': lib_.get('version'), 'threads': lib_.get('num_threads')}
+    except Exception:
+        pass
+    threads = blas.get('threads') or os.cpu_count()
+    return dict(value=B / (t_fit + t_pred), unit='predictions/s', cores=threads, kind='port',
                 sample=f'1 full fit (N={X.shape[0]}) + {nsub} of {B} predictions, prediction time scaled x{B // nsub}; '
                        f'fit {t_fit:.2f} s, predictions {t_pred:.2f} s (scaled); numpy {np.__version__}',
-                fit_s=t_fit, predict_s=t_pred), mean, var
+                fit_s=t_fit, predict_s=t_pred, host_cpus=os.cpu_count(), blas=blas,
+                fair={'value': B / (t_fit_fair + t_pred_fair), 'unit': 'predictions/s', 'predict_s': t_pred_fair,
+                      'note': 'solve_triangular for alpha and v = L^-1 ks instead of np.linalg.solve (LU)'}), mean, var
 
 
 def main():
@@ -64,7 +95,10 @@ def main():
     ap.add_argument('--d', type=int, default=6)
     ap.add_argument('--B', type=int, default=10000)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--config', default='C2', choices=['C2', 'C3'])
     args = ap.parse_args()
+    if args.config == 'C3':
+        return main_c3(args)
 
     import numpy as np
     import torch                     # first: one HIP runtime in the process (torch's), shared by the library
@@ -152,6 +186,12 @@ def main():
                          'avg_launch_ms': gemm_ms / max(gemm_n, 1), 'launches': gemm_n,
                          'peak_measured_mfma_only_ubench': mfma_rate},
             'phases_ms_per_step': {k: v[0] / args.steps for k, v in prof.items() if v[1] > 0},
+            'cholesky': (lambda ms, n: {'kernel': 'chol_chain_kernel (+ chol_worker_kernel x3, concurrent)', 'bound': 'mfma',
+                                        'achieved': (N ** 3 / 3.0) / (ms / max(n, 1) * 1e-3) * 1e-12 if ms > 0 else 0.0,
+                                        'peak': FP64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                                        'frac': ((N ** 3 / 3.0) / (ms / max(n, 1) * 1e-3) * 1e-12 / FP64_MFMA_PEAK_TFLOPS) if ms > 0 else 0.0,
+                                        'avg_launch_ms': ms / max(n, 1), 'launches': n,
+                                        'note': 'N^3/3 flops; latency-bound: 64 sequential 64x64 leaves on one CU'})(*prof['chain']),
             'cholesky_plus_inverse': {'ms': fac_ms / max(fac_n, 1),
                                       'tflops': (2.0 * N ** 3 / 3.0) / (fac_ms / max(fac_n, 1) * 1e-3) * 1e-12 if fac_ms > 0 else 0.0,
                                       'note': 'N^3/3 (potrf) + N^3/3 (trtri) flops: blocked right-looking Cholesky + level-batched inverse'},
@@ -170,6 +210,99 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out))
+
+
+def main_c3(args):
+    """BASELINE config C3: 6-output GP, N = 8192, d = 8; step = fit (with K^-1) + 30-step ME / TA / EM propagation."""
+    import numpy as np
+    import torch
+    import gp_oracle as go
+    from gp_mpc_amd._lib import Handle, get_lib
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+    N, d, Ny, T = (args.N if args.N != 4096 else 8192), 8, 6, 30
+    p = go.synthetic_problem(N, d, Ny, T, seed=1234 + rank, sn=1e-2)
+    lib = get_lib()
+    h = Handle(lib, p['X'], p['Y'], device=local_rank)
+    hyper = np.ascontiguousarray(p['hyper'])
+    x0, U = p['Z'][0, :Ny], p['Z'][:T, Ny:]
+    S0 = np.eye(d) * 1e-6
+    S0[:Ny, :Ny] = np.diag(hyper[:, d + 1] ** 2)
+    z0 = np.concatenate([x0, U[0]])
+    res = {}
+
+    def step():
+        h.fit(hyper, want_invK=True)
+        for m in ('ME', 'TA', 'EM'):
+            res[m] = h.rollout(m, z0, U, S0)
+
+    def sync():
+        h.synchronize()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+    steps, warmup = min(args.steps, 10), min(args.warmup, 2)
+    for _ in range(warmup):
+        step()
+    sync()
+    h.profile_enable(True)
+    h.profile_read(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    h.profile_enable(False)
+    prof = h.profile_read(reset=True)
+    # the roll-outs alone (phase brackets inside gpmpc_rollout are per launch; time them as whole calls)
+    t_roll = {}
+    for m in ('ME', 'TA', 'EM'):
+        h.synchronize()
+        t1 = time.perf_counter()
+        h.rollout(m, z0, U, S0)
+        t_roll[m] = (time.perf_counter() - t1) * 1e3
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=torch.device('cuda', local_rank))
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        fac_ms = prof['factor'][0] / max(prof['factor'][1], 1)
+        flops = Ny * 2.0 * N ** 3 / 3.0
+        em_ms, em_n = prof['em']
+        em_bytes = Ny * 4.0 * N * (N + 1)                       # the K^-1 lower triangles the a == b pair sums read
+        out = {
+            'metric': 'GP moment-matching propagation steps/sec, N=8192 Ny=6 d=8 fp64 (fit + 30-step ME/TA/EM per step)',
+            'value': world * 3 * T * steps / elapsed, 'unit': 'propagation steps/s', 'n_gpus': world, 'steps': steps,
+            'warmup': warmup, 'ms_per_step': elapsed / steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': 'C3: 6-output SE-ARD GP fit (K build + Cholesky + L^-1 + K^-1) + 30-step ME/TA/EM propagation',
+                       'N': N, 'd': d, 'Ny': Ny, 'horizon': T, 'parallelism': f'independent GP per GPU x{world}'},
+            'roofline': {'kernel': 'factorisation: two-level blocked Cholesky + pipelined triangular inverse (chain kernel + MFMA GEMM launches)',
+                         'bound': 'mfma', 'achieved': flops / (fac_ms * 1e-3) * 1e-12 if fac_ms > 0 else 0.0,
+                         'peak': FP64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': flops / (fac_ms * 1e-3) * 1e-12 / FP64_MFMA_PEAK_TFLOPS if fac_ms > 0 else 0.0,
+                         'traffic': None, 'avg_launch_ms': fac_ms, 'launches': prof['factor'][1],
+                         'note': '2 N^3 / 3 flops per output (potrf + trtri), HIP events around the whole factor phase'},
+            'em_pair_kernels': {'bound': 'hbm', 'achieved': em_bytes / (em_ms / max(em_n, 1) * 1e-3) * 1e-9 if em_ms > 0 else 0.0,
+                                'peak': 8000.0, 'unit': 'GB/s', 'avg_launch_ms': em_ms / max(em_n, 1), 'launches': em_n,
+                                'note': 'algorithmic bytes = lower triangles of the 6 K^-1; the kernel is bound by its 1.2e9 fp64 exp per input, not HBM'},
+            'phases_ms_per_step': {k: v[0] / steps for k, v in prof.items() if v[1] > 0},
+            'rollout_ms_per_call': t_roll,
+            'finite': bool(all(np.all(np.isfinite(r[0])) and np.all(np.isfinite(r[1])) for r in res.values())),
+            'device': lib.device_name(local_rank),
+        }
+        print(json.dumps(out))
+    h.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == '__main__':

@@ -22,7 +22,7 @@ OK, EINVAL, EHIP, ENOTFIT, ENOTPD, ENOMEM = 0, -1, -2, -3, -4, -5
 METHODS = {'ME': 0, 'TA': 1, 'EM': 2, 'old_ME': 3, 'old_TA': 4}
 MEAN_FUNCS = {'zero': 0, 'const': 1, 'linear': 2, 'polynomial': 3}     # gp_functions.py:25-69
 PTR_HOST, PTR_DEVICE = 0, 1
-PHASES = ['gram', 'factor', 'solve', 'invK', 'crosscov', 'vargemm', 'finish', 'em', 'nll']
+PHASES = ['gram', 'factor', 'solve', 'invK', 'crosscov', 'vargemm', 'finish', 'em', 'nll', 'chain']
 
 _dp = ctypes.POINTER(ctypes.c_double)
 _ip = ctypes.POINTER(ctypes.c_int)

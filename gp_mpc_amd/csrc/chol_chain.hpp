@@ -52,7 +52,11 @@ __global__ void __launch_bounds__(64) flag_gate_kernel(int* flags, long sFlags, 
 
 __global__ void __launch_bounds__(256) chol_chain_kernel(const double* Kmat, double* L, double* Inv, long ld, long sBatch,
                                                          int nb, int* flags, long sFlags, int* info, int crow_mode,
-                                                         int spin_limit, long long* trace, int merge_publish) {
+                                                         int spin_limit, long long* trace, int merge_publish,
+                                                         int kb = 0, int ke = -1) {
+    // [kb, ke): the block columns this launch factors (two-level execution: one launch per super-panel; the tiles of
+    // block kb then carry every earlier update by stream order, no flag).  Default: the whole matrix.
+    if (ke < 0) ke = nb;
     // optional time stamps (100 MHz wall clock), 8 per step, for tools/chain_trace.py
 #ifdef GPMPC_EMULATED
 #define CHAIN_STAMP(i) ((void)0)
@@ -78,11 +82,11 @@ __global__ void __launch_bounds__(256) chol_chain_kernel(const double* Kmat, dou
 
     for (int idx = tid; idx < 4096; idx += 256) {
         const int rr = idx >> 6, cc = idx & 63;
-        S[rr * LS + cc] = (cc <= rr) ? Kb[(long)rr * ld + cc] : 0.0;
+        S[rr * LS + cc] = (cc <= rr) ? Kb[(long)(64 * kb + rr) * ld + 64 * kb + cc] : 0.0;
         T[rr * LS + cc] = 0.0;
     }
     __syncthreads();
-    for (int k = 0; k < nb; ++k) {
+    for (int k = kb; k < ke; ++k) {
         const long o = (long)(64 * k) * ld + 64 * k;
         const long o10 = o + 64 * ld, o11 = o10 + 64;
         CHAIN_STAMP(0);
@@ -112,8 +116,8 @@ __global__ void __launch_bounds__(256) chol_chain_kernel(const double* Kmat, dou
                     }
                 }
             }
-        } pf{Kb, o10, o11, ld, k ? &tdone[2 * (k - 1)] : nullptr, k ? &tdone[2 * (k - 1) + 1] : nullptr, slot, tid,
-             k + 1 < nb, &pre, pu, ps};
+        } pf{Kb, o10, o11, ld, k > kb ? &tdone[2 * (k - 1)] : nullptr, k > kb ? &tdone[2 * (k - 1) + 1] : nullptr, slot, tid,
+             k + 1 < ke, &pre, pu, ps};
         pf.before();
         __syncthreads();
         pf.after();
@@ -132,9 +136,9 @@ __global__ void __launch_bounds__(256) chol_chain_kernel(const double* Kmat, dou
         }
         // merge_publish (tile-owner workers, which have slack): leafdone[k] goes out together with pan1[k]
         // a few microseconds later, saving one L2 write-back per step on this critical path
-        if (!merge_publish || k + 1 == nb) wg_publish(&leafdone[k], 1);
+        if (!merge_publish || k + 1 == ke) wg_publish(&leafdone[k], 1);
         CHAIN_STAMP(2);
-        if (k + 1 == nb) break;
+        if (k + 1 == ke) break;
         if (pre) {
             CHAIN_STAMP(3);
 #pragma unroll

@@ -215,6 +215,39 @@ static int ws_need_invK(Workspace& ws) {
     return GPMPC_OK;
 }
 
+struct Prof {
+    bool on = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[GPMPC_PH_COUNT];
+    std::vector<hipEvent_t> pool;
+    double total[GPMPC_PH_COUNT] = {0};
+    long count[GPMPC_PH_COUNT] = {0};
+};
+
+// HIP-event bracket of one phase on a stream (gpmpc_profile_*); inert unless profiling is on
+struct ProfScope {
+    Prof* pr;
+    hipStream_t st;
+    int phase;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ProfScope(Prof* pr_, hipStream_t st_, int ph) : pr(pr_), st(st_), phase(ph) {
+        if (!pr || !pr->on) return;
+        auto get = [&]() {
+            hipEvent_t e;
+            if (!pr->pool.empty()) { e = pr->pool.back(); pr->pool.pop_back(); }
+            else hipEventCreate(&e);
+            return e;
+        };
+        e0 = get();
+        e1 = get();
+        hipEventRecord(e0, st);
+    }
+    ~ProfScope() {
+        if (!e0) return;
+        hipEventRecord(e1, st);
+        pr->ev[phase].push_back({e0, e1});
+    }
+};
+
 struct Ctx {
     hipStream_t stream;
     int crow_mode;
@@ -224,6 +257,7 @@ struct Ctx {
     hipEvent_t* seg = nullptr;      // pool of n_seg events (segment hand-offs side -> aux, aux -> main)
     int n_seg = 0;
     int workers = 0;                // > 0: tile-owner worker kernel with this many CUs to share (chain mode 3)
+    Prof* prof = nullptr;           // the handle's profile (phase brackets inside the factorisation)
 };
 
 static GemmP gemm_base(const Ctx& cx) {
@@ -364,12 +398,140 @@ static void factor_blocked(const Ctx& cx, Workspace& ws, bool do_chol, int k0 = 
     if (k0 == 0) trtri_levels(cx, ws);
 }
 
+static long long* g_chain_trace = nullptr;   // developer aid: GPMPC_CHAIN_TRACE=<file> dumps the chain's time stamps
+
+// Two-level execution of the chained factorisation (batches of matrices -- C3's six outputs -- and Np > 4096, where the
+// trailing matrix does not fit the tile-owner workers' registers).  The plain flagged execution below updates the WHOLE
+// trailing matrix after every 64-column panel: a K = 64 product reads and writes 16 bytes of C per 128 flops and is
+// bound by that traffic (C3: 85 ms for 2.2e12 flop).  Here W block columns form a super-panel:
+//     for each super-panel [k0, k1):   chain kernel for blocks k0 .. k1-1 (one launch), panel rows and the trailing
+//                                      update INSIDE the super-panel's columns as flagged K = 64 launches (small);
+//                                      then ONE product A22 -= L21 L21^T with K = 64 W on everything to the right.
+// C traffic of the big updates falls by W and they run at the GEMM's MFMA rate; the inverse of a finished 512-row
+// segment runs on the third queue while the big update occupies the second.
+static bool factor_twolevel(const Ctx& cx, Workspace& ws, int spin_limit, int W) {
+    const int Np = ws.Np, nb = Np / 64, nf = chain_flag_count(nb);
+    const long ld = Np, sM = ws.mat(), sW = ws.wstride();
+    int* leafdone = ws.flags + 1;
+    int* pan1 = ws.flags + 1 + nb;
+    int* tdone = ws.flags + 1 + 2 * nb;
+    // The inverse follows panel by panel on the third queue -- right-looking blocked inversion of the row panels
+    // P_i = super-panel i: with S = sum over finished panels m of L[., P_m] X[P_m, .] accumulated IN the not yet final
+    // rows of Inv,
+    //     I_i = (L[P_i, P_i])^-1 (level-batched),    X[P_i, < r_i] = -I_i S[P_i, < r_i],
+    //     S[> P_i, < r_{i+1}] += L[> P_i, P_i] X[P_i, < r_{i+1}]                  (K = 64 W products)
+    // so every step only needs rows P_i of L -- final as soon as super-panel i is factored -- and after the last
+    // super-panel just its own inverse and one 64 W-row product remain (the tree-shaped inverse left the two products of
+    // its root, a third of the fit, for the end).  Needs a 64 W x Np scratch panel in ws.W and the event pool.
+    const bool panel_inv = cx.aux && cx.seg && cx.n_seg >= 3 && (long)64 * W * Np <= sW;
+    auto inverse_panel = [&](hipStream_t st, int k0, int k1) {
+        const int ri = 64 * k0, a = 64 * (k1 - k0), rn = 64 * k1, Mb = Np - rn;
+        trtri_range(cx, ws, st, ri, a);                                        // I_i
+        if (ri > 0) {
+            GemmP u = gemm_base(cx);                                           // T = -I_i S_i, then back into Inv[P_i, < r_i]
+            u.A = ws.Inv + (long)ri * ld + ri; u.lda = ld; u.sA = sM; u.a_mc = 0; u.kflags = KA_LE_M;
+            u.B = ws.Inv + (long)ri * ld; u.ldb = ld; u.sB = sM; u.b_nc = 1;
+            u.C = ws.W; u.ldc = ri; u.sC = sW;
+            u.M = a; u.N = ri; u.K = a; u.alpha = -1.0;
+            launch_gemm(u, ws.batch, st);
+            for (int b = 0; b < ws.batch; ++b)
+                hipMemcpy2DAsync(ws.Inv + b * sM + (long)ri * ld, ld * sizeof(double), ws.W + b * sW, (size_t)ri * sizeof(double),
+                                 (size_t)ri * sizeof(double), a, hipMemcpyDeviceToDevice, st);
+        }
+        if (Mb > 0) {
+            GemmP t = gemm_base(cx);                                           // new columns of S: L[> P_i, P_i] I_i
+            t.A = ws.L + (long)rn * ld + ri; t.lda = ld; t.sA = sM; t.a_mc = 0;
+            t.B = ws.Inv + (long)ri * ld + ri; t.ldb = ld; t.sB = sM; t.b_nc = 1; t.kflags = KB_GE_N;
+            t.C = ws.Inv + (long)rn * ld + ri; t.ldc = ld; t.sC = sM;
+            t.M = Mb; t.N = a; t.K = a;
+            launch_gemm(t, ws.batch, st);
+            if (ri > 0) {
+                GemmP v = gemm_base(cx);                                       // S[> P_i, < r_i] += L[> P_i, P_i] X[P_i, < r_i]
+                v.A = ws.L + (long)rn * ld + ri; v.lda = ld; v.sA = sM; v.a_mc = 0;
+                v.B = ws.Inv + (long)ri * ld; v.ldb = ld; v.sB = sM; v.b_nc = 1;
+                v.C = ws.Inv + (long)rn * ld; v.ldc = ld; v.sC = sM;
+                v.M = Mb; v.N = ri; v.K = a; v.beta = 1.0;
+                launch_gemm(v, ws.batch, st);
+            }
+        }
+    };
+    int ev = 0;                                                // event pool cursor (two per handed-over panel)
+    int inv_done = 0;                                          // block columns whose inverse panel has been enqueued
+    for (int k0 = 0; k0 < nb; k0 += W) {
+        const int k1 = std::min(nb, k0 + W);
+        // the chain of this super-panel starts when the previous big update (second queue) is complete
+        hipEventRecord(cx.join, cx.side);
+        hipStreamWaitEvent(cx.stream, cx.join, 0);
+        hipLaunchKernelGGL(chol_chain_kernel, dim3(1, 1, ws.batch), dim3(256), CHAIN_LDS_BYTES, cx.stream, (const double*)ws.K,
+                           ws.L, ws.Inv, ld, sM, nb, ws.flags, (long)nf, ws.info, cx.crow_mode, spin_limit, g_chain_trace, 0, k0,
+                           k1);
+        hipLaunchKernelGGL(flag_gate_kernel, dim3(ws.batch), dim3(64), 0, cx.side, ws.flags, (long)nf, 1 + k0, 1, -1, 0,
+                           spin_limit);                       // bulk workgroups only once this chain launch is resident
+        for (int k = k0; k < k1; ++k) {
+            const int off = 64 * k;
+            const long o11 = (long)off * ld + off;
+            const bool last = k + 1 == k1;                     // the chain stops after this leaf: row k+1 is the panel product's
+            const int r0 = off + (last ? 64 : 128), M2 = Np - r0;
+            if (M2 > 0) {
+                GemmP p = gemm_base(cx);                       // panel: L(i,k) = A(i,k) inv_kk^T
+                p.A = ws.K + (long)r0 * ld + off; p.lda = ld; p.sA = sM; p.a_mc = 0;
+                p.B = ws.Inv + o11; p.ldb = ld; p.sB = sM; p.b_nc = 0; p.kflags = KB_LE_N;
+                p.C = ws.L + (long)r0 * ld + off; p.ldc = ld; p.sC = sM;
+                p.M = M2; p.N = 64; p.K = 64;
+                p.wait_flag = leafdone + k; p.err = ws.flags; p.spin_limit = spin_limit; p.sFlags = nf;
+                launch_gemm(p, ws.batch, cx.side);
+            }
+            const int M1 = Np - off - 64, N1 = 64 * (k1 - k - 1);   // trailing update inside the super-panel's columns
+            if (!last && M1 > 64) {
+                const long o1 = (long)(off + 64) * ld;
+                GemmP q = gemm_base(cx);
+                q.A = ws.L + o1 + off; q.lda = ld; q.sA = sM; q.a_mc = 0;
+                q.B = ws.L + o1 + off; q.ldb = ld; q.sB = sM; q.b_nc = 0;
+                q.C = ws.K + o1 + off + 64; q.ldc = ld; q.sC = sM;
+                q.M = M1; q.N = N1; q.K = 64; q.alpha = -1.0; q.beta = 1.0; q.lower = 1;
+                q.wait_flag = pan1 + k; q.err = ws.flags; q.spin_limit = spin_limit; q.sFlags = nf;
+                q.skip00 = 1; q.done_flags = tdone + 2 * k;
+                launch_gemm(q, ws.batch, cx.side, 64);         // flags are defined on 64 x 64 tiles
+            }
+        }
+        // rows < 64 k1 of L are final: the inverse of this row panel goes to the third queue, next to the big update
+        if (panel_inv && k1 < nb && ev + 2 < cx.n_seg) {
+            hipEventRecord(cx.seg[ev], cx.side);
+            hipStreamWaitEvent(cx.aux, cx.seg[ev], 0);
+            ++ev;
+            hipEventRecord(cx.seg[ev], cx.stream);            // (the leaf's own stores: the chain launch has to be complete)
+            hipStreamWaitEvent(cx.aux, cx.seg[ev], 0);
+            ++ev;
+            if (inv_done < k0) inverse_panel(cx.aux, inv_done, k0);   // (panels skipped for want of events: as one)
+            inverse_panel(cx.aux, k0, k1);
+            inv_done = k1;
+        }
+        if (k1 < nb) {                                         // A22 -= L21 L21^T, K = 64 (k1 - k0)
+            const long r = 64L * k1, c0 = 64L * k0;
+            GemmP g = gemm_base(cx);
+            g.A = ws.L + r * ld + c0; g.lda = ld; g.sA = sM; g.a_mc = 0;
+            g.B = ws.L + r * ld + c0; g.ldb = ld; g.sB = sM; g.b_nc = 0;
+            g.C = ws.K + r * ld + r; g.ldc = ld; g.sC = sM;
+            g.M = Np - (int)r; g.N = Np - (int)r; g.K = 64 * (k1 - k0); g.alpha = -1.0; g.beta = 1.0; g.lower = 1;
+            launch_gemm(g, ws.batch, cx.side);
+        }
+    }
+    hipEventRecord(cx.join, cx.side);
+    hipStreamWaitEvent(cx.stream, cx.join, 0);
+    if (cx.aux && cx.seg) {
+        hipEventRecord(cx.seg[cx.n_seg - 1], cx.aux);
+        hipStreamWaitEvent(cx.stream, cx.seg[cx.n_seg - 1], 0);
+    }
+    if (!panel_inv) { trtri_levels(cx, ws); return true; }
+    inverse_panel(cx.stream, inv_done, nb);                    // what is left: the last panel (or everything not handed over)
+    return true;
+}
+
 // Chained factorisation: the sequential part of every panel step runs in ONE persistent workgroup
 // (chol_chain_kernel, main queue) that keeps a CU to itself, the bulk -- panel rows >= k+2 and the
 // trailing update -- in ordinary GEMM launches on the side queue; flags in ws.flags couple the two.
 // Returns false if the path is unavailable (no side queue).  A time-out inside the kernels is reported
 // through ws.flags[0] and handled by the caller (fallback to factor_blocked).
-static long long* g_chain_trace = nullptr;   // developer aid: GPMPC_CHAIN_TRACE=<file> dumps the chain's time stamps
 
 static bool factor_chain(const Ctx& cx, Workspace& ws, int spin_limit) {
     if (!cx.side || ws.Np < 128) return false;
@@ -388,6 +550,18 @@ static bool factor_chain(const Ctx& cx, Workspace& ws, int spin_limit) {
     int NW = ws.batch == 1 ? cx.workers - cx.workers / 8 : 0;
     if (NW > ntiles) NW = ntiles;
     const bool use_workers = NW >= 1 && nb >= 3 && (ntiles + NW - 1) / NW <= WORKER_MAXT;
+    // what the workers do not take: two-level panels (GPMPC_TWOLEVEL=<block columns per super-panel>, 0/1 = off)
+#ifdef GPMPC_EMULATED
+    static const int twolevel_W = getenv("GPMPC_TWOLEVEL") ? atoi(getenv("GPMPC_TWOLEVEL")) : 2;
+#else
+    static const int twolevel_W = getenv("GPMPC_TWOLEVEL") ? atoi(getenv("GPMPC_TWOLEVEL")) : 8;
+#endif
+    if (!use_workers && twolevel_W > 1 && nb >= 2 * twolevel_W && cx.aux && cx.seg) {
+        static const bool verbose2 = getenv("GPMPC_VERBOSE") != nullptr;
+        if (verbose2)
+            fprintf(stderr, "gpmpc: factor Np=%d batch=%d: two-level panels of %d block columns\n", Np, ws.batch, twolevel_W);
+        return factor_twolevel(cx, ws, spin_limit, twolevel_W);
+    }
     // Worker launches and the row-panel schedule of the inverse.  The workers run as up to three launches
     // (GPMPC_MAX_LAUNCHES), cut where the tree of the triangular inverse has its nodes on the right spine (Np = 4096:
     // blocks 0-31, 32-47, 48-63 with 224 / 96 / 32 workers: after half of the steps three quarters of the tiles are
@@ -454,9 +628,12 @@ static bool factor_chain(const Ctx& cx, Workspace& ws, int spin_limit) {
     // inverse pipelined segment by segment behind the chain: next to GEMM launches only
     const bool pipelined = !use_workers && cx.aux && cx.seg && Np >= 4 * SEGR;
     int seg_done = 0;
-    hipLaunchKernelGGL(chol_chain_kernel, dim3(1, 1, ws.batch), dim3(256), CHAIN_LDS_BYTES, cx.stream, (const double*)ws.K,
-                       ws.L, ws.Inv, ld, sM, nb, ws.flags, (long)nf, ws.info, cx.crow_mode, spin_limit, g_chain_trace,
-                       use_workers ? 1 : 0);
+    {   // the chain kernel ends with the last leaf, i.e. when L is complete: its duration is the Cholesky's
+        ProfScope t(cx.prof, cx.stream, GPMPC_PH_CHAIN);
+        hipLaunchKernelGGL(chol_chain_kernel, dim3(1, 1, ws.batch), dim3(256), CHAIN_LDS_BYTES, cx.stream, (const double*)ws.K,
+                           ws.L, ws.Inv, ld, sM, nb, ws.flags, (long)nf, ws.info, cx.crow_mode, spin_limit, g_chain_trace,
+                           use_workers ? 1 : 0);
+    }
     static const bool verbose = getenv("GPMPC_VERBOSE") != nullptr;
     if (verbose)
         fprintf(stderr, "gpmpc: factor Np=%d batch=%d: chain kernel + %s (%d launch%s), inverse %s\n", Np, ws.batch,
@@ -577,14 +754,6 @@ static int compute_invK(const Ctx& cx, Workspace& ws) {
 // ------------------------------------------------------------------------------------------------
 // model handle
 // ------------------------------------------------------------------------------------------------
-struct Prof {
-    bool on = false;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[GPMPC_PH_COUNT];
-    std::vector<hipEvent_t> pool;
-    double total[GPMPC_PH_COUNT] = {0};
-    long count[GPMPC_PH_COUNT] = {0};
-};
-
 struct gpmpc_gp {
     int device = 0, N = 0, Np = 0, d = 0, Ny = 0;
     hipStream_t own_stream = nullptr, stream = nullptr, side_stream = nullptr;
@@ -632,31 +801,12 @@ struct gpmpc_gp {
     Prof prof;
     Ctx cx() {
         return Ctx{stream, crow_mode, side_stream, ev_fork, ev_join, chain_mode >= 2 ? aux_stream : nullptr,
-                   seg_events.data(), (int)seg_events.size(), chain_mode >= 3 ? g_cu_count[device] : 0};
+                   seg_events.data(), (int)seg_events.size(), chain_mode >= 3 ? g_cu_count[device] : 0, &prof};
     }
 };
 
-struct PhaseTimer {
-    gpmpc_gp* h;
-    int phase;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    PhaseTimer(gpmpc_gp* h_, int ph) : h(h_), phase(ph) {
-        if (!h->prof.on) return;
-        auto get = [&]() {
-            hipEvent_t e;
-            if (!h->prof.pool.empty()) { e = h->prof.pool.back(); h->prof.pool.pop_back(); }
-            else hipEventCreate(&e);
-            return e;
-        };
-        e0 = get();
-        e1 = get();
-        hipEventRecord(e0, h->stream);
-    }
-    ~PhaseTimer() {
-        if (!e0) return;
-        hipEventRecord(e1, h->stream);
-        h->prof.ev[phase].push_back({e0, e1});
-    }
+struct PhaseTimer : ProfScope {
+    PhaseTimer(gpmpc_gp* h, int ph) : ProfScope(&h->prof, h->stream, ph) {}
 };
 
 static int prof_collect(gpmpc_gp* h) {
@@ -729,6 +879,10 @@ int gpmpc_mfma_selftest(int device, int* layout_out, double* tflops_out) {
 int gpmpc_destroy(gpmpc_gp* h);
 }  // extern "C"
 
+// events for hand-overs between the queues of the factorisation: segments of the pipelined inverse, or two per
+// super-panel of the two-level execution (>= 2 block columns each)
+static size_t seg_event_count(int Np) { return (size_t)std::max(3, std::max(Np / SEGR + 2, Np / 64 + 4)); }
+
 static int create_impl(gpmpc_gp* h, const double* X, const double* Y) {
     const int device = h->device, N = h->N, d = h->d, Ny = h->Ny;
     h->crow_mode = g_crow_mode[device];
@@ -741,7 +895,7 @@ static int create_impl(gpmpc_gp* h, const double* X, const double* Y) {
     // the persistent kernels ask for more than the default 64 KB of dynamic LDS (per device: set for every handle)
     HIPCHK(hipFuncSetAttribute((const void*)chol_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CHAIN_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)chol_worker_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WORKER_LDS_BYTES));
-    const size_t nseg = std::max(3, round_up(N, 64) / SEGR + 2);
+    const size_t nseg = seg_event_count(round_up(N, 64));
     for (size_t i = 0; i < nseg; ++i) {
         hipEvent_t e;
         HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -1097,7 +1251,7 @@ extern "C" int gpmpc_append(gpmpc_gp* h, int n, const double* Xnew, const double
         h->XT = XT1; h->Y = Y1; h->ws = ws1;
         h->N = N1; h->Np = Np1;
         h->have_invK = false;
-        const size_t need = Np1 / SEGR + 2;
+        const size_t need = seg_event_count(Np1);
         while (h->seg_events.size() < need) {
             hipEvent_t e;
             hipEventCreateWithFlags(&e, hipEventDisableTiming);
@@ -1114,7 +1268,7 @@ extern "C" int gpmpc_append(gpmpc_gp* h, int n, const double* Xnew, const double
         free_predict_scratch(h);
         h->XT = XT1; h->Y = Y1; h->ws = ws1;
         h->N = N1; h->Np = Np1;
-        const size_t need = Np1 / SEGR + 2;
+        const size_t need = seg_event_count(Np1);
         while (h->seg_events.size() < need) {
             hipEvent_t e;
             hipEventCreateWithFlags(&e, hipEventDisableTiming);

@@ -63,7 +63,8 @@ extern "C" {
 #define GPMPC_PH_FINISH 6     /* var / Jacobian / TA covariance assembly     */
 #define GPMPC_PH_EM 7         /* exact-moment N x N pair tiles               */
 #define GPMPC_PH_NLL 8        /* NLL reductions + gradient pass              */
-#define GPMPC_PH_COUNT 9
+#define GPMPC_PH_CHAIN 9      /* the persistent chain kernel alone = the Cholesky without the inverse (inside FACTOR) */
+#define GPMPC_PH_COUNT 10
 
 typedef struct gpmpc_gp gpmpc_gp; /* opaque model handle */
 
