@@ -258,6 +258,7 @@ struct Ctx {
     int n_seg = 0;
     int workers = 0;                // > 0: tile-owner worker kernel with this many CUs to share (chain mode 3)
     Prof* prof = nullptr;           // the handle's profile (phase brackets inside the factorisation)
+    hipStream_t bulk = nullptr;     // fourth queue (low priority): look-ahead part of the two-level trailing updates
 };
 
 static GemmP gemm_base(const Ctx& cx) {
@@ -455,11 +456,22 @@ static bool factor_twolevel(const Ctx& cx, Workspace& ws, int spin_limit, int W)
             }
         }
     };
-    int ev = 0;                                                // event pool cursor (two per handed-over panel)
+    int ev = 0;                                                // event pool cursor
     int inv_done = 0;                                          // block columns whose inverse panel has been enqueued
+    // Look-ahead: the K = 64 W update of super-panel s is split in A(s) = the NEXT super-panel's columns (second queue,
+    // what the chain needs next) and B(s) = everything right of them (fourth queue, low priority), so that B(s) overlaps
+    // the latency-bound factorisation of super-panel s+1.  Order on shared tiles: A(s) after B(s-1) (event), B(s) after
+    // the panels of s (event) and after B(s-1) (queue order).
+    static const bool lookahead_on = !(getenv("GPMPC_LOOKAHEAD") && atoi(getenv("GPMPC_LOOKAHEAD")) == 0);
+    const bool lookahead = lookahead_on && cx.bulk && cx.seg && cx.n_seg >= 4 * ((nb + W - 1) / W) + 2;
+    hipEvent_t evB_prev = nullptr;
+    if (lookahead) {
+        hipEventRecord(cx.join, cx.stream);                    // the fourth queue starts behind everything enqueued so far
+        hipStreamWaitEvent(cx.bulk, cx.join, 0);
+    }
     for (int k0 = 0; k0 < nb; k0 += W) {
-        const int k1 = std::min(nb, k0 + W);
-        // the chain of this super-panel starts when the previous big update (second queue) is complete
+        const int k1 = std::min(nb, k0 + W), k2 = std::min(nb, k1 + W);
+        // the chain of this super-panel starts when the update of its columns (second queue) is complete
         hipEventRecord(cx.join, cx.side);
         hipStreamWaitEvent(cx.stream, cx.join, 0);
         hipLaunchKernelGGL(chol_chain_kernel, dim3(1, 1, ws.batch), dim3(256), CHAIN_LDS_BYTES, cx.stream, (const double*)ws.K,
@@ -513,11 +525,35 @@ static bool factor_twolevel(const Ctx& cx, Workspace& ws, int spin_limit, int W)
             g.B = ws.L + r * ld + c0; g.ldb = ld; g.sB = sM; g.b_nc = 0;
             g.C = ws.K + r * ld + r; g.ldc = ld; g.sC = sM;
             g.M = Np - (int)r; g.N = Np - (int)r; g.K = 64 * (k1 - k0); g.alpha = -1.0; g.beta = 1.0; g.lower = 1;
-            launch_gemm(g, ws.batch, cx.side);
+            if (!lookahead || k2 >= nb) {
+                if (lookahead && evB_prev) hipStreamWaitEvent(cx.side, evB_prev, 0);
+                launch_gemm(g, ws.batch, cx.side);
+            } else {
+                hipEvent_t evP = cx.seg[ev++], evB = cx.seg[ev++];
+                hipEventRecord(evP, cx.side);                  // the panels of this super-panel are complete
+                if (evB_prev) hipStreamWaitEvent(cx.side, evB_prev, 0);
+                GemmP ga = g;                                  // A(s): columns of the next super-panel
+                ga.N = 64 * (k2 - k1);
+                launch_gemm(ga, ws.batch, cx.side);
+                const long r2 = 64L * k2;                      // B(s): the rest, on the fourth queue
+                GemmP gb = g;
+                gb.A = ws.L + r2 * ld + c0;
+                gb.B = ws.L + r2 * ld + c0;
+                gb.C = ws.K + r2 * ld + r2;
+                gb.M = Np - (int)r2; gb.N = Np - (int)r2;
+                hipStreamWaitEvent(cx.bulk, evP, 0);
+                launch_gemm(gb, ws.batch, cx.bulk);
+                hipEventRecord(evB, cx.bulk);
+                evB_prev = evB;
+            }
         }
     }
     hipEventRecord(cx.join, cx.side);
     hipStreamWaitEvent(cx.stream, cx.join, 0);
+    if (lookahead) {
+        hipEventRecord(cx.fork, cx.bulk);
+        hipStreamWaitEvent(cx.stream, cx.fork, 0);
+    }
     if (cx.aux && cx.seg) {
         hipEventRecord(cx.seg[cx.n_seg - 1], cx.aux);
         hipStreamWaitEvent(cx.stream, cx.seg[cx.n_seg - 1], 0);
@@ -761,7 +797,7 @@ struct gpmpc_gp {
     hipEvent_t ev_info = nullptr;       // "the factorisation's status words are on the host" (factor_with_jitter)
     int* pin = nullptr;                 // pinned host buffer for them
     size_t pin_ints = 0;
-    hipStream_t aux_stream = nullptr;
+    hipStream_t aux_stream = nullptr, bulk_stream = nullptr;
     std::vector<hipEvent_t> seg_events;
     int chain_mode = 1;      // 1: chained factorisation (falls back to 0 after a hand-off time-out)
 #ifdef GPMPC_EMULATED
@@ -801,7 +837,8 @@ struct gpmpc_gp {
     Prof prof;
     Ctx cx() {
         return Ctx{stream, crow_mode, side_stream, ev_fork, ev_join, chain_mode >= 2 ? aux_stream : nullptr,
-                   seg_events.data(), (int)seg_events.size(), chain_mode >= 3 ? g_cu_count[device] : 0, &prof};
+                   seg_events.data(), (int)seg_events.size(), chain_mode >= 3 ? g_cu_count[device] : 0, &prof,
+                   chain_mode >= 2 ? bulk_stream : nullptr};
     }
 };
 
@@ -880,8 +917,8 @@ int gpmpc_destroy(gpmpc_gp* h);
 }  // extern "C"
 
 // events for hand-overs between the queues of the factorisation: segments of the pipelined inverse, or two per
-// super-panel of the two-level execution (>= 2 block columns each)
-static size_t seg_event_count(int Np) { return (size_t)std::max(3, std::max(Np / SEGR + 2, Np / 64 + 4)); }
+// super-panel of the two-level execution (>= 2 block columns each; two more each with the look-ahead)
+static size_t seg_event_count(int Np) { return (size_t)std::max(3, std::max(Np / SEGR + 2, 2 * (Np / 64) + 8)); }
 
 static int create_impl(gpmpc_gp* h, const double* X, const double* Y) {
     const int device = h->device, N = h->N, d = h->d, Ny = h->Ny;
@@ -892,6 +929,11 @@ static int create_impl(gpmpc_gp* h, const double* X, const double* Y) {
     HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
     HIPCHK(hipStreamCreate(&h->aux_stream));
+    {
+        int lo = 0, hi = 0;                                    // (numerically larger = lower priority)
+        HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        HIPCHK(hipStreamCreateWithPriority(&h->bulk_stream, hipStreamDefault, lo));
+    }
     // the persistent kernels ask for more than the default 64 KB of dynamic LDS (per device: set for every handle)
     HIPCHK(hipFuncSetAttribute((const void*)chol_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CHAIN_LDS_BYTES));
     HIPCHK(hipFuncSetAttribute((const void*)chol_worker_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WORKER_LDS_BYTES));
@@ -966,6 +1008,7 @@ int gpmpc_destroy(gpmpc_gp* h) {
     if (h->ev_join) hipEventDestroy(h->ev_join);
     for (auto e : h->seg_events) hipEventDestroy(e);
     if (h->aux_stream) hipStreamDestroy(h->aux_stream);
+    if (h->bulk_stream) hipStreamDestroy(h->bulk_stream);
     if (h->side_stream) hipStreamDestroy(h->side_stream);
     if (h->own_stream) hipStreamDestroy(h->own_stream);
     delete h;

@@ -113,6 +113,9 @@ inline hipError_t hipMemcpy2DAsync(void* d, size_t dpitch, const void* s, size_t
 inline hipError_t hipMemset(void* d, int v, size_t n) { emu::drain(); std::memset(d, v, n); return hipSuccess; }
 inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { emu::drain(); std::memset(d, v, n); return hipSuccess; }
 inline hipError_t hipStreamCreate(hipStream_t* s) { static int next_id = 1; *s = new emu_stream{next_id++}; return hipSuccess; }
+constexpr unsigned hipStreamDefault = 0;
+inline hipError_t hipDeviceGetStreamPriorityRange(int* lo, int* hi) { *lo = 0; *hi = 0; return hipSuccess; }
+inline hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned, int) { return hipStreamCreate(s); }
 inline hipError_t hipStreamDestroy(hipStream_t s) { emu::drain(); delete s; return hipSuccess; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { emu::drain(); return hipSuccess; }
 inline hipError_t hipDeviceSynchronize() { emu::drain(); return hipSuccess; }
