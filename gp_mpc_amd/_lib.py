@@ -44,6 +44,7 @@ SIGNATURES = {
     'gpmpc_set_pointer_mode': (ctypes.c_int, [_vp, ctypes.c_int]),
     'gpmpc_set_stream': (ctypes.c_int, [_vp, _vp]),
     'gpmpc_synchronize': (ctypes.c_int, [_vp]),
+    'gpmpc_get_counter': (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.POINTER(ctypes.c_long)]),
     'gpmpc_profile_enable': (ctypes.c_int, [_vp, ctypes.c_int]),
     'gpmpc_profile_read': (ctypes.c_int, [_vp, ctypes.c_int, _dp, ctypes.POINTER(ctypes.c_long), ctypes.c_int]),
     'gpmpc_fit': (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp]),
@@ -227,6 +228,12 @@ class Handle:
 
     def synchronize(self):
         self.lib.check(self.lib.dll.gpmpc_synchronize(self.h))
+
+    def counter(self, name):
+        """'handoff_timeouts' | 'chained_factorisations' | 'single_queue_factorisations' (include/gpmpc.h)."""
+        v = ctypes.c_long(0)
+        self.lib.check(self.lib.dll.gpmpc_get_counter(self.h, name.encode(), ctypes.byref(v)))
+        return v.value
 
     def profile_enable(self, on=True):
         self.lib.check(self.lib.dll.gpmpc_profile_enable(self.h, int(on)))

@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -56,6 +57,10 @@ static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 // ------------------------------------------------------------------------------------------------
 // device bring-up + fp64 MFMA self-test
 // ------------------------------------------------------------------------------------------------
+// The persistent-kernel factorisation wants the whole chip (one CU-filling worker per CU and a CU for the chain): two of
+// them at once starve each other's workgroups of the residency their hand-offs rely on.  Handles of one process
+// therefore take turns on the device (a factorisation is ~2 ms at N = 4096).
+static std::mutex g_factor_mutex[64];
 static int g_crow_mode[64];
 static int g_cu_count[64];
 static bool g_dev_ready[64];
@@ -799,11 +804,19 @@ struct gpmpc_gp {
     size_t pin_ints = 0;
     hipStream_t aux_stream = nullptr, bulk_stream = nullptr;
     std::vector<hipEvent_t> seg_events;
-    int chain_mode = 1;      // 1: chained factorisation (falls back to 0 after a hand-off time-out)
+    int chain_mode = 1;      // 0: single queue; 1-3: chained factorisation (gpmpc_create)
+    // A hand-off time-out of the persistent kernels (GPU shared with work that keeps CUs from the workgroups that have
+    // to be co-resident) repeats THIS factorisation on the single-queue path; the next call tries the chained path
+    // again.  Only after CHAIN_STRIKES consecutive time-outs the handle stays on the single-queue path, and even then
+    // it re-arms after CHAIN_REARM fits, so a transient neighbour does not cost a factor of two for ever.
+    static constexpr int CHAIN_STRIKES = 3, CHAIN_REARM = 64;
+    int chain_strikes = 0, chain_parked = 0;
+    long n_timeouts = 0, n_chained = 0, n_single = 0;   // gpmpc_get_counter
 #ifdef GPMPC_EMULATED
     int spin_limit = 1 << 30;   // the emulator's polls are scheduler passes, not time
 #else
-    int spin_limit = 400000;    // ~0.3 s of polling with s_sleep before a waiter gives up
+    int spin_limit = 40000;     // ~30 ms of polling with s_sleep before a waiter gives up: a thousand step times of the
+                                // chain, and short enough for a control loop to survive the repeat on the other path
 #endif
     int ptr_mode = GPMPC_PTR_HOST;
     int crow_mode = 0;
@@ -1063,6 +1076,15 @@ int gpmpc_synchronize(gpmpc_gp* h) {
     return GPMPC_OK;
 }
 
+int gpmpc_get_counter(gpmpc_gp* h, const char* name, long* value) {
+    if (!h || !name || !value) return fail(GPMPC_EINVAL, "NULL argument");
+    if (std::strcmp(name, "handoff_timeouts") == 0) *value = h->n_timeouts;
+    else if (std::strcmp(name, "chained_factorisations") == 0) *value = h->n_chained;
+    else if (std::strcmp(name, "single_queue_factorisations") == 0) *value = h->n_single;
+    else return fail(GPMPC_EINVAL, "unknown counter '%s'", name);
+    return GPMPC_OK;
+}
+
 int gpmpc_profile_enable(gpmpc_gp* h, int enable) {
     if (!h) return fail(GPMPC_EINVAL, "NULL handle");
     h->prof.on = enable != 0;
@@ -1121,6 +1143,12 @@ static int factor_with_jitter(gpmpc_gp* h, Workspace& ws, const double* hyper_ho
     int* pin_info = h->pin;
     int* cerr = h->pin + nb;
     HIPCHK(hipMemcpyAsync(ws.hyper, hyper_host, (size_t)nb * (h->d + 2) * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    const int mode_configured = h->chain_mode;
+    if (h->chain_parked > 0 && --h->chain_parked == 0) h->chain_strikes = 0;      // re-arm the chained path
+    if (h->chain_parked > 0) h->chain_mode = 0;
+    struct Restore { gpmpc_gp* h; int m; ~Restore() { h->chain_mode = m; } } restore{h, mode_configured};
+    std::unique_lock<std::mutex> turn(g_factor_mutex[h->device], std::defer_lock);
+    if (h->chain_mode) turn.lock();               // held until the status words are back, i.e. the factorisation is done
     for (int attempt = 0; attempt < 2; ++attempt) {
         HIPCHK(hipMemcpyAsync(ws.jitter, jit.data(), nb * sizeof(double), hipMemcpyHostToDevice, h->stream));
         gram_and_factor(h, ws);
@@ -1165,17 +1193,24 @@ static int factor_with_jitter(gpmpc_gp* h, Workspace& ws, const double* hyper_ho
                         fprintf(stderr, "\n");
                     }
                 }
-                h->chain_mode = 0;
+                ++h->n_timeouts;
+                if (++h->chain_strikes >= gpmpc_gp::CHAIN_STRIKES) h->chain_parked = gpmpc_gp::CHAIN_REARM;
+                h->chain_mode = 0;                  // for the rest of THIS call (restored on return)
                 HIPCHK(hipStreamSynchronize(h->stream));
                 HIPCHK(hipStreamSynchronize(h->side_stream));
+                if (h->aux_stream) HIPCHK(hipStreamSynchronize(h->aux_stream));
+                if (h->bulk_stream) HIPCHK(hipStreamSynchronize(h->bulk_stream));
                 gram_and_factor(h, ws);
                 HIPCHK(hipMemcpyAsync(pin_info, ws.info, nb * sizeof(int), hipMemcpyDeviceToHost, h->stream));
                 HIPCHK(hipEventRecord(h->ev_info, h->stream));
                 if (post) post();
                 HIPCHK(hipEventSynchronize(h->ev_info));
                 for (int b = 0; b < nb; ++b) info[b] = pin_info[b];
+            } else {
+                h->chain_strikes = 0;
             }
         }
+        if (h->chain_mode) ++h->n_chained; else ++h->n_single;
         bool any = false;
         for (int b = 0; b < nb; ++b)
             if (info[b] != 0) {

@@ -16,8 +16,9 @@
  *     (gp_functions.py:129-130, optimize.py:338-340).  Z rows are z = [x, u] in the GP's own
  *     (standardised) input units; standardisation stays in the Python host class like
  *     gp_class.py:253-261.
- *   - one handle = one GP model = one HIP stream.  Calls on different handles are thread-safe,
- *     calls on one handle are serialised by the caller.
+ *   - one handle = one GP model = one HIP stream.  Calls on different handles are thread-safe (the
+ *     factorisations of different handles on one device take turns, see gpmpc_get_counter), calls on
+ *     one handle are serialised by the caller.
  */
 #ifndef GPMPC_H
 #define GPMPC_H
@@ -97,6 +98,13 @@ int gpmpc_hyper_width(const gpmpc_gp* h, int* width);
 int gpmpc_set_pointer_mode(gpmpc_gp* h, int mode);
 int gpmpc_set_stream(gpmpc_gp* h, void* hip_stream); /* NULL restores the handle's own stream */
 int gpmpc_synchronize(gpmpc_gp* h);
+/* Diagnostics of the factorisation path.  The fit runs its sequential chain and its bulk in persistent kernels that hand
+ * tiles over through flags and must be co-resident; on a GPU shared with other work a hand-off can time out (~30 ms),
+ * in which case THAT factorisation is repeated on the single-queue path (same result) and the next call tries again;
+ * after three consecutive time-outs the handle stays on the single-queue path for 64 fits.  Handles of one process
+ * take turns for the factorisation itself.  Counters: "handoff_timeouts", "chained_factorisations",
+ * "single_queue_factorisations". */
+int gpmpc_get_counter(gpmpc_gp* h, const char* name, long* value);
 int gpmpc_profile_enable(gpmpc_gp* h, int enable);   /* HIP-event brackets per phase on the handle's stream */
 int gpmpc_profile_read(gpmpc_gp* h, int phase, double* total_ms, long* launches, int reset);
 

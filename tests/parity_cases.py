@@ -324,8 +324,10 @@ def check_timeout_fallback(lib, N=560, d=4):
     finally:
         del os.environ['GPMPC_SPIN_LIMIT']
     X, Y, H, Z = p['X'], p['Y'], p['hyper'], p['Z']
-    for rep in range(2):                       # first fit: time-out + fallback; second: already on the fallback path
-        assert np.all(h.fit(H) == 0)
+    for rep in range(5):       # fits 1-3: time-out + repeat on the single-queue path (the chained path is tried again
+        assert np.all(h.fit(H) == 0)        # every time); from the third strike on the handle stays single-queue
+        assert h.counter('handoff_timeouts') == min(rep + 1, 3), (rep, h.counter('handoff_timeouts'))
+        assert h.counter('single_queue_factorisations') == rep + 1 and h.counter('chained_factorisations') == 0
         f = h.get_factors()
         o = go.fit(X, Y, H, want_invK=False)
         assert relF(f['chol'][0], o['chol'][0]) <= 1e-10
@@ -805,6 +807,7 @@ def check_two_handles_two_threads(lib, N, d=6, B=256, reps=6):
         h = Handle(lib, p['X'], p['Y'])
         assert np.all(h.fit(p['hyper']) == 0)
         refs.append(h.predict_mean_var(p['Z']))
+        assert h.counter('handoff_timeouts') == 0 and h.counter('chained_factorisations') == 1   # alone: no time-out
         h.close()
     handles = [Handle(lib, p['X'], p['Y']) for p in probs]
     errs = []
@@ -824,9 +827,15 @@ def check_two_handles_two_threads(lib, N, d=6, B=256, reps=6):
         t.start()
     for t in ts:
         t.join(timeout=600)
+    stats = [(hh.counter('chained_factorisations'), hh.counter('single_queue_factorisations'), hh.counter('handoff_timeouts'))
+             for hh in handles]
+    print('\n[two handles] (chained, single-queue, time-outs) per handle:', stats)
     for hh in handles:
         hh.close()
     assert not errs, errs
+    # the factorisations take turns on the device, so the persistent path must have served most of them even with the
+    # other handle's prediction kernels in flight
+    assert all(st[0] >= reps // 2 for st in stats), stats
 
 
 def check_mean_functions(lib, N=150, d=3, Ny=2, seed=31):
