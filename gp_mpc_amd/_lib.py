@@ -41,6 +41,7 @@ SIGNATURES = {
     'gpmpc_get_size': (ctypes.c_int, [_vp, _ip, _ip, _ip]),
     'gpmpc_set_mean_func': (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int]),
     'gpmpc_hyper_width': (ctypes.c_int, [_vp, _ip]),
+    'gpmpc_set_hyper_prior': (ctypes.c_int, [_vp, _vp]),
     'gpmpc_set_pointer_mode': (ctypes.c_int, [_vp, ctypes.c_int]),
     'gpmpc_set_stream': (ctypes.c_int, [_vp, _vp]),
     'gpmpc_synchronize': (ctypes.c_int, [_vp]),
@@ -218,6 +219,11 @@ class Handle:
         w = ctypes.c_int(0)
         self.lib.check(self.lib.dll.gpmpc_hyper_width(self.h, ctypes.byref(w)))
         self.nh = w.value
+
+    def set_hyper_prior(self, prior=None):
+        """prior: dict with the keys of optimize.py:158-165 (ell_mean, ell_std, sf_mean, sf_std, sn_mean, sn_std) or None."""
+        p6 = None if prior is None else _f64([prior[k] for k in ('ell_mean', 'ell_std', 'sf_mean', 'sf_std', 'sn_mean', 'sn_std')])
+        self.lib.check(self.lib.dll.gpmpc_set_hyper_prior(self.h, _ptr(p6)))
 
     def set_pointer_mode(self, device: bool):
         self.lib.check(self.lib.dll.gpmpc_set_pointer_mode(self.h, PTR_DEVICE if device else PTR_HOST))

@@ -829,6 +829,8 @@ struct gpmpc_gp {
     std::vector<double> hyper;           // host copy [Ny][nh()]: [ell.., sf, sn, mean parameters]
     // prior mean function (gp_functions.py:25-69): kind GPMPC_MEAN_*, its parameters per output on the device,
     // and the residual targets y - m(X) that alpha and the NLL are formed from
+    bool have_prior = false;             // Gaussian hyper-priors of calc_NLL (optimize.py:82-93)
+    double prior[6] = {0, 1, 0, 1, 0, 1};  // ell_mean, ell_std, sf_mean, sf_std, sn_mean, sn_std
     int mean_kind = 0;
     bool mean_add = false;               // add m(z) to the predicted mean (build_gp's meanFunc argument)
     double* mpar = nullptr;              // [Ny][MPW]
@@ -1047,6 +1049,19 @@ int gpmpc_set_mean_func(gpmpc_gp* h, int kind, int add_to_prediction) {
     h->fitted = false;
     h->have_invK = false;
     h->have_beta = false;
+    return GPMPC_OK;
+}
+
+int gpmpc_set_hyper_prior(gpmpc_gp* h, const double* prior6) {
+    if (!h) return fail(GPMPC_EINVAL, "NULL handle");
+    h->have_prior = prior6 != nullptr;
+    if (prior6) {
+        for (int k = 0; k < 6; ++k) {
+            if (!(prior6[k] == prior6[k]) || ((k & 1) && !(prior6[k] > 0.0)))
+                return fail(GPMPC_EINVAL, "prior[%d] = %g: means must be numbers, standard deviations positive", k, prior6[k]);
+            h->prior[k] = prior6[k];
+        }
+    }
     return GPMPC_OK;
 }
 
@@ -2063,6 +2078,27 @@ extern "C" int gpmpc_nll(gpmpc_gp* h, int a, const double* hyper_row, double* nl
     HIPCHK(hipMemcpyAsync(nll, ws.nll, sizeof(double), hipMemcpyDeviceToHost, h->stream));
     if (grad) HIPCHK(hipMemcpyAsync(grad, h->gradOut, (d + 2 + nmean) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->have_prior) {
+        // calc_NLL optimize.py:77-97, literally: `return NLL(...) + log_prior` with log_prior the sum of the Gaussian
+        // log-densities prior_gauss(theta, mu, s^2) = -(theta - mu)^2 / (2 s^2) - 1/2 log(2 pi s^2) of every ell_i and of
+        // sf^2 and sn^2 (the SQUARED hyper-parameters, :90-91).  (The log-prior is ADDED to the negative log-likelihood
+        // there, not subtracted; the reference never enables it, prior = None :157.)
+        const double two_pi = 6.283185307179586476925286766559;
+        auto lg = [&](double th, double mu, double sd) { return -(th - mu) * (th - mu) / (2.0 * sd * sd) - 0.5 * std::log(two_pi * sd * sd); };
+        auto dlg = [&](double th, double mu, double sd) { return -(th - mu) / (sd * sd); };
+        double lp = 0.0;
+        for (int k = 0; k < d; ++k) {
+            lp += lg(hyper_row[k], h->prior[0], h->prior[1]);
+            if (grad) grad[k] += dlg(hyper_row[k], h->prior[0], h->prior[1]);
+        }
+        const double sf = hyper_row[d], sn = hyper_row[d + 1];
+        lp += lg(sf * sf, h->prior[2], h->prior[3]) + lg(sn * sn, h->prior[4], h->prior[5]);
+        if (grad) {
+            grad[d] += dlg(sf * sf, h->prior[2], h->prior[3]) * 2.0 * sf;
+            grad[d + 1] += dlg(sn * sn, h->prior[4], h->prior[5]) * 2.0 * sn;
+        }
+        *nll += lp;
+    }
     return GPMPC_OK;
 }
 

@@ -95,6 +95,11 @@ int gpmpc_get_size(const gpmpc_gp* h, int* N, int* d, int* Ny);
  * reference raises there, gp_functions.py:309-311).  Changing the kind discards the factors. */
 int gpmpc_set_mean_func(gpmpc_gp* h, int kind, int add_to_prediction);
 int gpmpc_hyper_width(const gpmpc_gp* h, int* width);
+/* Gaussian hyper-priors of calc_NLL (optimize.py:77-93; unused by the reference itself, prior = None :157):
+ * prior6 = [ell_mean, ell_std, sf_mean, sf_std, sn_mean, sn_std]; gpmpc_nll then returns NLL + log_prior exactly as
+ * :97 does (log-densities of every ell_i, of sf^2 and of sn^2, ADDED to the negative log-likelihood), and its gradient
+ * follows.  NULL switches the priors off. */
+int gpmpc_set_hyper_prior(gpmpc_gp* h, const double* prior6);
 int gpmpc_set_pointer_mode(gpmpc_gp* h, int mode);
 int gpmpc_set_stream(gpmpc_gp* h, void* hip_stream); /* NULL restores the handle's own stream */
 int gpmpc_synchronize(gpmpc_gp* h);

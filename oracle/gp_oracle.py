@@ -246,6 +246,22 @@ def nll_mean_grad(hyper, X, y, func='zero'):
     return v, np.concatenate([g, gm])
 
 
+def nll_prior(hyper, X, y, prior, func='zero'):
+    """`calc_NLL` with hyper-priors, optimize.py:77-97 LITERALLY: prior_gauss(theta, mu, s2) = -(theta-mu)^2/(2 s2)
+    - 0.5 log(2 pi s2) summed over every ell_i (ell_mean, ell_std^2), over sf2 = hyper[Nx]^2 (sf_mean, sf_std^2) and
+    sn2 = hyper[Nx+1]^2 (sn_mean, sn_std^2), and `return NLL(...) + log_prior` (:97: the log-prior is added)."""
+    D = X.shape[1]
+
+    def prior_gauss(theta, mu, s2):
+        return -(theta - mu) ** 2 / (2 * s2) - 0.5 * np.log(2 * np.pi * s2)
+    log_prior = 0.0
+    for i in range(D):
+        log_prior += prior_gauss(hyper[i], prior['ell_mean'], prior['ell_std'] ** 2)
+    log_prior += prior_gauss(hyper[D] ** 2, prior['sf_mean'], prior['sf_std'] ** 2)
+    log_prior += prior_gauss(hyper[D + 1] ** 2, prior['sn_mean'], prior['sn_std'] ** 2)
+    return nll_mean(hyper, X, y, func) + log_prior
+
+
 def fit_mean(X, Y, hyper, func='zero', want_invK=True):
     """train_gp's recomputation at the optimum with a mean function, optimize.py:264-285: K, L, invK from the kernel
     part; alpha = K^-1 (y - m(X))."""

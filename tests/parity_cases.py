@@ -867,6 +867,19 @@ def check_mean_functions(lib, N=150, d=3, Ny=2, seed=31):
             ov, og = go.nll_mean_grad(H[a], X, Y[:, a], func)
             assert abs(v - go.nll_mean(H[a], X, Y[:, a], func)) / (abs(ov) + N) <= 1e-10
             assert np.max(np.abs(g - og) / (np.abs(og) + 1e-3 * np.abs(og).max())) <= 1e-6, (func, g, og)
+        if func == 'linear':      # Gaussian hyper-priors of calc_NLL (optimize.py:77-97), value and gradient
+            prior = dict(ell_mean=10.0, ell_std=10.0, sf_mean=10.0, sf_std=10.0, sn_mean=1e-5, sn_std=1e-2)   # (:158-165)
+            h.set_hyper_prior(prior)
+            v, g = h.nll(0, H[0], want_grad=True)
+            ref = go.nll_prior(H[0], X, Y[:, 0], prior, func)
+            assert abs(v - ref) / (abs(ref) + N) <= 1e-10
+            for k in range(d + 2):
+                e = np.zeros(h.nh)
+                e[k] = 1e-6 * max(1.0, abs(H[0, k]))
+                fd = (go.nll_prior(H[0] + e, X, Y[:, 0], prior, func) - go.nll_prior(H[0] - e, X, Y[:, 0], prior, func)) / (2 * e[k])
+                assert abs(fd - g[k]) <= 1e-5 * (abs(g[k]) + 1e-3 * np.abs(g).max()), (k, fd, g[k])
+            h.set_hyper_prior(None)
+            assert abs(h.nll(0, H[0]) - go.nll_mean(H[0], X, Y[:, 0], func)) / (abs(ref) + N) <= 1e-10
         # GP.__init__'s predictor (build_gp without meanFunc): ks^T alpha only
         ms = mean_scale(X, Z, Hk, o['alpha'])
         mean, var = h.predict_mean_var(Z)
