@@ -50,61 +50,104 @@ __device__ inline double small_solve(double* A, double* Bm, int d, int nrhs) {
     return det;
 }
 
+// Gauss-Jordan elimination with partial pivoting on the augmented matrix M = [A | B] (d rows, nc = d + nrhs columns,
+// row stride GJ_LD) held in LDS, executed by the whole workgroup (one thread per entry): on return the B part holds
+// A^-1 B; returns |det A| (same value in every thread).  `piv` is a 2-int LDS slot.
+constexpr int GJ_LD = 2 * DMAX;
+__device__ inline double gauss_jordan_lds(double* M, int d, int nc, int* piv) {
+    const int tid = threadIdx.x, r = tid / GJ_LD, c = tid % GJ_LD;
+    double det = 1.0;
+    for (int k = 0; k < d; ++k) {
+        if (tid == 0) {
+            int best = k;
+            double bv = fabs(M[k * GJ_LD + k]);
+            for (int q = k + 1; q < d; ++q)
+                if (fabs(M[q * GJ_LD + k]) > bv) { bv = fabs(M[q * GJ_LD + k]); best = q; }
+            piv[0] = best;
+        }
+        __syncthreads();
+        const int p = piv[0];
+        if (p != k && r == 0 && c < nc) {                    // swap rows k and p (one thread per column)
+            const double t = M[k * GJ_LD + c];
+            M[k * GJ_LD + c] = M[p * GJ_LD + c];
+            M[p * GJ_LD + c] = t;
+        }
+        __syncthreads();
+        const double pv = M[k * GJ_LD + k];
+        det *= fabs(pv);
+        const double f = (r < d && r != k) ? M[r * GJ_LD + k] / pv : 0.0;
+        const double rowk = (c < nc) ? M[k * GJ_LD + c] : 0.0;
+        __syncthreads();
+        if (r < d && c < nc) {
+            if (r == k) M[r * GJ_LD + c] = rowk / pv;
+            else M[r * GJ_LD + c] -= f * rowk;
+        }
+        __syncthreads();
+    }
+    return det;
+}
+
 // per-input small algebra.  Layout of `prep` per input b (doubles):
 //   [a < Ny]       iR_a[d*d], c_a                              -> Ny * (d*d + 1)
 //   [pair p]       S_p[d*d], t_p                               -> P  * (d*d + 1),  p = a(a+1)/2 + b
-// grid (ceil(B*(Ny+P)/64)), 64 threads: one thread per (input, item).
-__global__ void __launch_bounds__(64) em_prep_kernel(const double* __restrict__ hyper, const double* __restrict__ Sigma,
-                                                     double* __restrict__ prep, int B, int Ny, int d) {
+// grid (B * (Ny + P)), DMAX * GJ_LD threads: one workgroup per (input, item), its d x d systems solved in LDS.
+// (A first version gave each item ONE thread with its matrices in scratch memory: 0.28 ms per input at C3, an
+//  eighth of the whole exact-moment step, all of it latency.)
+__global__ void __launch_bounds__(DMAX * GJ_LD) em_prep_kernel(const double* __restrict__ hyper, const double* __restrict__ Sigma,
+                                                               double* __restrict__ prep, int B, int Ny, int d) {
     const int P = Ny * (Ny + 1) / 2, items = Ny + P;
-    const long gid = (long)blockIdx.x * 64 + threadIdx.x;
-    if (gid >= (long)B * items) return;
-    const int b = (int)(gid / items), it = (int)(gid % items);
+    const int b = blockIdx.x / items, it = blockIdx.x % items;
     const double* Sg = Sigma + (long)b * d * d;
     const int stride = d * d + 1;
     double* out = prep + ((long)b * items + it) * stride;
-    double A[DMAX * DMAX], R[DMAX * DMAX];
+    __shared__ double M[DMAX * GJ_LD];
+    __shared__ int piv[2];
+    const int tid = threadIdx.x, r = tid / GJ_LD, c = tid % GJ_LD;
     if (it < Ny) {
         const double* hy = hyper + (long)it * (d + 2);
         // iR = iLambda (I - (I + Sigma iLambda)^-1 (Sigma iLambda)),  R = Sigma + Lambda
-        for (int r = 0; r < d; ++r)
-            for (int c = 0; c < d; ++c) {
-                const double sil = Sg[r * d + c] / (hy[c] * hy[c]);
-                A[r * d + c] = sil + (r == c ? 1.0 : 0.0);
-                R[r * d + c] = sil;                 // right-hand side: Sigma iLambda
-            }
-        small_solve(A, R, d, d);                    // R <- (I + Sigma iLambda)^-1 Sigma iLambda
-        for (int r = 0; r < d; ++r)
-            for (int c = 0; c < d; ++c) out[r * d + c] = ((r == c ? 1.0 : 0.0) - R[r * d + c]) / (hy[r] * hy[r]);
-        double prod = 1.0;
-        for (int r = 0; r < d; ++r)
-            for (int c = 0; c < d; ++c) A[r * d + c] = Sg[r * d + c] + (r == c ? hy[r] * hy[r] : 0.0);
-        for (int r = 0; r < d; ++r) prod *= hy[r];
-        double dummy[1];
-        const double det = small_solve(A, dummy, d, 0);
-        out[d * d] = hy[d] * hy[d] / sqrt(det) * prod;
+        if (r < d && c < 2 * d) {
+            const int cc = c < d ? c : c - d;
+            const double sil = Sg[r * d + cc] / (hy[cc] * hy[cc]);
+            M[r * GJ_LD + c] = c < d ? sil + (r == cc ? 1.0 : 0.0) : sil;      // [I + Sigma iLambda | Sigma iLambda]
+        }
+        __syncthreads();
+        gauss_jordan_lds(M, d, 2 * d, piv);
+        if (r < d && c < d) out[r * d + c] = ((r == c ? 1.0 : 0.0) - M[r * GJ_LD + d + c]) / (hy[r] * hy[r]);
+        __syncthreads();
+        if (r < d && c < d) M[r * GJ_LD + c] = Sg[r * d + c] + (r == c ? hy[r] * hy[r] : 0.0);
+        __syncthreads();
+        const double det = gauss_jordan_lds(M, d, d, piv);
+        if (tid == 0) {
+            double prod = 1.0;
+            for (int q = 0; q < d; ++q) prod *= hy[q];
+            out[d * d] = hy[d] * hy[d] / sqrt(det) * prod;
+        }
     } else {
         int p = it - Ny, a = 0;
         while ((a + 1) * (a + 2) / 2 <= p) ++a;
         const int bb = p - a * (a + 1) / 2;
         const double* ha = hyper + (long)a * (d + 2);
         const double* hb = hyper + (long)bb * (d + 2);
-        for (int r = 0; r < d; ++r)
-            for (int c = 0; c < d; ++c) {
-                A[r * d + c] = Sg[r * d + c] * (1.0 / (ha[c] * ha[c]) + 1.0 / (hb[c] * hb[c])) + (r == c ? 1.0 : 0.0);
-                R[r * d + c] = Sg[r * d + c] * 0.5;
-            }
-        const double det = small_solve(A, R, d, d);  // R <- R2^-1 (Sigma / 2)
-        for (int e = 0; e < d * d; ++e) out[e] = R[e];
-        out[d * d] = 1.0 / sqrt(det);
+        if (r < d && c < 2 * d) {
+            const int cc = c < d ? c : c - d;
+            M[r * GJ_LD + c] = c < d ? Sg[r * d + cc] * (1.0 / (ha[cc] * ha[cc]) + 1.0 / (hb[cc] * hb[cc])) + (r == cc ? 1.0 : 0.0)
+                                     : Sg[r * d + cc] * 0.5;                     // [R2 | Sigma / 2]
+        }
+        __syncthreads();
+        const double det = gauss_jordan_lds(M, d, 2 * d, piv);
+        if (r < d && c < d) out[r * d + c] = M[r * GJ_LD + d + c];
+        if (tid == 0) out[d * d] = 1.0 / sqrt(det);
     }
 }
 
-// mean_a = sum_i q_i beta_ai.  grid (Ny, B), 256 threads.
+// mean_a = sum_i q_i beta_ai.  grid (Ny, B, EM_MEAN_CHUNKS), 256 threads: partial sums per chunk of the training
+// points (six workgroups for the whole sum took 0.2 ms at C3), added in a fixed order by em_mean_finish_kernel.
+constexpr int EM_MEAN_CHUNKS = 16;
 __global__ void __launch_bounds__(256) em_mean_kernel(const double* __restrict__ XT, const double* __restrict__ Z,
                                                       const double* __restrict__ beta, const double* __restrict__ prep,
-                                                      double* __restrict__ mean, int N, int Np, int d, int Ny) {
-    const int a = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+                                                      double* __restrict__ mpart, int N, int Np, int d, int Ny) {
+    const int a = blockIdx.x, b = blockIdx.y, ch = blockIdx.z, tid = threadIdx.x;
     const int P = Ny * (Ny + 1) / 2, stride = d * d + 1;
     const double* pr = prep + ((long)b * (Ny + P) + a) * stride;
     __shared__ double iR[DMAX * DMAX], mu[DMAX], red[4];
@@ -112,8 +155,9 @@ __global__ void __launch_bounds__(256) em_mean_kernel(const double* __restrict__
     if (tid < d) mu[tid] = Z[(long)b * d + tid];
     __syncthreads();
     const double c = pr[d * d];
+    const int clen = (N + EM_MEAN_CHUNKS - 1) / EM_MEAN_CHUNKS, ibeg = ch * clen, iend = min(N, ibeg + clen);
     double s = 0.0;
-    for (int i = tid; i < N; i += 256) {
+    for (int i = ibeg + tid; i < iend; i += 256) {
         double v[DMAX];
         for (int k = 0; k < d; ++k) v[k] = XT[(long)k * Np + i] - mu[k];
         double qf = 0.0;
@@ -127,7 +171,15 @@ __global__ void __launch_bounds__(256) em_mean_kernel(const double* __restrict__
     s = wave_sum(s);
     if ((tid & 63) == 0) red[tid >> 6] = s;
     __syncthreads();
-    if (tid == 0) mean[(long)b * Ny + a] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (tid == 0) mpart[((long)b * Ny + a) * EM_MEAN_CHUNKS + ch] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ void __launch_bounds__(256) em_mean_finish_kernel(const double* __restrict__ mpart, double* __restrict__ mean,
+                                                             int count) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= count) return;
+    double s = 0.0;
+    for (int ch = 0; ch < EM_MEAN_CHUNKS; ++ch) s += mpart[(long)e * EM_MEAN_CHUNKS + ch];
+    mean[e] = s;
 }
 
 constexpr int EMK = 8;   // cross-term depth handled by the MFMA path (d <= 8: two 16x16x4 steps)
@@ -245,7 +297,7 @@ __global__ void __launch_bounds__(256) em_pair_kernel(const double* __restrict__
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) ik[t][r] = iK[(long)irow[r] * Np + jt * 64 + 16 * t + fr];
+                for (int r = 0; r < 4; ++r) ik[t][r] = irow[r] < N ? iK[(long)irow[r] * Np + jt * 64 + 16 * t + fr] : 0.0;
         }
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -257,10 +309,12 @@ __global__ void __launch_bounds__(256) em_pair_kernel(const double* __restrict__
             const double bj = Cs[cur][EMK + 1][cl];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
+                // no per-entry masks: beta is zero in padded rows / columns, K^-1's padded rows are masked at the load
+                // above and its padded columns are exact zeros in live rows (identity padding), Q is finite everywhere
                 const double q = exp_lean((la[r] + lbj) + c[r]);
                 double wgt = bai[r] * bj;
                 if (diag) wgt -= ik[t][r];
-                acc += (j < N && irow[r] < N) ? mult * wgt * q : 0.0;
+                acc = fma(diag ? mult * wgt : wgt, q, acc);
             }
         }
         if (jt + 1 < jt_end) stage(cur ^ 1);

@@ -1926,8 +1926,7 @@ extern "C" int gpmpc_predict_em_sens(gpmpc_gp* h, int B, const double* Z, const 
                                       oC + (size_t)b0 * Ny * Ny));
             PhaseTimer t(h, GPMPC_PH_EM);
             if (b0 == 0) {
-                const long items = (long)B * (Ny + P);
-                hipLaunchKernelGGL(em_prep_kernel, dim3((unsigned)((items + 63) / 64)), dim3(64), 0, cx.stream, h->ws.hyper, dS,
+                hipLaunchKernelGGL(em_prep_kernel, dim3((unsigned)(B * (Ny + P))), dim3(DMAX * GJ_LD), 0, cx.stream, h->ws.hyper, dS,
                                    prep, B, Ny, d);
             }
             hipLaunchKernelGGL(em_mean_sens_kernel, dim3(Ny, nb), dim3(256), 0, cx.stream, h->XT, dZ, h->beta, prep,

@@ -33,16 +33,17 @@ static int predict_moments_chunk(gpmpc_gp* h, int method, int B, const double* d
         if (d > EMK) return fail(GPMPC_EINVAL, "EM: input dimension d=%d exceeds the MFMA cross-term depth %d", d, EMK);
         const int P = Ny * (Ny + 1) / 2, tiles = Np / 64;
         const long prepN = (long)B * (Ny + P) * (d * d + 1), partN = (long)B * P * tiles;
-        const long opsN = (long)B * P * (2 * EMK + 2) * Np;
-        CHK(ensure_em_scratch(h, (prepN + partN + opsN) * (long)sizeof(double)));
+        const long opsN = (long)B * P * (2 * EMK + 2) * Np, mpartN = (long)B * Ny * EM_MEAN_CHUNKS;
+        CHK(ensure_em_scratch(h, (prepN + partN + opsN + mpartN) * (long)sizeof(double)));
         double* prep = h->em;
         double* partial = h->em + prepN;
         double* ops = partial + partN;
-        const long items = (long)B * (Ny + P);
-        hipLaunchKernelGGL(em_prep_kernel, dim3((unsigned)((items + 63) / 64)), dim3(64), 0, cx.stream, h->ws.hyper, dSigma,
+        double* mpart = ops + opsN;
+        hipLaunchKernelGGL(em_prep_kernel, dim3((unsigned)(B * (Ny + P))), dim3(DMAX * GJ_LD), 0, cx.stream, h->ws.hyper, dSigma,
                            prep, B, Ny, d);
-        hipLaunchKernelGGL(em_mean_kernel, dim3(Ny, B), dim3(256), 0, cx.stream, h->XT, dZ, h->beta, prep, dMean, N, Np, d,
-                           Ny);
+        hipLaunchKernelGGL(em_mean_kernel, dim3(Ny, B, EM_MEAN_CHUNKS), dim3(256), 0, cx.stream, h->XT, dZ, h->beta, prep, mpart,
+                           N, Np, d, Ny);
+        hipLaunchKernelGGL(em_mean_finish_kernel, dim3((B * Ny + 255) / 256), dim3(256), 0, cx.stream, mpart, dMean, B * Ny);
         hipLaunchKernelGGL(em_operands_kernel, dim3((Np + 255) / 256, P, B), dim3(256), 0, cx.stream, h->XT, dZ, h->ws.hyper,
                            prep, ops, N, Np, d, Ny);
         hipLaunchKernelGGL((em_pair_kernel<false>), dim3(tiles, P, B), dim3(256), 0, cx.stream, ops, h->beta, h->ws.InvK,
