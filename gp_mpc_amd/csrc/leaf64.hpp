@@ -73,8 +73,13 @@ __device__ __forceinline__ void inv16(const double* S, double* T, int o, int lan
 
 // One wave: Cholesky of the 64 x 16 panel = rows 16t..63 of columns 16t..16t+15 of S (LDS), lane = row.
 // Returns the first non-positive pivot column (0-based within the panel) or -1.
-__device__ __forceinline__ int panel_potrf(double* S, double* Drinv, int t, int lane) {
-    const int o = 16 * t, r = lane;
+// The panel index is a template parameter: the source lanes of the ~270 v_readlane broadcasts per panel are then
+// instruction immediates instead of SGPRs computed from a loop variable (8.5 instead of 10.8 us for the four panels of
+// a leaf, tools/ubench/leaf_loop_bench.hip).
+template <int TT>
+__device__ __forceinline__ int panel_potrf(double* S, double* Drinv, int lane) {
+    constexpr int o = 16 * TT;
+    const int r = lane;
     double a[16], rinv[16];
     int bad = -1;
 #pragma unroll
@@ -122,9 +127,11 @@ __device__ __forceinline__ int leaf_body(double* S, double* T, double* U, double
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int bad = -1;
     if (do_chol) {
+#pragma unroll
         for (int t = 0; t < 4; ++t) {
             if (wave == 0 && (phases & 1)) {
-                const int b = panel_potrf(S, Dr, t, lane);
+                const int b = t == 0 ? panel_potrf<0>(S, Dr, lane) : t == 1 ? panel_potrf<1>(S, Dr, lane)
+                            : t == 2 ? panel_potrf<2>(S, Dr, lane) : panel_potrf<3>(S, Dr, lane);
                 if (b >= 0 && bad < 0) bad = 16 * t + b;
             } else if (wave == 1 && t >= 1 && (phases & 4)) {
                 inv16(S, T, 16 * (t - 1), lane, Dr);   // inverse of the previous diagonal block
