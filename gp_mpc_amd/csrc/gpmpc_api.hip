@@ -1125,8 +1125,7 @@ static void gram_and_factor(gpmpc_gp* h, Workspace& ws) {
     const Ctx cx = h->cx();
     {
         PhaseTimer t(h, GPMPC_PH_GRAM);
-        hipLaunchKernelGGL(gram_kernel, dim3(ws.Np / 64, ws.Np / 64, ws.batch), dim3(256), 0, cx.stream, h->XT,
-                           ws.hyper, ws.jitter, ws.K, h->N, ws.Np, h->d);
+        launch_gram(cx.stream, dim3(ws.Np / 64, ws.Np / 64, ws.batch), h->d, h->XT, ws.hyper, ws.jitter, ws.K, h->N, ws.Np);
     }
     {
         PhaseTimer t(h, GPMPC_PH_FACTOR);
@@ -1396,8 +1395,7 @@ extern "C" int gpmpc_append(gpmpc_gp* h, int n, const double* Xnew, const double
                                 Np0 * sizeof(double), R0 * sizeof(double), R0, hipMemcpyDeviceToDevice, cx.stream));
     }
     HIPCHK(hipMemsetAsync(ws1.info, 0, Ny * sizeof(int), cx.stream));
-    hipLaunchKernelGGL(gram_kernel, dim3(Np1 / 64, m / 64, Ny), dim3(256), 0, cx.stream, XT1, ws1.hyper, ws1.jitter, ws1.K, N1,
-                       Np1, d, R0 / 64);
+    launch_gram(cx.stream, dim3(Np1 / 64, m / 64, Ny), d, XT1, ws1.hyper, ws1.jitter, ws1.K, N1, Np1, R0 / 64);
     const long oS = (long)R0 * ld;                          // first strip row
     {
         GemmP p = gemm_base(cx);                            // L21 = K21 inv11^T
