@@ -592,13 +592,24 @@ __global__ void __launch_bounds__(64) rollout_feed_kernel(const double* __restri
 __global__ void __launch_bounds__(256) gemv_rows_kernel(const double* __restrict__ A, const double* __restrict__ x,
                                                         double* __restrict__ out, int Np, long sA, long sx, long so,
                                                         int lower) {
+    // 16-byte loads, two independent 1 KB wave loads in flight per iteration (rows are 512-byte aligned: Np % 64 == 0)
     const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const double* __restrict__ row = A + (long)blockIdx.y * sA + (long)i * Np;
-    const double* __restrict__ xv = x + (long)blockIdx.y * sx;
-    const int kend = lower ? i + 1 : Np;
-    double s = 0.0;
-    for (int k = lane; k < kend; k += 64) s += row[k] * xv[k];
-    s = wave_sum(s);
+    const double2* __restrict__ row = reinterpret_cast<const double2*>(A + (long)blockIdx.y * sA + (long)i * Np);
+    const double2* __restrict__ xv = reinterpret_cast<const double2*>(x + (long)blockIdx.y * sx);
+    const int kend = lower ? i + 1 : Np;                 // entries beyond the diagonal of a lower operand are exact zeros
+    const int nq = (kend + 1) >> 1;                      // double2 chunks (the odd tail multiplies a stored zero)
+    double s0 = 0.0, s1 = 0.0;
+    int q = lane;
+    for (; q + 64 < nq; q += 128) {
+        const double2 a0 = row[q], a1 = row[q + 64], b0 = xv[q], b1 = xv[q + 64];
+        s0 += a0.x * b0.x + a0.y * b0.y;
+        s1 += a1.x * b1.x + a1.y * b1.y;
+    }
+    if (q < nq) {
+        const double2 a0 = row[q], b0 = xv[q];
+        s0 += a0.x * b0.x + a0.y * b0.y;
+    }
+    const double s = wave_sum(s0 + s1);
     if (lane == 0) out[(long)blockIdx.y * so + i] = s;
 }
 
@@ -612,24 +623,40 @@ constexpr int GEMVT_ROWS = 256;
 __global__ void __launch_bounds__(256) gemv_lowerT_part_kernel(const double* __restrict__ A, const double* __restrict__ x,
                                                                double* __restrict__ part, int Np, long sA, long sx,
                                                                long sPart) {
-    __shared__ double red[4][64];
-    const int lane = threadIdx.x & 63, v = threadIdx.x >> 6, k0 = blockIdx.x * 64, k = k0 + lane;
+    // a lane owns TWO adjacent columns (16-byte loads, 1 KB per wave and row); the strictly upper entries it may touch
+    // inside the diagonal block are stored zeros.  grid (Np/128, chunks, batch).
+    __shared__ double red[4][128];
+    const int lane = threadIdx.x & 63, v = threadIdx.x >> 6, k0 = blockIdx.x * 128, k = k0 + 2 * lane;
     const int r0 = blockIdx.y * GEMVT_ROWS, r1 = min(Np, r0 + GEMVT_ROWS);
     double* __restrict__ po = part + (long)blockIdx.z * sPart + (long)blockIdx.y * Np;
+    const bool live = k < Np;                           // (Np is a multiple of 64, not of 128)
     if (r1 <= k0) {                                     // entirely above the diagonal
-        if (v == 0) po[k] = 0.0;
+        if (v == 0 && live) { po[k] = 0.0; po[k + 1] = 0.0; }
         return;
     }
     const double* __restrict__ Ab = A + (long)blockIdx.z * sA;
     const double* __restrict__ xv = x + (long)blockIdx.z * sx;
-    double s = 0.0;
-    for (int i = max(r0, k0) + v; i < r1; i += 4) {
-        const double a = (k <= i) ? Ab[(long)i * Np + k] : 0.0;
-        s += a * xv[i];
+    double s0 = 0.0, s1 = 0.0, t0 = 0.0, t1 = 0.0;
+    int i = max(r0, k0) + v;
+    const double2 zero2 = {0.0, 0.0};
+    for (; i + 4 < r1; i += 8) {
+        const double2 a = live ? *reinterpret_cast<const double2*>(Ab + (long)i * Np + k) : zero2;
+        const double2 b = live ? *reinterpret_cast<const double2*>(Ab + (long)(i + 4) * Np + k) : zero2;
+        const double xa = xv[i], xb = xv[i + 4];
+        s0 += a.x * xa; s1 += a.y * xa;
+        t0 += b.x * xb; t1 += b.y * xb;
     }
-    red[v][lane] = s;
+    if (i < r1) {
+        const double2 a = live ? *reinterpret_cast<const double2*>(Ab + (long)i * Np + k) : zero2;
+        s0 += a.x * xv[i]; s1 += a.y * xv[i];
+    }
+    red[v][2 * lane] = s0 + t0;
+    red[v][2 * lane + 1] = s1 + t1;
     __syncthreads();
-    if (v == 0) po[k] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    if (threadIdx.x < 128) {
+        const int c = threadIdx.x;
+        if (k0 + c < Np) po[k0 + c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+    }
 }
 // grid (Np/256, batch), 256 threads
 __global__ void __launch_bounds__(256) gemv_lowerT_finish_kernel(const double* __restrict__ part, double* __restrict__ out,

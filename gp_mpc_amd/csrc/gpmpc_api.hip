@@ -770,7 +770,7 @@ static void solve_alpha(const Ctx& cx, Workspace& ws, const double* y, long sy) 
     hipLaunchKernelGGL(gemv_rows_kernel, dim3(Np / 4, ws.batch), dim3(256), 0, cx.stream, ws.Inv, y, ws.w, Np, ws.mat(), sy,
                        (long)Np, 1);
     const int chunks = (Np + GEMVT_ROWS - 1) / GEMVT_ROWS;         // partial sums go through the (now idle) inverse scratch
-    hipLaunchKernelGGL(gemv_lowerT_part_kernel, dim3(Np / 64, chunks, ws.batch), dim3(256), 0, cx.stream, ws.Inv, ws.w, ws.W,
+    hipLaunchKernelGGL(gemv_lowerT_part_kernel, dim3((Np + 127) / 128, chunks, ws.batch), dim3(256), 0, cx.stream, ws.Inv, ws.w, ws.W,
                        Np, ws.mat(), (long)Np, ws.wstride());
     hipLaunchKernelGGL(gemv_lowerT_finish_kernel, dim3((Np + 255) / 256, ws.batch), dim3(256), 0, cx.stream, ws.W, ws.alpha, Np,
                        chunks, ws.wstride(), (long)Np);
