@@ -43,8 +43,12 @@ def test_emu_tank_model(emu, tank):
     pc.check_model_fixture(emu, tank, tolL=1e-10, tol_nll=1e-10)
 
 
-def test_emu_car_model(emu, car):
+def test_emu_car_model_cond_7e10_bars_5e10_L_1e7_nll(emu, car):
     pc.check_model_fixture(emu, car, tolL=5e-10, tol_nll=1e-7)
+
+
+def test_emu_gp_class_strict(emu):
+    pc.check_gp_class_strict(emu, N=150)
 
 
 def test_emu_synthetic(emu):

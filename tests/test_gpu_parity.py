@@ -58,8 +58,15 @@ def test_tank_model(lib, tank):
     pc.check_model_fixture(lib, tank, tolL=1e-10, tol_nll=1e-10)
 
 
-def test_car_model(lib, car):
+def test_car_model_cond_7e10_bars_5e10_L_1e7_nll(lib, car):
+    """The reference's car model has cond(K) up to 7e10: numpy re-deriving its own stored factor on another
+    LAPACK build is at 8e-11, so L is held to 5e-10 and the (cond-limited) NLL to 1e-7 here; the well-conditioned
+    synthetic sets below carry the plain 1e-10 bars."""
     pc.check_model_fixture(lib, car, tolL=5e-10, tol_nll=1e-7)
+
+
+def test_gp_class_strict_bars_on_well_conditioned_model(lib):
+    pc.check_gp_class_strict(lib)
 
 
 def test_synthetic_strict(lib):
