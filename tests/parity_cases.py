@@ -1177,3 +1177,45 @@ def check_gp_class_strict(lib, N=400, Ny=3, Nu=2, seed=29):
     osmse, omnlp = og.validate(Xraw[:50], Yraw[:50])
     assert np.allclose(smse, osmse, rtol=1e-9, atol=0) and np.allclose(mnlp, omnlp, rtol=1e-9, atol=1e-12)
     gp.close()
+
+
+def check_random_shapes(lib, n_cases=10, seed=2024, nmax=220):
+    """Seeded sweep over ragged shapes (N not a multiple of anything, d = 1..8, Ny = 1..3, B = 1..70): fit, mean / var /
+    Jacobian, TA and EM covariances, NLL + gradient against the oracle -- the indexing of every kernel with padding in
+    all of its dimensions at once."""
+    rng = np.random.default_rng(seed)
+    for case in range(n_cases):
+        N = int(rng.integers(1, nmax))
+        d = int(rng.integers(1, 9))
+        Ny = int(rng.integers(1, 4))
+        B = int(rng.integers(1, 71))
+        p = go.synthetic_problem(N, d, Ny, B, seed=int(rng.integers(1 << 30)), sn=0.1)
+        X, Y, Z, S = p['X'], p['Y'], p['Z'], p['Sigma'] * 30
+        H = np.hstack([rng.uniform(0.6, 2.5, (Ny, d)), rng.uniform(0.7, 1.6, (Ny, 1)), np.full((Ny, 1), 0.1)])
+        h = Handle(lib, X, Y)
+        assert np.all(h.fit(H, want_invK=True) == 0), (case, N, d, Ny)
+        o = go.fit(X, Y, H)
+        f = h.get_factors(invK=True)
+        tag = (case, N, d, Ny, B)
+        for a in range(Ny):
+            assert relF(f['chol'][a], o['chol'][a]) <= 1e-11, tag
+            assert relF(f['invK'][a], o['invK'][a]) <= 1e-9, tag
+        mean, cov, J = h.predict_jac('TA', Z, S)
+        om, ov, oJ = go.mean_var_jac(Z, X, H, o['alpha'], o['chol'])
+        ms = mean_scale(X, Z, H, o['alpha'])
+        assert np.max(np.abs(mean - om) / ms) <= 1e-10, tag
+        assert np.max(np.abs(J - oJ) / (ms / H[:, :d].min(axis=1))[..., None]) <= 1e-10, tag
+        assert np.max(np.abs(cov - go.ta_cov(ov, oJ, S))) <= 1e-10 * max(1.0, (H[:, d] ** 2).max()), tag
+        nb = min(B, 2)
+        me, ce = h.predict('EM', Z[:nb], S[:nb])
+        for b in range(nb):
+            em, ec = go.exact_moment(f['invK'], X, Y, H, Z[b], S[b])
+            sc = _em_scale(f['invK'], X, Y, H, Z[b], S[b]).max() + (H[:, d] ** 2).max()
+            assert np.max(np.abs(me[b] - em)) <= 1e-9 * max(1.0, np.abs(em).max()), tag
+            assert np.max(np.abs(ce[b] - ec)) <= 1e-9 * sc, tag
+        a = int(rng.integers(0, Ny))
+        v, g = h.nll(a, H[a], want_grad=True)
+        ovv, og = go.nll_grad(H[a], X, Y[:, a])
+        assert abs(v - ovv) <= 1e-10 * (abs(ovv) + N), tag
+        assert np.max(np.abs(g - og)) <= 1e-7 * (np.abs(og).max() + 1e-3), tag
+        h.close()

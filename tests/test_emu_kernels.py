@@ -185,3 +185,7 @@ def test_emu_callback_blocks(emu):
 
 def test_emu_training_native(emu, train_small):
     pc.check_training_native(emu, train_small)
+
+
+def test_emu_random_shapes(emu):
+    pc.check_random_shapes(emu, n_cases=8, nmax=160)

@@ -175,6 +175,10 @@ def test_training_native(lib, train_small):
     pc.check_training_native(lib, train_small)
 
 
+def test_random_shapes(lib):
+    pc.check_random_shapes(lib, n_cases=25, nmax=700)
+
+
 def test_edge_cases(lib):
     pc.check_edge_cases(lib)
 
