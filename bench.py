@@ -11,6 +11,9 @@ objects shard trivially, no data-path collective): weak scaling.
 --config C3 (secondary, same JSON shape; the default and the headline stay C2): BASELINE.json configs[2] --
 6-output GP, N=8192, d=8: one STEP = fit of all outputs with K^-1 + a 30-step uncertainty propagation with each
 of 'ME', 'TA', 'EM' (gpmpc_rollout); `value` = propagation steps/s over whole steps (fit included).
+--config C4: BASELINE.json configs[3] -- hyper-parameter training at N=4096, d=6: one STEP = 64 seeded restarts (4 L-BFGS
+iterations each) of `gpmpc_train_multistart`, restart r on rank r mod world, the (NLL, theta) table exchanged by ONE
+ncclAllGather over an RCCL communicator the library creates (strong scaling: the 64 restarts are fixed); `value` = restarts/s.
 
 Extra objects on the JSON line:
   roofline     -- the dominant kernel (variance GEMM V = L^-1 Ks with fused column sums of squares):
@@ -95,10 +98,12 @@ def main():
     ap.add_argument('--d', type=int, default=6)
     ap.add_argument('--B', type=int, default=10000)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--config', default='C2', choices=['C2', 'C3'])
+    ap.add_argument('--config', default='C2', choices=['C2', 'C3', 'C4'])
     args = ap.parse_args()
     if args.config == 'C3':
         return main_c3(args)
+    if args.config == 'C4':
+        return main_c4(args)
 
     import numpy as np
     import torch                     # first: one HIP runtime in the process (torch's), shared by the library
@@ -299,6 +304,73 @@ def main_c3(args):
             'device': lib.device_name(local_rank),
         }
         print(json.dumps(out))
+    h.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def main_c4(args):
+    """BASELINE config C4: log-marginal likelihood + gradient, 64 random restarts sharded over the ranks via RCCL."""
+    import numpy as np
+    import torch
+    import gp_oracle as go
+    from gp_mpc_amd._lib import Handle, get_lib
+    from gp_mpc_amd.train import lhs_starts, bounds_ipopt_path
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+    N, d, R, iters = args.N, args.d, 64, 4
+    p = go.synthetic_problem(N, d, 1, 1, seed=1234, sn=1e-2)             # the same problem on every rank (replicated X, y)
+    lib = get_lib()
+    h = Handle(lib, p['X'], p['Y'], device=local_rank)
+    lb, ub = bounds_ipopt_path(d)
+    starts = lhs_starts(R, lb, ub, 1234)[None]
+    box = [lib.rccl_unique_id() if rank == 0 else None]
+    if dist is not None:
+        dist.broadcast_object_list(box, src=0)
+    comm = lib.rccl_comm_create(local_rank, world, rank, box[0])          # (world = 1: a self-gather)
+    res = {}
+
+    def step():
+        res['r'] = h.train_multistart(starts, lb[None], ub[None], max_iter=iters, rank=rank, world=world, comm=comm, want_invK=False)
+
+    def sync():
+        h.synchronize()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+    steps, warmup = min(args.steps, 5), min(args.warmup, 1)
+    for _ in range(warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=torch.device('cuda', local_rank))
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    lib.rccl_comm_destroy(comm)
+    if rank == 0:
+        r = res['r']
+        print(json.dumps({
+            'metric': 'GP hyper-parameter training restarts/sec, N=4096 d=6 fp64 (64 restarts x 4 L-BFGS iterations, NLL + analytic gradient)',
+            'value': R * steps / elapsed, 'unit': 'restarts/s', 'n_gpus': world, 'steps': steps, 'warmup': warmup,
+            'ms_per_step': elapsed / steps * 1e3, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
+            'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': 'C4: 64 seeded restarts of the NLL minimisation, restart r on rank r mod world, one ncclAllGather of (NLL, theta)',
+                       'N': N, 'd': d, 'restarts': R, 'iterations': iters, 'parallelism': f'restart shard x{world} over RCCL'},
+            'best_nll': float(np.min(r['obj'])), 'finite_restarts': int(np.isfinite(r['obj']).sum()),
+            'device': lib.device_name(local_rank)}))
     h.close()
     if dist is not None:
         dist.barrier()
