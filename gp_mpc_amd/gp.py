@@ -373,16 +373,20 @@ class GP:
     # ------------------------------------------------------------------ linearisation
     def discrete_linearize(self, x0, u0, cov0):
         """x[k+1] = A x[k] + B u[k] around (x0, u0): Jacobians of the predicted mean w.r.t. the
-        standardised x and u (gp_class.py:647-661; for every method the mean of ME/TA/old_* is the
-        plain GP mean, whose analytic Jacobian the device evaluates).  DIFF: for 'EM' the reference
-        differentiates the exact-moment mean; here the GP-mean Jacobian is returned (identical for
-        cov0 -> 0, which is how mpc_class.py:596-625 calls it)."""
+        standardised x and u (gp_class.py:647-661: `jac_x`, `jac_u` of `__predict`'s mean, :239-242).  For ME / TA /
+        old_* that mean is the plain GP mean (analytic Jacobian on the device); for 'EM' it is the exact-moment mean,
+        whose derivative with respect to the input mean comes from `gpmpc_predict_em_sens` and depends on cov0."""
         x0 = np.asarray(x0, dtype=np.float64).reshape(-1)
         u0 = np.asarray(u0, dtype=np.float64).reshape(-1)
         if self.__normalize:
             x0 = self.standardize(x0, self.__meanX, self.__stdX)
             u0 = self.standardize(u0, self.__meanU, self.__stdU)
-        _, J = self._h.mean_jac(np.concatenate([x0, u0]).reshape(1, self.__Nx))
+        z = np.concatenate([x0, u0]).reshape(1, self.__Nx)
+        if self.__gp_method == 'EM':
+            S = np.asarray(cov0, dtype=np.float64).reshape(1, self.__Nx, self.__Nx)
+            J = self._h.predict_em_sens(z, S)[2]
+        else:
+            _, J = self._h.mean_jac(z)
         return J[0][:, :self.__Ny].copy(), J[0][:, self.__Ny:].copy()
 
     def jacobian(self, x0, u0, cov0):

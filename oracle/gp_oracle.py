@@ -701,13 +701,16 @@ class OracleGP:
 
     def discrete_linearize(self, x0, u0, cov0):
         """gp_class.py:647-661: Jacobian of predict()[0] w.r.t. the
-        STANDARDISED x and u (ME/TA: the analytic mean Jacobian)."""
+        STANDARDISED x and u (ME/TA/old_*: the analytic GP-mean Jacobian; EM: of the exact-moment mean)."""
         x0 = np.asarray(x0, dtype=np.float64).reshape(-1)
         u0 = np.asarray(u0, dtype=np.float64).reshape(-1)
         if self.normalize:
             x0 = (x0 - self.meta['meanX']) / self.meta['stdX']
             u0 = (u0 - self.meta['meanU']) / self.meta['stdU']
         z = np.concatenate([x0, u0]).reshape(1, self.Nx)
+        if self.gp_method == 'EM':        # jac of gp_exact_moment's mean w.r.t. the input mean (gp_class.py:220-224,239-242)
+            J = exact_moment_sens(self.invK, self.X, self.Y, self.hyper, z[0], np.asarray(cov0, dtype=np.float64))[0]
+            return J[:, :self.Ny].copy(), J[:, self.Ny:].copy()
         _, _, J = mean_var_jac(z, self.X, self.hyper, self.alpha, self.chol)
         return J[0][:, :self.Ny].copy(), J[0][:, self.Ny:].copy()
 

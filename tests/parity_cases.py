@@ -1166,11 +1166,15 @@ def check_gp_class_strict(lib, N=400, Ny=3, Nu=2, seed=29):
             assert np.max(np.abs(mean[:, 0] - om[:, 0]) / msc) <= 1e-10, (m, b, np.abs(mean - om).max())
             csc = _em_scale(o['invK'], p['X'], p['Y'], p['hyper'], zs, S).max() + sf2 if m == 'EM' else max(sf2, np.abs(oc).max())
             assert np.max(np.abs(cov - oc)) <= 1e-9 * csc, (m, b, np.abs(cov - oc).max(), csc)
+        for m in ('TA', 'EM'):              # EM: Jacobian of the exact-moment mean (depends on the input covariance)
+            gp.set_method(m)
+            og.set_method(m)
+            A, Bm = gp.discrete_linearize(x, u, S)
+            oA, oB = og.discrete_linearize(x, u, S)
+            assert np.max(np.abs(A - oA)) <= 1e-9 * max(1.0, np.abs(oA).max()) and np.max(np.abs(Bm - oB)) <= 1e-9 * max(1.0, np.abs(oB).max()), m
+        ta = gp.discrete_linearize(x, u, S * 0.0 + np.eye(Nx) * 1e-12)
         gp.set_method('TA')
-        og.set_method('TA')
-        A, Bm = gp.discrete_linearize(x, u, S)
-        oA, oB = og.discrete_linearize(x, u, S)
-        assert np.max(np.abs(A - oA)) <= 1e-10 * max(1.0, np.abs(oA).max()) and np.max(np.abs(Bm - oB)) <= 1e-10 * max(1.0, np.abs(oB).max())
+        assert np.allclose(ta[0], gp.discrete_linearize(x, u, S)[0], rtol=1e-6, atol=1e-8)      # EM(Sigma -> 0) = GP mean Jacobian
     Xraw = p['X'] * meta['stdZ'] + meta['meanZ']
     Yraw = p['Y'] * meta['stdY'] + meta['meanY']
     smse, mnlp = gp.validate(Xraw[:50], Yraw[:50], verbose=False)
