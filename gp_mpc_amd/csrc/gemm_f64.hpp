@@ -378,6 +378,15 @@ inline int gemm_pick_tile(const GemmP& p, int batch) {
         const long tT = ((onM ? p.M : p.N) + 127) / 128, tO = ((onM ? p.N : p.M) + 127) / 128;
         balanced = (double)(tO * batch) * (tT + 1) / 2.0 / 512.0 >= 1.0 || tT <= 2;   // (average per slot) / (heaviest tile)
     }
+    if (p.lower && p.kflags == (KA_GE_M | KB_GE_N)) {
+        // K^-1 = L^-T L^-1: tile (tm, tn <= tm) sums over k >= 128 tm, so tile (0, 0) is K / 16 slabs long while the
+        // average workgroup slot gets sum_tm (tm + 1)(T - tm) / 512 of them: at N = 4096 the one heaviest 128-row tile IS
+        // the duration of the launch (1.03 ms), with 64-row tiles four times as many slots share the long rows
+        const long T = (p.M + 127) / 128;
+        double total = 0.0;
+        for (long tm = 0; tm < T; ++tm) total += (double)(tm + 1) * (double)(T - tm);
+        balanced = total * batch / 512.0 >= 2.0 * (double)T;
+    }
     if (blocks(128) >= t128 && balanced) return 128;
     if (blocks(64) >= t64) return 64;
     return 32;

@@ -744,21 +744,30 @@ __global__ void __launch_bounds__(256) nll_grad_kernel(const double* __restrict_
     if (tid < DMAX + 2) out[tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
 }
 
-// fixed-order final reduction of the gradient partials -> grad[d+2]
-__global__ void __launch_bounds__(64) nll_grad_finish_kernel(const double* __restrict__ partial,
-                                                             const double* __restrict__ hyper,
-                                                             double* __restrict__ grad, int Np, int d) {
-    const int tid = threadIdx.x, tiles = Np / 64;
-    if (tid >= d + 2) return;
-    const int col = tid < d ? tid : (tid == d ? DMAX : DMAX + 1);
-    double s = 0.0;
-    for (int tm = 0; tm < tiles; ++tm)
-        for (int tn = 0; tn <= tm; ++tn) s += partial[((long)tm * tiles + tn) * (DMAX + 2) + col];
-    double g;
-    if (tid < d) g = 0.5 * s / (hyper[tid] * hyper[tid] * hyper[tid]);
-    else if (tid == d) g = 0.5 * s * 2.0 / hyper[d];
-    else g = 0.5 * s * 2.0 * hyper[d + 1];
-    grad[tid] = g;
+// final reduction of the gradient partials -> grad[d+2]: one wave per parameter in turn, lanes stride the lower tiles,
+// butterfly sum (a fixed order: deterministic).  (The first version let d + 2 threads walk all (Np/64)^2 / 2 partials one
+// after the other: 0.47 ms of dependent loads at N = 4096, a fifth of an NLL + gradient evaluation.)
+__global__ void __launch_bounds__(256) nll_grad_finish_kernel(const double* __restrict__ partial,
+                                                              const double* __restrict__ hyper,
+                                                              double* __restrict__ grad, int Np, int d) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tiles = Np / 64;
+    const long nt = (long)tiles * tiles;
+    for (int e = wave; e < d + 2; e += 4) {
+        const int col = e < d ? e : (e == d ? DMAX : DMAX + 1);
+        double s = 0.0;
+        for (long t = lane; t < nt; t += 64) {
+            const int tm = (int)(t / tiles), tn = (int)(t % tiles);
+            if (tn <= tm) s += partial[t * (DMAX + 2) + col];
+        }
+        s = wave_sum(s);
+        if (lane == 0) {
+            double g;
+            if (e < d) g = 0.5 * s / (hyper[e] * hyper[e] * hyper[e]);
+            else if (e == d) g = 0.5 * s * 2.0 / hyper[d];
+            else g = 0.5 * s * 2.0 * hyper[d + 1];
+            grad[e] = g;
+        }
+    }
 }
 
 // mirror the strictly-lower triangle into the upper one (K^-1 is exported as a full symmetric

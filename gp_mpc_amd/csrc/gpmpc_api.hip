@@ -2063,7 +2063,7 @@ extern "C" int gpmpc_nll(gpmpc_gp* h, int a, const double* hyper_row, double* nl
             PhaseTimer t(h, GPMPC_PH_NLL);
             hipLaunchKernelGGL(nll_grad_kernel, dim3(Np / 64, Np / 64), dim3(256), 0, cx.stream, h->XT, ws.hyper, ws.InvK,
                                ws.alpha, h->gradPartial, h->N, Np, d);
-            hipLaunchKernelGGL(nll_grad_finish_kernel, dim3(1), dim3(64), 0, cx.stream, h->gradPartial, ws.hyper,
+            hipLaunchKernelGGL(nll_grad_finish_kernel, dim3(1), dim3(256), 0, cx.stream, h->gradPartial, ws.hyper,
                                h->gradOut, Np, d);
             if (nmean)
                 hipLaunchKernelGGL(mean_grad_kernel, dim3(1), dim3(256), 0, cx.stream, h->XT, ws.alpha, h->gradOut + d + 2,
