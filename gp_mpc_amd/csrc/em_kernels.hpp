@@ -352,22 +352,29 @@ __global__ void __launch_bounds__(64) em_finish_kernel(const double* __restrict_
 // ---- derivative outputs of the exact moments ---------------------------------------------------
 // d mean / d(mu, Sigma) and d cov / d(mu, Sigma) of gp_exact_moment (what CasADi's AD hands to IPOPT when 'EM' is the
 // MPC's propagation method, gp_class.py:220-224).  With W = A o Q of an ORDERED output pair (a, c) (rows belong to
-// a, columns to c; W^(c,a) = W^(a,c)^T), v_i = x_i - mu, ij_j = v_j / ell_c^2, per 64-row strip the kernel leaves
-//     s0 = sum_i r_i,   S1 = sum_i r_i v_i,   S2 = sum_i r_i v_i v_i^T,   Xg = sum_i v_i g_i^T,
-//     r_i = sum_j W_ij (row sums),   g_i = sum_j W_ij ij_j,
+// a, columns to c; W^(c,a) = W^(a,c)^T), v_i = x_i - mu, ii_i = v_i / ell_a^2, the kernel leaves per 64-COLUMN strip
+//     s0 = sum_j c_j,   C1 = sum_j c_j v_j,   C2 = sum_j c_j v_j v_j^T,   X' = sum_j h_j v_j^T,
+//     c_j = sum_i W_ij (column sums),   h_j = sum_i W_ij ii_i,
 // from which em_sens_finish_kernel assembles, for the unordered pair (a >= c), with Lab = 1/ell_a^2 + 1/ell_c^2,
-// G = (Lab Sigma + I)^-1:
-//     z1 = S1^(a,c)/ell_a^2 + S1^(c,a)/ell_c^2                       (column sums of (a,c) are row sums of (c,a))
-//     ZZ = L_a^-1 S2^(a,c) L_a^-1 + L_c^-1 S2^(c,a) L_c^-1 + 2 L_a^-1 Xg^(a,c)     (maha's cross term is not symmetrised)
+// G = (Lab Sigma + I)^-1 (row sums of (a,c) are column sums of (c,a), so the kernel runs over ordered pairs):
+//     z1 = C1^(c,a)/ell_a^2 + C1^(a,c)/ell_c^2
+//     ZZ = L_a^-1 C2^(c,a) L_a^-1 + L_c^-1 C2^(a,c) L_c^-1 + 2 X'^(a,c) L_c^-1        (maha's cross term is not symmetrised)
 //     d(t s)/d mu = t G z1,    d(t s)/d Sigma = t (-1/2 G Lab s0 + 1/2 G ZZ G^T).
-// Same tile scheme as em_pair_kernel (cross terms on the matrix pipe, lean exp on the VALU) but every column tile is
-// visited (row sums need whole rows) and each lane carries 4 x (1 + EMK) extra accumulators.
+// The column moments are a matrix product: a 16 x 16 tile of W sits in the lanes in the accumulator layout, which IS the
+// A-operand layout of its transpose, so  [c_j | h_j] += W^T [1 | ii]  costs four v_mfma_f64_16x16x4_f64 per tile on the
+// matrix pipe, which the value kernel leaves two thirds idle, instead of nine VALU fma per entry (the first version: 64
+// accumulator registers per lane, one wave per SIMD, 8.2 ms per input at C3 against 1.5 ms for the value).
 constexpr int EM_NSS = 1 + EMK + 2 * EMK * EMK;     // values per (input, ordered pair, strip)
+// operand rows per (input, ordered pair): row side [U (EMK) | La | beta_a], column side [Wt (EMK) | Lb | beta_c], ii (EMK)
+constexpr int EM_OPS_ORD = 3 * EMK + 4;
+constexpr int EM_ROW0 = 0, EM_COL0 = EMK + 2, EM_II0 = 2 * EMK + 4;
 
-// operands for ORDERED pairs: same layout as em_operands_kernel, pair index po = a * Ny + c
+// operands for ORDERED pairs, pair index po = a * Ny + c.  beta rows are copied in (zero in padded points) so that the
+// pair kernel's tile fetch is one branch-free block of rows.
 __global__ void __launch_bounds__(256) em_operands_ordered_kernel(const double* __restrict__ XT, const double* __restrict__ Z,
                                                                   const double* __restrict__ hyper,
-                                                                  const double* __restrict__ prep, double* __restrict__ ops,
+                                                                  const double* __restrict__ prep,
+                                                                  const double* __restrict__ beta, double* __restrict__ ops,
                                                                   int N, int Np, int d, int Ny, int b0) {
     const int P = Ny * (Ny + 1) / 2, stride = d * d + 1;
     const int i = blockIdx.x * 256 + threadIdx.x, po = blockIdx.y, bl = blockIdx.z, b = b0 + bl;
@@ -376,7 +383,7 @@ __global__ void __launch_bounds__(256) em_operands_ordered_kernel(const double* 
     const double* S = prep + ((long)b * (Ny + P) + Ny + hi * (hi + 1) / 2 + lo) * stride;
     const double* ha = hyper + (long)a * (d + 2);
     const double* hb = hyper + (long)c * (d + 2);
-    double* o = ops + ((long)bl * Ny * Ny + po) * (2 * EMK + 2) * Np;
+    double* o = ops + ((long)bl * Ny * Ny + po) * EM_OPS_ORD * Np;
     double v[DMAX], ii[DMAX], ij[DMAX];
     double lka = 0.0, lkb = 0.0;
     for (int k = 0; k < d; ++k) {
@@ -391,136 +398,138 @@ __global__ void __launch_bounds__(256) em_operands_ordered_kernel(const double* 
         double ua = 0.0, ub = 0.0;
         if (cc < d)
             for (int k = 0; k < d; ++k) { ua += ii[k] * S[k * d + cc]; ub += ij[k] * S[k * d + cc]; }
-        o[(long)cc * Np + i] = 2.0 * ua;
-        o[(long)(EMK + cc) * Np + i] = (cc < d) ? ij[cc] : 0.0;
+        o[(long)(EM_ROW0 + cc) * Np + i] = 2.0 * ua;
+        o[(long)(EM_COL0 + cc) * Np + i] = (cc < d) ? ij[cc] : 0.0;
+        o[(long)(EM_II0 + cc) * Np + i] = (cc < d) ? ii[cc] : 0.0;
         if (cc < d) { qa += ua * ii[cc]; qb += ub * ij[cc]; }
     }
-    o[(long)(2 * EMK) * Np + i] = (2.0 * log(ha[d]) - 0.5 * lka) + qa;
-    o[(long)(2 * EMK + 1) * Np + i] = (2.0 * log(hb[d]) - 0.5 * lkb) + qb;
+    o[(long)(EM_ROW0 + EMK) * Np + i] = (2.0 * log(ha[d]) - 0.5 * lka) + qa;
+    o[(long)(EM_ROW0 + EMK + 1) * Np + i] = (i < N) ? beta[(long)a * Np + i] : 0.0;
+    o[(long)(EM_COL0 + EMK) * Np + i] = (2.0 * log(hb[d]) - 0.5 * lkb) + qb;
+    o[(long)(EM_COL0 + EMK + 1) * Np + i] = (i < N) ? beta[(long)c * Np + i] : 0.0;
 }
 
-// grid (Np/64, Ny*Ny, Bc), 256 threads.  part[((bl*Ny*Ny + po)*tiles + strip)*EM_NSS + e]
-__global__ void __launch_bounds__(256) em_pair_sens_kernel(const double* __restrict__ ops, const double* __restrict__ beta,
-                                                           const double* __restrict__ invK, const double* __restrict__ XT,
-                                                           const double* __restrict__ Z, double* __restrict__ part, int N,
-                                                           int Np, int Ny, int d, int b0, int crow_mode) {
-    const int ti = blockIdx.x, po = blockIdx.y, bl = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// grid (Np/64 column strips, Ny*Ny, Bc), 256 threads: wave w owns columns 64 tj + 16 w .. + 15 and sweeps the rows in
+// 64-row tiles staged through LDS (one-tile prefetch).  A lane's four accumulator rows of a 16-row sub-tile sit side
+// by side in LDS (position pos(il) below), so that La, beta_a and the feature operand of the moment products come
+// in as 128-bit reads.  part[((bl*Ny*Ny + po)*tiles + strip)*EM_NSS + e].  Launched once per kind like
+// em_pair_kernel: only the a == c variant carries the K^-1 registers.
+template <bool DIAG>
+__global__ void __launch_bounds__(256) em_pair_sens_kernel(const double* __restrict__ ops, const double* __restrict__ invK,
+                                                           const double* __restrict__ XT, const double* __restrict__ Z,
+                                                           double* __restrict__ part, int N, int Np, int Ny, int d, int b0,
+                                                           int crow_mode) {
+    const int tj = blockIdx.x, po = blockIdx.y, bl = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles = Np / 64, a = po / Ny, cb = po % Ny;
-    const bool diag = a == cb;
-    const double* __restrict__ o = ops + ((long)bl * Ny * Ny + po) * (2 * EMK + 2) * Np;
-    const double* __restrict__ Wt = o + (long)EMK * Np;
-    const double* __restrict__ La = o + (long)(2 * EMK) * Np;
-    const double* __restrict__ Lb = o + (long)(2 * EMK + 1) * Np;
-    const double* __restrict__ ba = beta + (long)a * Np;
-    const double* __restrict__ bbv = beta + (long)cb * Np;
+    if ((a == cb) != DIAG) return;
+    const double* __restrict__ o = ops + ((long)bl * Ny * Ny + po) * EM_OPS_ORD * Np;
     const double* __restrict__ iK = invK + (long)a * Np * Np;
-    __shared__ double Cs[2][EMK + 2][64];
-    __shared__ double Rw[64][EMK + 1];      // per strip row: r_i, g_i[EMK]
-    __shared__ double Vs[64][EMK];          // per strip row: v_i
-    const int fr = lane & 15, fk = lane >> 4, i0 = ti * 64 + 16 * wave;
-    const double a0 = o[(long)fk * Np + i0 + fr], a1 = o[(long)(4 + fk) * Np + i0 + fr];
-    double la[4], bai[4];
-    int irow[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        irow[r] = i0 + crow(lane, r, crow_mode);
-        la[r] = La[irow[r]];
-        bai[r] = (irow[r] < N) ? ba[irow[r]] : 0.0;
-    }
+    __shared__ double Us[2][EMK][64];             // row tile: U (A fragments of the cross term)
+    __shared__ __attribute__((aligned(32))) double LBs[2][64][2];              // row tile: {La, beta_a} at pos(il)
+    __shared__ __attribute__((aligned(32))) double Fs[2][16][16][4];           // row tile: features [sub-tile*4 + lane group][f][r];  f = 0: 1, 1..8: ii, 9..15: 0
+    __shared__ double Ds[64][EMK + 1];            // per strip column: c_j, h_j[EMK]
+    __shared__ double Vs[64][EMK];                // per strip column: v_j
+    const int fr = lane & 15, fk = lane >> 4, n0 = tj * 64, col = n0 + 16 * wave + fr;
+    const double* __restrict__ oc = o + (long)EM_COL0 * Np;
+    const double b0f = oc[(long)fk * Np + col], b1f = oc[(long)(4 + fk) * Np + col];     // B fragments: constant over the sweep
+    const double lbj = oc[(long)EMK * Np + col], bj = oc[(long)(EMK + 1) * Np + col];
     for (int e = tid; e < 64 * EMK; e += 256) {
-        const int rw = e / EMK, k = e % EMK, i = ti * 64 + rw;
-        Vs[rw][k] = (k < d && i < N) ? XT[(long)k * Np + i] - Z[(long)(b0 + bl) * d + k] : 0.0;
+        const int cl = e / EMK, k = e % EMK, j = n0 + cl;
+        Vs[cl][k] = (k < d && j < N) ? XT[(long)k * Np + j] - Z[(long)(b0 + bl) * d + k] : 0.0;
     }
-    double rs[4], gp[4][EMK];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        rs[r] = 0.0;
-#pragma unroll
-        for (int k = 0; k < EMK; ++k) gp[r][k] = 0.0;
+    for (int e = tid; e < 2 * 16 * 16 * 4; e += 256) {     // constant feature columns of both buffers
+        const int f = (e >> 2) & 15;
+        if (f == 0 || f > EMK) (&Fs[0][0][0][0])[e] = f == 0 ? 1.0 : 0.0;
     }
-    double st[3];
-    auto fetch = [&](int jt) {
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            const int e = tid + 256 * q, rw = e >> 6, cl = e & 63, j = jt * 64 + cl;
-            double v = 0.0;
-            if (rw < EMK) v = Wt[(long)rw * Np + j];
-            else if (rw == EMK) v = Lb[j];
-            else if (rw == EMK + 1) v = (j < N) ? bbv[j] : 0.0;
-            st[q] = v;
-        }
+    // position of row il (0..63) of a tile: sub-tile sb = il / 16, then (lane group g, register r) with crow(g*16, r) == il % 16
+    auto pos = [&](int il) {
+        const int w16 = il & 15, g = crow_mode == 0 ? (w16 & 3) : (w16 >> 2), r = crow_mode == 0 ? (w16 >> 2) : (w16 & 3);
+        return ((il >> 4) * 4 + g) * 4 + r;
+    };
+    const int scl = tid & 63, srw = tid >> 6, sp = pos(scl), spg = sp >> 2, spr = sp & 3;
+    double st[5];
+    auto fetch = [&](int it) {           // rows 0..9 (U, La, beta_a) and the 8 ii rows of 64 points: 5 coalesced loads per thread
+        const long i = (long)it * 64 + scl;
+        st[0] = o[(long)(EM_ROW0 + srw) * Np + i];
+        st[1] = o[(long)(EM_ROW0 + 4 + srw) * Np + i];
+        st[2] = o[(long)(EM_ROW0 + 8 + (srw & 1)) * Np + i];
+        st[3] = o[(long)(EM_II0 + srw) * Np + i];
+        st[4] = o[(long)(EM_II0 + 4 + srw) * Np + i];
     };
     auto stage = [&](int buf) {
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            const int e = tid + 256 * q, rw = e >> 6, cl = e & 63;
-            if (rw < EMK + 2) Cs[buf][rw][cl] = st[q];
-        }
+        Us[buf][srw][scl] = st[0];
+        Us[buf][4 + srw][scl] = st[1];
+        if (srw < 2) LBs[buf][sp][srw] = st[2];
+        Fs[buf][spg][1 + srw][spr] = st[3];
+        Fs[buf][spg][5 + srw][spr] = st[4];
     };
+    d4 D0 = d4{0.0, 0.0, 0.0, 0.0}, D1 = D0;   // [c_j | h_j] of this wave's 16 columns: D[j = crow(lane, r)][f = lane & 15]
     fetch(0);
     stage(0);
     __syncthreads();
     int cur = 0;
-    for (int jt = 0; jt < tiles; ++jt) {
-        if (jt + 1 < tiles) fetch(jt + 1);
+    for (int it = 0; it < tiles; ++it) {
+        if (it + 1 < tiles) fetch(it + 1);
+        double ik[4][4];
+        if (DIAG) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int cl = 16 * t + fr, j = jt * 64 + cl;
-            d4 c = d4{0.0, 0.0, 0.0, 0.0};
-            c = mfma16(a0, Cs[cur][fk][cl], c);
-            c = mfma16(a1, Cs[cur][4 + fk][cl], c);
-            const double lbj = Cs[cur][EMK][cl];
-            const double bj = Cs[cur][EMK + 1][cl];
-            double wt[EMK];
+            for (int sb = 0; sb < 4; ++sb)
 #pragma unroll
-            for (int k = 0; k < EMK; ++k) wt[k] = Cs[cur][k][cl];
+                for (int r = 0; r < 4; ++r) {
+                    const int i = it * 64 + 16 * sb + crow(lane, r, crow_mode);
+                    ik[sb][r] = i < N ? iK[(long)i * Np + col] : 0.0;
+                }
+        }
+        d4 c[4];
+#pragma unroll
+        for (int sb = 0; sb < 4; ++sb) {                                 // cross terms of the four 16-row sub-tiles
+            c[sb] = mfma16(Us[cur][fk][16 * sb + fr], b0f, d4{0.0, 0.0, 0.0, 0.0});
+            c[sb] = mfma16(Us[cur][4 + fk][16 * sb + fr], b1f, c[sb]);
+        }
+#pragma unroll
+        for (int sb = 0; sb < 4; ++sb) {
+            const double4 lb01 = *reinterpret_cast<const double4*>(&LBs[cur][(sb * 4 + fk) * 4][0]);
+            const double4 lb23 = *reinterpret_cast<const double4*>(&LBs[cur][(sb * 4 + fk) * 4 + 2][0]);
+            const double la[4] = {lb01.x, lb01.z, lb23.x, lb23.z}, bai[4] = {lb01.y, lb01.w, lb23.y, lb23.w};
+            const double4 ft = *reinterpret_cast<const double4*>(&Fs[cur][sb * 4 + fk][fr][0]);
+            const double f4[4] = {ft.x, ft.y, ft.z, ft.w};
+            double w[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const double q = exp_lean((la[r] + lbj) + c[r]);
+                const double q = exp_lean((la[r] + lbj) + c[sb][r]);
                 double wgt = bai[r] * bj;
-                if (diag) wgt -= iK[(long)irow[r] * Np + j];
-                const double w = (j < N && irow[r] < N) ? wgt * q : 0.0;
-                rs[r] += w;
-#pragma unroll
-                for (int k = 0; k < EMK; ++k) gp[r][k] += w * wt[k];
+                if (DIAG) wgt -= ik[sb][r];
+                w[r] = wgt * q;
             }
+            // D[j][f] += sum over the 4 rows register r holds: the accumulator layout of W is the A layout of W^T
+            D0 = mfma16(w[0], f4[0], D0);
+            D1 = mfma16(w[1], f4[1], D1);
+            D0 = mfma16(w[2], f4[2], D0);
+            D1 = mfma16(w[3], f4[3], D1);
         }
-        if (jt + 1 < tiles) stage(cur ^ 1);
+        if (it + 1 < tiles) stage(cur ^ 1);
         __syncthreads();
         cur ^= 1;
     }
-    // the 16 lanes with the same lane >> 4 hold the same 4 rows: butterfly over the low 4 lane bits
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-#pragma unroll
-        for (int m = 8; m >= 1; m >>= 1) {
-            rs[r] += __shfl_xor(rs[r], m);
-#pragma unroll
-            for (int k = 0; k < EMK; ++k) gp[r][k] += __shfl_xor(gp[r][k], m);
-        }
-        if (fr == 0) {
-            const int rw = irow[r] - ti * 64;
-            Rw[rw][0] = rs[r];
-#pragma unroll
-            for (int k = 0; k < EMK; ++k) Rw[rw][1 + k] = gp[r][k];
-        }
-    }
+    for (int r = 0; r < 4; ++r)
+        if (fr <= EMK) Ds[16 * wave + crow(lane, r, crow_mode)][fr] = D0[r] + D1[r];
     __syncthreads();
-    if (tid < EM_NSS) {        // fixed-order sums over the strip's 64 rows
+    if (tid < EM_NSS) {        // fixed-order sums over the strip's 64 columns
         double s = 0.0;
         if (tid == 0) {
-            for (int rw = 0; rw < 64; ++rw) s += Rw[rw][0];
+            for (int cl = 0; cl < 64; ++cl) s += Ds[cl][0];
         } else if (tid < 1 + EMK) {
             const int k = tid - 1;
-            for (int rw = 0; rw < 64; ++rw) s += Rw[rw][0] * Vs[rw][k];
+            for (int cl = 0; cl < 64; ++cl) s += Ds[cl][0] * Vs[cl][k];
         } else if (tid < 1 + EMK + EMK * EMK) {
             const int e = tid - 1 - EMK, k = e / EMK, l = e % EMK;
-            for (int rw = 0; rw < 64; ++rw) s += Rw[rw][0] * Vs[rw][k] * Vs[rw][l];
+            for (int cl = 0; cl < 64; ++cl) s += Ds[cl][0] * Vs[cl][k] * Vs[cl][l];
         } else {
             const int e = tid - 1 - EMK - EMK * EMK, k = e / EMK, l = e % EMK;
-            for (int rw = 0; rw < 64; ++rw) s += Vs[rw][k] * Rw[rw][1 + l];
+            for (int cl = 0; cl < 64; ++cl) s += Ds[cl][1 + k] * Vs[cl][l];
         }
-        part[(((long)bl * Ny * Ny + po) * tiles + ti) * EM_NSS + tid] = s;
+        part[(((long)bl * Ny * Ny + po) * tiles + tj) * EM_NSS + tid] = s;
     }
 }
 
@@ -638,13 +647,14 @@ __global__ void __launch_bounds__(64) em_sens_finish_kernel(const double* __rest
     small_solve(A, G, d, d);
     const double s0 = sa_[0];
     double z1[EMK], ZZ[EMK * EMK], T1[EMK * EMK];
-    for (int k = 0; k < d; ++k) z1[k] = ila[k] * sa_[1 + k] + ilc[k] * sc_[1 + k];
-    const double* S2a = sa_ + 1 + EMK;
-    const double* S2c = sc_ + 1 + EMK;
-    const double* Xg = sa_ + 1 + EMK + EMK * EMK;
+    // column moments of ordered (c, a) are the row moments of (a, c)
+    for (int k = 0; k < d; ++k) z1[k] = ila[k] * sc_[1 + k] + ilc[k] * sa_[1 + k];
+    const double* C2r = sc_ + 1 + EMK;
+    const double* C2c = sa_ + 1 + EMK;
+    const double* Xp = sa_ + 1 + EMK + EMK * EMK;
     for (int k = 0; k < d; ++k)
         for (int l = 0; l < d; ++l)
-            ZZ[k * EMK + l] = ila[k] * S2a[k * EMK + l] * ila[l] + ilc[k] * S2c[k * EMK + l] * ilc[l] + 2.0 * ila[k] * Xg[k * EMK + l];
+            ZZ[k * EMK + l] = ila[k] * C2r[k * EMK + l] * ila[l] + ilc[k] * C2c[k * EMK + l] * ilc[l] + 2.0 * Xp[k * EMK + l] * ilc[l];
     const double ma = mean[(long)b * Ny + a], mc = mean[(long)b * Ny + c];
     const double* dza = dm_dz + ((long)bl * Ny + a) * d;
     const double* dzc = dm_dz + ((long)bl * Ny + c) * d;

@@ -1892,13 +1892,13 @@ extern "C" int gpmpc_predict_em_sens(gpmpc_gp* h, int B, const double* Z, const 
     const Ctx cx = h->cx();
     const bool host = h->ptr_mode == GPMPC_PTR_HOST;
     const int P = Ny * (Ny + 1) / 2, PO = Ny * Ny, tiles = Np / 64;
-    const size_t per_in = (size_t)PO * ((size_t)(2 * EMK + 2) * Np + (size_t)tiles * EM_NSS + EM_NSS) * sizeof(double);
+    const size_t per_in = (size_t)PO * ((size_t)EM_OPS_ORD * Np + (size_t)tiles * EM_NSS + EM_NSS) * sizeof(double);
     int Bc = (int)std::max<size_t>(1, std::min<size_t>((size_t)B, ((size_t)512 << 20) / per_in));
     // one device block: [Z | Sigma | mean | cov | dm_dz | dm_dS | dc_dz | dc_dS | prep | ops | part | sums]
     const size_t nZ = (size_t)B * d, nS = (size_t)B * d * d, nM = (size_t)B * Ny, nC = (size_t)B * Ny * Ny;
     const size_t n1 = nM * d, n2 = nM * d * d, n3 = nC * d, n4 = nC * d * d;
     const size_t nPrep = (size_t)B * (Ny + P) * (d * d + 1);
-    const size_t nOps = (size_t)Bc * PO * (2 * EMK + 2) * Np, nPart = (size_t)Bc * PO * tiles * EM_NSS, nSum = (size_t)Bc * PO * EM_NSS;
+    const size_t nOps = (size_t)Bc * PO * EM_OPS_ORD * Np, nPart = (size_t)Bc * PO * tiles * EM_NSS, nSum = (size_t)Bc * PO * EM_NSS;
     double* buf = nullptr;
     HIPCHK(hipMalloc(&buf, (nZ + nS + nM + nC + n1 + n2 + n3 + n4 + nPrep + nOps + nPart + nSum) * sizeof(double)));
     double *bZ = buf, *bS = bZ + nZ, *bM = bS + nS, *bC = bM + nM, *b1 = bC + nC, *b2 = b1 + n1, *b3 = b2 + n2, *b4 = b3 + n3,
@@ -1930,9 +1930,11 @@ extern "C" int gpmpc_predict_em_sens(gpmpc_gp* h, int B, const double* Z, const 
             hipLaunchKernelGGL(em_mean_sens_kernel, dim3(Ny, nb), dim3(256), 0, cx.stream, h->XT, dZ, h->beta, prep,
                                o1 + (size_t)b0 * Ny * d, o2 + (size_t)b0 * Ny * d * d, N, Np, d, Ny, b0);
             hipLaunchKernelGGL(em_operands_ordered_kernel, dim3((Np + 255) / 256, PO, nb), dim3(256), 0, cx.stream, h->XT, dZ,
-                               h->ws.hyper, prep, ops, N, Np, d, Ny, b0);
-            hipLaunchKernelGGL(em_pair_sens_kernel, dim3(tiles, PO, nb), dim3(256), 0, cx.stream, ops, h->beta, h->ws.InvK, h->XT,
-                               dZ, part, N, Np, Ny, d, b0, cx.crow_mode);
+                               h->ws.hyper, prep, h->beta, ops, N, Np, d, Ny, b0);
+            hipLaunchKernelGGL(em_pair_sens_kernel<false>, dim3(tiles, PO, nb), dim3(256), 0, cx.stream, ops, h->ws.InvK, h->XT, dZ,
+                               part, N, Np, Ny, d, b0, cx.crow_mode);
+            hipLaunchKernelGGL(em_pair_sens_kernel<true>, dim3(tiles, PO, nb), dim3(256), 0, cx.stream, ops, h->ws.InvK, h->XT, dZ,
+                               part, N, Np, Ny, d, b0, cx.crow_mode);
             hipLaunchKernelGGL(em_sens_reduce_kernel, dim3(PO, nb), dim3(256), 0, cx.stream, part, sums, Ny, tiles);
             hipLaunchKernelGGL(em_sens_finish_kernel, dim3((unsigned)(((long)nb * P + 63) / 64)), dim3(64), 0, cx.stream, sums, prep,
                                h->ws.hyper, dS, oM, o1 + (size_t)b0 * Ny * d, o2 + (size_t)b0 * Ny * d * d,

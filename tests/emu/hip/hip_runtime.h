@@ -38,6 +38,7 @@ struct dim3 {
 extern dim3 threadIdx, blockIdx, blockDim, gridDim;
 
 struct alignas(16) double2 { double x, y; };
+struct alignas(32) double4 { double x, y, z, w; };
 using std::max;
 using std::min;
 inline int __double2loint(double v) { int64_t b; std::memcpy(&b, &v, 8); return (int)(uint32_t)(b & 0xffffffff); }
