@@ -94,6 +94,8 @@ struct GemmP {
     int epi;
     double* part;         // EPI_COLSUMSQ: part[b*sPart + tile_m*ldpart + n]
     long ldpart, sPart;
+    double* Ct;           // EPI_COLSUMSQ, optional: the product itself, transposed: Ct[b*sCt + n*ldct + m]
+    long ldct, sCt;
     int crow_mode;
     int pair;             // set by the launcher
     int tilesMe, tilesNe; // effective tile grid (after pairing), set by the launcher
@@ -107,6 +109,21 @@ struct GemmP {
     int* done_flags;      // tiles (1,0) and (1,1) publish done_flags[0] / done_flags[1] = 1
     long sFlags;          // batch stride of the three flag pointers
 };
+
+// the accumulators of one wave, written transposed (EPI_COLSUMSQ with Ct: the few-column products of the sensitivities)
+template <int TM, int TN>
+__device__ __forceinline__ void gemm_store_transposed(const GemmP& p, const d4 (&acc)[TM][TN], int mw, int nw, int lane) {
+    double* __restrict__ Ct = p.Ct + (long)blockIdx.z * p.sCt;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = mw + i * 16 + crow(lane, r, p.crow_mode), n = nw + j * 16 + (lane & 15);
+                if (m < p.M && n < p.N) Ct[(long)n * p.ldct + m] = acc[i][j][r];
+            }
+}
 
 template <int BM, int BN, int BK, int WGM, int WGN, bool AMC, bool BNC, bool SPLIT = GPMPC_GEMM_SPLIT, bool BUF = false>
 __global__ void __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) gemm_f64_kernel(GemmP p) {
@@ -332,6 +349,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) gemm_f64_kernel
         } else {
             // column sums of squares over this tile's BM rows (rows >= M hold exact zeros)
             double* red = &As[0][0][0][0];  // [WGM][BN], free after the final barrier of the K loop
+            if (p.Ct) gemm_store_transposed<TM, TN>(p, acc, m0 + wm * WM, n0 + wn * WN, lane);
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 double s = 0.0;

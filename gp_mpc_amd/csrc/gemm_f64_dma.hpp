@@ -237,6 +237,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN, WPS) gemm_f64_dma_kernel(GemmP
         } else {
             // column sums of squares over this tile's rows < M
             double* red = reinterpret_cast<double*>(smem);         // [WGM][BN]
+            if (p.Ct) gemm_store_transposed<TM, TN>(p, acc, m0 + wm * WM, n0 + wn * WN, lane);
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 double s = 0.0;

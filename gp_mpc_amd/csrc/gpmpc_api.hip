@@ -846,6 +846,7 @@ struct gpmpc_gp {
     long emBytes = 0;
     double* beta = nullptr;  // K^-1 y, [Ny][Np]
     double* UT = nullptr;    // K^-1 ks per test point (legacy methods, sensitivities)
+    double* VT = nullptr;    // L^-1 ks per test point (sensitivities: K^-1 ks = L^-T (L^-1 ks) without K^-1)
     double *sensH = nullptr, *sensV = nullptr;   // staging of gpmpc_predict_sens outputs in host-pointer mode
     double* ccpart = nullptr;                    // chunk partials of the small-batch cross-covariance kernel
     bool have_beta = false;
@@ -1013,7 +1014,7 @@ int gpmpc_destroy(gpmpc_gp* h) {
     hipFree(h->mpar); hipFree(h->Yc); hipFree(h->tmpar); hipFree(h->tYc);
     hipFree(h->Z); hipFree(h->Sigma); hipFree(h->KsT); hipFree(h->part); hipFree(h->meanT);
     hipFree(h->mean); hipFree(h->var); hipFree(h->J); hipFree(h->cov); hipFree(h->em);
-    hipFree(h->beta); hipFree(h->UT); hipFree(h->sensH); hipFree(h->sensV); hipFree(h->ccpart);
+    hipFree(h->beta); hipFree(h->UT); hipFree(h->VT); hipFree(h->sensH); hipFree(h->sensV); hipFree(h->ccpart);
     for (int ph = 0; ph < GPMPC_PH_COUNT; ++ph)
         for (auto& pr : h->prof.ev[ph]) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     for (auto e : h->prof.pool) hipEventDestroy(e);
@@ -1286,11 +1287,11 @@ extern "C" int gpmpc_fit(gpmpc_gp* h, const double* hyper, int want_invK, int* i
 // i.e. four GEMMs with K = R0 plus a factorisation of m rows -- O(N^2 m) instead of O(N^3).
 static void free_predict_scratch(gpmpc_gp* h) {
     hipFree(h->Z); hipFree(h->Sigma); hipFree(h->KsT); hipFree(h->part); hipFree(h->meanT);
-    hipFree(h->mean); hipFree(h->var); hipFree(h->J); hipFree(h->cov); hipFree(h->UT);
+    hipFree(h->mean); hipFree(h->var); hipFree(h->J); hipFree(h->cov); hipFree(h->UT); hipFree(h->VT);
     hipFree(h->sensH); hipFree(h->sensV); hipFree(h->em); hipFree(h->beta); hipFree(h->gradPartial); hipFree(h->gradOut);
     hipFree(h->ccpart); hipFree(h->Yc); hipFree(h->tYc);
     h->Yc = h->tYc = nullptr;
-    h->Z = h->Sigma = h->KsT = h->part = h->meanT = h->mean = h->var = h->J = h->cov = h->UT = nullptr;
+    h->Z = h->Sigma = h->KsT = h->part = h->meanT = h->mean = h->var = h->J = h->cov = h->UT = h->VT = nullptr;
     h->sensH = h->sensV = h->em = h->beta = h->gradPartial = h->gradOut = h->ccpart = nullptr;
     h->Bcap = 0;
     h->emBytes = 0;
@@ -1548,9 +1549,9 @@ static int ensure_scratch(gpmpc_gp* h, int B) {
     if (need <= h->Bcap) return GPMPC_OK;
     HIPCHK(hipStreamSynchronize(h->stream));
     hipFree(h->Z); hipFree(h->Sigma); hipFree(h->KsT); hipFree(h->part); hipFree(h->meanT);
-    hipFree(h->mean); hipFree(h->var); hipFree(h->J); hipFree(h->cov); hipFree(h->UT);
+    hipFree(h->mean); hipFree(h->var); hipFree(h->J); hipFree(h->cov); hipFree(h->UT); hipFree(h->VT);
     hipFree(h->sensH); hipFree(h->sensV); hipFree(h->ccpart);
-    h->UT = h->sensH = h->sensV = h->ccpart = nullptr;
+    h->UT = h->VT = h->sensH = h->sensV = h->ccpart = nullptr;
     h->Z = h->Sigma = h->KsT = h->part = h->meanT = h->mean = h->var = h->J = h->cov = nullptr;
     h->Bcap = 0;
     const size_t d = h->d, Ny = h->Ny, Np = h->Np, Bc = need;
@@ -1569,7 +1570,8 @@ static int ensure_scratch(gpmpc_gp* h, int B) {
 }
 
 // One chunk (B <= Bcap) with device pointers: mean/var (either may be NULL), optional J.
-static int predict_chunk(gpmpc_gp* h, int B, const double* dZ, double* dMean, double* dVar, double* dJ) {
+// VT (optional, with dVar): also keep V^T = (L^-1 Ks)^T, [Ny][Bp][Np], for the sensitivities
+static int predict_chunk(gpmpc_gp* h, int B, const double* dZ, double* dMean, double* dVar, double* dJ, double* VT = nullptr) {
     const Ctx cx = h->cx();
     const int Bp = round_up(B, 32), Np = h->Np, Ny = h->Ny;
     {
@@ -1584,7 +1586,7 @@ static int predict_chunk(gpmpc_gp* h, int B, const double* dZ, double* dMean, do
     // (tools/bench_smallb.py), its multi-column versions fall off quickly (B = 2 / 4 / 8: 0.41 / 0.52 / 0.82 ms)
     // while the DMA-staged GEMM below does any B <= 32 in 0.30-0.32 ms: GPMPC_VARSMALL_MAX (default 1) is the switch.
     static const int varsmall_max = getenv("GPMPC_VARSMALL_MAX") ? atoi(getenv("GPMPC_VARSMALL_MAX")) : 1;
-    if (dVar && B <= varsmall_max && B <= 8) {
+    if (dVar && !VT && B <= varsmall_max && B <= 8) {
         PhaseTimer t(h, GPMPC_PH_VARGEMM);   // stream L^-1 once (HBM-bound), no MFMA padding waste
         tilesM = Np / 32;
         const dim3 grid(tilesM, Ny);
@@ -1607,6 +1609,7 @@ static int predict_chunk(gpmpc_gp* h, int B, const double* dZ, double* dMean, do
         p.B = h->KsT; p.ldb = Np; p.sB = (long)Bp * Np; p.b_nc = 0;
         p.M = Np; p.N = Bp; p.K = Np;
         p.epi = EPI_COLSUMSQ; p.part = h->part; p.ldpart = Bp;
+        p.Ct = VT; p.ldct = Np; p.sCt = (long)Bp * Np;
         static const bool smallb_dma = !(getenv("GPMPC_SMALLB_DMA") && atoi(getenv("GPMPC_SMALLB_DMA")) == 0);
         const bool dma = smallb_dma && gemm_dma_supported(p);
         const int tm_rows = dma ? 64 : Bp <= 32 ? 32 : 128;
@@ -1623,6 +1626,7 @@ static int predict_chunk(gpmpc_gp* h, int B, const double* dZ, double* dMean, do
         p.B = h->KsT; p.ldb = Np; p.sB = (long)Bp * Np; p.b_nc = 0;
         p.M = Np; p.N = Bp; p.K = Np;
         p.epi = EPI_COLSUMSQ; p.part = h->part; p.ldpart = Bp;
+        p.Ct = VT; p.ldct = Np; p.sCt = (long)Bp * Np;
         const int tile = gemm_pick_tile(p, Ny);
         tilesM = (Np + tile - 1) / tile;
         p.sPart = (long)tilesM * Bp;
@@ -1821,12 +1825,9 @@ extern "C" int gpmpc_predict_sens(gpmpc_gp* h, int B, const double* Z, double* m
     const int d = h->d, Ny = h->Ny, Np = h->Np;
     const bool host = h->ptr_mode == GPMPC_PTR_HOST;
     const bool second = Hm || dvar;
-    if (second && !h->have_invK) {
-        PhaseTimer t(h, GPMPC_PH_INVK);
-        CHK(compute_invK(h->cx(), h->ws));
-        h->have_invK = true;
-    }
+    // (no K^-1 here: K^-1 ks = L^-T (L^-1 ks), and L^-1 ks is what the variance product forms anyway)
     if (second && !h->UT) HIPCHK(hipMalloc(&h->UT, (size_t)Ny * h->Bcap * Np * sizeof(double)));
+    if (second && !h->VT) HIPCHK(hipMalloc(&h->VT, (size_t)Ny * h->Bcap * Np * sizeof(double)));
     if (second && !h->sensH) {
         HIPCHK(hipMalloc(&h->sensH, (size_t)h->Bcap * Ny * d * d * sizeof(double)));
         HIPCHK(hipMalloc(&h->sensV, (size_t)h->Bcap * Ny * d * sizeof(double)));
@@ -1844,16 +1845,32 @@ extern "C" int gpmpc_predict_sens(gpmpc_gp* h, int B, const double* Z, double* m
         double* oJ = J ? (host ? h->J : J + (size_t)b0 * Ny * d) : nullptr;
         double* oH = host ? h->sensH : (Hm ? Hm + (size_t)b0 * Ny * d * d : h->sensH);
         double* oV = host ? h->sensV : (dvar ? dvar + (size_t)b0 * Ny * d : h->sensV);
-        CHK(predict_chunk(h, nb, dZ, oMean, oVar, oJ));
+        CHK(predict_chunk(h, nb, dZ, oMean, second ? (oVar ? oVar : h->var) : oVar, oJ, second ? h->VT : nullptr));
         if (second) {
-            const int Bp = round_up(nb, 32);            // the layout predict_chunk left in KsT
+            const int Bp = round_up(nb, 32);            // the layout predict_chunk left in KsT and VT
             PhaseTimer t(h, GPMPC_PH_FINISH);
-            GemmP p = gemm_base(cx);                     // UT[j][:] = KsT[j][:] K^-1
-            p.A = h->KsT; p.lda = Np; p.sA = (long)Bp * Np; p.a_mc = 0;
-            p.B = h->ws.InvK; p.ldb = Np; p.sB = h->ws.mat(); p.b_nc = 1;
-            p.C = h->UT; p.ldc = Np; p.sC = (long)Bp * Np;
-            p.M = Bp; p.N = Np; p.K = Np;
-            launch_gemm(p, Ny, cx.stream);
+            // UT[j][:] = (L^-T v_j)^T = (K^-1 ks_j)^T: one more pass over the lower triangle of L^-1, half the bytes of K^-1
+            GemmP p = gemm_base(cx);
+            if (Bp <= 64) {
+                // the streaming orientation of the variance product (rows of L^-T per workgroup, all columns): U = L^-T V,
+                // written transposed by the sum-of-squares epilogue (its sums land in `part`, free again, and are not used)
+                p.A = h->ws.Inv; p.lda = Np; p.sA = h->ws.mat(); p.a_mc = 1; p.kflags = KA_GE_M;
+                p.B = h->VT; p.ldb = Np; p.sB = (long)Bp * Np; p.b_nc = 0;
+                p.M = Np; p.N = Bp; p.K = Np;
+                p.epi = EPI_COLSUMSQ; p.part = h->part; p.ldpart = Bp; p.sPart = (long)(Np / 64) * Bp;
+                p.Ct = h->UT; p.ldct = Np; p.sCt = (long)Bp * Np;
+            }
+            if (Bp <= 64 && gemm_dma_supported(p)) {
+                if (Bp <= 32) launch_gemm_dma<64, 32, 4, 1, 3, 4>(p, Ny, cx.stream, 1 << 30, 2);
+                else launch_gemm_dma<64, 64, 2, 2, 3, 4>(p, Ny, cx.stream, 1 << 30, 2);
+            } else {
+                p = gemm_base(cx);
+                p.A = h->VT; p.lda = Np; p.sA = (long)Bp * Np; p.a_mc = 0;
+                p.B = h->ws.Inv; p.ldb = Np; p.sB = h->ws.mat(); p.b_nc = 1; p.kflags = KB_GE_N;
+                p.C = h->UT; p.ldc = Np; p.sC = (long)Bp * Np;
+                p.M = Bp; p.N = Np; p.K = Np;
+                launch_gemm(p, Ny, cx.stream);
+            }
             launch_sens(cx.stream, d, h->XT, dZ, h->ws.hyper, h->ws.alpha, h->KsT, h->UT, oH, oV, h->N, Np, nb, Bp, Ny);
             if (h->mean_kind == GPMPC_MEAN_POLYNOMIAL && h->mean_add)
                 hipLaunchKernelGGL(mean_add_kernel, dim3((unsigned)(((long)nb * Ny + 255) / 256)), dim3(256), 0, cx.stream, dZ,

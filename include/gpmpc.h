@@ -146,7 +146,8 @@ int gpmpc_mean_jac(gpmpc_gp* h, int B, const double* Z, double* mean, double* J)
  * from CasADi's AD of build_gp / build_TA_cov, gp_functions.py:114-173): besides mean[B x Ny], var[B x Ny]
  * and J[B x Ny x d] = d mean/dz also Hm[B x Ny x d x d] = d2 mean/dz2 and dvar[B x Ny x d] = d var/dz, from
  * which d cov/dz and d cov/dSigma of the 'ME' and 'TA' methods follow in closed form
- * (cov = diag(var) + J Sigma J^T).  Any output pointer may be NULL. */
+ * (cov = diag(var) + J Sigma J^T).  Any output pointer may be NULL.  d var/dz needs K^-1 ks: formed as
+ * L^-T (L^-1 ks) from the factor the variance already uses, so the call neither needs nor builds K^-1. */
 int gpmpc_predict_sens(gpmpc_gp* h, int B, const double* Z, double* mean, double* var, double* J,
                        double* Hm, double* dvar);
 /* 'EM' (gp_exact_moment gp_functions.py:344-418) with its first derivatives: besides mean[B x Ny] and cov[B x Ny x Ny]

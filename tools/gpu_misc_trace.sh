@@ -19,7 +19,9 @@ timeit('predict_sens B=30', lambda: h.predict_sens(p['Z'][:30]))
 timeit('predict_jac TA B=30', lambda: h.predict_jac('TA', p['Z'][:30], p['Sigma'][:30]))
 timeit('predict old_TA B=30', lambda: h.predict('old_TA', p['Z'][:30], p['Sigma'][:30]))
 q = go.synthetic_problem(64, 8, 6, 1, seed=5, sn=1e-2)
-t0 = time.perf_counter(); h.append(q['X'], q['Y']); print('append +64 at N=8192, Ny=6: %.1f ms' % ((time.perf_counter() - t0) * 1e3))
+t0 = time.perf_counter(); h.append(q['X'], q['Y']); print('append +64 at N=8192, Ny=6: %.1f ms' % ((time.perf_counter() - t0) * 1e3), 'handoff_timeouts', h.counter('handoff_timeouts'))
+q = go.synthetic_problem(64, 8, 6, 1, seed=6, sn=1e-2)
+t0 = time.perf_counter(); h.append(q['X'], q['Y']); print('append +64 again: %.1f ms' % ((time.perf_counter() - t0) * 1e3), 'handoff_timeouts', h.counter('handoff_timeouts'))
 PY
 python /tmp/misc.py
 timeout 600 rocprofv3 --kernel-trace --stats -d "$R/gpurun_out/misctrace" -o t -- python /tmp/misc.py > "$R/gpurun_out/misctrace.log" 2>&1
