@@ -355,13 +355,16 @@ class Handle:
                                                        _ptr(dvar)))
         return mean, var, J, Hm, dvar
 
-    def predict_em_sens(self, Z, Sigma):
+    def predict_em_sens(self, Z, Sigma, want_cov=True):
         """'EM' value and Jacobians: mean[B,Ny], cov[B,Ny,Ny], dmean_dz[B,Ny,d], dmean_dS[B,Ny,d,d],
-        dcov_dz[B,Ny,Ny,d], dcov_dS[B,Ny,Ny,d,d]."""
+        dcov_dz[B,Ny,Ny,d], dcov_dS[B,Ny,Ny,d,d].  want_cov=False: cov is None and its pair sums (a quarter of the
+        call) are not formed -- what a Jacobian callback wants."""
         Z = _f64(Z).reshape(-1, self.d)
         B, d, Ny = Z.shape[0], self.d, self.Ny
         Sigma = _f64(Sigma).reshape(B, d, d)
         out = [np.zeros(sh) for sh in ((B, Ny), (B, Ny, Ny), (B, Ny, d), (B, Ny, d, d), (B, Ny, Ny, d), (B, Ny, Ny, d, d))]
+        if not want_cov:
+            out[1] = None
         self.lib.check(self.lib.dll.gpmpc_predict_em_sens(self.h, B, _ptr(Z), _ptr(Sigma), *[_ptr(o) for o in out]))
         return tuple(out)
 

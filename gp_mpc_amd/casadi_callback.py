@@ -36,7 +36,7 @@ def jacobian_blocks(gp, x, u, S, fd_eps=1e-6):
     S = np.asarray(S, dtype=np.float64).reshape(Nx, Nx)
     method = gp._GP__gp_method
     if method in ('ME', 'TA', 'EM'):                         # exact, one device call
-        _, _, D = gp.predict_derivatives(x, u, S)
+        _, _, D = gp.predict_derivatives(x, u, S, values=False)
         vec_rows = lambda T, n: T.reshape(Ny * Ny, n, order='F')                    # [a, c, k] -> row a + Ny c
         dmS = D['dmean_dcov'].reshape(Ny, Nx * Nx, order='F')                        # [a, p, q] -> col p + Nx q
         dcS = D['dcov_dcov'].reshape(Ny * Ny, Nx, Nx, order='F').reshape(Ny * Ny, Nx * Nx, order='F')

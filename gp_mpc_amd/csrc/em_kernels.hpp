@@ -613,16 +613,16 @@ __global__ void __launch_bounds__(256) em_mean_sens_kernel(const double* __restr
     }
 }
 
-// assembly per (input, unordered pair a >= c).  One thread each; grid (ceil(Bc*P/64)), 64 threads.
-__global__ void __launch_bounds__(64) em_sens_finish_kernel(const double* __restrict__ sums, const double* __restrict__ prep,
-                                                            const double* __restrict__ hyper, const double* __restrict__ Sigma,
-                                                            const double* __restrict__ mean, const double* __restrict__ dm_dz,
-                                                            const double* __restrict__ dm_dS, double* __restrict__ dc_dz,
-                                                            double* __restrict__ dc_dS, int Bc, int Ny, int d, int b0) {
+// assembly per (input, unordered pair a >= c).  grid (Bc * P), DMAX * GJ_LD threads: one workgroup per item, its d x d
+// algebra in LDS with a thread per entry (one THREAD per item with the matrices in scratch memory took 0.31 ms at C3).
+__global__ void __launch_bounds__(DMAX * GJ_LD) em_sens_finish_kernel(const double* __restrict__ sums, const double* __restrict__ prep,
+                                                                      const double* __restrict__ hyper, const double* __restrict__ Sigma,
+                                                                      const double* __restrict__ mean, const double* __restrict__ dm_dz,
+                                                                      const double* __restrict__ dm_dS, double* __restrict__ dc_dz,
+                                                                      double* __restrict__ dc_dS, int Bc, int Ny, int d, int b0) {
     const int P = Ny * (Ny + 1) / 2, stride = d * d + 1;
-    const long gid = (long)blockIdx.x * 64 + threadIdx.x;
-    if (gid >= (long)Bc * P) return;
-    const int bl = (int)(gid / P), p = (int)(gid % P), b = b0 + bl;
+    const int tid = threadIdx.x, r = tid / GJ_LD, q = tid % GJ_LD;
+    const int bl = (int)blockIdx.x / P, p = (int)blockIdx.x % P, b = b0 + bl;
     int a = 0;
     while ((a + 1) * (a + 2) / 2 <= p) ++a;
     const int c = p - a * (a + 1) / 2;
@@ -632,55 +632,55 @@ __global__ void __launch_bounds__(64) em_sens_finish_kernel(const double* __rest
     const double t = prep[((long)b * (Ny + P) + Ny + p) * stride + d * d];
     const double* sa_ = sums + ((long)bl * Ny * Ny + a * Ny + c) * EM_NSS;      // ordered (a, c)
     const double* sc_ = sums + ((long)bl * Ny * Ny + c * Ny + a) * EM_NSS;      // ordered (c, a)
-    double ila[EMK], ilc[EMK], lab[EMK], A[DMAX * DMAX], G[DMAX * DMAX];
-    for (int k = 0; k < d; ++k) {
-        ila[k] = 1.0 / (ha[k] * ha[k]);
-        ilc[k] = 1.0 / (hc[k] * hc[k]);
-        lab[k] = ila[k] + ilc[k];
+    __shared__ double M[DMAX * GJ_LD], ila[EMK], ilc[EMK], lab[EMK], z1[EMK], ZZ[EMK * EMK], T1[EMK * EMK];
+    __shared__ int piv[2];
+    if (tid < d) {
+        ila[tid] = 1.0 / (ha[tid] * ha[tid]);
+        ilc[tid] = 1.0 / (hc[tid] * hc[tid]);
+        lab[tid] = ila[tid] + ilc[tid];
     }
-    // G = (Lab Sigma + I)^-1
-    for (int r = 0; r < d; ++r)
-        for (int q = 0; q < d; ++q) {
-            A[r * d + q] = lab[r] * Sg[r * d + q] + (r == q ? 1.0 : 0.0);
-            G[r * d + q] = (r == q) ? 1.0 : 0.0;
-        }
-    small_solve(A, G, d, d);
+    __syncthreads();
+    // G = (Lab Sigma + I)^-1: the right half of [Lab Sigma + I | I] after the elimination
+    if (r < d && q < 2 * d)
+        M[r * GJ_LD + q] = q < d ? lab[r] * Sg[r * d + q] + (r == q ? 1.0 : 0.0) : (q - d == r ? 1.0 : 0.0);
+    __syncthreads();
+    gauss_jordan_lds(M, d, 2 * d, piv);
+    auto G = [&](int k, int l) { return M[k * GJ_LD + d + l]; };
     const double s0 = sa_[0];
-    double z1[EMK], ZZ[EMK * EMK], T1[EMK * EMK];
     // column moments of ordered (c, a) are the row moments of (a, c)
-    for (int k = 0; k < d; ++k) z1[k] = ila[k] * sc_[1 + k] + ilc[k] * sa_[1 + k];
-    const double* C2r = sc_ + 1 + EMK;
-    const double* C2c = sa_ + 1 + EMK;
-    const double* Xp = sa_ + 1 + EMK + EMK * EMK;
-    for (int k = 0; k < d; ++k)
-        for (int l = 0; l < d; ++l)
-            ZZ[k * EMK + l] = ila[k] * C2r[k * EMK + l] * ila[l] + ilc[k] * C2c[k * EMK + l] * ilc[l] + 2.0 * Xp[k * EMK + l] * ilc[l];
+    if (tid < d) z1[tid] = ila[tid] * sc_[1 + tid] + ilc[tid] * sa_[1 + tid];
+    if (r < d && q < d) {
+        const double* C2r = sc_ + 1 + EMK;
+        const double* C2c = sa_ + 1 + EMK;
+        const double* Xp = sa_ + 1 + EMK + EMK * EMK;
+        ZZ[r * EMK + q] = ila[r] * C2r[r * EMK + q] * ila[q] + ilc[r] * C2c[r * EMK + q] * ilc[q] + 2.0 * Xp[r * EMK + q] * ilc[q];
+    }
+    __syncthreads();
     const double ma = mean[(long)b * Ny + a], mc = mean[(long)b * Ny + c];
     const double* dza = dm_dz + ((long)bl * Ny + a) * d;
     const double* dzc = dm_dz + ((long)bl * Ny + c) * d;
     const double* dSa = dm_dS + ((long)bl * Ny + a) * d * d;
     const double* dSc = dm_dS + ((long)bl * Ny + c) * d * d;
-    for (int k = 0; k < d; ++k) {
+    if (tid < d) {
         double s = 0.0;
-        for (int l = 0; l < d; ++l) s += G[k * d + l] * z1[l];
-        const double v = t * s - mc * dza[k] - ma * dzc[k];
-        dc_dz[(((long)bl * Ny + a) * Ny + c) * d + k] = v;
-        dc_dz[(((long)bl * Ny + c) * Ny + a) * d + k] = v;
+        for (int l = 0; l < d; ++l) s += G(tid, l) * z1[l];
+        const double v = t * s - mc * dza[tid] - ma * dzc[tid];
+        dc_dz[(((long)bl * Ny + a) * Ny + c) * d + tid] = v;
+        dc_dz[(((long)bl * Ny + c) * Ny + a) * d + tid] = v;
     }
-    for (int k = 0; k < d; ++k)
-        for (int l = 0; l < d; ++l) {
-            double s = 0.0;
-            for (int m = 0; m < d; ++m) s += G[k * d + m] * ZZ[m * EMK + l];
-            T1[k * EMK + l] = s;
-        }
-    for (int k = 0; k < d; ++k)
-        for (int l = 0; l < d; ++l) {
-            double s = 0.0;
-            for (int m = 0; m < d; ++m) s += T1[k * EMK + m] * G[l * d + m];       // (G ZZ G^T)_kl
-            const double v = t * (-0.5 * G[k * d + l] * lab[l] * s0 + 0.5 * s) - mc * dSa[k * d + l] - ma * dSc[k * d + l];
-            dc_dS[((((long)bl * Ny + a) * Ny + c) * d + k) * d + l] = v;
-            dc_dS[((((long)bl * Ny + c) * Ny + a) * d + k) * d + l] = v;
-        }
+    if (r < d && q < d) {
+        double s = 0.0;
+        for (int m = 0; m < d; ++m) s += G(r, m) * ZZ[m * EMK + q];
+        T1[r * EMK + q] = s;
+    }
+    __syncthreads();
+    if (r < d && q < d) {
+        double s = 0.0;
+        for (int m = 0; m < d; ++m) s += T1[r * EMK + m] * G(q, m);       // (G ZZ G^T)_rq
+        const double v = t * (-0.5 * G(r, q) * lab[q] * s0 + 0.5 * s) - mc * dSa[r * d + q] - ma * dSc[r * d + q];
+        dc_dS[((((long)bl * Ny + a) * Ny + c) * d + r) * d + q] = v;
+        dc_dS[((((long)bl * Ny + c) * Ny + a) * d + r) * d + q] = v;
+    }
 }
 
 // ---- legacy methods a12 ------------------------------------------------------------------------------

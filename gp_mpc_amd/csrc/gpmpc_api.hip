@@ -164,6 +164,76 @@ static const int SEGR = 128;
 static const int SEGR = 512;
 #endif
 
+// Large device blocks (the N x N matrices of a workspace) come from size classes -- a quarter of the power of two
+// below the request -- and go back to a small per-process list instead of to the driver: gpmpc_append builds its new
+// workspace before it drops the old one, and a fresh multi-GB hipMalloc was measured at anything between 0.3 ms and
+// 0.5 s on the same box (append +64 at C3 size: 9 ms or 500 ms).  With classes the blocks the previous append gave back fit
+// the next one (8-9 appends of 64 points per class at N = 8192).  The list is emptied when the last handle goes.
+struct DevBlock { void* p; size_t cls; int dev; };
+static std::mutex g_block_mutex;
+static std::vector<DevBlock> g_free_blocks, g_live_blocks;
+static int g_live_handles = 0;
+constexpr size_t BLOCK_MIN = (size_t)64 << 20;
+constexpr size_t BLOCK_LIST_MAX = 16;
+
+static size_t block_class(size_t bytes) {
+    size_t p2 = 1;
+    while (p2 * 2 <= bytes) p2 *= 2;
+    const size_t g = p2 / 4;
+    return (bytes + g - 1) / g * g;
+}
+
+static hipError_t block_alloc(double** out, size_t bytes) {
+    if (bytes < BLOCK_MIN) return hipMalloc(out, bytes);
+    const size_t cls = block_class(bytes);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    {
+        std::lock_guard<std::mutex> lk(g_block_mutex);
+        for (size_t i = 0; i < g_free_blocks.size(); ++i)
+            if (g_free_blocks[i].cls == cls && g_free_blocks[i].dev == dev) {
+                *out = (double*)g_free_blocks[i].p;
+                g_live_blocks.push_back(g_free_blocks[i]);
+                g_free_blocks.erase(g_free_blocks.begin() + i);
+                return hipSuccess;
+            }
+    }
+    const hipError_t e = hipMalloc(out, cls);
+    if (e == hipSuccess) {
+        std::lock_guard<std::mutex> lk(g_block_mutex);
+        g_live_blocks.push_back({(void*)*out, cls, dev});
+    }
+    return e;
+}
+
+static void block_free(double* p) {
+    if (!p) return;
+    (void)hipDeviceSynchronize();      // what hipFree implies: nothing in flight may still touch a block that is handed out again
+    {
+        std::lock_guard<std::mutex> lk(g_block_mutex);
+        for (size_t i = 0; i < g_live_blocks.size(); ++i)
+            if (g_live_blocks[i].p == (void*)p) {
+                const DevBlock b = g_live_blocks[i];
+                g_live_blocks.erase(g_live_blocks.begin() + i);
+                if (g_free_blocks.size() < BLOCK_LIST_MAX) {
+                    g_free_blocks.push_back(b);
+                    return;
+                }
+                break;
+            }
+    }
+    hipFree(p);
+}
+
+static void block_list_release() {
+    std::vector<DevBlock> drop;
+    {
+        std::lock_guard<std::mutex> lk(g_block_mutex);
+        drop.swap(g_free_blocks);
+    }
+    for (auto& b : drop) hipFree(b.p);
+}
+
 struct Workspace {
     int batch = 0, Np = 0, d = 0;
     double *K = nullptr, *L = nullptr, *Inv = nullptr, *InvK = nullptr, *W = nullptr;
@@ -186,10 +256,10 @@ static int ws_alloc(Workspace& ws, int batch, int Np, int d) {
     ws.Np = Np;
     ws.d = d;
     const size_t mb = (size_t)batch * Np * Np * sizeof(double);
-    HIPCHK(hipMalloc(&ws.K, mb));
-    HIPCHK(hipMalloc(&ws.L, mb));
-    HIPCHK(hipMalloc(&ws.Inv, mb));
-    HIPCHK(hipMalloc(&ws.W, (size_t)batch * ws.wstride() * sizeof(double)));
+    HIPCHK(block_alloc(&ws.K, mb));
+    HIPCHK(block_alloc(&ws.L, mb));
+    HIPCHK(block_alloc(&ws.Inv, mb));
+    HIPCHK(block_alloc(&ws.W, (size_t)batch * ws.wstride() * sizeof(double)));
     HIPCHK(hipMalloc(&ws.w, (size_t)batch * Np * sizeof(double)));
     HIPCHK(hipMalloc(&ws.alpha, (size_t)batch * Np * sizeof(double)));
     HIPCHK(hipMalloc(&ws.hyper, (size_t)batch * (d + 2) * sizeof(double)));
@@ -210,13 +280,13 @@ static int ws_alloc(Workspace& ws, int batch, int Np, int d) {
 }
 
 static void ws_free(Workspace& ws) {
-    hipFree(ws.K); hipFree(ws.L); hipFree(ws.Inv); hipFree(ws.InvK); hipFree(ws.W);
+    block_free(ws.K); block_free(ws.L); block_free(ws.Inv); block_free(ws.InvK); block_free(ws.W);
     hipFree(ws.w); hipFree(ws.alpha); hipFree(ws.hyper); hipFree(ws.jitter); hipFree(ws.nll); hipFree(ws.info); hipFree(ws.flags);
     ws = Workspace();
 }
 
 static int ws_need_invK(Workspace& ws) {
-    if (!ws.InvK) HIPCHK(hipMalloc(&ws.InvK, (size_t)ws.batch * ws.mat() * sizeof(double)));
+    if (!ws.InvK) HIPCHK(block_alloc(&ws.InvK, (size_t)ws.batch * ws.mat() * sizeof(double)));
     return GPMPC_OK;
 }
 
@@ -844,6 +914,8 @@ struct gpmpc_gp {
     double *mean = nullptr, *var = nullptr, *J = nullptr, *cov = nullptr;
     double* em = nullptr;  // exact-moment / legacy scratch
     long emBytes = 0;
+    double* ems = nullptr;   // scratch of gpmpc_predict_em_sens (grow-only)
+    long emsBytes = 0;
     double* beta = nullptr;  // K^-1 y, [Ny][Np]
     double* UT = nullptr;    // K^-1 ks per test point (legacy methods, sensitivities)
     double* VT = nullptr;    // L^-1 ks per test point (sensitivities: K^-1 ks = L^-T (L^-1 ks) without K^-1)
@@ -992,6 +1064,10 @@ int gpmpc_create(int device, int N, int d, int Ny, const double* X, const double
     if (d > DMAX) return fail(GPMPC_EINVAL, "input dimension d=%d exceeds the built-in maximum %d", d, DMAX);
     CHK(ensure_device(device));
     gpmpc_gp* h = new gpmpc_gp();
+    {
+        std::lock_guard<std::mutex> lk(g_block_mutex);
+        ++g_live_handles;
+    }
     h->device = device; h->N = N; h->d = d; h->Ny = Ny; h->Np = round_up(N, 64);
     const int rc = create_impl(h, X, Y);
     if (rc != GPMPC_OK) {                       // every early exit releases what was created so far
@@ -1013,7 +1089,7 @@ int gpmpc_destroy(gpmpc_gp* h) {
     hipFree(h->XT); hipFree(h->Y); hipFree(h->gradPartial); hipFree(h->gradOut);
     hipFree(h->mpar); hipFree(h->Yc); hipFree(h->tmpar); hipFree(h->tYc);
     hipFree(h->Z); hipFree(h->Sigma); hipFree(h->KsT); hipFree(h->part); hipFree(h->meanT);
-    hipFree(h->mean); hipFree(h->var); hipFree(h->J); hipFree(h->cov); hipFree(h->em);
+    hipFree(h->mean); hipFree(h->var); hipFree(h->J); hipFree(h->cov); hipFree(h->em); hipFree(h->ems);
     hipFree(h->beta); hipFree(h->UT); hipFree(h->VT); hipFree(h->sensH); hipFree(h->sensV); hipFree(h->ccpart);
     for (int ph = 0; ph < GPMPC_PH_COUNT; ++ph)
         for (auto& pr : h->prof.ev[ph]) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
@@ -1028,6 +1104,12 @@ int gpmpc_destroy(gpmpc_gp* h) {
     if (h->side_stream) hipStreamDestroy(h->side_stream);
     if (h->own_stream) hipStreamDestroy(h->own_stream);
     delete h;
+    bool last;
+    {
+        std::lock_guard<std::mutex> lk(g_block_mutex);
+        last = --g_live_handles == 0;
+    }
+    if (last) block_list_release();
     return GPMPC_OK;
 }
 
@@ -1288,13 +1370,13 @@ extern "C" int gpmpc_fit(gpmpc_gp* h, const double* hyper, int want_invK, int* i
 static void free_predict_scratch(gpmpc_gp* h) {
     hipFree(h->Z); hipFree(h->Sigma); hipFree(h->KsT); hipFree(h->part); hipFree(h->meanT);
     hipFree(h->mean); hipFree(h->var); hipFree(h->J); hipFree(h->cov); hipFree(h->UT); hipFree(h->VT);
-    hipFree(h->sensH); hipFree(h->sensV); hipFree(h->em); hipFree(h->beta); hipFree(h->gradPartial); hipFree(h->gradOut);
+    hipFree(h->sensH); hipFree(h->sensV); hipFree(h->em); hipFree(h->ems); hipFree(h->beta); hipFree(h->gradPartial); hipFree(h->gradOut);
     hipFree(h->ccpart); hipFree(h->Yc); hipFree(h->tYc);
     h->Yc = h->tYc = nullptr;
     h->Z = h->Sigma = h->KsT = h->part = h->meanT = h->mean = h->var = h->J = h->cov = h->UT = h->VT = nullptr;
-    h->sensH = h->sensV = h->em = h->beta = h->gradPartial = h->gradOut = h->ccpart = nullptr;
+    h->sensH = h->sensV = h->em = h->ems = h->beta = h->gradPartial = h->gradOut = h->ccpart = nullptr;
     h->Bcap = 0;
-    h->emBytes = 0;
+    h->emBytes = h->emsBytes = 0;
     h->have_beta = false;
     ws_free(h->tws);
 }
@@ -1916,8 +1998,8 @@ extern "C" int gpmpc_predict_em_sens(gpmpc_gp* h, int B, const double* Z, const 
     const size_t n1 = nM * d, n2 = nM * d * d, n3 = nC * d, n4 = nC * d * d;
     const size_t nPrep = (size_t)B * (Ny + P) * (d * d + 1);
     const size_t nOps = (size_t)Bc * PO * EM_OPS_ORD * Np, nPart = (size_t)Bc * PO * tiles * EM_NSS, nSum = (size_t)Bc * PO * EM_NSS;
-    double* buf = nullptr;
-    HIPCHK(hipMalloc(&buf, (nZ + nS + nM + nC + n1 + n2 + n3 + n4 + nPrep + nOps + nPart + nSum) * sizeof(double)));
+    CHK(ensure_em_scratch(h, (long)((nZ + nS + nM + nC + n1 + n2 + n3 + n4 + nPrep + nOps + nPart + nSum) * sizeof(double)), true));
+    double* buf = h->ems;
     double *bZ = buf, *bS = bZ + nZ, *bM = bS + nS, *bC = bM + nM, *b1 = bC + nC, *b2 = b1 + n1, *b3 = b2 + n2, *b4 = b3 + n3,
            *prep = b4 + n4, *ops = prep + nPrep, *part = ops + nOps, *sums = part + nPart;
     int rc = GPMPC_OK;
@@ -1937,8 +2019,9 @@ extern "C" int gpmpc_predict_em_sens(gpmpc_gp* h, int B, const double* Z, const 
         double* o4 = (!host && dcov_dS) ? dcov_dS : b4;
         for (int b0 = 0; b0 < B; b0 += Bc) {
             const int nb = std::min(Bc, B - b0);
+            // (the mean is an operand of d cov; the covariance itself -- the value kernels' pair sums -- only on request)
             CHK(predict_moments_chunk(h, GPMPC_EM, nb, dZ + (size_t)b0 * d, dS + (size_t)b0 * d * d, oM + (size_t)b0 * Ny,
-                                      oC + (size_t)b0 * Ny * Ny));
+                                      cov ? oC + (size_t)b0 * Ny * Ny : nullptr));
             PhaseTimer t(h, GPMPC_PH_EM);
             if (b0 == 0) {
                 hipLaunchKernelGGL(em_prep_kernel, dim3((unsigned)(B * (Ny + P))), dim3(DMAX * GJ_LD), 0, cx.stream, h->ws.hyper, dS,
@@ -1953,7 +2036,7 @@ extern "C" int gpmpc_predict_em_sens(gpmpc_gp* h, int B, const double* Z, const 
             hipLaunchKernelGGL(em_pair_sens_kernel<true>, dim3(tiles, PO, nb), dim3(256), 0, cx.stream, ops, h->ws.InvK, h->XT, dZ,
                                part, N, Np, Ny, d, b0, cx.crow_mode);
             hipLaunchKernelGGL(em_sens_reduce_kernel, dim3(PO, nb), dim3(256), 0, cx.stream, part, sums, Ny, tiles);
-            hipLaunchKernelGGL(em_sens_finish_kernel, dim3((unsigned)(((long)nb * P + 63) / 64)), dim3(64), 0, cx.stream, sums, prep,
+            hipLaunchKernelGGL(em_sens_finish_kernel, dim3((unsigned)(nb * P)), dim3(DMAX * GJ_LD), 0, cx.stream, sums, prep,
                                h->ws.hyper, dS, oM, o1 + (size_t)b0 * Ny * d, o2 + (size_t)b0 * Ny * d * d,
                                o3 + (size_t)b0 * Ny * Ny * d, o4 + (size_t)b0 * Ny * Ny * d * d, nb, Ny, d, b0);
             HIPCHK(hipGetLastError());
@@ -1974,7 +2057,6 @@ extern "C" int gpmpc_predict_em_sens(gpmpc_gp* h, int B, const double* Z, const 
     };
     rc = run();
     if (rc != GPMPC_OK) hipStreamSynchronize(h->stream);
-    hipFree(buf);
     return rc;
 }
 

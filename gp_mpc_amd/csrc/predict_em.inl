@@ -12,14 +12,16 @@ static int ensure_beta(gpmpc_gp* h) {
     return GPMPC_OK;
 }
 
-static int ensure_em_scratch(gpmpc_gp* h, long bytes) {
-    if (bytes <= h->emBytes) return GPMPC_OK;
+static int ensure_em_scratch(gpmpc_gp* h, long bytes, bool sens = false) {
+    double*& buf = sens ? h->ems : h->em;
+    long& have = sens ? h->emsBytes : h->emBytes;
+    if (bytes <= have) return GPMPC_OK;
     HIPCHK(hipStreamSynchronize(h->stream));
-    hipFree(h->em);
-    h->em = nullptr;
-    h->emBytes = 0;
-    HIPCHK(hipMalloc(&h->em, (size_t)bytes));
-    h->emBytes = bytes;
+    hipFree(buf);
+    buf = nullptr;
+    have = 0;
+    HIPCHK(hipMalloc(&buf, (size_t)bytes));
+    have = bytes;
     return GPMPC_OK;
 }
 
@@ -44,6 +46,10 @@ static int predict_moments_chunk(gpmpc_gp* h, int method, int B, const double* d
         hipLaunchKernelGGL(em_mean_kernel, dim3(Ny, B, EM_MEAN_CHUNKS), dim3(256), 0, cx.stream, h->XT, dZ, h->beta, prep, mpart,
                            N, Np, d, Ny);
         hipLaunchKernelGGL(em_mean_finish_kernel, dim3((B * Ny + 255) / 256), dim3(256), 0, cx.stream, mpart, dMean, B * Ny);
+        if (!dCov) {     // mean only (gpmpc_predict_em_sens without the covariance value)
+            HIPCHK(hipGetLastError());
+            return GPMPC_OK;
+        }
         hipLaunchKernelGGL(em_operands_kernel, dim3((Np + 255) / 256, P, B), dim3(256), 0, cx.stream, h->XT, dZ, h->ws.hyper,
                            prep, ops, N, Np, d, Ny);
         hipLaunchKernelGGL((em_pair_kernel<false>), dim3(tiles, P, B), dim3(256), 0, cx.stream, ops, h->beta, h->ws.InvK,

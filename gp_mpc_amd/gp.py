@@ -220,7 +220,7 @@ class GP:
             mean = self.inverse_mean(mean, self.__meanY, self.__stdY)
         return mean.reshape(self.__Ny, 1), c[0]
 
-    def predict_derivatives(self, x, u, cov):
+    def predict_derivatives(self, x, u, cov, values=True):
         """`predict` plus the exact first derivatives of both outputs with respect to all three inputs,
         for the 'ME', 'TA' and 'EM' methods -- what a casadi Callback standing in for `__predict`
         (gp_class.py:212-224) must provide through `get_jacobian`; the reference gets them from CasADi's
@@ -232,7 +232,9 @@ class GP:
           'dmean_dx' [Ny,Ny], 'dmean_du' [Ny,Nu], 'dmean_dcov' [Ny,Nx,Nx] (zero for ME / TA),
           'dcov_dx' [Ny,Ny,Ny], 'dcov_du' [Ny,Ny,Nu], 'dcov_dcov' [Ny,Ny,Nx,Nx],
         all with respect to the RAW x, u (the chain rule through the standardisation is applied; cov
-        stays in standardised units exactly as `predict` returns it, gp_class.py:262)."""
+        stays in standardised units exactly as `predict` returns it, gp_class.py:262).
+        values=False (a Jacobian callback): the returned cov is None for 'EM' -- its pair sums are a quarter
+        of the device call and the derivatives do not need them."""
         if self.__gp_method not in ('ME', 'TA', 'EM'):
             raise NotImplementedError("analytic derivatives exist for 'ME', 'TA' and 'EM'; use finite differences of "
                                       "GP.predict for '%s'" % self.__gp_method)
@@ -245,7 +247,8 @@ class GP:
         z = np.concatenate([x, u]).reshape(1, Nx)
         S = np.asarray(cov, dtype=np.float64).reshape(Nx, Nx)
         if self.__gp_method == 'EM':
-            mean, c, dmean, dmS, dcz, dcS = (a[0] for a in self._h.predict_em_sens(z, S.reshape(1, Nx, Nx)))
+            mean, c, dmean, dmS, dcz, dcS = (None if a is None else a[0]
+                                             for a in self._h.predict_em_sens(z, S.reshape(1, Nx, Nx), want_cov=values))
         else:
             mean, var, J, Hm, dvar = (a[0] for a in self._h.predict_sens(z))
             c = np.diag(var)

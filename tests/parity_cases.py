@@ -1023,6 +1023,9 @@ def check_em_sens(lib, N=150, d=4, Ny=3, B=5, seed=13, tol=1e-9):
     mean, cov, dm_dz, dm_dS, dc_dz, dc_dS = h.predict_em_sens(Z, S)
     m0, c0 = h.predict('EM', Z, S)
     assert np.array_equal(mean, m0) and np.array_equal(cov, c0)
+    nv = h.predict_em_sens(Z, S, want_cov=False)        # Jacobian-only call: no covariance value, same derivatives
+    assert nv[1] is None and np.array_equal(nv[0], mean)
+    assert all(np.array_equal(a, b) for a, b in zip(nv[2:], (dm_dz, dm_dS, dc_dz, dc_dS)))
     sf2 = (H[:, d] ** 2).max()
     for b in range(B):
         o1, o2, o3, o4 = go.exact_moment_sens(f['invK'], X, Y, H, Z[b], S[b])
