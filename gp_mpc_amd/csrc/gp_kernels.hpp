@@ -64,42 +64,57 @@ __device__ __forceinline__ bool recip_is_safe(double b) {
 // exp().  (On the reference's saved models, cond(K) up to 7e10, the choice of form moves chol(K) by
 // 1e-10 relative -- the parity bar -- so the K build follows the form the fixtures were made with;
 // the predict-side ks uses the direct-difference form that build_gp evaluates.)
-// grid (Np/64, Np/64, batch), 256 threads; tiles above the diagonal exit at once.  HBM-write bound:
-// 4 N (N+1) bytes per output.
+// grid (Np/64, 4 Np/64, batch), 256 threads: a workgroup writes 16 rows x 64 columns of a 64 x 64 tile (a whole tile per
+// workgroup made 2080 workgroups at C2 for 1024 resident ones: a third round for the last 32); tiles above the diagonal
+// exit at once.  4 N (N+1) bytes per output are written, but the kernel is bound by its fp64 VALU work (63 operations
+// per entry at d = 6 in the reference's operation order; 15 us at C2 against 11 us of HBM time).
 // D (the input dimension) is a template parameter: the column point's coordinates and the per-dimension constants live
-// in registers, the row point's are wave-uniform LDS reads, the distance loop is unrolled (71 -> ~45 us at C2).
+// in registers, the row point's are wave-uniform LDS reads, the distance loop is unrolled.  2 x_i is formed once per
+// row (exact), the division by ell^2 is Markstein's three-instruction form (same bits), exp is exp_lean (< 1 ulp like
+// the library's, without its special-case handling: -inf would give NaN, which the factorisation reports).
 template <int D>
 __global__ void __launch_bounds__(256) gram_kernel(const double* __restrict__ XT, const double* __restrict__ hyper,
                                                    const double* __restrict__ jitter, double* __restrict__ K,
                                                    int N, int Np, int tm0) {
 #pragma clang fp contract(off)
-    const int tn = blockIdx.x, tm = blockIdx.y + tm0, a = blockIdx.z;   // tm0: first tile row (gpmpc_append)
+    const int tn = blockIdx.x, tm = (int)(blockIdx.y >> 2) + tm0, rq = blockIdx.y & 3, a = blockIdx.z;   // tm0: first tile row (gpmpc_append)
     if (tn > tm) return;
-    __shared__ double Xr[D][64], Qr[D][64];
-    const int tid = threadIdx.x, m0 = tm * 64, n0 = tn * 64, c = tid & 63;
-    for (int idx = tid; idx < 64 * D; idx += 256) {
-        const int dd = idx >> 6, i = idx & 63;
+    __shared__ double X2r[D][16], Qr[D][16], Cs[2][D];
+    __shared__ int safe_s;
+    const int tid = threadIdx.x, m0 = tm * 64 + 16 * rq, n0 = tn * 64, c = tid & 63;
+    const double* hy = hyper + (long)a * (D + 2);
+    if (tid < 16 * D) {
+        const int dd = tid >> 4, i = tid & 15;
         const double xr = XT[(long)dd * Np + m0 + i];
-        Xr[dd][i] = xr;
+        X2r[dd][i] = 2.0 * xr;
         Qr[dd][i] = xr * xr;
     }
-    const double* hy = hyper + (long)a * (D + 2);
-    double xc[D], qc[D], e2[D], ie2[D];
-    bool fast_div = true;
+    if (tid == 255) {           // per-dimension constants once per workgroup
+        bool ok = true;
+        for (int dd = 0; dd < D; ++dd) {
+            const double e = hy[dd] * hy[dd];
+            Cs[0][dd] = e;
+            Cs[1][dd] = 1.0 / e;
+            ok = ok && recip_is_safe(e);
+        }
+        safe_s = ok ? 1 : 0;
+    }
+    double xc[D], qc[D];
 #pragma unroll
     for (int dd = 0; dd < D; ++dd) {
         xc[dd] = XT[(long)dd * Np + n0 + c];
         qc[dd] = xc[dd] * xc[dd];
-        e2[dd] = hy[dd] * hy[dd];
-        ie2[dd] = 1.0 / e2[dd];
-        fast_div = fast_div && recip_is_safe(e2[dd]);
     }
     const double sf2 = hy[D] * hy[D], sn2 = hy[D + 1] * hy[D + 1], jit = jitter[a];
     __syncthreads();
+    double e2[D], ie2[D];
+#pragma unroll
+    for (int dd = 0; dd < D; ++dd) { e2[dd] = Cs[0][dd]; ie2[dd] = Cs[1][dd]; }
+    const bool fast_div = safe_s != 0;
     double* __restrict__ Ka = K + (long)a * Np * Np;
     const int j = n0 + c;
-#pragma unroll 4
-    for (int s = 0; s < 16; ++s) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
         const int r = (tid >> 6) + 4 * s, i = m0 + r;
         double v;
         if (i >= N || j >= N) {
@@ -110,10 +125,10 @@ __global__ void __launch_bounds__(256) gram_kernel(const double* __restrict__ XT
             double dist = 0.0;
 #pragma unroll
             for (int dd = 0; dd < D; ++dd) {
-                const double t = (Qr[dd][r] + qc[dd]) - 2.0 * (Xr[dd][r] * xc[dd]);
+                const double t = (Qr[dd][r] + qc[dd]) - X2r[dd][r] * xc[dd];      // 2 (x_i x_j) == (2 x_i) x_j exactly
                 dist = div_by_const(t, e2[dd], ie2[dd], fast_div) + dist;
             }
-            v = sf2 * exp(-0.5 * dist);
+            v = sf2 * exp_lean(-0.5 * dist);
             if (i == j) v = (v + sn2) + jit;
         }
         Ka[(long)i * Np + j] = v;
@@ -122,7 +137,7 @@ __global__ void __launch_bounds__(256) gram_kernel(const double* __restrict__ XT
 
 inline void launch_gram(hipStream_t st, dim3 grid, int d, const double* XT, const double* hyper, const double* jitter, double* K,
                         int N, int Np, int tm0 = 0) {
-#define GPMPC_GK(DD) case DD: hipLaunchKernelGGL((gram_kernel<DD>), grid, dim3(256), 0, st, XT, hyper, jitter, K, N, Np, tm0); break;
+#define GPMPC_GK(DD) case DD: hipLaunchKernelGGL((gram_kernel<DD>), dim3(grid.x, 4 * grid.y, grid.z), dim3(256), 0, st, XT, hyper, jitter, K, N, Np, tm0); break;
     switch (d) {
         GPMPC_GK(1) GPMPC_GK(2) GPMPC_GK(3) GPMPC_GK(4) GPMPC_GK(5) GPMPC_GK(6) GPMPC_GK(7) GPMPC_GK(8)
         GPMPC_GK(9) GPMPC_GK(10) GPMPC_GK(11) GPMPC_GK(12) GPMPC_GK(13) GPMPC_GK(14) GPMPC_GK(15) GPMPC_GK(16)
