@@ -236,7 +236,8 @@ class Handle:
         self.lib.check(self.lib.dll.gpmpc_synchronize(self.h))
 
     def counter(self, name):
-        """'handoff_timeouts' | 'chained_factorisations' | 'single_queue_factorisations' (include/gpmpc.h)."""
+        """'handoff_timeouts' | 'chained_factorisations' | 'single_queue_factorisations' | 'workspace_blocks_fresh' |
+        'workspace_blocks_reused' (include/gpmpc.h)."""
         v = ctypes.c_long(0)
         self.lib.check(self.lib.dll.gpmpc_get_counter(self.h, name.encode(), ctypes.byref(v)))
         return v.value

@@ -173,6 +173,7 @@ struct DevBlock { void* p; size_t cls; int dev; };
 static std::mutex g_block_mutex;
 static std::vector<DevBlock> g_free_blocks, g_live_blocks;
 static int g_live_handles = 0;
+static long g_block_reuses = 0, g_block_fresh = 0;   // process-wide, read through gpmpc_get_counter
 constexpr size_t BLOCK_MIN = (size_t)64 << 20;
 constexpr size_t BLOCK_LIST_MAX = 16;
 
@@ -193,6 +194,7 @@ static hipError_t block_alloc(double** out, size_t bytes) {
         for (size_t i = 0; i < g_free_blocks.size(); ++i)
             if (g_free_blocks[i].cls == cls && g_free_blocks[i].dev == dev) {
                 *out = (double*)g_free_blocks[i].p;
+                ++g_block_reuses;
                 g_live_blocks.push_back(g_free_blocks[i]);
                 g_free_blocks.erase(g_free_blocks.begin() + i);
                 return hipSuccess;
@@ -201,6 +203,7 @@ static hipError_t block_alloc(double** out, size_t bytes) {
     const hipError_t e = hipMalloc(out, cls);
     if (e == hipSuccess) {
         std::lock_guard<std::mutex> lk(g_block_mutex);
+        ++g_block_fresh;
         g_live_blocks.push_back({(void*)*out, cls, dev});
     }
     return e;
@@ -1179,6 +1182,10 @@ int gpmpc_get_counter(gpmpc_gp* h, const char* name, long* value) {
     if (std::strcmp(name, "handoff_timeouts") == 0) *value = h->n_timeouts;
     else if (std::strcmp(name, "chained_factorisations") == 0) *value = h->n_chained;
     else if (std::strcmp(name, "single_queue_factorisations") == 0) *value = h->n_single;
+    else if (std::strcmp(name, "workspace_blocks_reused") == 0 || std::strcmp(name, "workspace_blocks_fresh") == 0) {
+        std::lock_guard<std::mutex> lk(g_block_mutex);
+        *value = std::strcmp(name, "workspace_blocks_reused") == 0 ? g_block_reuses : g_block_fresh;
+    }
     else return fail(GPMPC_EINVAL, "unknown counter '%s'", name);
     return GPMPC_OK;
 }

@@ -108,7 +108,9 @@ int gpmpc_synchronize(gpmpc_gp* h);
  * in which case THAT factorisation is repeated on the single-queue path (same result) and the next call tries again;
  * after three consecutive time-outs the handle stays on the single-queue path for 64 fits.  Handles of one process
  * take turns for the factorisation itself.  Counters: "handoff_timeouts", "chained_factorisations",
- * "single_queue_factorisations". */
+ * "single_queue_factorisations"; process-wide: "workspace_blocks_fresh" / "workspace_blocks_reused" (the N x N blocks
+ * of a workspace, >= 64 MB, come from size classes and return to a free list: gpmpc_append at large N re-uses what the
+ * previous append gave back instead of paying for fresh multi-GB allocations). */
 int gpmpc_get_counter(gpmpc_gp* h, const char* name, long* value);
 int gpmpc_profile_enable(gpmpc_gp* h, int enable);   /* HIP-event brackets per phase on the handle's stream */
 int gpmpc_profile_read(gpmpc_gp* h, int phase, double* total_ms, long* launches, int reset);

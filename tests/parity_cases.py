@@ -370,6 +370,38 @@ def check_append(lib, N0, n, d=4, Ny=2, sn=0.1, seed=5):
     h.close()
 
 
+def check_append_series(lib, N0=3000, d=4, seed=21):
+    """A run of appends at a size whose N x N blocks (>= 64 MB) go through the size-class free list (gpmpc_api.hip,
+    block_alloc): every new workspace after the second is built in blocks the previous append gave back -- while a second
+    model keeps fitting and predicting in between, so a block handed out twice would show.  Factors and predictions
+    against the oracle's full fit after every step."""
+    steps = (64, 10, 64, 30, 20)          # Np = 3072, 3136, 3200, 3200, 3200: one size class (72-82 MB -> 84 MB blocks)
+    p = go.synthetic_problem(N0 + sum(steps), d, 1, 20, seed=seed, sn=0.1)
+    X, Y, H, Z = p['X'], p['Y'], p['hyper'], p['Z']
+    q = go.synthetic_problem(2980, d, 1, 20, seed=seed + 1, sn=0.1)
+    h = Handle(lib, X[:N0], Y[:N0])
+    other = Handle(lib, q['X'], q['Y'])
+    assert np.all(h.fit(H) == 0) and np.all(other.fit(q['hyper']) == 0)
+    om_other, ov_other = other.predict_mean_var(q['Z'])
+    reused0, n = h.counter('workspace_blocks_reused'), N0
+    for k, m in enumerate(steps):
+        assert np.all(h.append(X[n:n + m], Y[n:n + m]) == 0)
+        n += m
+        assert np.all(other.fit(q['hyper']) == 0)                       # takes and returns nothing, but runs on the same device
+        m1, v1 = other.predict_mean_var(q['Z'])
+        assert np.array_equal(m1, om_other) and np.array_equal(v1, ov_other)
+        o = go.fit(X[:n], Y[:n], H, want_invK=False)
+        assert relF(h.get_factors()['chol'][0], o['chol'][0]) <= 1e-10, k
+        mean, var = h.predict_mean_var(Z)
+        om, ov, _ = go.mean_var_jac(Z, X[:n], H, o['alpha'], o['chol'], False)
+        assert np.max(np.abs(mean - om) / mean_scale(X[:n], Z, H, o['alpha'])) <= 1e-10, k
+        assert np.max(np.abs(var - ov) / H[:, d] ** 2) <= 1e-10, k
+    # K, L and L^-1 of every workspace after the first new one come from the list (the scratch W is below the 64 MB threshold)
+    assert h.counter('workspace_blocks_reused') - reused0 >= 3 * (len(steps) - 1), h.counter('workspace_blocks_reused') - reused0
+    h.close()
+    other.close()
+
+
 def check_append_after_set_factors(lib, N0=300, n=10, d=4, Ny=2, seed=8):
     """load_model path followed by update_data_all (gp_class.py:58-66, :474-550): `gpmpc_set_factors` never runs the
     jitter rule, so the strip update must find a defined (zero) jitter on the device.  Compared with a full refit."""

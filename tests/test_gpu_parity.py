@@ -133,6 +133,10 @@ def test_append(lib):
     pc.check_append(lib, N0=2000, n=90, d=6, Ny=1, sn=1e-2)
 
 
+def test_append_series_through_the_block_list(lib):
+    pc.check_append_series(lib)
+
+
 def test_append_after_set_factors_and_rollback(lib):
     pc.check_append_after_set_factors(lib)
     pc.check_append_after_set_factors(lib, N0=2000, n=90, d=6, Ny=1)
