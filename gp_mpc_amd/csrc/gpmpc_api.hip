@@ -874,6 +874,8 @@ struct gpmpc_gp {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_info = nullptr;       // "the factorisation's status words are on the host" (factor_with_jitter)
     int* pin = nullptr;                 // pinned host buffer for them
+    double* io_dev = nullptr;           // host-pointer mode, small calls: one device block [inputs | outputs] ...
+    double* io_pin = nullptr;           // ... and its pinned host mirror: ONE copy each way instead of one per array
     size_t pin_ints = 0;
     hipStream_t aux_stream = nullptr, bulk_stream = nullptr;
     std::vector<hipEvent_t> seg_events;
@@ -1099,6 +1101,8 @@ int gpmpc_destroy(gpmpc_gp* h) {
     for (auto e : h->prof.pool) hipEventDestroy(e);
     if (h->ev_info) hipEventDestroy(h->ev_info);
     if (h->pin) hipHostFree(h->pin);
+    if (h->io_pin) hipHostFree(h->io_pin);
+    hipFree(h->io_dev);
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
     if (h->ev_join) hipEventDestroy(h->ev_join);
     for (auto e : h->seg_events) hipEventDestroy(e);
@@ -1633,6 +1637,53 @@ static int chunk_size(const gpmpc_gp* h) {
     return (int)c;
 }
 
+// Host-pointer calls with little data (an MPC's shooting nodes at the reference's model sizes): the inputs are staged in
+// a pinned buffer and go up in one copy, every output is a slice of one device block and comes down in one copy.  With a
+// pageable hipMemcpyAsync per array a 'ME' prediction at N = 200 took 71 us of which the kernels are 30
+// (tools/gpu_small_latency.sh); packed it takes one upload, the launches, one download and one synchronisation.
+constexpr size_t IO_PACK_DOUBLES = 32768;      // 256 KB
+struct IoPack {
+    gpmpc_gp* h;
+    bool on = false;
+    size_t nin = 0, n = 0;
+    struct Out { double* host; size_t off, cnt; };
+    std::vector<Out> outs;
+    static size_t pad(size_t c) { return (c + 1) & ~(size_t)1; }     // slices stay 16-byte aligned
+    // total: doubles of all inputs and outputs (each padded); false -> the caller copies array by array as before
+    int begin(gpmpc_gp* hh, bool host, size_t total) {
+        h = hh;
+        on = host && total <= IO_PACK_DOUBLES;
+        if (!on) return GPMPC_OK;
+        if (!h->io_dev) HIPCHK(hipMalloc(&h->io_dev, IO_PACK_DOUBLES * sizeof(double)));
+        if (!h->io_pin) HIPCHK(hipHostMalloc((void**)&h->io_pin, IO_PACK_DOUBLES * sizeof(double), hipHostMallocDefault));
+        return GPMPC_OK;
+    }
+    const double* in(const double* src, size_t cnt) {                  // call for all inputs first, then upload()
+        std::memcpy(h->io_pin + n, src, cnt * sizeof(double));
+        const double* dptr = h->io_dev + n;
+        n += pad(cnt);
+        nin = n;
+        return dptr;
+    }
+    int upload() {
+        if (nin) HIPCHK(hipMemcpyAsync(h->io_dev, h->io_pin, nin * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        return GPMPC_OK;
+    }
+    double* out(double* host_dst, size_t cnt) {                        // device slice for an output (nullptr for a NULL output)
+        if (!host_dst) return nullptr;
+        outs.push_back({host_dst, n, cnt});
+        double* dptr = h->io_dev + n;
+        n += pad(cnt);
+        return dptr;
+    }
+    int download() {                                                   // one copy, one synchronisation, scatter on the host
+        if (n > nin) HIPCHK(hipMemcpyAsync(h->io_pin + nin, h->io_dev + nin, (n - nin) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        for (const Out& o : outs) std::memcpy(o.host, h->io_pin + o.off, o.cnt * sizeof(double));
+        return GPMPC_OK;
+    }
+};
+
 static int ensure_scratch(gpmpc_gp* h, int B) {
     const int need = round_up(B < chunk_size(h) ? B : chunk_size(h), 64);
     if (need <= h->Bcap) return GPMPC_OK;
@@ -1760,18 +1811,34 @@ static int predict_driver(gpmpc_gp* h, int method, int B, const double* Z, const
         const int nb = (B - b0 < h->Bcap) ? B - b0 : h->Bcap;
         const double* dZ = Z + (size_t)b0 * d;
         const double* dS = Sigma ? Sigma + (size_t)b0 * d * d : nullptr;
-        if (host) {
-            HIPCHK(hipMemcpyAsync(h->Z, dZ, (size_t)nb * d * sizeof(double), hipMemcpyHostToDevice, h->stream));
-            dZ = h->Z;
-            if (dS && cov && need_sigma) {
-                HIPCHK(hipMemcpyAsync(h->Sigma, dS, (size_t)nb * d * d * sizeof(double), hipMemcpyHostToDevice, h->stream));
-                dS = h->Sigma;
+        const bool up_sigma = dS && cov && need_sigma;
+        const size_t cZ = (size_t)nb * d, cS = (size_t)nb * d * d, cM = (size_t)nb * Ny, cJ = cM * d, cC = cM * Ny;
+        IoPack io;
+        CHK(io.begin(h, host, IoPack::pad(cZ) + (up_sigma ? IoPack::pad(cS) : 0) + (mean ? IoPack::pad(cM) : 0) +
+                                  (var ? IoPack::pad(cM) : 0) + (J ? IoPack::pad(cJ) : 0) + (cov ? IoPack::pad(cC) : 0)));
+        double *oMean, *oVar, *oJ, *oCov;
+        if (io.on) {
+            dZ = io.in(dZ, cZ);
+            if (up_sigma) dS = io.in(dS, cS);
+            CHK(io.upload());
+            oMean = io.out(mean ? mean + (size_t)b0 * Ny : nullptr, cM);
+            oVar = io.out(var ? var + (size_t)b0 * Ny : nullptr, cM);
+            oJ = io.out(J ? J + (size_t)b0 * Ny * d : nullptr, cJ);
+            oCov = io.out(cov ? cov + (size_t)b0 * Ny * Ny : nullptr, cC);
+        } else {
+            if (host) {
+                HIPCHK(hipMemcpyAsync(h->Z, dZ, cZ * sizeof(double), hipMemcpyHostToDevice, h->stream));
+                dZ = h->Z;
+                if (up_sigma) {
+                    HIPCHK(hipMemcpyAsync(h->Sigma, dS, cS * sizeof(double), hipMemcpyHostToDevice, h->stream));
+                    dS = h->Sigma;
+                }
             }
+            oMean = mean ? (host ? h->mean : mean + (size_t)b0 * Ny) : nullptr;
+            oVar = var ? (host ? h->var : var + (size_t)b0 * Ny) : nullptr;
+            oJ = J ? (host ? h->J : J + (size_t)b0 * Ny * d) : nullptr;
+            oCov = cov ? (host ? h->cov : cov + (size_t)b0 * Ny * Ny) : nullptr;
         }
-        double* oMean = mean ? (host ? h->mean : mean + (size_t)b0 * Ny) : nullptr;
-        double* oVar = var ? (host ? h->var : var + (size_t)b0 * Ny) : nullptr;
-        double* oJ = J ? (host ? h->J : J + (size_t)b0 * Ny * d) : nullptr;
-        double* oCov = cov ? (host ? h->cov : cov + (size_t)b0 * Ny * Ny) : nullptr;
         if (moments) {
             CHK(predict_moments_chunk(h, method, nb, dZ, dS, oMean ? oMean : h->mean, oCov));
         } else {
@@ -1786,7 +1853,9 @@ static int predict_driver(gpmpc_gp* h, int method, int B, const double* Z, const
                                    vbuf, jbuf, ta ? dS : (const double*)nullptr, oCov, nb, Ny, d);
             }
         }
-        if (host) {
+        if (io.on) {
+            CHK(io.download());
+        } else if (host) {
             if (mean) HIPCHK(hipMemcpyAsync(mean + (size_t)b0 * Ny, h->mean, (size_t)nb * Ny * sizeof(double), hipMemcpyDeviceToHost, h->stream));
             if (var) HIPCHK(hipMemcpyAsync(var + (size_t)b0 * Ny, h->var, (size_t)nb * Ny * sizeof(double), hipMemcpyDeviceToHost, h->stream));
             if (J) HIPCHK(hipMemcpyAsync(J + (size_t)b0 * Ny * d, h->J, (size_t)nb * Ny * d * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -1925,15 +1994,32 @@ extern "C" int gpmpc_predict_sens(gpmpc_gp* h, int B, const double* Z, double* m
     for (int b0 = 0; b0 < B; b0 += h->Bcap) {
         const int nb = (B - b0 < h->Bcap) ? B - b0 : h->Bcap;
         const double* dZ = Z + (size_t)b0 * d;
-        if (host) {
-            HIPCHK(hipMemcpyAsync(h->Z, dZ, (size_t)nb * d * sizeof(double), hipMemcpyHostToDevice, h->stream));
-            dZ = h->Z;
+        const size_t cZ = (size_t)nb * d, cM = (size_t)nb * Ny, cJ = cM * d, cH = cJ * d;
+        IoPack io;
+        CHK(io.begin(h, host, IoPack::pad(cZ) + (mean ? IoPack::pad(cM) : 0) + (var ? IoPack::pad(cM) : 0) + (J ? IoPack::pad(cJ) : 0) +
+                                  (Hm ? IoPack::pad(cH) : 0) + (dvar ? IoPack::pad(cJ) : 0)));
+        double *oMean, *oVar, *oJ, *oH, *oV;
+        if (io.on) {
+            dZ = io.in(dZ, cZ);
+            CHK(io.upload());
+            oMean = io.out(mean ? mean + (size_t)b0 * Ny : nullptr, cM);
+            oVar = io.out(var ? var + (size_t)b0 * Ny : nullptr, cM);
+            oJ = io.out(J ? J + (size_t)b0 * Ny * d : nullptr, cJ);
+            oH = io.out(Hm ? Hm + (size_t)b0 * Ny * d * d : nullptr, cH);
+            oV = io.out(dvar ? dvar + (size_t)b0 * Ny * d : nullptr, cJ);
+            if (!oH) oH = h->sensH;
+            if (!oV) oV = h->sensV;
+        } else {
+            if (host) {
+                HIPCHK(hipMemcpyAsync(h->Z, dZ, cZ * sizeof(double), hipMemcpyHostToDevice, h->stream));
+                dZ = h->Z;
+            }
+            oMean = mean ? (host ? h->mean : mean + (size_t)b0 * Ny) : nullptr;
+            oVar = var ? (host ? h->var : var + (size_t)b0 * Ny) : nullptr;
+            oJ = J ? (host ? h->J : J + (size_t)b0 * Ny * d) : nullptr;
+            oH = host ? h->sensH : (Hm ? Hm + (size_t)b0 * Ny * d * d : h->sensH);
+            oV = host ? h->sensV : (dvar ? dvar + (size_t)b0 * Ny * d : h->sensV);
         }
-        double* oMean = mean ? (host ? h->mean : mean + (size_t)b0 * Ny) : nullptr;
-        double* oVar = var ? (host ? h->var : var + (size_t)b0 * Ny) : nullptr;
-        double* oJ = J ? (host ? h->J : J + (size_t)b0 * Ny * d) : nullptr;
-        double* oH = host ? h->sensH : (Hm ? Hm + (size_t)b0 * Ny * d * d : h->sensH);
-        double* oV = host ? h->sensV : (dvar ? dvar + (size_t)b0 * Ny * d : h->sensV);
         CHK(predict_chunk(h, nb, dZ, oMean, second ? (oVar ? oVar : h->var) : oVar, oJ, second ? h->VT : nullptr));
         if (second) {
             const int Bp = round_up(nb, 32);            // the layout predict_chunk left in KsT and VT
@@ -1965,7 +2051,9 @@ extern "C" int gpmpc_predict_sens(gpmpc_gp* h, int B, const double* Z, double* m
                 hipLaunchKernelGGL(mean_add_kernel, dim3((unsigned)(((long)nb * Ny + 255) / 256)), dim3(256), 0, cx.stream, dZ,
                                    h->mpar, (double*)nullptr, (double*)nullptr, oH, h->mean_kind, nb, Ny, d);
         }
-        if (host) {
+        if (io.on) {
+            CHK(io.download());
+        } else if (host) {
             if (mean) HIPCHK(hipMemcpyAsync(mean + (size_t)b0 * Ny, h->mean, (size_t)nb * Ny * sizeof(double), hipMemcpyDeviceToHost, h->stream));
             if (var) HIPCHK(hipMemcpyAsync(var + (size_t)b0 * Ny, h->var, (size_t)nb * Ny * sizeof(double), hipMemcpyDeviceToHost, h->stream));
             if (J) HIPCHK(hipMemcpyAsync(J + (size_t)b0 * Ny * d, h->J, (size_t)nb * Ny * d * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -2012,7 +2100,16 @@ extern "C" int gpmpc_predict_em_sens(gpmpc_gp* h, int B, const double* Z, const 
     int rc = GPMPC_OK;
     auto run = [&]() -> int {
         const double *dZ = Z, *dS = Sigma;
-        if (host) {
+        // few inputs (an MPC's nodes): [Z | Sigma] goes up and [mean .. dcov_dS] comes down through the pinned mirror, one copy each
+        const size_t nOut = nM + nC + n1 + n2 + n3 + n4;
+        IoPack io;
+        CHK(io.begin(h, host, std::max(nZ + nS, nOut)));
+        if (io.on) {
+            std::memcpy(h->io_pin, Z, nZ * sizeof(double));
+            std::memcpy(h->io_pin + nZ, Sigma, nS * sizeof(double));
+            HIPCHK(hipMemcpyAsync(bZ, h->io_pin, (nZ + nS) * sizeof(double), hipMemcpyHostToDevice, h->stream));
+            dZ = bZ; dS = bS;
+        } else if (host) {
             HIPCHK(hipMemcpyAsync(bZ, Z, nZ * sizeof(double), hipMemcpyHostToDevice, h->stream));
             HIPCHK(hipMemcpyAsync(bS, Sigma, nS * sizeof(double), hipMemcpyHostToDevice, h->stream));
             dZ = bZ; dS = bS;
@@ -2048,7 +2145,15 @@ extern "C" int gpmpc_predict_em_sens(gpmpc_gp* h, int B, const double* Z, const 
                                o3 + (size_t)b0 * Ny * Ny * d, o4 + (size_t)b0 * Ny * Ny * d * d, nb, Ny, d, b0);
             HIPCHK(hipGetLastError());
         }
-        if (host) {
+        if (io.on) {
+            // (the upload has been consumed: every kernel above is ordered behind it on the stream, and this copy behind them)
+            HIPCHK(hipMemcpyAsync(h->io_pin, bM, nOut * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            auto take = [&](double* dst, const double* dev_src, size_t n) {
+                if (dst) std::memcpy(dst, h->io_pin + (dev_src - bM), n * sizeof(double));
+            };
+            take(mean, bM, nM); take(cov, bC, nC); take(dmean_dz, b1, n1); take(dmean_dS, b2, n2); take(dcov_dz, b3, n3); take(dcov_dS, b4, n4);
+        } else if (host) {
             auto down = [&](double* dst, const double* src, size_t n) {
                 return dst ? hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyDeviceToHost, h->stream) : hipSuccess;
             };
