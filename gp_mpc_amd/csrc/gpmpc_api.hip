@@ -874,6 +874,12 @@ struct gpmpc_gp {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_info = nullptr;       // "the factorisation's status words are on the host" (factor_with_jitter)
     int* pin = nullptr;                 // pinned host buffer for them
+    double* roll_dev = nullptr;         // gpmpc_rollout: device staging [inputs | trajectories | scratch] (grow-only) ...
+    double* roll_pin = nullptr;         // ... and its pinned mirror
+    size_t roll_cap = 0;
+    struct RollGraph { std::vector<long> key; hipGraphExec_t exec = nullptr; hipGraph_t graph = nullptr; };
+    std::vector<RollGraph> roll_graphs; // captured T-step loops (launch-bound at small N), keyed by everything the launches depend on
+    std::vector<long> roll_warm;        // key of the last plain run: a loop is captured only after it ran once uncaptured
     double* io_dev = nullptr;           // host-pointer mode, small calls: one device block [inputs | outputs] ...
     double* io_pin = nullptr;           // ... and its pinned host mirror: ONE copy each way instead of one per array
     size_t pin_ints = 0;
@@ -1085,6 +1091,17 @@ int gpmpc_create(int device, int N, int d, int Ny, const double* X, const double
     return GPMPC_OK;
 }
 
+static void drop_roll_graphs(gpmpc_gp* h) {
+#ifndef GPMPC_EMULATED
+    for (auto& g : h->roll_graphs) {
+        if (g.exec) hipGraphExecDestroy(g.exec);
+        if (g.graph) hipGraphDestroy(g.graph);
+    }
+#endif
+    h->roll_graphs.clear();
+    h->roll_warm.clear();
+}
+
 int gpmpc_destroy(gpmpc_gp* h) {
     if (!h) return GPMPC_OK;
     hipSetDevice(h->device);
@@ -1103,6 +1120,9 @@ int gpmpc_destroy(gpmpc_gp* h) {
     if (h->pin) hipHostFree(h->pin);
     if (h->io_pin) hipHostFree(h->io_pin);
     hipFree(h->io_dev);
+    drop_roll_graphs(h);
+    if (h->roll_pin) hipHostFree(h->roll_pin);
+    hipFree(h->roll_dev);
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
     if (h->ev_join) hipEventDestroy(h->ev_join);
     for (auto e : h->seg_events) hipEventDestroy(e);
@@ -1905,59 +1925,124 @@ static int rollout_impl(gpmpc_gp* h, int method, int T, const double* z0, const 
         CHK(compute_invK(h->cx(), h->ws));
         h->have_invK = true;
     }
-    // device staging: [z | Sigma | sa | sb | U | mean (T) | cov (T) | var | J | Kz | k0 | Kc]
+    // device staging (grow-only, with a pinned mirror): inputs [z | Sigma | sa | sb | Kz | k0 | Kc | U], then the
+    // trajectories [mean (T) | cov (T)] and scratch [var | J]: one copy up, one copy down ([U |] mean | cov)
     const int nu1 = std::max(Nu, 1);
     const size_t nz = d, nS = (size_t)d * d, nU = (size_t)T * nu1, nM = (size_t)T * Ny, nC = (size_t)T * Ny * Ny;
     const size_t nK = (size_t)nu1 * Ny;
-    const size_t total = nz + nS + 2 * Ny + nU + nM + nC + Ny + (size_t)Ny * d + 2 * nK + nu1;
-    double* buf = nullptr;
-    HIPCHK(hipMalloc(&buf, total * sizeof(double)));
-    double *dz = buf, *dS = dz + nz, *dsa = dS + nS, *dsb = dsa + Ny, *dU = dsb + Ny, *dM = dU + nU, *dC = dM + nM,
-           *dV = dC + nC, *dJ = dV + Ny, *dKz = dJ + (size_t)Ny * d, *dk0 = dKz + nK, *dKc = dk0 + nu1;
-    std::vector<double> one(Ny, 1.0), zero(Ny, 0.0);
-    auto up = [&](double* dst, const double* src, size_t n) {
-        return hipMemcpyAsync(dst, src, n * sizeof(double), hipMemcpyHostToDevice, h->stream);
-    };
-    hipError_t e = up(dz, z0, nz);
-    if (e == hipSuccess) e = up(dS, Sigma0, nS);
-    if (e == hipSuccess) e = up(dsa, sa ? sa : one.data(), Ny);
-    if (e == hipSuccess) e = up(dsb, sb ? sb : zero.data(), Ny);
-    if (e == hipSuccess && !fb && Nu > 0) e = up(dU, U, (size_t)T * Nu);
-    if (e == hipSuccess && fb) e = up(dKz, Kz, nK);
-    if (e == hipSuccess && fb) e = up(dk0, k0, Nu);
-    if (e == hipSuccess && fb) e = up(dKc, Kc, nK);
-    if (e == hipSuccess && fb) e = up(dU, z0 + Ny, Nu);          // the first control comes with z0
-    int rc = GPMPC_OK;
-    if (e != hipSuccess) rc = fail(GPMPC_EHIP, "%s", hipGetErrorString(e));
-    for (int t = 0; t < T && rc == GPMPC_OK; ++t) {
-        if (t > 0)
-            hipLaunchKernelGGL(rollout_feed_kernel, dim3(1), dim3(64), 0, h->stream, dM + (size_t)(t - 1) * Ny,
-                               dC + (size_t)(t - 1) * Ny * Ny, dU + (size_t)t * nu1, dsa, dsb, dz, dS, Ny, d,
-                               fb ? dKz : (const double*)nullptr, fb ? dk0 : (const double*)nullptr,
-                               fb ? dKc : (const double*)nullptr, fb ? dU + (size_t)t * nu1 : (double*)nullptr);
-        double* oM = dM + (size_t)t * Ny;
-        double* oC = dC + (size_t)t * Ny * Ny;
-        if (moments) {
-            rc = predict_moments_chunk(h, method, 1, dz, dS, oM, oC);
-        } else {
-            const bool ta = method == GPMPC_TA;
-            rc = predict_chunk(h, 1, dz, oM, dV, ta ? dJ : nullptr);
-            if (rc == GPMPC_OK)
-                hipLaunchKernelGGL(cov_assemble_kernel, dim3((unsigned)((Ny * Ny + 255) / 256)), dim3(256), 0, h->stream, dV, dJ,
-                                   ta ? dS : (const double*)nullptr, oC, 1, Ny, d);
+    const size_t nIn = nz + nS + 2 * Ny + 2 * nK + nu1 + nU;
+    const size_t total = nIn + nM + nC + Ny + (size_t)Ny * d;
+    if (total > h->roll_cap) {
+        HIPCHK(hipStreamSynchronize(h->stream));
+        drop_roll_graphs(h);
+        hipFree(h->roll_dev);
+        if (h->roll_pin) hipHostFree(h->roll_pin);
+        h->roll_dev = h->roll_pin = nullptr;
+        h->roll_cap = 0;
+        HIPCHK(hipMalloc(&h->roll_dev, total * sizeof(double)));
+        HIPCHK(hipHostMalloc((void**)&h->roll_pin, total * sizeof(double), hipHostMallocDefault));
+        h->roll_cap = total;
+    }
+    double* buf = h->roll_dev;
+    double *dz = buf, *dS = dz + nz, *dsa = dS + nS, *dsb = dsa + Ny, *dKz = dsb + Ny, *dk0 = dKz + nK, *dKc = dk0 + nu1,
+           *dU = dKc + nK, *dM = dU + nU, *dC = dM + nM, *dV = dC + nC, *dJ = dV + Ny;
+    {
+        double* pz = h->roll_pin;
+        auto put = [&](double* dev_dst, const double* src, size_t n) { std::memcpy(pz + (dev_dst - buf), src, n * sizeof(double)); };
+        std::memset(pz, 0, nIn * sizeof(double));
+        put(dz, z0, nz);
+        put(dS, Sigma0, nS);
+        for (int a = 0; a < Ny; ++a) pz[(dsa - buf) + a] = sa ? sa[a] : 1.0;
+        if (sb) put(dsb, sb, Ny);
+        if (!fb && Nu > 0) put(dU, U, (size_t)T * Nu);
+        if (fb) {
+            put(dKz, Kz, nK);
+            put(dk0, k0, Nu);
+            put(dKc, Kc, nK);
+            put(dU, z0 + Ny, Nu);                                  // the first control comes with z0
         }
     }
+    HIPCHK(hipMemcpyAsync(buf, h->roll_pin, nIn * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    int rc = GPMPC_OK;
+    auto enqueue_steps = [&]() -> int {
+        int r = GPMPC_OK;
+        for (int t = 0; t < T && r == GPMPC_OK; ++t) {
+            if (t > 0)
+                hipLaunchKernelGGL(rollout_feed_kernel, dim3(1), dim3(64), 0, h->stream, dM + (size_t)(t - 1) * Ny,
+                                   dC + (size_t)(t - 1) * Ny * Ny, dU + (size_t)t * nu1, dsa, dsb, dz, dS, Ny, d,
+                                   fb ? dKz : (const double*)nullptr, fb ? dk0 : (const double*)nullptr,
+                                   fb ? dKc : (const double*)nullptr, fb ? dU + (size_t)t * nu1 : (double*)nullptr);
+            double* oM = dM + (size_t)t * Ny;
+            double* oC = dC + (size_t)t * Ny * Ny;
+            if (moments) {
+                r = predict_moments_chunk(h, method, 1, dz, dS, oM, oC);
+            } else {
+                const bool ta = method == GPMPC_TA;
+                r = predict_chunk(h, 1, dz, oM, dV, ta ? dJ : nullptr);
+                if (r == GPMPC_OK)
+                    hipLaunchKernelGGL(cov_assemble_kernel, dim3((unsigned)((Ny * Ny + 255) / 256)), dim3(256), 0, h->stream, dV, dJ,
+                                       ta ? dS : (const double*)nullptr, oC, 1, Ny, d);
+            }
+        }
+        return r;
+    };
+    // The loop is 6-9 dependent launches per step: at the reference's model sizes that is all the time there is (26 us per
+    // 'ME' step at N = 200).  After one plain run with the same key -- every lazy allocation and kernel attribute is then in
+    // place -- the T-step loop is captured into a hipGraph and replayed; the key holds every address and size a launch bakes in.
+    bool done = false;
+    if (moments) CHK(ensure_beta(h));        // lazily refreshed after a fit: must not hide inside (or be missing from) a captured loop
+#ifndef GPMPC_EMULATED
+    static const bool use_graph = !(getenv("GPMPC_ROLLOUT_GRAPH") && atoi(getenv("GPMPC_ROLLOUT_GRAPH")) == 0);
+    static const int graph_max_np = getenv("GPMPC_ROLLOUT_GRAPH_NP") ? atoi(getenv("GPMPC_ROLLOUT_GRAPH_NP")) : 2048;
+    if (use_graph && !h->prof.on && h->Np <= graph_max_np) {
+        const std::vector<long> key = {method, T, fb ? 1 : 0, Nu, h->N, h->Np, Ny, d, h->mean_kind, h->mean_add ? 1 : 0, h->Bcap,
+                                       (long)buf, (long)h->XT, (long)h->ws.hyper, (long)h->ws.alpha, (long)h->ws.Inv,
+                                       (long)h->ws.InvK, (long)h->beta, (long)h->KsT, (long)h->meanT, (long)h->part,
+                                       (long)h->ccpart, (long)h->em, h->emBytes, (long)h->UT, (long)h->mpar, (long)h->stream};
+        gpmpc_gp::RollGraph* g = nullptr;
+        for (auto& e : h->roll_graphs)
+            if (e.key == key) g = &e;
+        if (!g && h->roll_warm == key) {
+            gpmpc_gp::RollGraph ng;
+            if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                const int r = enqueue_steps();
+                const hipError_t ee = hipStreamEndCapture(h->stream, &ng.graph);
+                if (r == GPMPC_OK && ee == hipSuccess && ng.graph && hipGraphInstantiate(&ng.exec, ng.graph, nullptr, nullptr, 0) == hipSuccess) {
+                    ng.key = key;
+                    if (h->roll_graphs.size() >= 8) drop_roll_graphs(h);
+                    h->roll_graphs.push_back(ng);
+                    g = &h->roll_graphs.back();
+                } else {
+                    if (ng.graph) hipGraphDestroy(ng.graph);
+                    (void)hipGetLastError();
+                }
+            }
+        }
+        if (g) {
+            HIPCHK(hipGraphLaunch(g->exec, h->stream));
+            done = true;
+        } else {
+            h->roll_warm = key;
+        }
+    }
+#endif
+    if (!done) rc = enqueue_steps();
     if (rc == GPMPC_OK) {
-        e = hipMemcpyAsync(mean, dM, nM * sizeof(double), hipMemcpyDeviceToHost, h->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(cov, dC, nC * sizeof(double), hipMemcpyDeviceToHost, h->stream);
-        if (e == hipSuccess && Uout && Nu > 0) e = hipMemcpyAsync(Uout, dU, (size_t)T * Nu * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+        const bool wantU = Uout && Nu > 0;
+        double* first = wantU ? dU : dM;
+        hipError_t e = hipMemcpyAsync(h->roll_pin + (first - buf), first, ((wantU ? nU : 0) + nM + nC) * sizeof(double),
+                                      hipMemcpyDeviceToHost, h->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
         if (e == hipSuccess) e = hipGetLastError();
-        if (e != hipSuccess) rc = fail(GPMPC_EHIP, "%s", hipGetErrorString(e));
+        if (e != hipSuccess) return fail(GPMPC_EHIP, "%s", hipGetErrorString(e));
+        std::memcpy(mean, h->roll_pin + (dM - buf), nM * sizeof(double));
+        std::memcpy(cov, h->roll_pin + (dC - buf), nC * sizeof(double));
+        if (wantU) {
+            if (nu1 == Nu) std::memcpy(Uout, h->roll_pin + (dU - buf), (size_t)T * Nu * sizeof(double));
+        }
     } else {
         hipStreamSynchronize(h->stream);
     }
-    hipFree(buf);
     return rc;
 }
 

@@ -764,6 +764,37 @@ def check_rollout_vs_host_loop(h, p, Ny, d, T, em_tol=(1e-9, 1e-6)):
             assert np.max(np.abs(m[0] - m_me[0])) <= 10 * np.abs(S0).max() * max(1.0, np.abs(m_me[0]).max())
 
 
+def check_rollout_replay(lib, N=150, Ny=2, d=3, T=6, seed=31):
+    """Repeated identical roll-outs go through the captured hipGraph from the third call on (gpmpc_api.hip, rollout_impl):
+    the replays must give the bits of the first, plain run; new inputs must be picked up by a replay (they live in the
+    staging block, not in the graph); so must a refit with other hyper-parameters (same buffers, new contents) -- checked
+    against the host-driven loop again; and a different horizon must not hit the cached loop."""
+    p = go.synthetic_problem(N, d, Ny, 8, seed=seed, sn=0.1)
+    h = Handle(lib, p['X'], p['Y'])
+    assert np.all(h.fit(p['hyper'], want_invK=True) == 0)
+    x0, U, S0 = rollout_inputs(p, Ny, d, T)
+    z0 = np.concatenate([x0, U[0]])
+    for method in ('ME', 'TA', 'EM'):
+        first = h.rollout(method, z0, U, S0)
+        for _ in range(4):
+            again = h.rollout(method, z0, U, S0)
+            assert np.array_equal(first[0], again[0]) and np.array_equal(first[1], again[1]), method
+        z1 = z0.copy()
+        z1[0] += 0.05
+        moved = h.rollout(method, z1, 0.5 * U, S0)
+        assert not np.array_equal(moved[0], first[0])
+        back = h.rollout(method, z0, U, S0)
+        assert np.array_equal(first[0], back[0]) and np.array_equal(first[1], back[1]), method
+        short = h.rollout(method, z0, U[:T - 2], S0)
+        assert np.array_equal(short[0], first[0][:T - 2]) and np.array_equal(short[1], first[1][:T - 2]), method
+    H2 = p['hyper'].copy()
+    H2[:, :d] *= 1.3
+    assert np.all(h.fit(H2, want_invK=True) == 0)
+    for _ in range(3):
+        check_rollout_vs_host_loop(h, p, Ny, d, T)
+    h.close()
+
+
 def check_rollout_vs_oracle(lib, N, Ny, d, T, seed=77, uscale=0.3):
     """T-step propagation (EM / TA / ME) on the device against the oracle (restatement of gp_class.py:777-804 over
     gp_exact_moment / build_gp / build_TA_cov) on a well-conditioned model (sn = 0.1), in two ways:

@@ -189,3 +189,7 @@ def test_emu_training_native(emu, train_small):
 
 def test_emu_random_shapes(emu):
     pc.check_random_shapes(emu, n_cases=8, nmax=160)
+
+
+def test_emu_rollout_replay(emu):
+    pc.check_rollout_replay(emu)

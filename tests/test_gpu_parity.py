@@ -213,3 +213,7 @@ def test_c3_size_properties(lib):
     for b in range(4):
         assert np.array_equal(cS[b], cS[b].T) and np.linalg.eigvalsh(cS[b]).min() > -1e-8
     h.close()
+
+
+def test_rollout_replay(lib):
+    pc.check_rollout_replay(lib)

@@ -24,7 +24,10 @@ for (N, d, Ny) in ((200, 5, 3), (60, 6, 4), (1000, 5, 3)):
         timeit('predict EM B=%d' % B, lambda: h.predict('EM', Z, S))
         timeit('predict_sens B=%d' % B, lambda: h.predict_sens(Z))
         timeit('predict_em_sens B=%d' % B, lambda: h.predict_em_sens(Z, S, want_cov=False), 50)
-    U = np.zeros((30, 0))
+    U = np.tile(p['Z'][0, Ny:], (30, 1))
+    S0 = np.eye(d) * 1e-6
+    for m in ('ME', 'TA', 'EM'):
+        timeit('rollout %s, 30 steps' % m, lambda: h.rollout(m, p['Z'][0], U, S0), 30)
     h.close()
 PY
 python /tmp/lat.py
