@@ -479,6 +479,30 @@ def check_sensitivities(lib, g, nprobe=12):
     h.close()
 
 
+def check_sensitivities_batches(lib, N=330, d=4, Ny=2, seed=41):
+    """gpmpc_predict_sens over the batch sizes that take different routes for V = L^-1 Ks and U = L^-T V (32- and
+    64-column streaming tiles with the transposed store; beyond 64 columns the row-major product), on a model with
+    several 64-row tiles so that the triangular K ranges of both passes matter.  Against the oracle's closed forms."""
+    p = go.synthetic_problem(N, d, Ny, 100, seed=seed, sn=0.1)
+    X, Y, H, Z = p['X'], p['Y'], p['hyper'], p['Z']
+    sf2, ell_min = H[:, d] ** 2, H[:, :d].min(axis=1)
+    h = Handle(lib, X, Y)
+    assert np.all(h.fit(H) == 0)
+    f = h.get_factors()
+    oH, odv = go.mean_var_sens(Z, X, H, f['alpha'], f['chol'])
+    om, ov, oJ = go.mean_var_jac(Z, X, H, f['alpha'], f['chol'])
+    ms = mean_scale(X, Z, H, f['alpha'])
+    for B in (3, 33, 64, 70, 100):
+        mean, var, J, Hm, dvar = h.predict_sens(Z[:B])
+        assert np.max(np.abs(mean - om[:B]) / ms[:B]) <= 1e-10 and np.max(np.abs(var - ov[:B]) / sf2) <= 1e-10, B
+        assert np.max(np.abs(J - oJ[:B]) / (ms[:B] / ell_min)[..., None]) <= 1e-10, B
+        assert np.max(np.abs(Hm - oH[:B]) / (ms[:B] / ell_min ** 2)[..., None, None]) <= 1e-10, B
+        assert np.max(np.abs(dvar - odv[:B]) / (sf2 / ell_min)[None, :, None]) <= 1e-10, (B, np.max(np.abs(dvar - odv[:B])))
+        m2, v2 = h.predict_mean_var(Z[:B])                    # the variance of the value path (fused sums, no V kept)
+        assert np.array_equal(m2, mean) and np.allclose(v2, var, rtol=0, atol=1e-13 * sf2.max()), B
+    h.close()
+
+
 def check_gp_class(lib, g, tmp_path, em_rollout=True):
     """The Python `GP` surface (reference gp_class.py) against `OracleGP` on a saved reference model."""
     from gp_mpc_amd.gp import GP

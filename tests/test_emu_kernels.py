@@ -118,6 +118,7 @@ def test_emu_append_after_set_factors_and_rollback(emu):
 def test_emu_sensitivities(emu, tank, car):
     pc.check_sensitivities(emu, tank)
     pc.check_sensitivities(emu, car, nprobe=5)
+    pc.check_sensitivities_batches(emu)
 
 
 def test_emu_gp_class(emu, tank, tmp_path):

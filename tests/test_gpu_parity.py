@@ -146,6 +146,7 @@ def test_append_after_set_factors_and_rollback(lib):
 def test_sensitivities(lib, tank, car):
     pc.check_sensitivities(lib, tank)
     pc.check_sensitivities(lib, car, nprobe=20)
+    pc.check_sensitivities_batches(lib)
 
 
 def test_gp_class(lib, tank, tmp_path):
