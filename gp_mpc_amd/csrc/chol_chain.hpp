@@ -22,7 +22,7 @@
 
 namespace gpmpc {
 
-constexpr int CHAIN_LDS_BYTES = 150000;
+constexpr int CHAIN_LDS_BYTES = 150400;   // S, T, U, P (64 x LS each), the packed lower triangle Qp, Dr, slot
 
 // flag layout per matrix (ints): [0] error, [1 .. nb] leafdone, [1+nb .. 2nb] pan1, [1+2nb .. 1+4nb) tdone[k][2],
 // and for the tile-owner workers (chol_worker.hpp): [1+4nb .. 1+5nb) pancount, [1+5nb .. 1+6nb) row2done,
@@ -69,7 +69,9 @@ __global__ void __launch_bounds__(256) chol_chain_kernel(const double* Kmat, dou
     double* U = T + 64 * LS;
     double* Dr = U + 64 * LS;
     int* slot = (int*)(Dr + 64);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double* P = Dr + 64 + 2;            // prefetched A(k+1,k), row stride LS
+    double* Qp = P + 64 * LS;           // prefetched lower triangle of A(k+1,k+1), packed: (r, c) at r (r + 1) / 2 + c
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const long mb = (long)blockIdx.z * sBatch;
     const double* __restrict__ Kb = Kmat + mb;
     double* __restrict__ Lb = L + mb;
@@ -90,37 +92,50 @@ __global__ void __launch_bounds__(256) chol_chain_kernel(const double* Kmat, dou
         const long o = (long)(64 * k) * ld + 64 * k;
         const long o10 = o + 64 * ld, o11 = o10 + 64;
         CHAIN_STAMP(0);
-        // Prefetch for the second half of the step: as soon as the two tiles A(k+1,k), A(k+1,k+1) carry
-        // the trailing update of step k-1 their loads are issued, into registers, and the HBM latency hides
-        // behind the leaf.  Two attempts: at the start of the step and two thirds into the leaf.
+        // Prefetch for the second half of the step: if the two tiles A(k+1,k), A(k+1,k+1) carry the trailing update of
+        // step k-1 two thirds into the leaf (they usually do), waves 2 and 3 -- idle from there on -- issue their loads and
+        // put them into LDS (P, Qp) while wave 0 factors the last panel.  (The first version kept them in 64 registers of
+        // every thread across the rest of the leaf; the compiler parked those in AGPRs, which means waiting for the loads
+        // inside the leaf: 20.1 us per leaf against 17.9 without the prefetch.)
         bool pre = false;
-        double pu[16], ps[16];
         struct Prefetch {
-            const double* Kb; long o10, o11, ld; const int* f0; const int* f1; int* slot; int tid; bool active;
-            bool* pre; double* pu; double* ps;
+            const double* Kb; long o10, o11, ld; const int* f0; const int* f1; int* slot; int tid, wave; bool active;
+            bool* pre; double* P; double* Qp;
             __device__ __forceinline__ void before() {
-                if (active && !*pre && tid == 0) {
+                if (active && tid == 0) {
                     const int ok = !f0 || (flag_load(f0) >= 1 && flag_load(f1) >= 1);
                     if (ok && f0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                     *slot = ok;
                 }
             }
             __device__ __forceinline__ void after() {
-                if (active && !*pre && *slot != 0) {
-                    *pre = true;
+                if (active && *slot != 0) *pre = true;
+            }
+            // waves 2 and 3, behind the barrier that precedes the last panel: 128 threads, 2048 double2 per tile, thread u
+            // takes slots u + 128 i = (row 4 i + u / 32, columns 2 (u % 32) ..).  Loads and LDS stores sit in ONE region
+            // without a barrier in between: nothing fetched is live across the leaf's synchronisation points.
+            __device__ __forceinline__ void land() {
+                if (*pre) {
+                    const int u = tid - 128, r0 = u >> 5, c = (u & 31) * 2;
+                    double2 pu[16], ps[16];
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
-                        const int idx = tid + 256 * i, rr = idx >> 6, cc = idx & 63;
-                        pu[i] = Kb[o10 + (long)rr * ld + cc];
-                        ps[i] = (cc <= rr) ? Kb[o11 + (long)rr * ld + cc] : 0.0;
+                        const int rr = 4 * i + r0;
+                        pu[i] = *reinterpret_cast<const double2*>(&Kb[o10 + (long)rr * ld + c]);
+                        ps[i] = (c <= rr) ? *reinterpret_cast<const double2*>(&Kb[o11 + (long)rr * ld + c]) : double2{0.0, 0.0};
+                    }
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const int rr = 4 * i + r0;
+                        P[rr * LS + c] = pu[i].x;
+                        P[rr * LS + c + 1] = pu[i].y;
+                        if (c <= rr) Qp[rr * (rr + 1) / 2 + c] = ps[i].x;
+                        if (c + 1 <= rr) Qp[rr * (rr + 1) / 2 + c + 1] = ps[i].y;
                     }
                 }
             }
-        } pf{Kb, o10, o11, ld, k > kb ? &tdone[2 * (k - 1)] : nullptr, k > kb ? &tdone[2 * (k - 1) + 1] : nullptr, slot, tid,
-             k + 1 < ke, &pre, pu, ps};
-        pf.before();
-        __syncthreads();
-        pf.after();
+        } pf{Kb, o10, o11, ld, k > kb ? &tdone[2 * (k - 1)] : nullptr, k > kb ? &tdone[2 * (k - 1) + 1] : nullptr, slot, tid, wave,
+             k + 1 < ke, &pre, P, Qp};
         const int bad = leaf_body(S, T, U, Dr, 1, 15, crow_mode, pf);
         CHAIN_STAMP(1);
         if (tid == 0 && bad >= 0) atomicCAS(&info[blockIdx.z], 0, 64 * k + bad + 1);
@@ -139,39 +154,44 @@ __global__ void __launch_bounds__(256) chol_chain_kernel(const double* Kmat, dou
         if (!merge_publish || k + 1 == ke) wg_publish(&leafdone[k], 1);
         CHAIN_STAMP(2);
         if (k + 1 == ke) break;
+        const double* Asrc = P;                       // A(k+1,k): put there by the prefetch, else fetched now
         if (pre) {
             CHAIN_STAMP(3);
+            __syncthreads();                          // every thread is done reading S (the L_kk stores above)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
+            for (int i = 0; i < 16; ++i) {           // next diagonal block (S is free: L_kk has been stored)
                 const int idx = tid + 256 * i, rr = idx >> 6, cc = idx & 63;
-                U[rr * LS + cc] = pu[i];
+                S[rr * LS + cc] = (cc <= rr) ? Qp[rr * (rr + 1) / 2 + cc] : 0.0;
             }
         } else {
             // the two tiles below/right of the diagonal block must carry the trailing update of step k-1
             if (!wg_wait2(&tdone[2 * (k - 1)], 1, &tdone[2 * (k - 1) + 1], 1, err, spin_limit, slot, 1000000 + 1000 * k)) return;
             CHAIN_STAMP(3);
+            double pu[16], ps[16];
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int idx = tid + 256 * i, rr = idx >> 6, cc = idx & 63;
                 pu[i] = Kb[o10 + (long)rr * ld + cc];
                 ps[i] = (cc <= rr) ? Kb[o11 + (long)rr * ld + cc] : 0.0;
             }
+            __syncthreads();                          // every thread is done reading S (the L_kk stores above)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int idx = tid + 256 * i, rr = idx >> 6, cc = idx & 63;
-                U[rr * LS + cc] = pu[i];
+                P[rr * LS + cc] = pu[i];
+                S[rr * LS + cc] = ps[i];
             }
         }
         __syncthreads();
         CHAIN_STAMP(4);
-        // L_{k+1,k} = A_{k+1,k} inv_kk^T: wave w computes the 16-row strip w (4 tiles, depth 64)
+        // L_{k+1,k} = A_{k+1,k} inv_kk^T: wave w computes the 16-row strip w (4 tiles; inv_kk is lower triangular, so
+        // tile tj needs depth 16 (tj + 1) only), straight from P into U
         d4 acc[4];
 #pragma unroll
         for (int tj = 0; tj < 4; ++tj) {
             acc[tj] = d4{0.0, 0.0, 0.0, 0.0};
-            acc[tj] = lds_mm16<true>(U, 16 * wave, 0, T, 16 * tj, 0, 64, lane, acc[tj]);
+            acc[tj] = lds_mm16<true>(Asrc, 16 * wave, 0, T, 16 * tj, 0, 16 * (tj + 1), lane, acc[tj]);
         }
-        __syncthreads();
 #pragma unroll
         for (int tj = 0; tj < 4; ++tj) lds_put16(U, 16 * wave, 16 * tj, acc[tj], 1.0, lane, crow_mode);
         __syncthreads();
@@ -182,11 +202,6 @@ __global__ void __launch_bounds__(256) chol_chain_kernel(const double* Kmat, dou
             u.x = U[rr * LS + cc];
             u.y = U[rr * LS + cc + 1];
             *reinterpret_cast<double2*>(&Lb[o10 + (long)rr * ld + cc]) = u;
-        }
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int idx = tid + 256 * i, rr = idx >> 6, cc = idx & 63;
-            S[rr * LS + cc] = ps[i];                                              // next diagonal block
         }
         CHAIN_STAMP(5);
         if (merge_publish) wg_publish(&leafdone[k], 1, &pan1[k]);

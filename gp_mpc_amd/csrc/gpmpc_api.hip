@@ -767,6 +767,7 @@ static bool factor_chain(const Ctx& cx, Workspace& ws, int spin_limit) {
                                chain_ready_index(nb) + 2 * i + 1, 1, -1, 0, spin_limit);
             const int ri = r[i], a = r[i + 1] - r[i];
             trtri_range(cx, ws, cx.aux, ri, a);                                    // I_i
+            if (i + 2 == L) hipEventRecord(cx.seg[cx.n_seg - 2], cx.aux);         // the side queue's last use of the level scratch
             const double* Ii = ws.Inv + (long)ri * ld + ri;
             const double* Si = i ? ws.W + wofs[i] : nullptr;                       // a x ri
             for (int jj = i + 1; jj < L; ++jj) {
@@ -820,10 +821,15 @@ static bool factor_chain(const Ctx& cx, Workspace& ws, int spin_limit) {
     hipEventRecord(cx.join, cx.side);
     hipStreamWaitEvent(cx.stream, cx.join, 0);
     if (split) {                                            // the last panel: its own inverse, then -I S
-        hipEventRecord(cx.seg[cx.n_seg - 1], cx.aux);
-        hipStreamWaitEvent(cx.stream, cx.seg[cx.n_seg - 1], 0);
+        // The inverse of the last panel needs nothing from the side queue but the level scratch, which that queue left
+        // long ago (event recorded behind its last trtri_range); only the product waits for its S.  (Waiting for the
+        // whole side queue first put its last product, which ends ~50 us after the chain, in front of these eight
+        // latency-bound launches.)
+        hipStreamWaitEvent(cx.stream, cx.seg[cx.n_seg - 2], 0);
         const int rl = r[L - 1], h = Np - rl;
         trtri_range(cx, ws, cx.stream, rl, h);
+        hipEventRecord(cx.seg[cx.n_seg - 1], cx.aux);
+        hipStreamWaitEvent(cx.stream, cx.seg[cx.n_seg - 1], 0);
         product(cx.stream, ws.Inv + (long)rl * ld + rl, ld, KA_LE_M, ws.W + wofs[L - 1], rl, ws.Inv + (long)rl * ld, ld,
                 h, rl, h, -1.0, 0.0);
         return true;

@@ -114,17 +114,22 @@ __device__ __forceinline__ int panel_potrf(double* S, double* Drinv, int lane) {
 //
 // `hook` lets the caller slip work of its own behind the factorisation: hook.before() runs (all threads)
 // just before the barrier that follows the third 16-column panel, hook.after() right after it -- about
-// two thirds into the leaf.  The chain kernel uses it to poll a flag (before) and to issue the global
-// loads of its next tiles (after), whose latency then hides behind the rest of the leaf.
+// two thirds into the leaf -- and hook.land() in waves 2 and 3 while wave 0 factors the last panel.  The chain kernel
+// uses them to poll a flag (before), to issue the global loads of its next tiles in waves 2 and 3 (after) and to put
+// what they fetched into LDS (land): the latency hides behind the last panel and no register is held across the leaf.
 struct LeafNoHook {
     __device__ __forceinline__ void before() {}
     __device__ __forceinline__ void after() {}
+    __device__ __forceinline__ void land() {}
 };
 
 template <class Hook>
 __device__ __forceinline__ int leaf_body(double* S, double* T, double* U, double* Dr, int do_chol, int phases,
                                          int crow_mode, Hook& hook) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // (wave-uniform by construction; said so to the compiler: the per-wave roles below become scalar branches, and what
+    //  one role keeps in registers -- the chain kernel's prefetch in waves 2 and 3 -- is not live in the others' code)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int bad = -1;
     if (do_chol) {
 #pragma unroll
@@ -135,6 +140,8 @@ __device__ __forceinline__ int leaf_body(double* S, double* T, double* U, double
                 if (b >= 0 && bad < 0) bad = 16 * t + b;
             } else if (wave == 1 && t >= 1 && (phases & 4)) {
                 inv16(S, T, 16 * (t - 1), lane, Dr);   // inverse of the previous diagonal block
+            } else if (wave >= 2 && t == 3) {
+                hook.land();                            // waves 2 and 3 have nothing else to do behind the last panel
             }
             if (t == 2) hook.before();
             __syncthreads();
