@@ -479,6 +479,30 @@ def check_sensitivities(lib, g, nprobe=12):
     h.close()
 
 
+def check_io_pack_boundary(lib, N=100, d=3, Ny=2, seed=51):
+    """Host-pointer calls stage small argument sets through one pinned block (IoPack, gpmpc_api.hip: 32768 doubles); just
+    below and just above that size the same call takes the two copy routes and must give the same numbers, and both
+    must match the oracle."""
+    B1, B2 = 1300, 1400            # 'TA' with J: 24 doubles per point (+ padding) -> the limit falls near B = 1365
+    p = go.synthetic_problem(N, d, Ny, B2, seed=seed, sn=0.1)
+    X, Y, H, Z, S = p['X'], p['Y'], p['hyper'], p['Z'], p['Sigma']
+    h = Handle(lib, X, Y)
+    assert np.all(h.fit(H) == 0)
+    f = h.get_factors()
+    sf2 = H[:, d] ** 2
+    ma, ca, Ja = h.predict_jac('TA', Z[:B1], S[:B1])
+    mb, cb, Jb = h.predict_jac('TA', Z[:B2], S[:B2])
+    assert np.array_equal(ma, mb[:B1]) and np.array_equal(Ja, Jb[:B1])
+    assert np.allclose(ca, cb[:B1], rtol=0, atol=1e-13 * sf2.max())
+    om, ov, oJ = go.mean_var_jac(Z, X, H, f['alpha'], f['chol'])
+    oc = go.ta_cov(ov, oJ, S)
+    ms = mean_scale(X, Z, H, f['alpha'])
+    assert np.max(np.abs(mb - om) / ms) <= 1e-10 and np.max(np.abs(cb - oc)) <= 1e-10 * sf2.max() * max(1.0, np.abs(oc).max())
+    m1, v1 = h.predict_mean_var(Z[:1])      # and the smallest call there is
+    assert np.array_equal(m1, mb[:1]) and abs(v1[0, 0] - cb[0, 0, 0] + (oJ[0] @ S[0] @ oJ[0].T)[0, 0]) <= 1e-12 * sf2.max()
+    h.close()
+
+
 def check_sensitivities_batches(lib, N=330, d=4, Ny=2, seed=41):
     """gpmpc_predict_sens over the batch sizes that take different routes for V = L^-1 Ks and U = L^-T V (32- and
     64-column streaming tiles with the transposed store; beyond 64 columns the row-major product), on a model with

@@ -194,3 +194,7 @@ def test_emu_random_shapes(emu):
 
 def test_emu_rollout_replay(emu):
     pc.check_rollout_replay(emu)
+
+
+def test_emu_io_pack_boundary(emu):
+    pc.check_io_pack_boundary(emu)

@@ -218,3 +218,7 @@ def test_c3_size_properties(lib):
 
 def test_rollout_replay(lib):
     pc.check_rollout_replay(lib)
+
+
+def test_io_pack_boundary(lib):
+    pc.check_io_pack_boundary(lib)
