@@ -1300,6 +1300,52 @@ def check_gp_class_strict(lib, N=400, Ny=3, Nu=2, seed=29):
     gp.close()
 
 
+def check_wide_inputs(lib, N=130, Ny=2, B=9, seed=77):
+    """Input dimensions above the 8 the exact-moment kernels take (their cross term is one 16 x 16 x 8 matrix product): the
+    other paths are instantiated for d up to 16 -- fit, mean / var / Jacobian, TA covariance, second-order outputs, the
+    legacy methods, NLL + gradient, roll-out -- and 'EM' must refuse with an error, not compute something."""
+    from gp_mpc_amd._lib import GpmpcError
+    for d in (9, 12, 16):
+        p = go.synthetic_problem(N, d, Ny, B, seed=seed + d, sn=0.1)
+        X, Y, Z, S = p['X'], p['Y'], p['Z'], p['Sigma']
+        H = p['hyper'].copy()
+        H[:, :d] *= np.linspace(1.5, 3.0, d)[None, :]          # d is large: keep the kernel from going diagonal
+        h = Handle(lib, X, Y)
+        assert np.all(h.fit(H, want_invK=True) == 0)
+        o = go.fit(X, Y, H)
+        f = h.get_factors(invK=True)
+        sf2, ell_min = H[:, d] ** 2, H[:, :d].min(axis=1)
+        for a in range(Ny):
+            assert relF(f['chol'][a], o['chol'][a]) <= 1e-11, d
+        mean, cov, J = h.predict_jac('TA', Z, S)
+        om, ov, oJ = go.mean_var_jac(Z, X, H, o['alpha'], o['chol'])
+        ms = mean_scale(X, Z, H, o['alpha'])
+        assert np.max(np.abs(mean - om) / ms) <= 1e-10 and np.max(np.abs(J - oJ) / (ms / ell_min)[..., None]) <= 1e-10, d
+        assert np.max(np.abs(cov - go.ta_cov(ov, oJ, S))) <= 1e-10 * max(1.0, sf2.max()), d
+        m2, v2, J2, Hm, dvar = h.predict_sens(Z)
+        oH, odv = go.mean_var_sens(Z, X, H, o['alpha'], o['chol'])
+        assert np.max(np.abs(Hm - oH) / (ms / ell_min ** 2)[..., None, None]) <= 1e-10, d
+        assert np.max(np.abs(dvar - odv) / (sf2 / ell_min)[None, :, None]) <= 1e-10, d
+        for method in ('old_ME', 'old_TA'):
+            mm, cc = h.predict(method, Z, S)
+            for b in range(B):
+                rm, rc = go.old_ta(f['invK'], X, Y, H, Z[b], S[b]) if method == 'old_TA' else go.old_me(f['invK'], X, Y, H, Z[b])
+                assert np.allclose(mm[b], rm, rtol=0, atol=1e-9 * max(1.0, np.abs(rm).max())), (d, method)
+                assert np.allclose(cc[b], rc, rtol=0, atol=1e-9 * max(1.0, sf2.max())), (d, method)
+        for a in range(Ny):
+            v, g = h.nll(a, H[a], want_grad=True)
+            ref = go.nll(H[a], X, Y[:, a])
+            assert abs(v - ref) / (abs(ref) + N) <= 1e-10, d
+            assert np.allclose(g, go.nll_grad(H[a], X, Y[:, a])[1], rtol=1e-8, atol=1e-8 * (abs(ref) + N)), d
+        try:
+            h.predict('EM', Z[:1], S[:1])
+            raised = False
+        except GpmpcError as e:
+            raised = 'dimension' in str(e)
+        assert raised, d
+        h.close()
+
+
 def check_random_shapes(lib, n_cases=10, seed=2024, nmax=220):
     """Seeded sweep over ragged shapes (N not a multiple of anything, d = 1..8, Ny = 1..3, B = 1..70): fit, mean / var /
     Jacobian, TA and EM covariances, NLL + gradient against the oracle -- the indexing of every kernel with padding in

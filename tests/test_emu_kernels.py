@@ -198,3 +198,7 @@ def test_emu_rollout_replay(emu):
 
 def test_emu_io_pack_boundary(emu):
     pc.check_io_pack_boundary(emu)
+
+
+def test_emu_wide_inputs(emu):
+    pc.check_wide_inputs(emu)

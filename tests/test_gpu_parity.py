@@ -222,3 +222,7 @@ def test_rollout_replay(lib):
 
 def test_io_pack_boundary(lib):
     pc.check_io_pack_boundary(lib)
+
+
+def test_wide_inputs(lib):
+    pc.check_wide_inputs(lib)
