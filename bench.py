@@ -89,7 +89,27 @@ def cpu_baseline(p, B):
                       'note': 'solve_triangular for alpha and v = L^-1 ks instead of np.linalg.solve (LU)'}), mean, var
 
 
+_REAL_STDOUT = None
+
+
+def _own_stdout():
+    """The contract is ONE JSON line on stdout (rank 0).  Libraries in the process write there too -- RCCL prints a version
+    banner from C stdio, flushed at exit, i.e. AFTER a Python print -- so file descriptor 1 is pointed at stderr for
+    everything else and the line goes to a private duplicate of the original stdout."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.fdopen(os.dup(1), 'w')
+        os.dup2(2, 1)
+
+
+def _emit(obj):
+    _REAL_STDOUT.write(json.dumps(obj) + '\n')
+    _REAL_STDOUT.flush()
+
+
 def main():
+    _own_stdout()
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
@@ -214,7 +234,7 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out))
+        _emit(out)
 
 
 def main_c3(args):
@@ -303,7 +323,7 @@ def main_c3(args):
             'finite': bool(all(np.all(np.isfinite(r[0])) and np.all(np.isfinite(r[1])) for r in res.values())),
             'device': lib.device_name(local_rank),
         }
-        print(json.dumps(out))
+        _emit(out)
     h.close()
     if dist is not None:
         dist.barrier()
@@ -362,7 +382,7 @@ def main_c4(args):
     lib.rccl_comm_destroy(comm)
     if rank == 0:
         r = res['r']
-        print(json.dumps({
+        _emit({
             'metric': 'GP hyper-parameter training restarts/sec, N=4096 d=6 fp64 (64 restarts x 4 L-BFGS iterations, NLL + analytic gradient)',
             'value': R * steps / elapsed, 'unit': 'restarts/s', 'n_gpus': world, 'steps': steps, 'warmup': warmup,
             'ms_per_step': elapsed / steps * 1e3, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
@@ -370,7 +390,7 @@ def main_c4(args):
             'config': {'workload': 'C4: 64 seeded restarts of the NLL minimisation, restart r on rank r mod world, one ncclAllGather of (NLL, theta)',
                        'N': N, 'd': d, 'restarts': R, 'iterations': iters, 'parallelism': f'restart shard x{world} over RCCL'},
             'best_nll': float(np.min(r['obj'])), 'finite_restarts': int(np.isfinite(r['obj']).sum()),
-            'device': lib.device_name(local_rank)}))
+            'device': lib.device_name(local_rank)})
     h.close()
     if dist is not None:
         dist.barrier()
