@@ -184,6 +184,8 @@ static size_t block_class(size_t bytes) {
     return (bytes + g - 1) / g * g;
 }
 
+static void block_list_release();
+
 static hipError_t block_alloc(double** out, size_t bytes) {
     if (bytes < BLOCK_MIN) return hipMalloc(out, bytes);
     const size_t cls = block_class(bytes);
@@ -200,11 +202,22 @@ static hipError_t block_alloc(double** out, size_t bytes) {
                 return hipSuccess;
             }
     }
-    const hipError_t e = hipMalloc(out, cls);
+    hipError_t e = hipMalloc(out, cls);
+    size_t got = cls;
+    if (e != hipSuccess) {                 // out of memory with the class rounding: give the idle blocks back, then ask for the exact size
+        (void)hipGetLastError();
+        block_list_release();
+        e = hipMalloc(out, cls);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            got = bytes;
+            e = hipMalloc(out, bytes);
+        }
+    }
     if (e == hipSuccess) {
         std::lock_guard<std::mutex> lk(g_block_mutex);
         ++g_block_fresh;
-        g_live_blocks.push_back({(void*)*out, cls, dev});
+        g_live_blocks.push_back({(void*)*out, got, dev});
     }
     return e;
 }
