@@ -2472,7 +2472,10 @@ extern "C" int gpmpc_train_multistart(gpmpc_gp* h, int nstart, const double* sta
         P.logv.resize(nh);
         for (int k = 0; k < nh; ++k) {
             if (!(P.lb[k] <= P.ub[k])) return fail(GPMPC_EINVAL, "empty box for hyper-parameter %d of output %d", k, a);
-            P.logv[k] = k < d + 2 && P.lb[k] > 0.0 && P.ub[k] < inf;
+            // length scales and sf in log space (their boxes span many decades).  NOT the noise sn: the NLL sees it as sn^2,
+            // so d NLL / d log sn = 2 sn^2 (...) vanishes at the reference's start sn = 1e-5 and a log-space search leaves it
+            // there -- on the fixture whose optimum has sn on its upper bound it stopped 5.6 above the reference's NLL.
+            P.logv[k] = k < d + 1 && P.lb[k] > 0.0 && P.ub[k] < inf;
         }
         P.eval = [&](const double* th, double* f, double* g) -> bool {
             const int rc = gpmpc_nll(h, a, th, f, g, nullptr);

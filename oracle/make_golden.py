@@ -132,12 +132,32 @@ def synthetic(optimize, GP):
     print('train_small hyper', H, 'nll', nll, 'jitter flags', probe_jit.tolist())
 
 
+def synthetic2(optimize, GP):
+    """A second run of the reference's numpy training path: three inputs with different scales, one output whose noise
+    (3e-2) sits above the reference's upper bound on sn (1e-2, optimize.py:441-442), so the optimum has an active bound."""
+    rng = np.random.default_rng(20190607)
+    N, d = 60, 3
+    X = rng.uniform(-1, 1, (N, d)) * np.array([1.0, 4.0, 0.3])
+    Y = (np.tanh(X[:, 0]) + 0.2 * np.sin(X[:, 1]) + X[:, 2] ** 2 + 3e-2 * rng.standard_normal(N))[:, None]
+    opt = optimize.train_gp_numpy(X, Y, multistart=1, optimizer_opts={'disp': False})  # reference a8
+    H = opt['hyper']
+    nll = np.array([float(optimize.calc_NLL_numpy(H[0], X, Y[:, 0]))])
+    Z = rng.uniform(-1, 1, (12, d)) * np.array([1.0, 4.0, 0.3])
+    g = ref_gp(GP, X, H, opt['chol'])
+    covar = g.covar(Z.copy())[:1]
+    K = optimize.calc_cov_matrix(X, H[0, :d], H[0, d] ** 2)[None]
+    np.savez_compressed(os.path.join(OUT, 'train_small2.npz'), X=X, Y=Y, hyper=H, chol=opt['chol'], alpha=opt['alpha'],
+                        invK=opt['invK'], nll=nll, Z=Z, ref_covar=covar, ref_K=K)
+    print('train_small2 hyper', H, 'nll', nll)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     optimize, GP = import_reference()
     from_model(optimize, GP, 'tank', 24, 1)
     from_model(optimize, GP, 'car', 24, 2)
     synthetic(optimize, GP)
+    synthetic2(optimize, GP)
 
 
 if __name__ == '__main__':

@@ -53,3 +53,8 @@ def car():
 @pytest.fixture(scope='session')
 def train_small():
     return dict(np.load(os.path.join(GOLDEN, 'train_small.npz')))
+
+
+@pytest.fixture(scope='session')
+def train_small2():
+    return dict(np.load(os.path.join(GOLDEN, 'train_small2.npz')))

@@ -1216,6 +1216,22 @@ def check_callback_blocks(lib, N=120, Ny=3, Nu=2, seed=17):
     gp.close()
 
 
+def check_training_active_bound(lib, t):
+    """a8 on the second reference-made fixture (train_small2.npz): the optimum lies ON the upper bound of sn.  Both
+    optimisers over the device's NLL + gradient -- scipy SLSQP through the GP class and the native projected L-BFGS behind
+    `gpmpc_train_multistart` -- must end at least as low as the reference's optimum, on the bound, at its length scales."""
+    from gp_mpc_amd.train import train_gp
+    check_training(lib, t)
+    X, Y, d = t['X'], t['Y'], t['X'].shape[1]
+    h = Handle(lib, X, Y)
+    opt = train_gp(h, X, Y, multistart=1, numpy_path_conventions=True, optimizer='native')
+    H = opt['hyper']
+    ours = go.nll(H[0], X, Y[:, 0])
+    assert ours <= t['nll'][0] + 1e-6 * abs(t['nll'][0]), (ours, t['nll'][0])
+    assert abs(H[0, d + 1] - 1e-2) <= 1e-6 and np.allclose(H[0], t['hyper'][0], rtol=5e-2), (H[0], t['hyper'][0])
+    h.close()
+
+
 def check_training_native(lib, t):
     """a8 behind the C ABI (`gpmpc_train_multistart`): from the reference's initial point inside the reference's box
     (both conventions) the native projected L-BFGS must reach an NLL at least as good as `train_gp_numpy`'s SLSQP

@@ -202,3 +202,7 @@ def test_emu_io_pack_boundary(emu):
 
 def test_emu_wide_inputs(emu):
     pc.check_wide_inputs(emu)
+
+
+def test_emu_training_active_bound(emu, train_small2):
+    pc.check_training_active_bound(emu, train_small2)

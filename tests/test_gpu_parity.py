@@ -226,3 +226,7 @@ def test_io_pack_boundary(lib):
 
 def test_wide_inputs(lib):
     pc.check_wide_inputs(lib)
+
+
+def test_training_active_bound(lib, train_small2):
+    pc.check_training_active_bound(lib, train_small2)

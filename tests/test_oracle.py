@@ -109,6 +109,26 @@ def test_train_reproduces_reference_optimum(train_small):
         assert abs(go.nll(t['hyper'][a], t['X'], t['Y'][:, a]) - t['nll'][a]) <= 1e-9
 
 
+def test_train_reproduces_reference_optimum_with_an_active_bound(train_small2):
+    """a8 once more, on the second fixture the reference's own train_gp_numpy produced (oracle/make_golden.py::synthetic2):
+    three inputs of different scale and a noise level above the reference's upper bound on sn, so that the optimum sits ON
+    the bound (sn = 1e-2, optimize.py:441-442) -- the restated bounds and SLSQP call must land there too."""
+    t = train_small2
+    X, Y, d = t['X'], t['Y'], t['X'].shape[1]
+    assert abs(t['hyper'][0, d + 1] - 1e-2) <= 1e-7          # SLSQP stops a hair inside the bound
+    opt = go.train(X, Y, multistart=1)
+    assert np.allclose(opt['hyper'], t['hyper'], rtol=1e-4, atol=1e-9), (opt['hyper'], t['hyper'])
+    assert relF(opt['chol'][0], t['chol'][0]) <= 1e-3
+    f = go.fit(X, Y, t['hyper'])
+    assert relF(f['chol'][0], t['chol'][0]) <= 1e-10 and relF(f['invK'][0], t['invK'][0]) <= 1e-6
+    assert relF(f['alpha'][0], t['alpha'][0]) <= 1e-7
+    assert abs(go.nll(t['hyper'][0], X, Y[:, 0]) - t['nll'][0]) <= 1e-9 * (abs(t['nll'][0]) + len(X))
+    K = go.cov_se_ard(X, X, t['hyper'][0, :d], t['hyper'][0, d] ** 2)
+    assert np.max(np.abs(K - t['ref_K'][0])) <= 1e-14 * t['hyper'][0, d] ** 2
+    _, var, _ = go.mean_var_jac(t['Z'], X, t['hyper'], t['alpha'], t['chol'], False)
+    assert np.max(np.abs(var[:, 0] - np.diag(t['ref_covar'][0]))) <= 1e-10 * t['hyper'][0, d] ** 2
+
+
 def test_nll_gradient_vs_finite_differences(tank):
     g = tank
     X, y = g['X'], g['Y'][:, 1]
