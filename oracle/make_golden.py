@@ -151,6 +151,24 @@ def synthetic2(optimize, GP):
     print('train_small2 hyper', H, 'nll', nll)
 
 
+def synthetic3(optimize, GP):
+    """Third training run: standardised data, three outputs with noise 1e-3, 3e-2 and 0.3.  The reference's SLSQP (finite-
+    difference gradient) ends with sn on its LOWER bound for the first output and does not leave the start at all for the
+    other two (their NLL at the start is 8e5 and 3e7): what `train_gp_numpy` returns in such cases is part of a8 too."""
+    rng = np.random.default_rng(77)
+    N, d = 45, 2
+    X = rng.standard_normal((N, d))
+    F = np.stack([np.sin(1.5 * X[:, 0]) + 0.3 * X[:, 1], np.cos(X[:, 0] * X[:, 1]), X[:, 0] ** 2 - 0.5 * X[:, 1]], axis=1)
+    Y = F + np.array([1e-3, 3e-2, 0.3]) * rng.standard_normal((N, 3))
+    Y = (Y - Y.mean(0)) / Y.std(0)
+    opt = optimize.train_gp_numpy(X, Y, multistart=1, optimizer_opts={'disp': False})  # reference a8
+    H = opt['hyper']
+    nll = np.array([float(optimize.calc_NLL_numpy(H[a], X, Y[:, a])) for a in range(3)])
+    np.savez_compressed(os.path.join(OUT, 'train_small3.npz'), X=X, Y=Y, hyper=H, chol=opt['chol'], alpha=opt['alpha'],
+                        invK=opt['invK'], nll=nll)
+    print('train_small3 hyper', H, 'nll', nll)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     optimize, GP = import_reference()
@@ -158,6 +176,7 @@ def main():
     from_model(optimize, GP, 'car', 24, 2)
     synthetic(optimize, GP)
     synthetic2(optimize, GP)
+    synthetic3(optimize, GP)
 
 
 if __name__ == '__main__':

@@ -58,3 +58,8 @@ def train_small():
 @pytest.fixture(scope='session')
 def train_small2():
     return dict(np.load(os.path.join(GOLDEN, 'train_small2.npz')))
+
+
+@pytest.fixture(scope='session')
+def train_small3():
+    return dict(np.load(os.path.join(GOLDEN, 'train_small3.npz')))

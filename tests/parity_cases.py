@@ -1232,6 +1232,26 @@ def check_training_active_bound(lib, t):
     h.close()
 
 
+def check_training_beats_failed_reference_search(lib, t):
+    """a8 on the third reference-made fixture (train_small3.npz): where the reference's finite-difference SLSQP ends on a
+    bound or never leaves its start, both optimisers over the device's NLL + analytic gradient must end at least as low --
+    far lower for the two outputs the reference leaves at NLL 8e5 and 3e7 -- with finite factors."""
+    from gp_mpc_amd.train import train_gp
+    X, Y, d = t['X'], t['Y'], t['X'].shape[1]
+    for optimizer in ('native', 'scipy'):
+        h = Handle(lib, X, Y)
+        opt = train_gp(h, X, Y, multistart=1, numpy_path_conventions=True, optimizer=optimizer)
+        H = opt['hyper']
+        for a in range(Y.shape[1]):
+            ours = go.nll(H[a], X, Y[:, a])
+            assert ours <= t['nll'][a] + 1e-6 * abs(t['nll'][a]), (optimizer, a, ours, t['nll'][a])
+        if optimizer == 'native':
+            assert go.nll(H[1], X, Y[:, 1]) < 1e3 and go.nll(H[2], X, Y[:, 2]) < 1e3      # it does leave the start
+        f = h.get_factors()
+        assert np.all(np.isfinite(f['chol'])) and np.all(np.isfinite(f['alpha']))
+        h.close()
+
+
 def check_training_native(lib, t):
     """a8 behind the C ABI (`gpmpc_train_multistart`): from the reference's initial point inside the reference's box
     (both conventions) the native projected L-BFGS must reach an NLL at least as good as `train_gp_numpy`'s SLSQP

@@ -206,3 +206,7 @@ def test_emu_wide_inputs(emu):
 
 def test_emu_training_active_bound(emu, train_small2):
     pc.check_training_active_bound(emu, train_small2)
+
+
+def test_emu_training_beats_failed_reference_search(emu, train_small3):
+    pc.check_training_beats_failed_reference_search(emu, train_small3)

@@ -230,3 +230,7 @@ def test_wide_inputs(lib):
 
 def test_training_active_bound(lib, train_small2):
     pc.check_training_active_bound(lib, train_small2)
+
+
+def test_training_beats_failed_reference_search(lib, train_small3):
+    pc.check_training_beats_failed_reference_search(lib, train_small3)

@@ -129,6 +129,23 @@ def test_train_reproduces_reference_optimum_with_an_active_bound(train_small2):
     assert np.max(np.abs(var[:, 0] - np.diag(t['ref_covar'][0]))) <= 1e-10 * t['hyper'][0, d] ** 2
 
 
+def test_train_reproduces_reference_when_its_search_fails(train_small3):
+    """a8, third fixture (oracle/make_golden.py::synthetic3): the reference's SLSQP run ends with sn on its LOWER bound for
+    the first output and does not leave the starting point for the other two (NLL 8e5 and 3e7 there).  The restated
+    training must do exactly the same -- same bounds, same start, same finite-difference SLSQP call -- and the factors at
+    whatever it returns must match."""
+    t = train_small3
+    X, Y = t['X'], t['Y']
+    opt = go.train(X, Y, multistart=1)
+    assert np.allclose(opt['hyper'], t['hyper'], rtol=1e-6, atol=1e-12), (opt['hyper'], t['hyper'])
+    assert np.array_equal(opt['hyper'][1:], t['hyper'][1:])              # the untouched starts, bit for bit
+    for a in range(3):
+        assert abs(go.nll(t['hyper'][a], X, Y[:, a]) - t['nll'][a]) <= 1e-9 * (abs(t['nll'][a]) + len(X))
+    f = go.fit(X, Y, t['hyper'])
+    for a in (1, 2):                                                     # (output 0 has sn = 1e-10: cond(K) ~ 1e12)
+        assert relF(f['chol'][a], t['chol'][a]) <= 1e-9 and relF(f['alpha'][a], t['alpha'][a]) <= 1e-6
+
+
 def test_nll_gradient_vs_finite_differences(tank):
     g = tank
     X, y = g['X'], g['Y'][:, 1]
