@@ -36,13 +36,14 @@ class GP:
     def __init__(self, X, Y, mean_func="zero", gp_method="TA",
                  optimizer_opts=None, hyper=None, normalize=True, multistart=1,
                  xlb=None, xub=None, ulb=None, uub=None, meta=None,
-                 optimize_nummeric=True, device=0, lib=None, predict_adds_mean=False):
+                 optimize_nummeric=True, device=0, lib=None, predict_adds_mean=False, optimizer='native'):
         """Initialize and optimize GP model (gp_class.py:21-75).
 
         Extra arguments: `device` (GPU ordinal), `lib` (a loaded `GpmpcLib`; default: the in-tree
         libgpmpc_hip.so, raising if it is missing) and `predict_adds_mean`: the reference builds its predictor
         WITHOUT the mean function (`build_gp(...)` is called with its default meanFunc='zero', gp_class.py:68-71),
         so a model trained with mean_func != 'zero' predicts ks^T alpha only; that is the default here too.
+        `optimizer`: 'native' (default) or 'scipy', see gp_mpc_amd.train.train_gp.
         True gives build_gp(..., meanFunc=mean_func) (gp_functions.py:131,135): mean(z) = ks^T alpha + m(z)."""
         self._lib = lib if lib is not None else _lib.get_lib()
         self._device = device
@@ -78,7 +79,7 @@ class GP:
             self.optimize(X=X, Y=Y, opts=optimizer_opts, mean_func=mean_func,
                           xlb=xlb, xub=xub, ulb=ulb, uub=uub,
                           multistart=multistart, normalize=normalize,
-                          optimize_nummeric=optimize_nummeric)
+                          optimize_nummeric=optimize_nummeric, optimizer=optimizer)
         else:
             # load_model branch (gp_class.py:58-66): stored X is already standardised
             self.__hyper = np.array(hyper['hyper'], dtype=np.float64)
@@ -118,7 +119,7 @@ class GP:
     def optimize(self, X=None, Y=None, opts=None, mean_func='zero',
                  xlb=None, xub=None, ulb=None, uub=None,
                  multistart=1, normalize=True, warm_start=False,
-                 optimize_nummeric=True, random_restarts=False, seed=1234, gradient='analytic', optimizer='scipy'):
+                 optimize_nummeric=True, random_restarts=False, seed=1234, gradient='analytic', optimizer='native'):
         """Optimize hyper-parameters (gp_class.py:78-142).  DIFF: both of the reference's optimiser
         back-ends (scipy SLSQP with finite differences / CasADi+IPOPT) are replaced by one driver
         (`gp_mpc_amd.train.train_gp`) that evaluates the NLL and its analytic gradient on the GPU;

@@ -1252,6 +1252,32 @@ def check_training_beats_failed_reference_search(lib, t):
         h.close()
 
 
+def check_training_never_worse(lib, n_cases=6, seed=5):
+    """Seeded data sets (standardised, 1-3 inputs, noise 3e-4 .. 0.1) from the reference's single start: the native search
+    behind `gpmpc_train_multistart` -- the default of `GP` / `train_gp` -- must end at or below BOTH the restated reference
+    (`go.train`: SLSQP with finite differences, which reproduces `train_gp_numpy` on the fixtures) and SLSQP with the
+    device's analytic gradient.  (Found with this sweep: the latter can end far above the reference, and both SLSQP variants
+    stay at the start, NLL ~1e9, when the noise exceeds the sn bound.)"""
+    from gp_mpc_amd.train import train_gp
+    rng = np.random.default_rng(seed)
+    for case in range(n_cases):
+        N, d = int(rng.integers(25, 60)), int(rng.integers(1, 4))
+        X = rng.standard_normal((N, d))
+        w = rng.standard_normal((d,))
+        noise = 10 ** rng.uniform(-3.5, -1)
+        y = np.sin(X @ w) + 0.4 * np.cos(X[:, 0] * 1.7) + noise * rng.standard_normal(N)
+        Y = ((y - y.mean()) / y.std())[:, None]
+        res = {}
+        for optimizer in ('native', 'scipy'):
+            h = Handle(lib, X, Y)
+            opt = train_gp(h, X, Y, multistart=1, numpy_path_conventions=True, optimizer=optimizer)
+            res[optimizer] = go.nll(opt['hyper'][0], X, Y[:, 0])
+            h.close()
+        ref = go.nll(go.train(X, Y, multistart=1)['hyper'][0], X, Y[:, 0])
+        best = min(ref, res['scipy'])
+        assert res['native'] <= best + 1e-4 * (abs(best) + N), (case, N, d, noise, ref, res)
+
+
 def check_training_native(lib, t):
     """a8 behind the C ABI (`gpmpc_train_multistart`): from the reference's initial point inside the reference's box
     (both conventions) the native projected L-BFGS must reach an NLL at least as good as `train_gp_numpy`'s SLSQP

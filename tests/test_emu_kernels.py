@@ -210,3 +210,7 @@ def test_emu_training_active_bound(emu, train_small2):
 
 def test_emu_training_beats_failed_reference_search(emu, train_small3):
     pc.check_training_beats_failed_reference_search(emu, train_small3)
+
+
+def test_emu_training_never_worse(emu):
+    pc.check_training_never_worse(emu)
