@@ -160,6 +160,8 @@ def test_training(lib, train_small):
 def test_em_sens(lib):
     pc.check_em_sens(lib)
     pc.check_em_sens(lib, N=600, d=8, Ny=6, B=3, seed=4)          # C3's output / input dimensions
+    pc.check_em_sens(lib, N=100, d=1, Ny=3, B=2, seed=7)          # one input dimension
+    pc.check_em_sens(lib, N=47, d=7, Ny=4, B=1, seed=8)           # ragged, nearly the full cross-term depth
 
 
 def test_callback_blocks(lib):
