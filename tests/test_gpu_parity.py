@@ -236,3 +236,7 @@ def test_training_active_bound(lib, train_small2):
 
 def test_training_beats_failed_reference_search(lib, train_small3):
     pc.check_training_beats_failed_reference_search(lib, train_small3)
+
+
+def test_training_never_worse(lib):
+    pc.check_training_never_worse(lib, n_cases=10)
