@@ -26,7 +26,7 @@ print(json.dumps({'bench': 'C4 NLL evaluation', 'N': N, 'd': d, 'nll_ms': t_val 
                   'phases_ms_per_eval': {k: v[0] / 20 for k, v in prof.items() if v[1]}}))
 t0 = time.perf_counter()
 opt = train_gp(h, p['X'], p['Y'], multistart=int(os.environ.get('C4_RESTARTS', 8)), random_restarts=True, seed=1234,
-               numpy_path_conventions=False, optimizer_opts={'maxiter': 5})
+               numpy_path_conventions=False, optimizer_opts={'maxiter': 5}, optimizer='scipy')
 dt = time.perf_counter() - t0
 print(json.dumps({'bench': 'C4 multistart (5 SLSQP iterations per restart)', 'restarts': int(os.environ.get('C4_RESTARTS', 8)),
                   'world': opt['world'], 'total_s': dt, 'n_eval_this_rank': opt['n_eval'], 'evals_per_s': opt['n_eval'] / dt,
