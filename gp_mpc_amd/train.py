@@ -119,7 +119,9 @@ def train_gp(handle, X, Y, multistart=1, hyper_init=None, optimizer_opts=None,
     # differences (`gradient`, `method`, `optimizer_opts` apply to it).  On ten seeded data sets and the three reference-made
     # fixtures the native search always ended at or below both SLSQP variants; SLSQP with the analytic gradient ended ABOVE the
     # reference's own finite-difference SLSQP once (41441 against -12.96) and, like the reference, does not leave the start
-    # when the noise level exceeds the sn bound (tests/golden/train_small3.npz).
+    # when the noise level exceeds the sn bound (tests/golden/train_small3.npz).  gradient='finite' makes the scipy call the
+    # reference's literally (SLSQP differencing the objective), but not its results: the differences amplify the 1e-11 between
+    # the device's and numpy's NLL, and SLSQP's path is sensitive to that -- the bit-for-bit restatement is oracle/gp_oracle.py.
     if mean_func not in MEAN_PARAMS:
         raise NameError('No mean function called: ' + str(mean_func))
     if optimizer not in ('scipy', 'native'):
