@@ -24,7 +24,8 @@ def main():
     t = dict(np.load(os.path.join(ROOT, 'tests', 'golden', 'train_small.npz')))
     h = Handle(lib, t['X'], t['Y'])
     opt = train_gp(h, t['X'], t['Y'], multistart=multistart, random_restarts=True, seed=1234,
-                   numpy_path_conventions=False, optimizer_opts={'maxiter': 60}, optimizer=optimizer)
+                   numpy_path_conventions=False, optimizer_opts={'maxiter': 60 if optimizer == 'scipy' else 25},
+                   optimizer=optimizer)
     f = h.get_factors()
     np.savez(os.path.join(out_dir, f'{optimizer}_rank{rank}_of{world}.npz'), hyper=opt['hyper'], obj=opt['obj'],
              chol=f['chol'], alpha=f['alpha'], n_eval=opt['n_eval'])
