@@ -1,0 +1,535 @@
+// api_factor.inl -- part of gpmpc_api.hip (one translation unit; included in order, not compiled alone).
+// Concern: factor scheduling: triangular inverse (level-batched / pipelined), the executions of the blocked Cholesky (single queue, chain + flagged GEMMs, chain + tile-owner workers, two-level panels), alpha, K^-1.
+
+static GemmP gemm_base(const Ctx& cx) {
+    GemmP p;
+    std::memset(&p, 0, sizeof(p));
+    p.alpha = 1.0;
+    p.crow_mode = cx.crow_mode;
+    return p;
+}
+
+// Fit factorisation = right-looking blocked Cholesky (NB = 64) + level-by-level batched triangular
+// inverse.  K is consumed (trailing updates in place), L and Inv = L^-1 are written; [batch][Np x Np].
+//
+//   for each 64-column panel k:   leaf: L_kk = chol(A_kk), inv_kk = L_kk^-1        (one workgroup)
+//                                 panel: L21 = A21 inv_kk^T                         (MFMA)
+//                                 trailing: A22 -= L21 L21^T  (lower)               (MFMA)
+//   then for s = 64, 128, ...:    every node [L11 0; L21 L22] with |L11| = s in ONE batched launch pair:
+//                                 W = L21 inv11,  inv21 = -inv22 W                  (MFMA GEMMs)
+//
+// Three executions of this algorithm, chosen per call by factor_chain / its caller:
+//   * factor_blocked: one queue, three launches per panel (fallback, gpmpc_cholesky, gpmpc_append);
+//   * factor_chain with flagged GEMM launches: the leaf / row k+1 / diagonal-tile chain in ONE persistent
+//     workgroup (chol_chain.hpp), panel and trailing GEMMs on a side queue coupled through flags, the
+//     inverse pipelined behind the chain on a third queue (trtri_segment);
+//   * factor_chain with tile-owner workers (chol_worker.hpp): the trailing matrix lives in the registers
+//     of persistent workgroups, in two launches so that the CUs the second one leaves free invert the left
+//     half while the chain finishes.
+// (The first version recursed on [L11 0; L21 L22] with the inverse products inside the recursion: 4
+// latency-bound launches per node on the chain, 5.5 ms at N = 4096; a plain second stream next to the
+// single-queue version did not pay because the leaf slows down 3-8x when it shares a CU with MFMA waves.)
+
+// level-by-level batched inverse of the diagonal range [base, base + n) (rows), given its 64-blocks
+static void trtri_range(const Ctx& cx, Workspace& ws, hipStream_t stream, long base0, int n) {
+    const long ld = ws.Np, sM = ws.mat(), sW = ws.wstride();
+    for (int s = 64; s < n; s *= 2) {
+        const int nfull = n / (2 * s);                  // nodes with a full right child
+        const int rem = n - nfull * 2 * s;              // tail: a partial node exists if rem > s
+        for (int part = 0; part < 2; ++part) {
+            int nodes, h2;
+            long base;
+            if (part == 0) { nodes = nfull; h2 = s; base = base0; }
+            else { nodes = rem > s ? 1 : 0; h2 = rem - s; base = base0 + (long)nfull * 2 * s; }
+            if (nodes == 0) continue;
+            const long o11 = base * ld + base, o21 = (base + s) * ld + base, o22 = (base + s) * ld + base + s;
+            const long snode = (long)2 * s * (ld + 1);
+            GemmP t = gemm_base(cx);                    // W = L21 inv11
+            t.A = ws.L + o21; t.lda = ld; t.a_mc = 0;
+            t.B = ws.Inv + o11; t.ldb = ld; t.b_nc = 1; t.kflags = KB_GE_N;
+            t.C = ws.W; t.ldc = s;
+            t.M = h2; t.N = s; t.K = s;
+            t.zdiv = nodes; t.sA = snode; t.sB = snode; t.sC = (long)s * s; t.sA2 = sM; t.sB2 = sM; t.sC2 = sW;
+            launch_gemm(t, nodes * ws.batch, stream);
+            GemmP u = gemm_base(cx);                    // inv21 = -inv22 W
+            u.A = ws.Inv + o22; u.lda = ld; u.a_mc = 0; u.kflags = KA_LE_M;
+            u.B = ws.W; u.ldb = s; u.b_nc = 1;
+            u.C = ws.Inv + o21; u.ldc = ld;
+            u.M = h2; u.N = s; u.K = h2; u.alpha = -1.0;
+            u.zdiv = nodes; u.sA = snode; u.sB = (long)s * s; u.sC = snode; u.sA2 = sM; u.sB2 = sW; u.sC2 = sM;
+            launch_gemm(u, nodes * ws.batch, stream);
+        }
+    }
+}
+
+static void trtri_levels(const Ctx& cx, Workspace& ws) { trtri_range(cx, ws, cx.stream, 0, ws.Np); }
+
+// One node [L11 0; L21 L22] of the inverse tree above the segment level, split in its two products so
+// that the first can run as soon as the left child is inverted: W = L21 inv11 (into the node's own
+// slot `wo` of ws.W), later inv21 = -inv22 W.
+static void trtri_node_w(const Ctx& cx, Workspace& ws, hipStream_t stream, long base, int s, int h2, long wo) {
+    const long ld = ws.Np, sM = ws.mat();
+    GemmP t = gemm_base(cx);
+    t.A = ws.L + (base + s) * ld + base; t.lda = ld; t.sA = sM; t.a_mc = 0;
+    t.B = ws.Inv + base * ld + base; t.ldb = ld; t.sB = sM; t.b_nc = 1; t.kflags = KB_GE_N;
+    t.C = ws.W + wo; t.ldc = s; t.sC = ws.wstride();
+    t.M = h2; t.N = s; t.K = s;
+    launch_gemm(t, ws.batch, stream);
+}
+static void trtri_node_inv(const Ctx& cx, Workspace& ws, hipStream_t stream, long base, int s, int h2, long wo) {
+    const long ld = ws.Np, sM = ws.mat();
+    GemmP u = gemm_base(cx);
+    u.A = ws.Inv + (base + s) * ld + base + s; u.lda = ld; u.sA = sM; u.a_mc = 0; u.kflags = KA_LE_M;
+    u.B = ws.W + wo; u.ldb = s; u.sB = ws.wstride(); u.b_nc = 1;
+    u.C = ws.Inv + (base + s) * ld + base; u.ldc = ld; u.sC = sM;
+    u.M = h2; u.N = s; u.K = h2; u.alpha = -1.0;
+    launch_gemm(u, ws.batch, stream);
+}
+
+// The part of the inverse that becomes computable when rows [seg0, seg1) are factored (seg0 a multiple of
+// SEGR): the levels inside the segment, then, smallest first, the second product of every higher node
+// whose right child ends at seg1 and the first product of every node whose left child ends there.
+static void trtri_segment(const Ctx& cx, Workspace& ws, hipStream_t stream, int seg0, int seg1) {
+    const int Np = ws.Np;
+    trtri_range(cx, ws, stream, seg0, seg1 - seg0);
+    long wo = ws.hw() * ws.hw();
+    for (int s = SEGR; s < Np; s *= 2)
+        for (long base = 0; base + s < Np; base += 2 * (long)s) {
+            const int h2 = (int)std::min<long>(s, Np - base - s);
+            if (base + s + h2 == seg1) trtri_node_inv(cx, ws, stream, base, s, h2, wo);
+            wo += (long)h2 * s;
+        }
+    wo = ws.hw() * ws.hw();
+    for (int s = SEGR; s < Np; s *= 2)
+        for (long base = 0; base + s < Np; base += 2 * (long)s) {
+            const int h2 = (int)std::min<long>(s, Np - base - s);
+            if (base + s == seg1) trtri_node_w(cx, ws, stream, base, s, h2, wo);
+            wo += (long)h2 * s;
+        }
+}
+
+static void factor_blocked(const Ctx& cx, Workspace& ws, bool do_chol, int k0 = 0) {
+    const int Np = ws.Np, nb = Np / 64;
+    const long ld = Np, sM = ws.mat();
+    if (!do_chol) {   // inverse only (gpmpc_set_factors): all diagonal blocks are independent
+        hipLaunchKernelGGL(leaf64_kernel, dim3(nb, 1, ws.batch), dim3(256), 0, cx.stream, (const double*)ws.L, ws.L,
+                           ws.Inv, ld, sM, 0, 0, ws.info, cx.crow_mode, 15);
+        trtri_levels(cx, ws);
+        return;
+    }
+    for (int k = k0; k < nb; ++k) {     // k0 > 0: block columns < k0 are already factored and applied (gpmpc_append)
+        const int off = 64 * k, M = Np - off - 64;
+        hipLaunchKernelGGL(leaf64_kernel, dim3(1, 1, ws.batch), dim3(256), 0, cx.stream, (const double*)ws.K, ws.L, ws.Inv,
+                           ld, sM, off, 1, ws.info, cx.crow_mode, 15);
+        if (M <= 0) break;
+        const long o11 = (long)off * ld + off, o21 = (long)(off + 64) * ld + off, o22 = (long)(off + 64) * ld + off + 64;
+        GemmP p = gemm_base(cx);                        // panel: L21 = A21 inv_kk^T
+        p.A = ws.K + o21; p.lda = ld; p.sA = sM; p.a_mc = 0;
+        p.B = ws.Inv + o11; p.ldb = ld; p.sB = sM; p.b_nc = 0; p.kflags = KB_LE_N;
+        p.C = ws.L + o21; p.ldc = ld; p.sC = sM;
+        p.M = M; p.N = 64; p.K = 64;
+        launch_gemm(p, ws.batch, cx.stream);
+        GemmP q = gemm_base(cx);                        // trailing update: A22 -= L21 L21^T (lower)
+        q.A = ws.L + o21; q.lda = ld; q.sA = sM; q.a_mc = 0;
+        q.B = ws.L + o21; q.ldb = ld; q.sB = sM; q.b_nc = 0;
+        q.C = ws.K + o22; q.ldc = ld; q.sC = sM;
+        q.M = M; q.N = M; q.K = 64; q.alpha = -1.0; q.beta = 1.0; q.lower = 1;
+        launch_gemm(q, ws.batch, cx.stream);
+    }
+    if (k0 == 0) trtri_levels(cx, ws);
+}
+
+static long long* g_chain_trace = nullptr;   // developer aid: GPMPC_CHAIN_TRACE=<file> dumps the chain's time stamps
+
+// Two-level execution of the chained factorisation (batches of matrices -- C3's six outputs -- and Np > 4096, where the
+// trailing matrix does not fit the tile-owner workers' registers).  The plain flagged execution below updates the WHOLE
+// trailing matrix after every 64-column panel: a K = 64 product reads and writes 16 bytes of C per 128 flops and is
+// bound by that traffic (C3: 85 ms for 2.2e12 flop).  Here W block columns form a super-panel:
+//     for each super-panel [k0, k1):   chain kernel for blocks k0 .. k1-1 (one launch), panel rows and the trailing
+//                                      update INSIDE the super-panel's columns as flagged K = 64 launches (small);
+//                                      then ONE product A22 -= L21 L21^T with K = 64 W on everything to the right.
+// C traffic of the big updates falls by W and they run at the GEMM's MFMA rate; the inverse of a finished 512-row
+// segment runs on the third queue while the big update occupies the second.
+static bool factor_twolevel(const Ctx& cx, Workspace& ws, int spin_limit, int W) {
+    const int Np = ws.Np, nb = Np / 64, nf = chain_flag_count(nb);
+    const long ld = Np, sM = ws.mat(), sW = ws.wstride();
+    int* leafdone = ws.flags + 1;
+    int* pan1 = ws.flags + 1 + nb;
+    int* tdone = ws.flags + 1 + 2 * nb;
+    // The inverse follows panel by panel on the third queue -- right-looking blocked inversion of the row panels
+    // P_i = super-panel i: with S = sum over finished panels m of L[., P_m] X[P_m, .] accumulated IN the not yet final
+    // rows of Inv,
+    //     I_i = (L[P_i, P_i])^-1 (level-batched),    X[P_i, < r_i] = -I_i S[P_i, < r_i],
+    //     S[> P_i, < r_{i+1}] += L[> P_i, P_i] X[P_i, < r_{i+1}]                  (K = 64 W products)
+    // so every step only needs rows P_i of L -- final as soon as super-panel i is factored -- and after the last
+    // super-panel just its own inverse and one 64 W-row product remain (the tree-shaped inverse left the two products of
+    // its root, a third of the fit, for the end).  Needs a 64 W x Np scratch panel in ws.W and the event pool.
+    const bool panel_inv = cx.aux && cx.seg && cx.n_seg >= 3 && (long)64 * W * Np <= sW;
+    auto inverse_panel = [&](hipStream_t st, int k0, int k1) {
+        const int ri = 64 * k0, a = 64 * (k1 - k0), rn = 64 * k1, Mb = Np - rn;
+        trtri_range(cx, ws, st, ri, a);                                        // I_i
+        if (ri > 0) {
+            GemmP u = gemm_base(cx);                                           // T = -I_i S_i, then back into Inv[P_i, < r_i]
+            u.A = ws.Inv + (long)ri * ld + ri; u.lda = ld; u.sA = sM; u.a_mc = 0; u.kflags = KA_LE_M;
+            u.B = ws.Inv + (long)ri * ld; u.ldb = ld; u.sB = sM; u.b_nc = 1;
+            u.C = ws.W; u.ldc = ri; u.sC = sW;
+            u.M = a; u.N = ri; u.K = a; u.alpha = -1.0;
+            launch_gemm(u, ws.batch, st);
+            for (int b = 0; b < ws.batch; ++b)
+                hipMemcpy2DAsync(ws.Inv + b * sM + (long)ri * ld, ld * sizeof(double), ws.W + b * sW, (size_t)ri * sizeof(double),
+                                 (size_t)ri * sizeof(double), a, hipMemcpyDeviceToDevice, st);
+        }
+        if (Mb > 0) {
+            GemmP t = gemm_base(cx);                                           // new columns of S: L[> P_i, P_i] I_i
+            t.A = ws.L + (long)rn * ld + ri; t.lda = ld; t.sA = sM; t.a_mc = 0;
+            t.B = ws.Inv + (long)ri * ld + ri; t.ldb = ld; t.sB = sM; t.b_nc = 1; t.kflags = KB_GE_N;
+            t.C = ws.Inv + (long)rn * ld + ri; t.ldc = ld; t.sC = sM;
+            t.M = Mb; t.N = a; t.K = a;
+            launch_gemm(t, ws.batch, st);
+            if (ri > 0) {
+                GemmP v = gemm_base(cx);                                       // S[> P_i, < r_i] += L[> P_i, P_i] X[P_i, < r_i]
+                v.A = ws.L + (long)rn * ld + ri; v.lda = ld; v.sA = sM; v.a_mc = 0;
+                v.B = ws.Inv + (long)ri * ld; v.ldb = ld; v.sB = sM; v.b_nc = 1;
+                v.C = ws.Inv + (long)rn * ld; v.ldc = ld; v.sC = sM;
+                v.M = Mb; v.N = ri; v.K = a; v.beta = 1.0;
+                launch_gemm(v, ws.batch, st);
+            }
+        }
+    };
+    int ev = 0;                                                // event pool cursor
+    int inv_done = 0;                                          // block columns whose inverse panel has been enqueued
+    // Look-ahead: the K = 64 W update of super-panel s is split in A(s) = the NEXT super-panel's columns (second queue,
+    // what the chain needs next) and B(s) = everything right of them (fourth queue, low priority), so that B(s) overlaps
+    // the latency-bound factorisation of super-panel s+1.  Order on shared tiles: A(s) after B(s-1) (event), B(s) after
+    // the panels of s (event) and after B(s-1) (queue order).
+    static const bool lookahead_on = !(getenv("GPMPC_LOOKAHEAD") && atoi(getenv("GPMPC_LOOKAHEAD")) == 0);
+    const bool lookahead = lookahead_on && cx.bulk && cx.seg && cx.n_seg >= 4 * ((nb + W - 1) / W) + 2;
+    hipEvent_t evB_prev = nullptr;
+    if (lookahead) {
+        hipEventRecord(cx.join, cx.stream);                    // the fourth queue starts behind everything enqueued so far
+        hipStreamWaitEvent(cx.bulk, cx.join, 0);
+    }
+    for (int k0 = 0; k0 < nb; k0 += W) {
+        const int k1 = std::min(nb, k0 + W), k2 = std::min(nb, k1 + W);
+        // the chain of this super-panel starts when the update of its columns (second queue) is complete
+        hipEventRecord(cx.join, cx.side);
+        hipStreamWaitEvent(cx.stream, cx.join, 0);
+        hipLaunchKernelGGL(chol_chain_kernel, dim3(1, 1, ws.batch), dim3(256), CHAIN_LDS_BYTES, cx.stream, (const double*)ws.K,
+                           ws.L, ws.Inv, ld, sM, nb, ws.flags, (long)nf, ws.info, cx.crow_mode, spin_limit, g_chain_trace, 0, k0,
+                           k1);
+        hipLaunchKernelGGL(flag_gate_kernel, dim3(ws.batch), dim3(64), 0, cx.side, ws.flags, (long)nf, 1 + k0, 1, -1, 0,
+                           spin_limit);                       // bulk workgroups only once this chain launch is resident
+        for (int k = k0; k < k1; ++k) {
+            const int off = 64 * k;
+            const long o11 = (long)off * ld + off;
+            const bool last = k + 1 == k1;                     // the chain stops after this leaf: row k+1 is the panel product's
+            const int r0 = off + (last ? 64 : 128), M2 = Np - r0;
+            if (M2 > 0) {
+                GemmP p = gemm_base(cx);                       // panel: L(i,k) = A(i,k) inv_kk^T
+                p.A = ws.K + (long)r0 * ld + off; p.lda = ld; p.sA = sM; p.a_mc = 0;
+                p.B = ws.Inv + o11; p.ldb = ld; p.sB = sM; p.b_nc = 0; p.kflags = KB_LE_N;
+                p.C = ws.L + (long)r0 * ld + off; p.ldc = ld; p.sC = sM;
+                p.M = M2; p.N = 64; p.K = 64;
+                p.wait_flag = leafdone + k; p.err = ws.flags; p.spin_limit = spin_limit; p.sFlags = nf;
+                launch_gemm(p, ws.batch, cx.side);
+            }
+            const int M1 = Np - off - 64, N1 = 64 * (k1 - k - 1);   // trailing update inside the super-panel's columns
+            if (!last && M1 > 64) {
+                const long o1 = (long)(off + 64) * ld;
+                GemmP q = gemm_base(cx);
+                q.A = ws.L + o1 + off; q.lda = ld; q.sA = sM; q.a_mc = 0;
+                q.B = ws.L + o1 + off; q.ldb = ld; q.sB = sM; q.b_nc = 0;
+                q.C = ws.K + o1 + off + 64; q.ldc = ld; q.sC = sM;
+                q.M = M1; q.N = N1; q.K = 64; q.alpha = -1.0; q.beta = 1.0; q.lower = 1;
+                q.wait_flag = pan1 + k; q.err = ws.flags; q.spin_limit = spin_limit; q.sFlags = nf;
+                q.skip00 = 1; q.done_flags = tdone + 2 * k;
+                launch_gemm(q, ws.batch, cx.side, 64);         // flags are defined on 64 x 64 tiles
+            }
+        }
+        // rows < 64 k1 of L are final: the inverse of this row panel goes to the third queue, next to the big update
+        if (panel_inv && k1 < nb && ev + 2 < cx.n_seg) {
+            hipEventRecord(cx.seg[ev], cx.side);
+            hipStreamWaitEvent(cx.aux, cx.seg[ev], 0);
+            ++ev;
+            hipEventRecord(cx.seg[ev], cx.stream);            // (the leaf's own stores: the chain launch has to be complete)
+            hipStreamWaitEvent(cx.aux, cx.seg[ev], 0);
+            ++ev;
+            if (inv_done < k0) inverse_panel(cx.aux, inv_done, k0);   // (panels skipped for want of events: as one)
+            inverse_panel(cx.aux, k0, k1);
+            inv_done = k1;
+        }
+        if (k1 < nb) {                                         // A22 -= L21 L21^T, K = 64 (k1 - k0)
+            const long r = 64L * k1, c0 = 64L * k0;
+            GemmP g = gemm_base(cx);
+            g.A = ws.L + r * ld + c0; g.lda = ld; g.sA = sM; g.a_mc = 0;
+            g.B = ws.L + r * ld + c0; g.ldb = ld; g.sB = sM; g.b_nc = 0;
+            g.C = ws.K + r * ld + r; g.ldc = ld; g.sC = sM;
+            g.M = Np - (int)r; g.N = Np - (int)r; g.K = 64 * (k1 - k0); g.alpha = -1.0; g.beta = 1.0; g.lower = 1;
+            if (!lookahead || k2 >= nb) {
+                if (lookahead && evB_prev) hipStreamWaitEvent(cx.side, evB_prev, 0);
+                launch_gemm(g, ws.batch, cx.side);
+            } else {
+                hipEvent_t evP = cx.seg[ev++], evB = cx.seg[ev++];
+                hipEventRecord(evP, cx.side);                  // the panels of this super-panel are complete
+                if (evB_prev) hipStreamWaitEvent(cx.side, evB_prev, 0);
+                GemmP ga = g;                                  // A(s): columns of the next super-panel
+                ga.N = 64 * (k2 - k1);
+                launch_gemm(ga, ws.batch, cx.side);
+                const long r2 = 64L * k2;                      // B(s): the rest, on the fourth queue
+                GemmP gb = g;
+                gb.A = ws.L + r2 * ld + c0;
+                gb.B = ws.L + r2 * ld + c0;
+                gb.C = ws.K + r2 * ld + r2;
+                gb.M = Np - (int)r2; gb.N = Np - (int)r2;
+                hipStreamWaitEvent(cx.bulk, evP, 0);
+                launch_gemm(gb, ws.batch, cx.bulk);
+                hipEventRecord(evB, cx.bulk);
+                evB_prev = evB;
+            }
+        }
+    }
+    hipEventRecord(cx.join, cx.side);
+    hipStreamWaitEvent(cx.stream, cx.join, 0);
+    if (lookahead) {
+        hipEventRecord(cx.fork, cx.bulk);
+        hipStreamWaitEvent(cx.stream, cx.fork, 0);
+    }
+    if (cx.aux && cx.seg) {
+        hipEventRecord(cx.seg[cx.n_seg - 1], cx.aux);
+        hipStreamWaitEvent(cx.stream, cx.seg[cx.n_seg - 1], 0);
+    }
+    if (!panel_inv) { trtri_levels(cx, ws); return true; }
+    inverse_panel(cx.stream, inv_done, nb);                    // what is left: the last panel (or everything not handed over)
+    return true;
+}
+
+// Chained factorisation: the sequential part of every panel step runs in ONE persistent workgroup
+// (chol_chain_kernel, main queue) that keeps a CU to itself, the bulk -- panel rows >= k+2 and the
+// trailing update -- in ordinary GEMM launches on the side queue; flags in ws.flags couple the two.
+// Returns false if the path is unavailable (no side queue).  A time-out inside the kernels is reported
+// through ws.flags[0] and handled by the caller (fallback to factor_blocked).
+
+static bool factor_chain(const Ctx& cx, Workspace& ws, int spin_limit) {
+    if (!cx.side || ws.Np < 128) return false;
+    const int Np = ws.Np, nb = Np / 64, nf = chain_flag_count(nb);
+    const long ld = Np, sM = ws.mat();
+    hipMemsetAsync(ws.flags, 0, (size_t)ws.batch * nf * sizeof(int), cx.stream);
+    hipEventRecord(cx.fork, cx.stream);
+    hipStreamWaitEvent(cx.side, cx.fork, 0);
+    // bulk work as tile-owner workers: 7 of 8 CUs run one, the trailing matrix lives in their registers
+    // A worker fills a CU (512 threads x ~250 VGPRs) and the chain needs an empty CU too.  Measured on MI355X
+    // (start-time stamps of the workers): workgroups are dealt to the shader engines (8 CUs each) in a fixed
+    // rotation and a workgroup that does not fit on "its" engine waits there even when CUs are free elsewhere
+    // -- with 8 workers on the engine that also got the chain, the 8th started 234 ms late, after the others'
+    // polls had timed out.  So: 7 workers per engine, nothing else in flight but the chain (one matrix only).
+    const int ntiles = (nb - 1) * nb / 2 - 1;            // tiles kept in registers (chol_worker.hpp)
+    int NW = ws.batch == 1 ? cx.workers - cx.workers / 8 : 0;
+    if (NW > ntiles) NW = ntiles;
+    const bool use_workers = NW >= 1 && nb >= 3 && (ntiles + NW - 1) / NW <= WORKER_MAXT;
+    // what the workers do not take: two-level panels (GPMPC_TWOLEVEL=<block columns per super-panel>, 0/1 = off)
+#ifdef GPMPC_EMULATED
+    static const int twolevel_W = getenv("GPMPC_TWOLEVEL") ? atoi(getenv("GPMPC_TWOLEVEL")) : 2;
+#else
+    static const int twolevel_W = getenv("GPMPC_TWOLEVEL") ? atoi(getenv("GPMPC_TWOLEVEL")) : 8;
+#endif
+    if (!use_workers && twolevel_W > 1 && nb >= 2 * twolevel_W && cx.aux && cx.seg) {
+        static const bool verbose2 = getenv("GPMPC_VERBOSE") != nullptr;
+        if (verbose2)
+            fprintf(stderr, "gpmpc: factor Np=%d batch=%d: two-level panels of %d block columns\n", Np, ws.batch, twolevel_W);
+        return factor_twolevel(cx, ws, spin_limit, twolevel_W);
+    }
+    // Worker launches and the row-panel schedule of the inverse.  The workers run as up to three launches
+    // (GPMPC_MAX_LAUNCHES), cut where the tree of the triangular inverse has its nodes on the right spine (Np = 4096:
+    // blocks 0-31, 32-47, 48-63 with 224 / 96 / 32 workers: after half of the steps three quarters of the tiles are
+    // finished, and so on; a fourth launch for blocks 56-63 was measured slower, 2.33 against 2.11 ms).  A launch i that has finished leaves rows P_i = [r_i, r_i+1) of L final, and the CUs the NEXT launch does
+    // not need run -- behind a gate that waits until that launch is resident, its workgroups need whole CUs -- the
+    // part of L^-1 that is computable by then.  With S_j = (L[P_j, <r] L^-1[<r, <r]) for a later panel P_j, kept as a
+    // matrix of its own and grown panel by panel,
+    //     I_i = (L[P_i, P_i])^-1 (level-batched, trtri_range),    L^-1[P_i, <r_i] = -I_i S_i,
+    //     W_j = L[P_j, P_i] I_i,   S_j <- [S_j - W_j S_i | W_j]                                    for every j > i,
+    // so that after the chain only the LAST panel's own inverse and ONE product -I S remain.
+    // (History, N = 4096, factor time: two launches 2.22-2.24 ms, three 2.11; pieces gated on the chain's progress by
+    //  polling kernels instead of launch boundaries were slower)
+    int s_top = 64;                                         // rows of the left child of the inverse tree's root
+    while (2 * s_top < Np) s_top *= 2;
+    static const bool split_ok = !(getenv("GPMPC_WORKER_SPLIT") && atoi(getenv("GPMPC_WORKER_SPLIT")) == 0);
+    static const int max_launches = getenv("GPMPC_MAX_LAUNCHES") ? atoi(getenv("GPMPC_MAX_LAUNCHES")) : 3;
+    static const int nw2_env = getenv("GPMPC_NW2") ? atoi(getenv("GPMPC_NW2")) : 0;   // (tuning aids)
+    static const int nw3_env = getenv("GPMPC_NW3") ? atoi(getenv("GPMPC_NW3")) : 0;
+    static const int nw4_env = getenv("GPMPC_NW4") ? atoi(getenv("GPMPC_NW4")) : 0;
+    // second launch: 96 of 256 CUs, <= 6 tiles per worker at Np = 4096 (measured: 64 / 96 / 128 / 160 / 192 workers ->
+    // 2.44 / 2.40 / 2.43 / 2.53 / 2.61 ms; with the DMA-staged workers 64 .. 160 are within 1 %)
+    const int nw_rule[4] = {NW, nw2_env > 0 ? nw2_env : std::max(1, cx.workers * 3 / 8),
+                            nw3_env > 0 ? nw3_env : std::max(1, cx.workers / 8), nw4_env > 0 ? nw4_env : std::max(1, cx.workers / 16)};
+    int r[6] = {0, Np, Np, Np, Np, Np}, nws[5] = {NW, 0, 0, 0, 0};   // panel starts r[0..L], r[L] = Np; workers per launch
+    int L = 1;
+    long wofs[5] = {0, 0, 0, 0, 0};                         // S_j of panel j (1 <= j < L) inside ws.W, ld = r[j]
+    if (use_workers && split_ok && cx.aux && cx.seg) {
+        long wo = ws.hw() * ws.hw();
+        static const int cut1 = getenv("GPMPC_CUT1") ? atoi(getenv("GPMPC_CUT1")) : 0;   // (tuning aid: block of the first cut)
+        int start = (cut1 > 0 && 64 * cut1 < Np) ? 64 * cut1 : s_top;
+        while (L < 4 && L < max_launches && L + 1 <= cx.n_seg - 1) {
+            const int a = start - r[L - 1];                 // rows of the panel the new cut closes
+            const int nbr = (Np - start) / 64, nt = (nbr - 1) * nbr / 2 - 1;
+            int nw = nw_rule[L];
+            if (nt > 0 && nw > nt) nw = nt;
+            if (a < SEGR || nbr < 3 || nt < 1 || (nt + nw - 1) / nw > WORKER_MAXT) break;
+            r[L] = start; nws[L] = nw; ++L;
+            int nxt = 64;                                   // next cut: the left child of what remains
+            while (2 * nxt < Np - start) nxt *= 2;
+            static const int cut2 = getenv("GPMPC_CUT2") ? atoi(getenv("GPMPC_CUT2")) : 0;   // (tuning aid: block of the second cut)
+            if (L == 2 && cut2 > 0 && 64 * cut2 > start && 64 * cut2 < Np) nxt = 64 * cut2 - start;
+            start += nxt;
+            if (start >= Np) break;
+        }
+        r[L] = Np;
+        // storage of S_j: panels 1 .. L-2 a_j x r_j, the last panel (Np - r[L-1]) x r[L-1]; drop cuts that do not fit
+        for (;;) {
+            long need = wo;
+            for (int jj = 1; jj < L; ++jj) { wofs[jj] = need; need += (long)(r[jj + 1] - r[jj]) * r[jj]; }
+            if (L == 1 || need <= ws.wstride()) break;
+            --L; r[L] = Np;
+        }
+    }
+    const bool split = L >= 2;
+    auto product = [&](hipStream_t st, const double* A, long lda, int kfl, const double* B, long ldb, double* C, long ldc,
+                       int M, int N, int K, double alpha, double beta) {   // C = alpha A B + beta C, A K-contiguous, B N-contiguous
+        GemmP g = gemm_base(cx);
+        g.A = A; g.lda = lda; g.sA = 0; g.a_mc = 0;
+        g.B = B; g.ldb = ldb; g.sB = 0; g.b_nc = 1;
+        g.C = C; g.ldc = ldc; g.sC = 0;
+        g.kflags = kfl; g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.beta = beta;
+        launch_gemm(g, 1, st);
+    };
+    // inverse pipelined segment by segment behind the chain: next to GEMM launches only
+    const bool pipelined = !use_workers && cx.aux && cx.seg && Np >= 4 * SEGR;
+    int seg_done = 0;
+    {   // the chain kernel ends with the last leaf, i.e. when L is complete: its duration is the Cholesky's
+        ProfScope t(cx.prof, cx.stream, GPMPC_PH_CHAIN);
+        hipLaunchKernelGGL(chol_chain_kernel, dim3(1, 1, ws.batch), dim3(256), CHAIN_LDS_BYTES, cx.stream, (const double*)ws.K,
+                           ws.L, ws.Inv, ld, sM, nb, ws.flags, (long)nf, ws.info, cx.crow_mode, spin_limit, g_chain_trace,
+                           use_workers ? 1 : 0);
+    }
+    static const bool verbose = getenv("GPMPC_VERBOSE") != nullptr;
+    if (verbose)
+        fprintf(stderr, "gpmpc: factor Np=%d batch=%d: chain kernel + %s (%d launch%s), inverse %s\n", Np, ws.batch,
+                use_workers ? "tile-owner workers" : "GEMM launches", use_workers ? L : 0, L == 1 ? "" : "es",
+                split ? "by row panels behind the worker launches" : pipelined ? "pipelined" : "at the end");
+    if (use_workers) {
+        for (int i = 0; i < L; ++i) {
+            int* ready = i ? ws.flags + chain_ready_index(nb) + 2 * (i - 1) : nullptr;   // arrival counter + flag of launch i
+            hipLaunchKernelGGL(chol_worker_kernel, dim3(nws[i], 1, ws.batch), dim3(WORKER_THREADS), WORKER_LDS_BYTES, cx.side,
+                               ws.K, ws.L, (const double*)ws.Inv, ld, sM, nb, ws.flags, (long)nf, cx.crow_mode, spin_limit,
+                               r[i] / 64, i + 1 < L ? (r[i + 1] - r[i]) / 64 : nb, ready, g_chain_trace);
+            if (i + 1 == L) break;
+            // launch i finished: rows P_i of L are final.  Behind launch i + 1, once it is resident:
+            hipEventRecord(cx.seg[i], cx.side);
+            hipStreamWaitEvent(cx.aux, cx.seg[i], 0);
+            hipLaunchKernelGGL(flag_gate_kernel, dim3(ws.batch), dim3(64), 0, cx.aux, ws.flags, (long)nf,
+                               chain_ready_index(nb) + 2 * i + 1, 1, -1, 0, spin_limit);
+            const int ri = r[i], a = r[i + 1] - r[i];
+            trtri_range(cx, ws, cx.aux, ri, a);                                    // I_i
+            if (i + 2 == L) hipEventRecord(cx.seg[cx.n_seg - 2], cx.aux);         // the side queue's last use of the level scratch
+            const double* Ii = ws.Inv + (long)ri * ld + ri;
+            const double* Si = i ? ws.W + wofs[i] : nullptr;                       // a x ri
+            for (int jj = i + 1; jj < L; ++jj) {
+                const int rj = r[jj], hj = r[jj + 1] - r[jj];
+                double* Sj = ws.W + wofs[jj];
+                product(cx.aux, ws.L + (long)rj * ld + ri, ld, KB_GE_N, Ii, ld, Sj + ri, rj, hj, a, a, 1.0, 0.0);        // W_j
+                if (i) product(cx.aux, Sj + ri, rj, 0, Si, ri, Sj, rj, hj, ri, a, -1.0, 1.0);                            // S_j -= W_j S_i
+            }
+            if (i) product(cx.aux, Ii, ld, KA_LE_M, Si, ri, ws.Inv + (long)ri * ld, ld, a, ri, a, -1.0, 0.0);             // L^-1[P_i, <r_i]
+        }
+    } else {
+        hipLaunchKernelGGL(chain_gate_kernel, dim3(ws.batch), dim3(64), 0, cx.side, ws.flags, (long)nf, spin_limit);
+        int* leafdone = ws.flags + 1;
+        int* pan1 = ws.flags + 1 + nb;
+        int* tdone = ws.flags + 1 + 2 * nb;
+        for (int k = 0; k + 1 < nb; ++k) {
+            const int off = 64 * k;
+            const long o11 = (long)off * ld + off;
+            const int M2 = Np - off - 128;                       // panel rows >= k+2 (row k+1 is the chain's)
+            if (M2 > 0) {
+                const long o2 = (long)(off + 128) * ld + off;
+                GemmP p = gemm_base(cx);
+                p.A = ws.K + o2; p.lda = ld; p.sA = sM; p.a_mc = 0;
+                p.B = ws.Inv + o11; p.ldb = ld; p.sB = sM; p.b_nc = 0; p.kflags = KB_LE_N;
+                p.C = ws.L + o2; p.ldc = ld; p.sC = sM;
+                p.M = M2; p.N = 64; p.K = 64;
+                p.wait_flag = leafdone + k; p.err = ws.flags; p.spin_limit = spin_limit; p.sFlags = nf;
+                launch_gemm(p, ws.batch, cx.side);
+            }
+            const int M1 = Np - off - 64;                        // trailing update from block k+1 on, minus tile (k+1,k+1)
+            if (M1 > 64) {
+                const long o1 = (long)(off + 64) * ld;
+                GemmP q = gemm_base(cx);
+                q.A = ws.L + o1 + off; q.lda = ld; q.sA = sM; q.a_mc = 0;
+                q.B = ws.L + o1 + off; q.ldb = ld; q.sB = sM; q.b_nc = 0;
+                q.C = ws.K + o1 + off + 64; q.ldc = ld; q.sC = sM;
+                q.M = M1; q.N = M1; q.K = 64; q.alpha = -1.0; q.beta = 1.0; q.lower = 1;
+                q.wait_flag = pan1 + k; q.err = ws.flags; q.spin_limit = spin_limit; q.sFlags = nf;
+                q.skip00 = 1; q.done_flags = tdone + 2 * k;
+                launch_gemm(q, ws.batch, cx.side, 64);           // flags are defined on 64 x 64 tiles
+                // rows [.., 64(k+1)) are final once this update has consumed panel k: a finished segment goes to aux
+                if (pipelined && (off + 64) % SEGR == 0 && seg_done < cx.n_seg - 1) {
+                    hipEventRecord(cx.seg[seg_done], cx.side);
+                    hipStreamWaitEvent(cx.aux, cx.seg[seg_done], 0);
+                    trtri_segment(cx, ws, cx.aux, seg_done * SEGR, (seg_done + 1) * SEGR);
+                    ++seg_done;
+                }
+            }
+        }
+    }
+    hipEventRecord(cx.join, cx.side);
+    hipStreamWaitEvent(cx.stream, cx.join, 0);
+    if (split) {                                            // the last panel: its own inverse, then -I S
+        // The inverse of the last panel needs nothing from the side queue but the level scratch, which that queue left
+        // long ago (event recorded behind its last trtri_range); only the product waits for its S.  (Waiting for the
+        // whole side queue first put its last product, which ends ~50 us after the chain, in front of these eight
+        // latency-bound launches.)
+        hipStreamWaitEvent(cx.stream, cx.seg[cx.n_seg - 2], 0);
+        const int rl = r[L - 1], h = Np - rl;
+        trtri_range(cx, ws, cx.stream, rl, h);
+        hipEventRecord(cx.seg[cx.n_seg - 1], cx.aux);
+        hipStreamWaitEvent(cx.stream, cx.seg[cx.n_seg - 1], 0);
+        product(cx.stream, ws.Inv + (long)rl * ld + rl, ld, KA_LE_M, ws.W + wofs[L - 1], rl, ws.Inv + (long)rl * ld, ld,
+                h, rl, h, -1.0, 0.0);
+        return true;
+    }
+    if (!pipelined) { trtri_levels(cx, ws); return true; }
+    // segments the side queue could not hand over (the last ones) are inverted after the chain, on the main queue
+    hipEventRecord(cx.seg[cx.n_seg - 1], cx.aux);
+    hipStreamWaitEvent(cx.stream, cx.seg[cx.n_seg - 1], 0);
+    for (int sg = seg_done; sg * SEGR < Np; ++sg) trtri_segment(cx, ws, cx.stream, sg * SEGR, std::min(Np, (sg + 1) * SEGR));
+    return true;
+}
+
+// w = L^-1 y and alpha = L^-T w as two HBM-bound matrix-vector products with the explicit inverse.
+// y: [batch] vectors with stride sy.
+static void solve_alpha(const Ctx& cx, Workspace& ws, const double* y, long sy) {
+    const int Np = ws.Np;
+    hipLaunchKernelGGL(gemv_rows_kernel, dim3(Np / 4, ws.batch), dim3(256), 0, cx.stream, ws.Inv, y, ws.w, Np, ws.mat(), sy,
+                       (long)Np, 1);
+    const int chunks = (Np + GEMVT_ROWS - 1) / GEMVT_ROWS;         // partial sums go through the (now idle) inverse scratch
+    hipLaunchKernelGGL(gemv_lowerT_part_kernel, dim3((Np + 127) / 128, chunks, ws.batch), dim3(256), 0, cx.stream, ws.Inv, ws.w, ws.W,
+                       Np, ws.mat(), (long)Np, ws.wstride());
+    hipLaunchKernelGGL(gemv_lowerT_finish_kernel, dim3((Np + 255) / 256, ws.batch), dim3(256), 0, cx.stream, ws.W, ws.alpha, Np,
+                       chunks, ws.wstride(), (long)Np);
+}
+
+// K^-1 = L^-T L^-1 (lower triangle by MFMA, then mirrored)
+static int compute_invK(const Ctx& cx, Workspace& ws) {
+    CHK(ws_need_invK(ws));
+    const long ld = ws.Np, sM = ws.mat();
+    GemmP p = gemm_base(cx);
+    p.A = ws.Inv; p.lda = ld; p.sA = sM; p.a_mc = 1;
+    p.B = ws.Inv; p.ldb = ld; p.sB = sM; p.b_nc = 1;
+    p.kflags = KA_GE_M | KB_GE_N;
+    p.C = ws.InvK; p.ldc = ld; p.sC = sM;
+    p.M = ws.Np; p.N = ws.Np; p.K = ws.Np; p.lower = 1;
+    launch_gemm(p, ws.batch, cx.stream);
+    hipLaunchKernelGGL(symmetrize_kernel, dim3(ws.Np / 64, ws.Np / 64, ws.batch), dim3(256), 0, cx.stream, ws.InvK,
+                       ws.Np);
+    return GPMPC_OK;
+}
+

@@ -1,0 +1,155 @@
+// api_rollout.inl -- part of gpmpc_api.hip (one translation unit; included in order, not compiled alone).
+// Concern: T-step propagation on the device (open loop / state feedback), hipGraph replay.
+static int rollout_impl(gpmpc_gp* h, int method, int T, const double* z0, const double* U, const double* Sigma0,
+                        const double* sa, const double* sb, const double* Kz, const double* k0, const double* Kc,
+                        double* mean, double* cov, double* Uout) {
+    if (!h) return fail(GPMPC_EINVAL, "NULL handle");
+    if (!h->fitted) return fail(GPMPC_ENOTFIT, "model has no factors (call gpmpc_fit or gpmpc_set_factors)");
+    if (method < GPMPC_ME || method > GPMPC_OLD_TA) return fail(GPMPC_EINVAL, "No GP method with code %d", method);
+    const int d = h->d, Ny = h->Ny, Nu = d - Ny;
+    const bool fb = Kz != nullptr;
+    if (T <= 0 || !z0 || !Sigma0 || !mean || !cov || (!fb && Nu > 0 && !U)) return fail(GPMPC_EINVAL, "bad T or NULL argument");
+    if (Nu < 0) return fail(GPMPC_EINVAL, "roll-out needs d >= Ny (inputs are [state, control])");
+    if (fb && (Nu == 0 || !k0 || !Kc)) return fail(GPMPC_EINVAL, "feedback roll-out needs controls and Kz, k0, Kc");
+    if (method == GPMPC_OLD_TA && h->mean_kind)
+        return fail(GPMPC_EINVAL, "'old_TA' with a non-zero mean function raises in the reference (gp_functions.py:309-311); not served");
+    HIPCHK(hipSetDevice(h->device));
+    CHK(ensure_scratch(h, 1));
+    const bool moments = method == GPMPC_EM || method == GPMPC_OLD_ME || method == GPMPC_OLD_TA;
+    if (moments && !h->have_invK) {
+        CHK(compute_invK(h->cx(), h->ws));
+        h->have_invK = true;
+    }
+    // device staging (grow-only, with a pinned mirror): inputs [z | Sigma | sa | sb | Kz | k0 | Kc | U], then the
+    // trajectories [mean (T) | cov (T)] and scratch [var | J]: one copy up, one copy down ([U |] mean | cov)
+    const int nu1 = std::max(Nu, 1);
+    const size_t nz = d, nS = (size_t)d * d, nU = (size_t)T * nu1, nM = (size_t)T * Ny, nC = (size_t)T * Ny * Ny;
+    const size_t nK = (size_t)nu1 * Ny;
+    const size_t nIn = nz + nS + 2 * Ny + 2 * nK + nu1 + nU;
+    const size_t total = nIn + nM + nC + Ny + (size_t)Ny * d;
+    if (total > h->roll_cap) {
+        HIPCHK(hipStreamSynchronize(h->stream));
+        drop_roll_graphs(h);
+        hipFree(h->roll_dev);
+        if (h->roll_pin) hipHostFree(h->roll_pin);
+        h->roll_dev = h->roll_pin = nullptr;
+        h->roll_cap = 0;
+        HIPCHK(hipMalloc(&h->roll_dev, total * sizeof(double)));
+        HIPCHK(hipHostMalloc((void**)&h->roll_pin, total * sizeof(double), hipHostMallocDefault));
+        h->roll_cap = total;
+    }
+    double* buf = h->roll_dev;
+    double *dz = buf, *dS = dz + nz, *dsa = dS + nS, *dsb = dsa + Ny, *dKz = dsb + Ny, *dk0 = dKz + nK, *dKc = dk0 + nu1,
+           *dU = dKc + nK, *dM = dU + nU, *dC = dM + nM, *dV = dC + nC, *dJ = dV + Ny;
+    {
+        double* pz = h->roll_pin;
+        auto put = [&](double* dev_dst, const double* src, size_t n) { std::memcpy(pz + (dev_dst - buf), src, n * sizeof(double)); };
+        std::memset(pz, 0, nIn * sizeof(double));
+        put(dz, z0, nz);
+        put(dS, Sigma0, nS);
+        for (int a = 0; a < Ny; ++a) pz[(dsa - buf) + a] = sa ? sa[a] : 1.0;
+        if (sb) put(dsb, sb, Ny);
+        if (!fb && Nu > 0) put(dU, U, (size_t)T * Nu);
+        if (fb) {
+            put(dKz, Kz, nK);
+            put(dk0, k0, Nu);
+            put(dKc, Kc, nK);
+            put(dU, z0 + Ny, Nu);                                  // the first control comes with z0
+        }
+    }
+    HIPCHK(hipMemcpyAsync(buf, h->roll_pin, nIn * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    int rc = GPMPC_OK;
+    auto enqueue_steps = [&]() -> int {
+        int r = GPMPC_OK;
+        for (int t = 0; t < T && r == GPMPC_OK; ++t) {
+            if (t > 0)
+                hipLaunchKernelGGL(rollout_feed_kernel, dim3(1), dim3(64), 0, h->stream, dM + (size_t)(t - 1) * Ny,
+                                   dC + (size_t)(t - 1) * Ny * Ny, dU + (size_t)t * nu1, dsa, dsb, dz, dS, Ny, d,
+                                   fb ? dKz : (const double*)nullptr, fb ? dk0 : (const double*)nullptr,
+                                   fb ? dKc : (const double*)nullptr, fb ? dU + (size_t)t * nu1 : (double*)nullptr);
+            double* oM = dM + (size_t)t * Ny;
+            double* oC = dC + (size_t)t * Ny * Ny;
+            if (moments) {
+                r = predict_moments_chunk(h, method, 1, dz, dS, oM, oC);
+            } else {
+                const bool ta = method == GPMPC_TA;
+                r = predict_chunk(h, 1, dz, oM, dV, ta ? dJ : nullptr);
+                if (r == GPMPC_OK)
+                    hipLaunchKernelGGL(cov_assemble_kernel, dim3((unsigned)((Ny * Ny + 255) / 256)), dim3(256), 0, h->stream, dV, dJ,
+                                       ta ? dS : (const double*)nullptr, oC, 1, Ny, d);
+            }
+        }
+        return r;
+    };
+    // The loop is 6-9 dependent launches per step: at the reference's model sizes that is all the time there is (26 us per
+    // 'ME' step at N = 200).  After one plain run with the same key -- every lazy allocation and kernel attribute is then in
+    // place -- the T-step loop is captured into a hipGraph and replayed; the key holds every address and size a launch bakes in.
+    bool done = false;
+    if (moments) CHK(ensure_beta(h));        // lazily refreshed after a fit: must not hide inside (or be missing from) a captured loop
+#ifndef GPMPC_EMULATED
+    static const bool use_graph = !(getenv("GPMPC_ROLLOUT_GRAPH") && atoi(getenv("GPMPC_ROLLOUT_GRAPH")) == 0);
+    static const int graph_max_np = getenv("GPMPC_ROLLOUT_GRAPH_NP") ? atoi(getenv("GPMPC_ROLLOUT_GRAPH_NP")) : 2048;
+    if (use_graph && !h->prof.on && h->Np <= graph_max_np) {
+        const std::vector<long> key = {method, T, fb ? 1 : 0, Nu, h->N, h->Np, Ny, d, h->mean_kind, h->mean_add ? 1 : 0, h->Bcap,
+                                       (long)buf, (long)h->XT, (long)h->ws.hyper, (long)h->ws.alpha, (long)h->ws.Inv,
+                                       (long)h->ws.InvK, (long)h->beta, (long)h->KsT, (long)h->meanT, (long)h->part,
+                                       (long)h->ccpart, (long)h->em, h->emBytes, (long)h->UT, (long)h->mpar, (long)h->stream};
+        gpmpc_gp::RollGraph* g = nullptr;
+        for (auto& e : h->roll_graphs)
+            if (e.key == key) g = &e;
+        if (!g && h->roll_warm == key) {
+            gpmpc_gp::RollGraph ng;
+            if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                const int r = enqueue_steps();
+                const hipError_t ee = hipStreamEndCapture(h->stream, &ng.graph);
+                if (r == GPMPC_OK && ee == hipSuccess && ng.graph && hipGraphInstantiate(&ng.exec, ng.graph, nullptr, nullptr, 0) == hipSuccess) {
+                    ng.key = key;
+                    if (h->roll_graphs.size() >= 8) drop_roll_graphs(h);
+                    h->roll_graphs.push_back(ng);
+                    g = &h->roll_graphs.back();
+                } else {
+                    if (ng.graph) hipGraphDestroy(ng.graph);
+                    (void)hipGetLastError();
+                }
+            }
+        }
+        if (g) {
+            HIPCHK(hipGraphLaunch(g->exec, h->stream));
+            done = true;
+        } else {
+            h->roll_warm = key;
+        }
+    }
+#endif
+    if (!done) rc = enqueue_steps();
+    if (rc == GPMPC_OK) {
+        const bool wantU = Uout && Nu > 0;
+        double* first = wantU ? dU : dM;
+        hipError_t e = hipMemcpyAsync(h->roll_pin + (first - buf), first, ((wantU ? nU : 0) + nM + nC) * sizeof(double),
+                                      hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e == hipSuccess) e = hipGetLastError();
+        if (e != hipSuccess) return fail(GPMPC_EHIP, "%s", hipGetErrorString(e));
+        std::memcpy(mean, h->roll_pin + (dM - buf), nM * sizeof(double));
+        std::memcpy(cov, h->roll_pin + (dC - buf), nC * sizeof(double));
+        if (wantU) {
+            if (nu1 == Nu) std::memcpy(Uout, h->roll_pin + (dU - buf), (size_t)T * Nu * sizeof(double));
+        }
+    } else {
+        hipStreamSynchronize(h->stream);
+    }
+    return rc;
+}
+
+extern "C" int gpmpc_rollout(gpmpc_gp* h, int method, int T, const double* z0, const double* U, const double* Sigma0,
+                             const double* sa, const double* sb, double* mean, double* cov) {
+    return rollout_impl(h, method, T, z0, U, Sigma0, sa, sb, nullptr, nullptr, nullptr, mean, cov, nullptr);
+}
+
+extern "C" int gpmpc_rollout_feedback(gpmpc_gp* h, int method, int T, const double* z0, const double* Sigma0, const double* sa,
+                                      const double* sb, const double* Kz, const double* k0, const double* Kc, double* mean,
+                                      double* cov, double* U_out) {
+    if (!Kz) return fail(GPMPC_EINVAL, "Kz is NULL");
+    return rollout_impl(h, method, T, z0, nullptr, Sigma0, sa, sb, Kz, k0, Kc, mean, cov, U_out);
+}
+

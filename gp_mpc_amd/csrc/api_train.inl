@@ -1,0 +1,214 @@
+// api_train.inl -- part of gpmpc_api.hip (one translation unit; included in order, not compiled alone).
+// Concern: NLL (+ gradient), multistart training, RCCL binding of the restart shard.
+// ------------------------------------------------------------------------------------------------
+// a7 NLL (+ analytic gradient) on the separate single-output training workspace
+// ------------------------------------------------------------------------------------------------
+extern "C" int gpmpc_nll(gpmpc_gp* h, int a, const double* hyper_row, double* nll, double* grad, int* jitter_out) {
+    if (!h || !hyper_row || !nll || a < 0 || a >= h->Ny) return fail(GPMPC_EINVAL, "bad arguments");
+    HIPCHK(hipSetDevice(h->device));
+    const int d = h->d, Np = h->Np;
+    for (int k = 0; k < d + 1; ++k)
+        if (!(hyper_row[k] == hyper_row[k]) || hyper_row[k] == 0.0)
+            return fail(GPMPC_EINVAL, "hyper_row[%d] = %g is not a usable SE-ARD parameter", k, hyper_row[k]);
+    if (!h->tws.K) {
+        CHK(ws_alloc(h->tws, 1, Np, d));
+        HIPCHK(hipMalloc(&h->gradPartial, (size_t)(Np / 64) * (Np / 64) * (DMAX + 2) * sizeof(double)));
+        HIPCHK(hipMalloc(&h->gradOut, (DMAX + 2 + MPW) * sizeof(double)));
+    }
+    Workspace& ws = h->tws;
+    int info = 0;
+    const Ctx cx = h->cx();
+    if (grad) CHK(ws_need_invK(ws));
+    // prior mean: the objective is evaluated on y - m(X) (calc_NLL optimize.py:43,75,96)
+    std::vector<double> kpart;
+    CHK(upload_mean_and_residual(h, hyper_row, 1, kpart, &h->tmpar, h->Y + (size_t)a * Np, &h->tYc));
+    const double* ytrain = h->mean_kind ? h->tYc : h->Y + (size_t)a * Np;
+    const int nmean = mean_param_count(h->mean_kind, d);
+    // everything that follows the factorisation is enqueued before the host waits for `info` (factor_with_jitter)
+    CHK(factor_with_jitter(h, ws, hyper_row, &info, [&]() {
+        {
+            PhaseTimer t(h, GPMPC_PH_SOLVE);
+            solve_alpha(cx, ws, ytrain, Np);
+        }
+        {
+            PhaseTimer t(h, GPMPC_PH_NLL);
+            hipLaunchKernelGGL(nll_reduce_kernel, dim3(1), dim3(256), 0, cx.stream, ws.L, ws.w, ws.nll, h->N, Np);
+        }
+        if (grad) {
+            {
+                PhaseTimer t(h, GPMPC_PH_INVK);
+                GemmP p = gemm_base(cx);  // lower triangle of K^-1 = L^-T L^-1 is all the gradient pass reads
+                p.A = ws.Inv; p.lda = Np; p.sA = ws.mat(); p.a_mc = 1;
+                p.B = ws.Inv; p.ldb = Np; p.sB = ws.mat(); p.b_nc = 1;
+                p.kflags = KA_GE_M | KB_GE_N;
+                p.C = ws.InvK; p.ldc = Np; p.sC = ws.mat();
+                p.M = Np; p.N = Np; p.K = Np; p.lower = 1;
+                launch_gemm(p, 1, cx.stream);
+            }
+            PhaseTimer t(h, GPMPC_PH_NLL);
+            hipLaunchKernelGGL(nll_grad_kernel, dim3(Np / 64, Np / 64), dim3(256), 0, cx.stream, h->XT, ws.hyper, ws.InvK,
+                               ws.alpha, h->gradPartial, h->N, Np, d);
+            hipLaunchKernelGGL(nll_grad_finish_kernel, dim3(1), dim3(256), 0, cx.stream, h->gradPartial, ws.hyper,
+                               h->gradOut, Np, d);
+            if (nmean)
+                hipLaunchKernelGGL(mean_grad_kernel, dim3(1), dim3(256), 0, cx.stream, h->XT, ws.alpha, h->gradOut + d + 2,
+                                   h->mean_kind, h->N, Np, d);
+        }
+    }));
+    if (jitter_out) *jitter_out = info;
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(nll, ws.nll, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (grad) HIPCHK(hipMemcpyAsync(grad, h->gradOut, (d + 2 + nmean) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->have_prior) {
+        // calc_NLL optimize.py:77-97, literally: `return NLL(...) + log_prior` with log_prior the sum of the Gaussian
+        // log-densities prior_gauss(theta, mu, s^2) = -(theta - mu)^2 / (2 s^2) - 1/2 log(2 pi s^2) of every ell_i and of
+        // sf^2 and sn^2 (the SQUARED hyper-parameters, :90-91).  (The log-prior is ADDED to the negative log-likelihood
+        // there, not subtracted; the reference never enables it, prior = None :157.)
+        const double two_pi = 6.283185307179586476925286766559;
+        auto lg = [&](double th, double mu, double sd) { return -(th - mu) * (th - mu) / (2.0 * sd * sd) - 0.5 * std::log(two_pi * sd * sd); };
+        auto dlg = [&](double th, double mu, double sd) { return -(th - mu) / (sd * sd); };
+        double lp = 0.0;
+        for (int k = 0; k < d; ++k) {
+            lp += lg(hyper_row[k], h->prior[0], h->prior[1]);
+            if (grad) grad[k] += dlg(hyper_row[k], h->prior[0], h->prior[1]);
+        }
+        const double sf = hyper_row[d], sn = hyper_row[d + 1];
+        lp += lg(sf * sf, h->prior[2], h->prior[3]) + lg(sn * sn, h->prior[4], h->prior[5]);
+        if (grad) {
+            grad[d] += dlg(sf * sf, h->prior[2], h->prior[3]) * 2.0 * sf;
+            grad[d + 1] += dlg(sn * sn, h->prior[4], h->prior[5]) * 2.0 * sn;
+        }
+        *nll += lp;
+    }
+    return GPMPC_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// a8 multistart training behind the C ABI (train_gp_numpy optimize.py:359-503 / train_gp :100-294)
+// ------------------------------------------------------------------------------------------------
+extern "C" int gpmpc_rccl_unique_id(char* id128) {
+    if (!id128) return fail(GPMPC_EINVAL, "NULL id buffer");
+    RcclApi& R = rccl_api();
+    if (!R.ok()) return fail(GPMPC_EHIP, "librccl.so could not be loaded: %s", dlerror() ? dlerror() : "missing symbols");
+    RcclId id;
+    const int rc = R.GetUniqueId(&id);
+    if (rc != 0) return fail(GPMPC_EHIP, "ncclGetUniqueId failed: %s", R.GetErrorString ? R.GetErrorString(rc) : "?");
+    std::memcpy(id128, id.internal, 128);
+    return GPMPC_OK;
+}
+
+extern "C" int gpmpc_rccl_comm_create(int device, int world, int rank, const char* id128, void** comm_out) {
+    if (!id128 || !comm_out || world < 1 || rank < 0 || rank >= world) return fail(GPMPC_EINVAL, "bad arguments");
+    *comm_out = nullptr;
+    CHK(ensure_device(device));
+    RcclApi& R = rccl_api();
+    if (!R.ok()) return fail(GPMPC_EHIP, "librccl.so could not be loaded");
+    RcclId id;
+    std::memcpy(id.internal, id128, 128);
+    HIPCHK(hipDeviceSynchronize());
+    (void)hipGetLastError();      // RCCL treats a stale "last error" of this thread (e.g. hipErrorNotReady of an event query) as its own
+    const int rc = R.CommInitRank(comm_out, world, id, rank);
+    if (rc != 0) return fail(GPMPC_EHIP, "ncclCommInitRank failed: %s", R.GetErrorString ? R.GetErrorString(rc) : "?");
+    return GPMPC_OK;
+}
+
+extern "C" int gpmpc_rccl_comm_destroy(void* comm) {
+    if (!comm) return GPMPC_OK;
+    RcclApi& R = rccl_api();
+    if (!R.ok()) return fail(GPMPC_EHIP, "librccl.so could not be loaded");
+    return R.CommDestroy(comm) == 0 ? GPMPC_OK : fail(GPMPC_EHIP, "ncclCommDestroy failed");
+}
+
+extern "C" int gpmpc_train_multistart(gpmpc_gp* h, int nstart, const double* starts, const double* lb, const double* ub,
+                                      int max_iter, double tol, int rank, int world, void* rccl_comm, int want_invK,
+                                      double* hyper_opt, double* obj, double* theta_all, int* info) {
+    if (!h || nstart <= 0 || !starts || !lb || !ub || !hyper_opt) return fail(GPMPC_EINVAL, "NULL argument or nstart <= 0");
+    if (world < 1 || rank < 0 || rank >= world) return fail(GPMPC_EINVAL, "bad rank %d / world %d", rank, world);
+    HIPCHK(hipSetDevice(h->device));
+    const int Ny = h->Ny, nh = h->nh(), d = h->d, row = nh + 1;
+    const double inf = std::numeric_limits<double>::infinity();
+    if (max_iter <= 0) max_iter = 200;
+    if (!(tol > 0.0)) tol = 1e-8;
+    std::vector<double> table((size_t)Ny * nstart * row, 0.0);   // [a][r][NLL, theta...]; not-owned / failed: +inf
+    int hip_rc = GPMPC_OK;
+    for (int a = 0; a < Ny; ++a) {
+        BoxProblem P;
+        P.n = nh;
+        P.lb.assign(lb + (size_t)a * nh, lb + (size_t)(a + 1) * nh);
+        P.ub.assign(ub + (size_t)a * nh, ub + (size_t)(a + 1) * nh);
+        P.logv.resize(nh);
+        for (int k = 0; k < nh; ++k) {
+            if (!(P.lb[k] <= P.ub[k])) return fail(GPMPC_EINVAL, "empty box for hyper-parameter %d of output %d", k, a);
+            // length scales and sf in log space (their boxes span many decades).  NOT the noise sn: the NLL sees it as sn^2,
+            // so d NLL / d log sn = 2 sn^2 (...) vanishes at the reference's start sn = 1e-5 and a log-space search leaves it
+            // there -- on the fixture whose optimum has sn on its upper bound it stopped 5.6 above the reference's NLL.
+            P.logv[k] = k < d + 1 && P.lb[k] > 0.0 && P.ub[k] < inf;
+        }
+        P.eval = [&](const double* th, double* f, double* g) -> bool {
+            const int rc = gpmpc_nll(h, a, th, f, g, nullptr);
+            if (rc == GPMPC_EHIP || rc == GPMPC_ENOMEM) hip_rc = rc;
+            return rc == GPMPC_OK;
+        };
+        for (int r = 0; r < nstart; ++r) {
+            double* out = &table[((size_t)a * nstart + r) * row];
+            out[0] = inf;
+            if (r % world != rank) continue;
+            BoxResult res = minimize_box_lbfgs(P, starts + ((size_t)a * nstart + r) * nh, max_iter, tol);
+            if (hip_rc != GPMPC_OK) return hip_rc;               // device failure: g_err holds the text
+            // The linear noise variable is badly scaled against the log variables (its whole box is 1e-2 wide): once the
+            // first search has stopped with iterations to spare, a second one from there with sn in log space -- where its
+            // gradient no longer vanishes -- polishes the optimum (third reference-made fixture: -95.7 -> the -197.7 that
+            // SLSQP with the analytic gradient finds; the reference's own run stops at -80.3).
+            if (res.ok && res.iters < max_iter && P.lb[d + 1] > 0.0 && P.ub[d + 1] < inf) {
+                BoxProblem P2 = P;
+                P2.logv[d + 1] = 1;
+                const BoxResult res2 = minimize_box_lbfgs(P2, res.theta.data(), max_iter - res.iters, tol);
+                if (hip_rc != GPMPC_OK) return hip_rc;
+                if (res2.ok && res2.f < res.f) res = res2;
+            }
+            std::memcpy(out + 1, res.theta.data(), nh * sizeof(double));
+            if (res.ok) out[0] = res.f;
+        }
+    }
+    if (rccl_comm) {    // one all-gather of the whole table: (1 + nh) doubles per restart (also at world = 1: a self-gather)
+        RcclApi& R = rccl_api();
+        if (!R.ok()) return fail(GPMPC_EHIP, "librccl.so could not be loaded");
+        const size_t cnt = table.size();
+        double *dsend = nullptr, *drecv = nullptr;
+        HIPCHK(hipMalloc(&dsend, cnt * sizeof(double)));
+        HIPCHK(hipMalloc(&drecv, cnt * world * sizeof(double)));
+        HIPCHK(hipMemcpyAsync(dsend, table.data(), cnt * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        (void)hipGetLastError();
+        const int rc = R.AllGather(dsend, drecv, cnt, RCCL_FLOAT64, rccl_comm, h->stream);
+        std::vector<double> all(cnt * world);
+        if (rc == 0) {
+            HIPCHK(hipMemcpyAsync(all.data(), drecv, all.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+        }
+        hipFree(dsend);
+        hipFree(drecv);
+        if (rc != 0) return fail(GPMPC_EHIP, "ncclAllGather failed: %s", R.GetErrorString ? R.GetErrorString(rc) : "?");
+        for (int a = 0; a < Ny; ++a)
+            for (int r = 0; r < nstart; ++r)
+                std::memcpy(&table[((size_t)a * nstart + r) * row], &all[(size_t)(r % world) * cnt + ((size_t)a * nstart + r) * row],
+                            row * sizeof(double));
+    }
+    const bool merged = world == 1 || rccl_comm != nullptr;
+    bool all_ok = true;
+    for (int a = 0; a < Ny; ++a) {
+        int best = -1;
+        for (int r = 0; r < nstart; ++r) {
+            const double* e = &table[((size_t)a * nstart + r) * row];
+            if (obj) obj[(size_t)a * nstart + r] = e[0];
+            if (theta_all) std::memcpy(theta_all + ((size_t)a * nstart + r) * nh, e + 1, nh * sizeof(double));
+            if (e[0] < inf && (best < 0 || e[0] < table[((size_t)a * nstart + best) * row])) best = r;   // first minimum: np.argmin
+        }
+        if (best >= 0) std::memcpy(hyper_opt + (size_t)a * nh, &table[((size_t)a * nstart + best) * row + 1], nh * sizeof(double));
+        else all_ok = false;
+    }
+    if (!merged) return GPMPC_OK;                               // caller merges the ranks' tables and calls gpmpc_fit
+    if (!all_ok) return fail(GPMPC_ENOTPD, "every restart of an output failed (K not positive definite along the way)");
+    return gpmpc_fit(h, hyper_opt, want_invK, info);            // optimize.py:476-494 at theta*
+}
+

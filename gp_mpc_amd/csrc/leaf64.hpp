@@ -105,6 +105,91 @@ __device__ __forceinline__ int panel_potrf(double* S, double* Drinv, int lane) {
     return bad;
 }
 
+// ---- DPP row broadcasts (gfx90a+: `row_newbcast:K` is the one DPP control the 64-bit ALU accepts) ------------------
+// rowb<K>(v): lane l receives the value lane (l & ~15) + K holds -- a broadcast inside each group of 16 lanes without the
+// SGPR round trip of v_readlane (two readlanes + their SGPR-write latency per double).  fnma_rowb<K>(acc, b, own):
+// acc -= rowb<K>(b) * own as ONE v_fmac_f64_dpp.  The hazard "VALU writes a VGPR, a DPP operand reads it within 2 wait
+// states" is invisible to the compiler inside inline assembly, so every statement starts with the s_nop that covers it.
+#ifdef GPMPC_EMULATED
+template <int K> __device__ __forceinline__ double rowb(double v) { return emu::wave_xchg(v, (emu::lane() & ~15) + K); }
+template <int K, bool NOP = true> __device__ __forceinline__ void fnma_rowb(double& acc, double b, double own) {
+    acc = __builtin_fma(-rowb<K>(b), own, acc);
+}
+#else
+template <int K> __device__ __forceinline__ double rowb(double v) {
+    return __longlong_as_double(__builtin_amdgcn_update_dpp(0ll, __double_as_longlong(v), 0x150 + K, 0xf, 0xf, true));
+}
+template <int K, bool NOP = true> __device__ __forceinline__ void fnma_rowb(double& acc, double b, double own) {
+    if constexpr (NOP)
+        asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                     : "+v"(acc) : "v"(b), "v"(own), "n"(K));
+    else    // the caller guarantees that `b` was not written by one of the two preceding VALU instructions
+        asm volatile("v_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                     : "+v"(acc) : "v"(b), "v"(own), "n"(K));
+}
+#endif
+
+// rsqrt of a positive double: v_rsq_f64 (about 2^-26) + one third-order correction.
+__device__ __forceinline__ double rsqrt_newton(double x) {
+#ifdef GPMPC_EMULATED
+    return 1.0 / std::sqrt(x);
+#else
+    const double y0 = __builtin_amdgcn_rsq(x);
+    const double e = __builtin_fma(-x * y0, y0, 1.0);                       // 1 - x y0^2
+    return __builtin_fma(y0 * e, __builtin_fma(e, 0.375, 0.5), y0);         // y0 (1 + e/2 + 3 e^2/8)
+#endif
+}
+
+// One wave: Cholesky of the 64 x 16 panel, DPP form.  Lane l owns panel row l in a[] (as panel_potrf) AND row o + (l & 15)
+// of the 16 x 16 diagonal block in d[] -- the diagonal block is replicated in the four 16-lane groups so that
+// row_newbcast:k delivers L_kj to every lane.  Column j: x = pivot (rowb<j>), y = rsqrt(x), d[j] *= y, a[j] *= y, then for
+// k > j: d[k] -= L_kj d[j], a[k] -= L_kj a[j].  MODE 1: broadcast by v_mov_b64_dpp + two v_fma_f64 (compiler-scheduled);
+// MODE 2: two v_fmac_f64_dpp.
+template <int TT, int MODE>
+__device__ __forceinline__ int panel_potrf_dpp(double* S, double* Drinv, int lane) {
+    constexpr int o = 16 * TT;
+    const int r = lane, i = lane & 15;
+    double a[16], d[16];
+    int bad = -1;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) { a[c] = S[r * LS + o + c]; d[c] = S[(o + i) * LS + o + c]; }
+    double yk = 0.0;
+#define GPMPC_PANEL_COL(j)                                                                              \
+    {                                                                                                     \
+        const double x = rowb<j>(d[j]);                                                                   \
+        if (!(x > 0.0) && bad < 0) bad = j;                                                               \
+        const double y = rsqrt_newton(x);                                                                 \
+        if (i == j) yk = y;                                                                               \
+        d[j] *= y;                                                                                        \
+        a[j] *= y;                                                                                        \
+        GPMPC_PANEL_UPD(j, 1) GPMPC_PANEL_UPD(j, 2) GPMPC_PANEL_UPD(j, 3) GPMPC_PANEL_UPD(j, 4) GPMPC_PANEL_UPD(j, 5)   \
+        GPMPC_PANEL_UPD(j, 6) GPMPC_PANEL_UPD(j, 7) GPMPC_PANEL_UPD(j, 8) GPMPC_PANEL_UPD(j, 9) GPMPC_PANEL_UPD(j, 10)  \
+        GPMPC_PANEL_UPD(j, 11) GPMPC_PANEL_UPD(j, 12) GPMPC_PANEL_UPD(j, 13) GPMPC_PANEL_UPD(j, 14) GPMPC_PANEL_UPD(j, 15) \
+    }
+#define GPMPC_PANEL_UPD(j, k)                                                                            \
+    if constexpr (k > j) {                                                                                \
+        if constexpr (MODE == 2) {                                                                        \
+            fnma_rowb<k, k == j + 1>(d[k], d[j], d[j]);   /* d[j] = (asm volatile keeps statement order) */ \
+            fnma_rowb<k, false>(a[k], d[j], a[j]);                                                        \
+        } else {                                                                                          \
+            const double b = rowb<k>(d[j]);                                                               \
+            d[k] = __builtin_fma(-b, d[j], d[k]);                                                         \
+            a[k] = __builtin_fma(-b, a[j], a[k]);                                                         \
+        }                                                                                                 \
+    }
+    GPMPC_PANEL_COL(0) GPMPC_PANEL_COL(1) GPMPC_PANEL_COL(2) GPMPC_PANEL_COL(3) GPMPC_PANEL_COL(4) GPMPC_PANEL_COL(5)
+    GPMPC_PANEL_COL(6) GPMPC_PANEL_COL(7) GPMPC_PANEL_COL(8) GPMPC_PANEL_COL(9) GPMPC_PANEL_COL(10) GPMPC_PANEL_COL(11)
+    GPMPC_PANEL_COL(12) GPMPC_PANEL_COL(13) GPMPC_PANEL_COL(14) GPMPC_PANEL_COL(15)
+#undef GPMPC_PANEL_COL
+#undef GPMPC_PANEL_UPD
+    if (lane < 16) Drinv[o + lane] = yk;     // 1 / L_cc for the diagonal-inverse wave
+    if (r >= o) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) S[r * LS + o + c] = (r - o >= 16 || c <= r - o) ? a[c] : 0.0;
+    }
+    return __builtin_amdgcn_readfirstlane(bad);
+}
+
 // The factor + invert body shared by leaf64_kernel and the persistent chain kernel (chol_chain.hpp).
 // 256 threads; S holds the (lower) 64 x 64 block on entry and L on exit, T receives L^-1 (its strictly
 // upper 16 x 16 blocks must be zero on entry and stay zero), U and Dr are scratch.  Returns the first

@@ -121,7 +121,8 @@ def train_gp(handle, X, Y, multistart=1, hyper_init=None, optimizer_opts=None,
     # reference's own finite-difference SLSQP once (41441 against -12.96) and, like the reference, does not leave the start
     # when the noise level exceeds the sn bound (tests/golden/train_small3.npz).  gradient='finite' makes the scipy call the
     # reference's literally (SLSQP differencing the objective), but not its results: the differences amplify the 1e-11 between
-    # the device's and numpy's NLL, and SLSQP's path is sensitive to that -- the bit-for-bit restatement is oracle/gp_oracle.py.
+    # the device's and numpy's NLL, and SLSQP's path is sensitive to that -- the bit-for-bit restatement of the reference's training lives with the test
+    # infrastructure, outside this package.
     if mean_func not in MEAN_PARAMS:
         raise NameError('No mean function called: ' + str(mean_func))
     if optimizer not in ('scipy', 'native'):
