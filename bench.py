@@ -6,7 +6,13 @@ fp64: one STEP = K build + Cholesky (+ L^-1, alpha) at fixed hyper-parameters + 
 predictions, everything through the C ABI of libgpmpc_hip.so with X, Y, Z and the outputs resident
 in HBM (device pointer mode).  `value` = predictions/s over whole steps (fit included), summed over
 ranks.  With --gpus N every rank runs its own model / test batch on its own GPU (independent GP
-objects shard trivially, no data-path collective): weak scaling.
+objects shard trivially, no data-path collective): weak scaling.  `python bench.py --gpus N` launches its N ranks
+itself (one process per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, rank 0 prints the line); under
+torch.distributed.run the ranks it finds in the environment are used.  For N > 1 the line also carries `restart_shard`:
+the ONE part of the path that shards (BASELINE config C4) -- 64 seeded restarts of the NLL minimisation, restart r on
+rank r mod N, ONE ncclAllGather of the (NLL, theta) table inside gpmpc_train_multistart -- as restarts/s (strong
+scaling) with `rccl_ranks` = ncclCommCount of the communicator that carried it.  For N = 1 the line carries `secondary`:
+two steps of C3 and one of C4 after the timed C2 region.
 
 --config C3 (secondary, same JSON shape; the default and the headline stay C2): BASELINE.json configs[2] --
 6-output GP, N=8192, d=8: one STEP = fit of all outputs with K^-1 + a 30-step uncertainty propagation with each
@@ -108,6 +114,215 @@ def _emit(obj):
     _REAL_STDOUT.flush()
 
 
+def _launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks here, one process per GPU, and pass rank 0's JSON
+    line through.  (The driver's torch.distributed.run form sets WORLD_SIZE itself and never reaches this.)"""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
+    out, _ = procs[0].communicate()
+    deadline = time.time() + 120.0          # rank 0 is done: the others leave their last barrier within moments, or are stuck
+    rcs = [procs[0].returncode]
+    for q in procs[1:]:
+        try:
+            rcs.append(q.wait(timeout=max(1.0, deadline - time.time())))
+        except subprocess.TimeoutExpired:
+            q.kill()                        # (this very process, by its handle)
+            rcs.append('killed after rank 0 had exited')
+    if any(rcs):
+        raise SystemExit('bench.py: rank exit codes %s' % rcs)
+    lines = [ln for ln in out.decode().splitlines() if ln.strip()]
+    _REAL_STDOUT.write(lines[-1] + '\n')
+    _REAL_STDOUT.flush()
+
+
+class Ranks:
+    """This process's place in the job: rank / world from the environment, the torch device, the process group
+    (nccl = RCCL on a GPU box; gloo when tests/ points GPMPC_BENCH_LIB at the emulated library on a CPU box)."""
+
+    def __init__(self):
+        import torch
+        self.torch = torch
+        self.rank = int(os.environ.get('RANK', '0'))
+        self.local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+        self.world = int(os.environ.get('WORLD_SIZE', '1'))
+        self.test_lib = os.environ.get('GPMPC_BENCH_LIB')       # set by tests/test_bench_launcher.py only
+        self.gpu = torch.cuda.is_available() and not self.test_lib
+        if not self.gpu and not self.test_lib:
+            raise SystemExit('bench.py needs a GPU (torch.cuda.is_available() is False)')
+        if self.gpu:
+            torch.cuda.set_device(self.local_rank)
+        self.dev_index = self.local_rank if self.gpu else 0      # (the emulated test library has one device)
+        self.device = torch.device('cuda', self.local_rank) if self.gpu else torch.device('cpu')
+        self.dist = None
+        if self.world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            if self.gpu:
+                dist.init_process_group('nccl', rank=self.rank, world_size=self.world, device_id=self.device)
+            else:
+                dist.init_process_group('gloo', rank=self.rank, world_size=self.world)
+            self.dist = dist
+        if self.test_lib:
+            from gp_mpc_amd._lib import GpmpcLib
+            self.lib = GpmpcLib(self.test_lib)
+        else:
+            from gp_mpc_amd._lib import get_lib
+            self.lib = get_lib()
+
+    def sync(self, h=None):
+        if h is not None:
+            h.synchronize()
+        if self.gpu:
+            self.torch.cuda.synchronize()
+        if self.dist is not None:
+            self.dist.barrier()
+
+    def max_over_ranks(self, seconds):
+        if self.dist is None:
+            return seconds
+        t = self.torch.tensor([seconds], dtype=self.torch.float64, device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+def timed(rk, h, step, steps, warmup, profile=True):
+    """`warmup` untimed steps, then exactly `steps` steps between (barrier + synchronize) pairs; max over the ranks."""
+    for _ in range(warmup):
+        step()
+    rk.sync(h)
+    if profile:
+        h.profile_enable(True)
+        h.profile_read(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    rk.sync(h)
+    elapsed = time.perf_counter() - t0
+    prof = None
+    if profile:
+        h.profile_enable(False)
+        prof = h.profile_read(reset=True)
+    return rk.max_over_ranks(elapsed), prof
+
+
+def run_c3(rk, steps, warmup, N=8192):
+    """BASELINE config C3: 6-output GP, N = 8192, d = 8; step = fit (with K^-1) + 30-step ME / TA / EM propagation."""
+    import numpy as np
+    import gp_oracle as go
+    from gp_mpc_amd._lib import Handle
+    d, Ny, T = 8, 6, 30
+    p = go.synthetic_problem(N, d, Ny, T, seed=1234 + rk.rank, sn=1e-2)
+    h = Handle(rk.lib, p['X'], p['Y'], device=rk.dev_index)
+    hyper = np.ascontiguousarray(p['hyper'])
+    x0, U = p['Z'][0, :Ny], p['Z'][:T, Ny:]
+    S0 = np.eye(d) * 1e-6
+    S0[:Ny, :Ny] = np.diag(hyper[:, d + 1] ** 2)
+    z0 = np.concatenate([x0, U[0]])
+    res = {}
+
+    def step():
+        h.fit(hyper, want_invK=True)
+        for m in ('ME', 'TA', 'EM'):
+            res[m] = h.rollout(m, z0, U, S0)
+
+    elapsed, prof = timed(rk, h, step, steps, warmup)
+    # the roll-outs alone (phase brackets inside gpmpc_rollout are per launch; time them as whole calls)
+    t_roll = {}
+    for m in ('ME', 'TA', 'EM'):
+        h.synchronize()
+        t1 = time.perf_counter()
+        h.rollout(m, z0, U, S0)
+        t_roll[m] = (time.perf_counter() - t1) * 1e3
+    fac_ms = prof['factor'][0] / max(prof['factor'][1], 1)
+    flops = Ny * 2.0 * N ** 3 / 3.0
+    em_ms, em_n = prof['em']
+    em_bytes = Ny * 4.0 * N * (N + 1)                       # the K^-1 lower triangles the a == b pair sums read
+    world = rk.world
+    out = {
+        'metric': 'GP moment-matching propagation steps/sec, N=8192 Ny=6 d=8 fp64 (fit + 30-step ME/TA/EM per step)',
+        'value': world * 3 * T * steps / elapsed, 'unit': 'propagation steps/s', 'n_gpus': world, 'steps': steps,
+        'warmup': warmup, 'ms_per_step': elapsed / steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+        'config': {'workload': 'C3: 6-output SE-ARD GP fit (K build + Cholesky + L^-1 + K^-1) + 30-step ME/TA/EM propagation',
+                   'N': N, 'd': d, 'Ny': Ny, 'horizon': T, 'parallelism': f'independent GP per GPU x{world}'},
+        'roofline': {'kernel': 'factorisation: two-level blocked Cholesky + pipelined triangular inverse (chain kernel + MFMA GEMM launches)',
+                     'bound': 'mfma', 'achieved': flops / (fac_ms * 1e-3) * 1e-12 if fac_ms > 0 else 0.0,
+                     'peak': FP64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                     'frac': flops / (fac_ms * 1e-3) * 1e-12 / FP64_MFMA_PEAK_TFLOPS if fac_ms > 0 else 0.0,
+                     'traffic': None, 'avg_launch_ms': fac_ms, 'launches': prof['factor'][1],
+                     'note': '2 N^3 / 3 flops per output (potrf + trtri), HIP events around the whole factor phase'},
+        'em_pair_kernels': {'bound': 'hbm', 'achieved': em_bytes / (em_ms / max(em_n, 1) * 1e-3) * 1e-9 if em_ms > 0 else 0.0,
+                            'peak': 8000.0, 'unit': 'GB/s', 'avg_launch_ms': em_ms / max(em_n, 1), 'launches': em_n,
+                            'note': 'algorithmic bytes = lower triangles of the 6 K^-1; the kernel is bound by its 1.2e9 fp64 exp per input, not HBM'},
+        'phases_ms_per_step': {k: v[0] / steps for k, v in prof.items() if v[1] > 0},
+        'rollout_ms_per_call': t_roll,
+        'finite': bool(all(np.all(np.isfinite(r[0])) and np.all(np.isfinite(r[1])) for r in res.values())),
+        'device': rk.lib.device_name(rk.dev_index),
+    }
+    h.close()
+    return out
+
+
+def run_c4(rk, steps, warmup, N=4096, d=6, R=64, iters=4):
+    """BASELINE config C4: log-marginal likelihood + gradient, R random restarts sharded over the ranks: restart r on
+    rank r mod world inside gpmpc_train_multistart, ONE ncclAllGather of the (NLL, theta) table over an RCCL communicator
+    the library creates (on a CPU test box: the ranks' tables merged over gloo by gp_mpc_amd.train)."""
+    import numpy as np
+    import gp_oracle as go
+    from gp_mpc_amd._lib import Handle
+    from gp_mpc_amd.train import lhs_starts, bounds_ipopt_path, sharded_multistart
+    rank, world = rk.rank, rk.world
+    p = go.synthetic_problem(N, d, 1, 1, seed=1234, sn=1e-2)             # the same problem on every rank (replicated X, y)
+    h = Handle(rk.lib, p['X'], p['Y'], device=rk.dev_index)
+    lb, ub = bounds_ipopt_path(d)
+    starts = lhs_starts(R, lb, ub, 1234)[None]
+    comm, rccl_ranks = None, 0
+    if rk.gpu:
+        box = [rk.lib.rccl_unique_id() if rank == 0 else None]
+        if rk.dist is not None:
+            rk.dist.broadcast_object_list(box, src=0)
+        comm = rk.lib.rccl_comm_create(rk.dev_index, world, rank, box[0])     # (world = 1: a self-gather)
+        rccl_ranks = rk.lib.rccl_comm_count(comm)
+    res = {}
+
+    def step():
+        res['r'] = sharded_multistart(h, starts, lb[None], ub[None], max_iter=iters, dist=rk.dist, rank=rank, world=world,
+                                      comm=comm, want_invK=False)
+
+    elapsed, _ = timed(rk, h, step, steps, warmup, profile=False)
+    if comm is not None:
+        rk.lib.rccl_comm_destroy(comm)
+    r = res['r']
+    out = {
+        'metric': 'GP hyper-parameter training restarts/sec, N=%d d=%d fp64 (%d restarts x %d L-BFGS iterations, NLL + analytic gradient)' % (N, d, R, iters),
+        'value': R * steps / elapsed, 'unit': 'restarts/s', 'n_gpus': world, 'steps': steps, 'warmup': warmup,
+        'ms_per_step': elapsed / steps * 1e3, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
+        'dtype': 'f64', 'data': 'synthetic',
+        'config': {'workload': 'C4: %d seeded restarts of the NLL minimisation, restart r on rank r mod world, one all-gather of (NLL, theta)' % R,
+                   'N': N, 'd': d, 'restarts': R, 'iterations': iters, 'parallelism': f'restart shard x{world} over RCCL'},
+        'rccl_ranks': rccl_ranks,
+        'exchange': 'ncclAllGather inside gpmpc_train_multistart' if comm is not None else 'host merge over torch.distributed (no RCCL: test build)',
+        'best_nll': float(np.min(r['obj'])), 'finite_restarts': int(np.isfinite(r['obj']).sum()),
+        'evaluations_this_rank': int(r['evaluations']), 'restarts_this_rank': len(range(rank, R, world)),
+        'device': rk.lib.device_name(rk.dev_index)}
+    h.close()
+    return out
+
+
 def main():
     _own_stdout()
     ap = argparse.ArgumentParser()
@@ -118,36 +333,34 @@ def main():
     ap.add_argument('--d', type=int, default=6)
     ap.add_argument('--B', type=int, default=10000)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-secondary', action='store_true', help='skip the C3 / C4 steps after the timed C2 region')
+    ap.add_argument('--restarts', type=int, default=64, help='restarts of the restart-shard leg (C4)')
     ap.add_argument('--config', default='C2', choices=['C2', 'C3', 'C4'])
     args = ap.parse_args()
-    if args.config == 'C3':
-        return main_c3(args)
-    if args.config == 'C4':
-        return main_c4(args)
-
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        return _launch_ranks(args.gpus)
     import numpy as np
     import torch                     # first: one HIP runtime in the process (torch's), shared by the library
     import gp_oracle as go
-    from gp_mpc_amd._lib import Handle, get_lib
-
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs a GPU (torch.cuda.is_available() is False)')
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+    from gp_mpc_amd._lib import Handle
+    rk = Ranks()
+    rank, local_rank, world = rk.rank, rk.dev_index, rk.world
+    lib = rk.lib
+    if args.config == 'C3':
+        out = run_c3(rk, min(args.steps, 10), min(args.warmup, 2), N=args.N if args.N != 4096 else 8192)
+    elif args.config == 'C4':
+        out = run_c4(rk, min(args.steps, 5), min(args.warmup, 1), N=args.N, d=args.d, R=args.restarts)
+    if args.config != 'C2':
+        rk.close()
+        if rank == 0:
+            _emit(out)
+        return
 
     N, d, B = args.N, args.d, args.B
     p = go.synthetic_problem(N, d, 1, B, seed=1234 + rank, sn=1e-2)
-    lib = get_lib()
     layout, mfma_rate = lib.mfma_selftest(local_rank)
     h = Handle(lib, p['X'], p['Y'], device=local_rank)
-    dev = torch.device('cuda', local_rank)
+    dev = rk.device
     z = torch.from_numpy(p['Z']).to(dev)
     mean = torch.empty((B, 1), dtype=torch.float64, device=dev)
     var = torch.empty((B, 1), dtype=torch.float64, device=dev)
@@ -158,37 +371,18 @@ def main():
         h.fit(hyper)                                                    # K build + Cholesky + L^-1 + alpha
         h.predict_mean_var_dev(B, z.data_ptr(), mean.data_ptr(), var.data_ptr())   # 10k mean+var
 
-    def sync():
-        h.synchronize()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
+    elapsed, prof = timed(rk, h, step, args.steps, args.warmup)
 
-    for _ in range(args.warmup):
-        step()
-    sync()
-    h.profile_enable(True)
-    h.profile_read(reset=True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    sync()
-    elapsed = time.perf_counter() - t0
-    h.profile_enable(False)
-    prof = h.profile_read(reset=True)
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    # HBM traffic of the dominant kernel from committed rocprofv3 PMC passes (profiles/), if present
-    traffic = None
+    # HBM traffic of the dominant kernel: NOT measured in this run (rocprofv3 --pmc serialises dispatches); it is read
+    # from the committed PMC passes under profiles/ and labelled as such
+    traffic, traffic_source = None, None
     tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
             if tj.get('N') == N and tj.get('B') == B:
                 traffic = tj['hbm_bytes_per_launch']
+                traffic_source = 'profiles/traffic.json (' + str(tj.get('source', 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, committed')) + ')'
         except Exception:
             traffic = None
     out = None
@@ -207,7 +401,7 @@ def main():
                        'N': N, 'd': d, 'Ny': 1, 'B': B, 'parallelism': f'independent GP per GPU x{world}'},
             'roofline': {'kernel': 'gemm_f64_dma_kernel<2,4,2,4> 128x128 tile (variance GEMM + column sum of squares)',
                          'bound': 'mfma', 'achieved': achieved, 'peak': FP64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved / FP64_MFMA_PEAK_TFLOPS, 'traffic': traffic,
+                         'frac': achieved / FP64_MFMA_PEAK_TFLOPS, 'traffic': traffic, 'traffic_source': traffic_source,
                          'avg_launch_ms': gemm_ms / max(gemm_n, 1), 'launches': gemm_n,
                          'peak_measured_mfma_only_ubench': mfma_rate},
             'phases_ms_per_step': {k: v[0] / args.steps for k, v in prof.items() if v[1] > 0},
@@ -220,7 +414,7 @@ def main():
             'cholesky_plus_inverse': {'ms': fac_ms / max(fac_n, 1),
                                       'tflops': (2.0 * N ** 3 / 3.0) / (fac_ms / max(fac_n, 1) * 1e-3) * 1e-12 if fac_ms > 0 else 0.0,
                                       'note': 'N^3/3 (potrf) + N^3/3 (trtri) flops: blocked right-looking Cholesky + level-batched inverse'},
-            'predict_only_per_s': B / ((prof['crosscov'][0] + prof['vargemm'][0] + prof['finish'][0]) / args.steps * 1e-3),
+            'predict_only_per_s': B / max((prof['crosscov'][0] + prof['vargemm'][0] + prof['finish'][0]) / args.steps * 1e-3, 1e-12),
             'device': lib.device_name(local_rank), 'mfma_layout': layout,
         }
         if world == 1 and not args.no_cpu_baseline:
@@ -230,171 +424,30 @@ def main():
             out['parity_vs_cpu'] = {'mean_maxabs': float(np.abs(gm - cmean).max()),
                                     'var_maxabs_over_sf2': float(np.abs(gv - cvar).max())}
     h.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    del z, mean, var
+    if world > 1:
+        # the restart shard, the one part of the path that shards: strong scaling over the ranks, through RCCL
+        rs = run_c4(rk, 2, 1, N=N, d=d, R=args.restarts)
+        if rank == 0:
+            out['restart_shard'] = {k: rs[k] for k in ('metric', 'value', 'unit', 'scaling', 'ms_per_step', 'steps', 'warmup',
+                                                        'rccl_ranks', 'exchange', 'best_nll', 'finite_restarts',
+                                                        'evaluations_this_rank', 'restarts_this_rank', 'config')}
+    elif not args.no_secondary:
+        # driver-witnessed secondary configurations (outside the timed C2 region): 2 steps of C3, 1 of C4
+        c3 = run_c3(rk, 2, 1)
+        c4 = run_c4(rk, 1, 1, N=N, d=d, R=args.restarts)
+        if rank == 0:
+            out['secondary'] = {
+                'c3': {'workload': c3['config']['workload'], 'ms_per_step': c3['ms_per_step'], 'steps': c3['steps'],
+                       'propagation_steps_per_s': c3['value'], 'factor_ms': c3['roofline']['avg_launch_ms'],
+                       'factor_tflops': c3['roofline']['achieved'], 'factor_frac': c3['roofline']['frac'],
+                       'rollout_ms_per_call': c3['rollout_ms_per_call'], 'finite': c3['finite']},
+                'c4': {'workload': c4['config']['workload'], 'restarts_per_s': c4['value'], 'ms_per_step': c4['ms_per_step'],
+                       'steps': c4['steps'], 'rccl_ranks': c4['rccl_ranks'], 'exchange': c4['exchange'],
+                       'best_nll': c4['best_nll'], 'finite_restarts': c4['finite_restarts']}}
+    rk.close()
     if rank == 0:
         _emit(out)
-
-
-def main_c3(args):
-    """BASELINE config C3: 6-output GP, N = 8192, d = 8; step = fit (with K^-1) + 30-step ME / TA / EM propagation."""
-    import numpy as np
-    import torch
-    import gp_oracle as go
-    from gp_mpc_amd._lib import Handle, get_lib
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
-    N, d, Ny, T = (args.N if args.N != 4096 else 8192), 8, 6, 30
-    p = go.synthetic_problem(N, d, Ny, T, seed=1234 + rank, sn=1e-2)
-    lib = get_lib()
-    h = Handle(lib, p['X'], p['Y'], device=local_rank)
-    hyper = np.ascontiguousarray(p['hyper'])
-    x0, U = p['Z'][0, :Ny], p['Z'][:T, Ny:]
-    S0 = np.eye(d) * 1e-6
-    S0[:Ny, :Ny] = np.diag(hyper[:, d + 1] ** 2)
-    z0 = np.concatenate([x0, U[0]])
-    res = {}
-
-    def step():
-        h.fit(hyper, want_invK=True)
-        for m in ('ME', 'TA', 'EM'):
-            res[m] = h.rollout(m, z0, U, S0)
-
-    def sync():
-        h.synchronize()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-    steps, warmup = min(args.steps, 10), min(args.warmup, 2)
-    for _ in range(warmup):
-        step()
-    sync()
-    h.profile_enable(True)
-    h.profile_read(reset=True)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    sync()
-    elapsed = time.perf_counter() - t0
-    h.profile_enable(False)
-    prof = h.profile_read(reset=True)
-    # the roll-outs alone (phase brackets inside gpmpc_rollout are per launch; time them as whole calls)
-    t_roll = {}
-    for m in ('ME', 'TA', 'EM'):
-        h.synchronize()
-        t1 = time.perf_counter()
-        h.rollout(m, z0, U, S0)
-        t_roll[m] = (time.perf_counter() - t1) * 1e3
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=torch.device('cuda', local_rank))
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    if rank == 0:
-        fac_ms = prof['factor'][0] / max(prof['factor'][1], 1)
-        flops = Ny * 2.0 * N ** 3 / 3.0
-        em_ms, em_n = prof['em']
-        em_bytes = Ny * 4.0 * N * (N + 1)                       # the K^-1 lower triangles the a == b pair sums read
-        out = {
-            'metric': 'GP moment-matching propagation steps/sec, N=8192 Ny=6 d=8 fp64 (fit + 30-step ME/TA/EM per step)',
-            'value': world * 3 * T * steps / elapsed, 'unit': 'propagation steps/s', 'n_gpus': world, 'steps': steps,
-            'warmup': warmup, 'ms_per_step': elapsed / steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': 'C3: 6-output SE-ARD GP fit (K build + Cholesky + L^-1 + K^-1) + 30-step ME/TA/EM propagation',
-                       'N': N, 'd': d, 'Ny': Ny, 'horizon': T, 'parallelism': f'independent GP per GPU x{world}'},
-            'roofline': {'kernel': 'factorisation: two-level blocked Cholesky + pipelined triangular inverse (chain kernel + MFMA GEMM launches)',
-                         'bound': 'mfma', 'achieved': flops / (fac_ms * 1e-3) * 1e-12 if fac_ms > 0 else 0.0,
-                         'peak': FP64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': flops / (fac_ms * 1e-3) * 1e-12 / FP64_MFMA_PEAK_TFLOPS if fac_ms > 0 else 0.0,
-                         'traffic': None, 'avg_launch_ms': fac_ms, 'launches': prof['factor'][1],
-                         'note': '2 N^3 / 3 flops per output (potrf + trtri), HIP events around the whole factor phase'},
-            'em_pair_kernels': {'bound': 'hbm', 'achieved': em_bytes / (em_ms / max(em_n, 1) * 1e-3) * 1e-9 if em_ms > 0 else 0.0,
-                                'peak': 8000.0, 'unit': 'GB/s', 'avg_launch_ms': em_ms / max(em_n, 1), 'launches': em_n,
-                                'note': 'algorithmic bytes = lower triangles of the 6 K^-1; the kernel is bound by its 1.2e9 fp64 exp per input, not HBM'},
-            'phases_ms_per_step': {k: v[0] / steps for k, v in prof.items() if v[1] > 0},
-            'rollout_ms_per_call': t_roll,
-            'finite': bool(all(np.all(np.isfinite(r[0])) and np.all(np.isfinite(r[1])) for r in res.values())),
-            'device': lib.device_name(local_rank),
-        }
-        _emit(out)
-    h.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
-
-
-def main_c4(args):
-    """BASELINE config C4: log-marginal likelihood + gradient, 64 random restarts sharded over the ranks via RCCL."""
-    import numpy as np
-    import torch
-    import gp_oracle as go
-    from gp_mpc_amd._lib import Handle, get_lib
-    from gp_mpc_amd.train import lhs_starts, bounds_ipopt_path
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
-    N, d, R, iters = args.N, args.d, 64, 4
-    p = go.synthetic_problem(N, d, 1, 1, seed=1234, sn=1e-2)             # the same problem on every rank (replicated X, y)
-    lib = get_lib()
-    h = Handle(lib, p['X'], p['Y'], device=local_rank)
-    lb, ub = bounds_ipopt_path(d)
-    starts = lhs_starts(R, lb, ub, 1234)[None]
-    box = [lib.rccl_unique_id() if rank == 0 else None]
-    if dist is not None:
-        dist.broadcast_object_list(box, src=0)
-    comm = lib.rccl_comm_create(local_rank, world, rank, box[0])          # (world = 1: a self-gather)
-    res = {}
-
-    def step():
-        res['r'] = h.train_multistart(starts, lb[None], ub[None], max_iter=iters, rank=rank, world=world, comm=comm, want_invK=False)
-
-    def sync():
-        h.synchronize()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-    steps, warmup = min(args.steps, 5), min(args.warmup, 1)
-    for _ in range(warmup):
-        step()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    sync()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=torch.device('cuda', local_rank))
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    lib.rccl_comm_destroy(comm)
-    if rank == 0:
-        r = res['r']
-        _emit({
-            'metric': 'GP hyper-parameter training restarts/sec, N=4096 d=6 fp64 (64 restarts x 4 L-BFGS iterations, NLL + analytic gradient)',
-            'value': R * steps / elapsed, 'unit': 'restarts/s', 'n_gpus': world, 'steps': steps, 'warmup': warmup,
-            'ms_per_step': elapsed / steps * 1e3, 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
-            'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': 'C4: 64 seeded restarts of the NLL minimisation, restart r on rank r mod world, one ncclAllGather of (NLL, theta)',
-                       'N': N, 'd': d, 'restarts': R, 'iterations': iters, 'parallelism': f'restart shard x{world} over RCCL'},
-            'best_nll': float(np.min(r['obj'])), 'finite_restarts': int(np.isfinite(r['obj']).sum()),
-            'device': lib.device_name(local_rank)})
-    h.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
 
 
 if __name__ == '__main__':

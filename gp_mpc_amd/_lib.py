@@ -63,10 +63,11 @@ SIGNATURES = {
     'gpmpc_covar': (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp]),
     'gpmpc_nll': (ctypes.c_int, [_vp, ctypes.c_int, _vp, _dp, _vp, _ip]),
     'gpmpc_train_multistart': (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp, ctypes.c_int, ctypes.c_double, ctypes.c_int,
-                                              ctypes.c_int, _vp, ctypes.c_int, _vp, _vp, _vp, _vp]),
+                                              ctypes.c_int, _vp, ctypes.c_int, _vp, _vp, _vp, _vp, _ip]),
     'gpmpc_rccl_unique_id': (ctypes.c_int, [ctypes.c_char_p]),
     'gpmpc_rccl_comm_create': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.POINTER(_vp)]),
     'gpmpc_rccl_comm_destroy': (ctypes.c_int, [_vp]),
+    'gpmpc_rccl_comm_count': (ctypes.c_int, [_vp, _ip]),
     'gpmpc_kernel_matrix': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp,
                                            ctypes.c_double, _vp]),
     'gpmpc_cholesky': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _vp, _vp, _ip]),
@@ -156,6 +157,12 @@ class GpmpcLib:
     def rccl_comm_destroy(self, comm):
         self.check(self.dll.gpmpc_rccl_comm_destroy(comm))
 
+    def rccl_comm_count(self, comm):
+        """ncclCommCount of a communicator made by rccl_comm_create: the number of ranks RCCL itself sees."""
+        n = ctypes.c_int(0)
+        self.check(self.dll.gpmpc_rccl_comm_count(comm, ctypes.byref(n)))
+        return n.value
+
     # -- low-level dense ops
     def cholesky(self, A, device=0, want_inverse=False):
         A = _f64(A).copy()
@@ -196,6 +203,7 @@ class Handle:
         h = ctypes.c_void_p()
         lib.check(lib.dll.gpmpc_create(device, self.N, self.d, self.Ny, _ptr(X), _ptr(Y), ctypes.byref(h)))
         self.h = h
+        self.device = int(device)            # the GPU this model lives on (an RCCL communicator for it must be made there)
         self.device_mode = False
         self.nh = self.d + 2                 # entries of a hyper row: [ell.., sf, sn] + mean-function parameters
 
@@ -237,7 +245,7 @@ class Handle:
 
     def counter(self, name):
         """'handoff_timeouts' | 'chained_factorisations' | 'single_queue_factorisations' | 'workspace_blocks_fresh' |
-        'workspace_blocks_reused' (include/gpmpc.h)."""
+        'workspace_blocks_reused' | 'train_iterations' | 'train_evaluations' (include/gpmpc.h)."""
         v = ctypes.c_long(0)
         self.lib.check(self.lib.dll.gpmpc_get_counter(self.h, name.encode(), ctypes.byref(v)))
         return v.value
@@ -397,19 +405,24 @@ class Handle:
         return (val.value, grad) if want_grad else val.value
 
     def train_multistart(self, starts, lb, ub, max_iter=0, tol=0.0, rank=0, world=1, comm=None, want_invK=True):
-        """gpmpc_train_multistart: starts[Ny, nstart, nh], lb / ub[Ny, nh] -> dict(hyper, obj, theta, info)."""
+        """gpmpc_train_multistart: starts[Ny, nstart, nh], lb / ub[Ny, nh] -> dict(hyper, obj, theta, info, status,
+        iterations, evaluations).  `status` is this rank's device status (0 = fine) when the caller does the exchange
+        itself (world > 1, comm None): a rank with status != 0 must still join the exchange and report it."""
         starts = _f64(starts).reshape(self.Ny, -1, self.nh)
         nstart = starts.shape[1]
         lb, ub = _f64(lb).reshape(self.Ny, self.nh), _f64(ub).reshape(self.Ny, self.nh)
         hyper, obj = np.zeros((self.Ny, self.nh)), np.zeros((self.Ny, nstart))
         theta = np.zeros((self.Ny, nstart, self.nh))
         info = np.zeros(self.Ny, dtype=np.int32)
+        status = ctypes.c_int(0)
         rc = self.lib.dll.gpmpc_train_multistart(self.h, nstart, _ptr(starts), _ptr(lb), _ptr(ub), int(max_iter), float(tol),
                                                  int(rank), int(world), comm, int(want_invK), _ptr(hyper), _ptr(obj),
-                                                 _ptr(theta), info.ctypes.data_as(ctypes.c_void_p))
+                                                 _ptr(theta), info.ctypes.data_as(ctypes.c_void_p), ctypes.byref(status))
         self.info = info
         self.lib.check(rc)
-        return dict(hyper=hyper, obj=obj, theta=theta, info=info)
+        return dict(hyper=hyper, obj=obj, theta=theta, info=info, status=status.value,
+                    status_text=(self.lib.dll.gpmpc_last_error() or b'').decode('utf-8', 'replace') if status.value else '',
+                    iterations=self.counter('train_iterations'), evaluations=self.counter('train_evaluations'))
 
     # -- raw device-pointer entry points (device pointer mode)
     def predict_mean_var_dev(self, B, z_ptr, mean_ptr, var_ptr):

@@ -28,6 +28,7 @@ struct gpmpc_gp {
     static constexpr int CHAIN_STRIKES = 3, CHAIN_REARM = 64;
     int chain_strikes = 0, chain_parked = 0;
     long n_timeouts = 0, n_chained = 0, n_single = 0;   // gpmpc_get_counter
+    long train_iters = 0, train_evals = 0;              // of the last gpmpc_train_multistart (this rank's restarts)
 #ifdef GPMPC_EMULATED
     int spin_limit = 1 << 30;   // the emulator's polls are scheduler passes, not time
 #else
@@ -341,6 +342,8 @@ int gpmpc_get_counter(gpmpc_gp* h, const char* name, long* value) {
     if (std::strcmp(name, "handoff_timeouts") == 0) *value = h->n_timeouts;
     else if (std::strcmp(name, "chained_factorisations") == 0) *value = h->n_chained;
     else if (std::strcmp(name, "single_queue_factorisations") == 0) *value = h->n_single;
+    else if (std::strcmp(name, "train_iterations") == 0) *value = h->train_iters;
+    else if (std::strcmp(name, "train_evaluations") == 0) *value = h->train_evals;
     else if (std::strcmp(name, "workspace_blocks_reused") == 0 || std::strcmp(name, "workspace_blocks_fresh") == 0) {
         std::lock_guard<std::mutex> lk(g_block_mutex);
         *value = std::strcmp(name, "workspace_blocks_reused") == 0 ? g_block_reuses : g_block_fresh;

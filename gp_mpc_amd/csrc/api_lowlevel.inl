@@ -86,6 +86,11 @@ extern "C" int gpmpc_set_tuning(const char* name, int value) {
         g_cu_count[0] = value;
         return GPMPC_OK;
     }
+    if (std::strcmp(name, "fail_nll_after") == 0) {      // fault injection for the tests of the restart shard's failure paths
+        if (value < 0) return fail(GPMPC_EINVAL, "fail_nll_after must be >= 0");
+        g_fail_nll_after = value;
+        return GPMPC_OK;
+    }
     return fail(GPMPC_EINVAL, "unknown tuning knob '%s'", name);
 }
 

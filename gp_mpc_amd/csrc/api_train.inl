@@ -3,8 +3,13 @@
 // ------------------------------------------------------------------------------------------------
 // a7 NLL (+ analytic gradient) on the separate single-output training workspace
 // ------------------------------------------------------------------------------------------------
+// gpmpc_set_tuning("fail_nll_after", n): the n-th NLL evaluation of the process from now on reports a device failure
+// (GPMPC_EHIP) without touching the device -- how the tests reach the failure paths of the restart shard (0 = off).
+static int g_fail_nll_after = 0;
+
 extern "C" int gpmpc_nll(gpmpc_gp* h, int a, const double* hyper_row, double* nll, double* grad, int* jitter_out) {
     if (!h || !hyper_row || !nll || a < 0 || a >= h->Ny) return fail(GPMPC_EINVAL, "bad arguments");
+    if (g_fail_nll_after > 0 && --g_fail_nll_after == 0) return fail(GPMPC_EHIP, "injected device failure (fail_nll_after)");
     HIPCHK(hipSetDevice(h->device));
     const int d = h->d, Np = h->Np;
     for (int k = 0; k < d + 1; ++k)
@@ -90,7 +95,7 @@ extern "C" int gpmpc_nll(gpmpc_gp* h, int a, const double* hyper_row, double* nl
 extern "C" int gpmpc_rccl_unique_id(char* id128) {
     if (!id128) return fail(GPMPC_EINVAL, "NULL id buffer");
     RcclApi& R = rccl_api();
-    if (!R.ok()) return fail(GPMPC_EHIP, "librccl.so could not be loaded: %s", dlerror() ? dlerror() : "missing symbols");
+    if (!R.ok()) return fail(GPMPC_EHIP, "librccl.so could not be loaded: %s", R.load_error.c_str());
     RcclId id;
     const int rc = R.GetUniqueId(&id);
     if (rc != 0) return fail(GPMPC_EHIP, "ncclGetUniqueId failed: %s", R.GetErrorString ? R.GetErrorString(rc) : "?");
@@ -103,7 +108,7 @@ extern "C" int gpmpc_rccl_comm_create(int device, int world, int rank, const cha
     *comm_out = nullptr;
     CHK(ensure_device(device));
     RcclApi& R = rccl_api();
-    if (!R.ok()) return fail(GPMPC_EHIP, "librccl.so could not be loaded");
+    if (!R.ok()) return fail(GPMPC_EHIP, "librccl.so could not be loaded: %s", R.load_error.c_str());
     RcclId id;
     std::memcpy(id.internal, id128, 128);
     HIPCHK(hipDeviceSynchronize());
@@ -120,9 +125,17 @@ extern "C" int gpmpc_rccl_comm_destroy(void* comm) {
     return R.CommDestroy(comm) == 0 ? GPMPC_OK : fail(GPMPC_EHIP, "ncclCommDestroy failed");
 }
 
+extern "C" int gpmpc_rccl_comm_count(void* comm, int* count) {
+    if (!comm || !count) return fail(GPMPC_EINVAL, "NULL communicator or output");
+    RcclApi& R = rccl_api();
+    if (!R.ok() || !R.CommCount) return fail(GPMPC_EHIP, "librccl.so could not be loaded: %s", R.load_error.c_str());
+    const int rc = R.CommCount(comm, count);
+    return rc == 0 ? GPMPC_OK : fail(GPMPC_EHIP, "ncclCommCount failed: %s", R.GetErrorString ? R.GetErrorString(rc) : "?");
+}
+
 extern "C" int gpmpc_train_multistart(gpmpc_gp* h, int nstart, const double* starts, const double* lb, const double* ub,
                                       int max_iter, double tol, int rank, int world, void* rccl_comm, int want_invK,
-                                      double* hyper_opt, double* obj, double* theta_all, int* info) {
+                                      double* hyper_opt, double* obj, double* theta_all, int* info, int* status) {
     if (!h || nstart <= 0 || !starts || !lb || !ub || !hyper_opt) return fail(GPMPC_EINVAL, "NULL argument or nstart <= 0");
     if (world < 1 || rank < 0 || rank >= world) return fail(GPMPC_EINVAL, "bad rank %d / world %d", rank, world);
     HIPCHK(hipSetDevice(h->device));
@@ -130,15 +143,21 @@ extern "C" int gpmpc_train_multistart(gpmpc_gp* h, int nstart, const double* sta
     const double inf = std::numeric_limits<double>::infinity();
     if (max_iter <= 0) max_iter = 200;
     if (!(tol > 0.0)) tol = 1e-8;
-    std::vector<double> table((size_t)Ny * nstart * row, 0.0);   // [a][r][NLL, theta...]; not-owned / failed: +inf
-    int hip_rc = GPMPC_OK;
-    for (int a = 0; a < Ny; ++a) {
+    // [a][r][NLL, theta...]; not-owned / failed: +inf.  One more word travels with the table: this rank's status (0 = fine,
+    // else the GPMPC_E* code of a device failure).  A rank that fails does NOT return before the exchange -- its peers
+    // would wait in the collective for ever -- it sends +inf rows and its code; every rank then returns that error.
+    std::vector<double> table((size_t)Ny * nstart * row + 1, 0.0);
+    int local_rc = GPMPC_OK;
+    std::string local_err;
+    long iters_total = 0, evals_total = 0;
+    for (int a = 0; a < Ny && local_rc == GPMPC_OK; ++a) {
         BoxProblem P;
         P.n = nh;
         P.lb.assign(lb + (size_t)a * nh, lb + (size_t)(a + 1) * nh);
         P.ub.assign(ub + (size_t)a * nh, ub + (size_t)(a + 1) * nh);
         P.logv.resize(nh);
         for (int k = 0; k < nh; ++k) {
+            // (argument errors are the same on every rank: returning here cannot strand a peer)
             if (!(P.lb[k] <= P.ub[k])) return fail(GPMPC_EINVAL, "empty box for hyper-parameter %d of output %d", k, a);
             // length scales and sf in log space (their boxes span many decades).  NOT the noise sn: the NLL sees it as sn^2,
             // so d NLL / d log sn = 2 sn^2 (...) vanishes at the reference's start sn = 1e-5 and a log-space search leaves it
@@ -146,54 +165,74 @@ extern "C" int gpmpc_train_multistart(gpmpc_gp* h, int nstart, const double* sta
             P.logv[k] = k < d + 1 && P.lb[k] > 0.0 && P.ub[k] < inf;
         }
         P.eval = [&](const double* th, double* f, double* g) -> bool {
+            if (local_rc != GPMPC_OK) return false;              // after a device failure: every point is unusable
             const int rc = gpmpc_nll(h, a, th, f, g, nullptr);
-            if (rc == GPMPC_EHIP || rc == GPMPC_ENOMEM) hip_rc = rc;
+            if (rc == GPMPC_EHIP || rc == GPMPC_ENOMEM) { local_rc = rc; local_err = g_err; }
             return rc == GPMPC_OK;
         };
         for (int r = 0; r < nstart; ++r) {
             double* out = &table[((size_t)a * nstart + r) * row];
             out[0] = inf;
-            if (r % world != rank) continue;
+            if (r % world != rank || local_rc != GPMPC_OK) continue;
             BoxResult res = minimize_box_lbfgs(P, starts + ((size_t)a * nstart + r) * nh, max_iter, tol);
-            if (hip_rc != GPMPC_OK) return hip_rc;               // device failure: g_err holds the text
+            iters_total += res.iters; evals_total += res.evals;
             // The linear noise variable is badly scaled against the log variables (its whole box is 1e-2 wide): once the
             // first search has stopped with iterations to spare, a second one from there with sn in log space -- where its
             // gradient no longer vanishes -- polishes the optimum (third reference-made fixture: -95.7 -> the -197.7 that
             // SLSQP with the analytic gradient finds; the reference's own run stops at -80.3).
-            if (res.ok && res.iters < max_iter && P.lb[d + 1] > 0.0 && P.ub[d + 1] < inf) {
+            if (res.ok && res.iters < max_iter && P.lb[d + 1] > 0.0 && P.ub[d + 1] < inf && local_rc == GPMPC_OK) {
                 BoxProblem P2 = P;
                 P2.logv[d + 1] = 1;
                 const BoxResult res2 = minimize_box_lbfgs(P2, res.theta.data(), max_iter - res.iters, tol);
-                if (hip_rc != GPMPC_OK) return hip_rc;
+                iters_total += res2.iters; evals_total += res2.evals;
                 if (res2.ok && res2.f < res.f) res = res2;
             }
             std::memcpy(out + 1, res.theta.data(), nh * sizeof(double));
-            if (res.ok) out[0] = res.f;
+            if (res.ok && local_rc == GPMPC_OK) out[0] = res.f;
         }
     }
+    h->train_iters = iters_total;
+    h->train_evals = evals_total;
+    if (local_rc != GPMPC_OK)                                   // whatever this rank found is not to be trusted
+        for (size_t e = 0; e + 1 < table.size(); e += row) table[e] = inf;
+    table.back() = (double)local_rc;
+    const size_t cnt = table.size();
     if (rccl_comm) {    // one all-gather of the whole table: (1 + nh) doubles per restart (also at world = 1: a self-gather)
         RcclApi& R = rccl_api();
-        if (!R.ok()) return fail(GPMPC_EHIP, "librccl.so could not be loaded");
-        const size_t cnt = table.size();
-        double *dsend = nullptr, *drecv = nullptr;
-        HIPCHK(hipMalloc(&dsend, cnt * sizeof(double)));
-        HIPCHK(hipMalloc(&drecv, cnt * world * sizeof(double)));
-        HIPCHK(hipMemcpyAsync(dsend, table.data(), cnt * sizeof(double), hipMemcpyHostToDevice, h->stream));
-        (void)hipGetLastError();
-        const int rc = R.AllGather(dsend, drecv, cnt, RCCL_FLOAT64, rccl_comm, h->stream);
+        // (a missing librccl is the same on every rank of a node, and the communicator could not exist without it)
+        if (!R.ok()) return fail(GPMPC_EHIP, "librccl.so could not be loaded: %s", R.load_error.c_str());
+        struct DevBuf {                                            // freed on every path
+            double* p = nullptr;
+            ~DevBuf() { if (p) (void)hipFree(p); }
+        } dsend, drecv;
         std::vector<double> all(cnt * world);
-        if (rc == 0) {
-            HIPCHK(hipMemcpyAsync(all.data(), drecv, all.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-            HIPCHK(hipStreamSynchronize(h->stream));
-        }
-        hipFree(dsend);
-        hipFree(drecv);
+        hipError_t he = hipMalloc(&dsend.p, cnt * sizeof(double));
+        if (he == hipSuccess) he = hipMalloc(&drecv.p, cnt * world * sizeof(double));
+        if (he == hipSuccess) he = hipMemcpyAsync(dsend.p, table.data(), cnt * sizeof(double), hipMemcpyHostToDevice, h->stream);
+        // A rank that cannot even stage its table cannot join the collective; nothing this library can do would free its
+        // peers then (they time out in RCCL).  With a few KB per rank that means the device is gone.
+        if (he != hipSuccess) return fail(GPMPC_EHIP, "staging the restart table failed: %s", hipGetErrorString(he));
+        (void)hipGetLastError();
+        const int rc = R.AllGather(dsend.p, drecv.p, cnt, RCCL_FLOAT64, rccl_comm, h->stream);
         if (rc != 0) return fail(GPMPC_EHIP, "ncclAllGather failed: %s", R.GetErrorString ? R.GetErrorString(rc) : "?");
+        HIPCHK(hipMemcpyAsync(all.data(), drecv.p, all.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        for (int q = 0; q < world; ++q) {
+            const int peer_rc = (int)all[(size_t)q * cnt + cnt - 1];
+            if (peer_rc != GPMPC_OK) {
+                if (q == rank) return fail(peer_rc, "%s", local_err.c_str());
+                return fail(peer_rc, "rank %d of the restart shard reported a device failure (code %d)", q, peer_rc);
+            }
+        }
         for (int a = 0; a < Ny; ++a)
             for (int r = 0; r < nstart; ++r)
                 std::memcpy(&table[((size_t)a * nstart + r) * row], &all[(size_t)(r % world) * cnt + ((size_t)a * nstart + r) * row],
                             row * sizeof(double));
+    } else if (local_rc != GPMPC_OK && world == 1) {
+        return fail(local_rc, "%s", local_err.c_str());
     }
+    // (world > 1 without a communicator: the caller merges the ranks' tables; a failed rank reports through `status`)
+    if (status) *status = local_rc;
     const bool merged = world == 1 || rccl_comm != nullptr;
     bool all_ok = true;
     for (int a = 0; a < Ny; ++a) {
@@ -207,7 +246,10 @@ extern "C" int gpmpc_train_multistart(gpmpc_gp* h, int nstart, const double* sta
         if (best >= 0) std::memcpy(hyper_opt + (size_t)a * nh, &table[((size_t)a * nstart + best) * row + 1], nh * sizeof(double));
         else all_ok = false;
     }
-    if (!merged) return GPMPC_OK;                               // caller merges the ranks' tables and calls gpmpc_fit
+    if (!merged) {                                              // caller merges the ranks' tables and calls gpmpc_fit
+        if (local_rc != GPMPC_OK) g_err = local_err;            // (text for gpmpc_last_error; the code is in *status)
+        return GPMPC_OK;
+    }
     if (!all_ok) return fail(GPMPC_ENOTPD, "every restart of an output failed (K not positive definite along the way)");
     return gpmpc_fit(h, hyper_opt, want_invK, info);            // optimize.py:476-494 at theta*
 }

@@ -143,23 +143,25 @@ __device__ __forceinline__ double rsqrt_newton(double x) {
 // One wave: Cholesky of the 64 x 16 panel, DPP form.  Lane l owns panel row l in a[] (as panel_potrf) AND row o + (l & 15)
 // of the 16 x 16 diagonal block in d[] -- the diagonal block is replicated in the four 16-lane groups so that
 // row_newbcast:k delivers L_kj to every lane.  Column j: x = pivot (rowb<j>), y = rsqrt(x), d[j] *= y, a[j] *= y, then for
-// k > j: d[k] -= L_kj d[j], a[k] -= L_kj a[j].  MODE 1: broadcast by v_mov_b64_dpp + two v_fma_f64 (compiler-scheduled);
-// MODE 2: two v_fmac_f64_dpp.
+// k > j: d[k] -= L_kj d[j], a[k] -= L_kj a[j] as two v_fmac_f64_dpp (MODE 2; MODE 1 = v_mov_b64_dpp + two v_fma_f64, the
+// compiler-scheduled form kept for the micro-benchmark).  Measured (tools/ubench/panel_dpp_bench.hip, one wave, idle
+// chip): a v_fmac_f64_dpp issues like a plain v_fma_f64 (2.8 ns), "two v_readlane + fma" costs 9.8 ns.
+// No per-column test of the pivot: a non-positive or NaN pivot makes y NaN (rsq of a negative; 0 x inf in the
+// correction), the NaN spreads to every later column, so ONE test of the last y decides, and only then the stored
+// reciprocals are scanned for the first bad column (same `info` as the per-column test of panel_potrf).
 template <int TT, int MODE>
 __device__ __forceinline__ int panel_potrf_dpp(double* S, double* Drinv, int lane) {
     constexpr int o = 16 * TT;
     const int r = lane, i = lane & 15;
     double a[16], d[16];
-    int bad = -1;
 #pragma unroll
     for (int c = 0; c < 16; ++c) { a[c] = S[r * LS + o + c]; d[c] = S[(o + i) * LS + o + c]; }
-    double yk = 0.0;
+    double y = 0.0;
 #define GPMPC_PANEL_COL(j)                                                                              \
     {                                                                                                     \
         const double x = rowb<j>(d[j]);                                                                   \
-        if (!(x > 0.0) && bad < 0) bad = j;                                                               \
-        const double y = rsqrt_newton(x);                                                                 \
-        if (i == j) yk = y;                                                                               \
+        y = rsqrt_newton(x);                                                                              \
+        Drinv[o + j] = y;      /* uniform value, uniform address: 1 / L_jj for the diagonal-inverse wave */ \
         d[j] *= y;                                                                                        \
         a[j] *= y;                                                                                        \
         GPMPC_PANEL_UPD(j, 1) GPMPC_PANEL_UPD(j, 2) GPMPC_PANEL_UPD(j, 3) GPMPC_PANEL_UPD(j, 4) GPMPC_PANEL_UPD(j, 5)   \
@@ -169,7 +171,7 @@ __device__ __forceinline__ int panel_potrf_dpp(double* S, double* Drinv, int lan
 #define GPMPC_PANEL_UPD(j, k)                                                                            \
     if constexpr (k > j) {                                                                                \
         if constexpr (MODE == 2) {                                                                        \
-            fnma_rowb<k, k == j + 1>(d[k], d[j], d[j]);   /* d[j] = (asm volatile keeps statement order) */ \
+            fnma_rowb<k, k == j + 1>(d[k], d[j], d[j]);   /* (asm volatile keeps the statement order) */   \
             fnma_rowb<k, false>(a[k], d[j], a[j]);                                                        \
         } else {                                                                                          \
             const double b = rowb<k>(d[j]);                                                               \
@@ -182,12 +184,47 @@ __device__ __forceinline__ int panel_potrf_dpp(double* S, double* Drinv, int lan
     GPMPC_PANEL_COL(12) GPMPC_PANEL_COL(13) GPMPC_PANEL_COL(14) GPMPC_PANEL_COL(15)
 #undef GPMPC_PANEL_COL
 #undef GPMPC_PANEL_UPD
-    if (lane < 16) Drinv[o + lane] = yk;     // 1 / L_cc for the diagonal-inverse wave
     if (r >= o) {
 #pragma unroll
         for (int c = 0; c < 16; ++c) S[r * LS + o + c] = (r - o >= 16 || c <= r - o) ? a[c] : 0.0;
     }
-    return __builtin_amdgcn_readfirstlane(bad);
+    int bad = -1;
+    if (!(y * 0.0 == 0.0)) {                 // NaN or infinity in the last reciprocal (wave-uniform, rare)
+        for (int c = 15; c >= 0; --c) {
+            const double yc = Drinv[o + c];
+            if (!(yc * 0.0 == 0.0)) bad = c;
+        }
+    }
+    return bad;
+}
+
+// One wave: inverse of the 16 x 16 lower-triangular block at (o,o) of S into T, DPP form of inv16: lane (q, r) owns row r of
+// the block (replicated in the four 16-lane groups) and builds column r of the inverse by forward substitution,
+// x_i = (delta_ir - sum_{k<i} L_ik x_k) / L_ii with L_ik = rowb<i>(a[k]) folded into one v_fmac_f64_dpp.
+__device__ __forceinline__ void inv16_dpp(const double* S, double* T, int o, int lane, const double* Drinv) {
+    const int r = lane & 15;
+    double a[16], x[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) a[c] = (c <= r) ? S[(o + r) * LS + o + c] : 0.0;
+#define GPMPC_INV_TERM(i, k) if constexpr (k < i) fnma_rowb<i, false>(s, a[k], x[k]);
+#define GPMPC_INV_ROW(i)                                                                                 \
+    {                                                                                                     \
+        double s = (i == r) ? 1.0 : 0.0;                                                                  \
+        GPMPC_INV_TERM(i, 0) GPMPC_INV_TERM(i, 1) GPMPC_INV_TERM(i, 2) GPMPC_INV_TERM(i, 3) GPMPC_INV_TERM(i, 4)          \
+        GPMPC_INV_TERM(i, 5) GPMPC_INV_TERM(i, 6) GPMPC_INV_TERM(i, 7) GPMPC_INV_TERM(i, 8) GPMPC_INV_TERM(i, 9)          \
+        GPMPC_INV_TERM(i, 10) GPMPC_INV_TERM(i, 11) GPMPC_INV_TERM(i, 12) GPMPC_INV_TERM(i, 13) GPMPC_INV_TERM(i, 14)     \
+        x[i] = s * Drinv[o + i];                                                                          \
+    }
+    // (the DPP operands a[k] are loaded once, long before their first use: no hazard inside the substitution)
+    GPMPC_INV_ROW(0) GPMPC_INV_ROW(1) GPMPC_INV_ROW(2) GPMPC_INV_ROW(3) GPMPC_INV_ROW(4) GPMPC_INV_ROW(5) GPMPC_INV_ROW(6)
+    GPMPC_INV_ROW(7) GPMPC_INV_ROW(8) GPMPC_INV_ROW(9) GPMPC_INV_ROW(10) GPMPC_INV_ROW(11) GPMPC_INV_ROW(12)
+    GPMPC_INV_ROW(13) GPMPC_INV_ROW(14) GPMPC_INV_ROW(15)
+#undef GPMPC_INV_ROW
+#undef GPMPC_INV_TERM
+    if (lane < 16) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) T[(o + i) * LS + o + r] = x[i];
+    }
 }
 
 // The factor + invert body shared by leaf64_kernel and the persistent chain kernel (chol_chain.hpp).
@@ -202,6 +239,14 @@ __device__ __forceinline__ int panel_potrf_dpp(double* S, double* Drinv, int lan
 // two thirds into the leaf -- and hook.land() in waves 2 and 3 while wave 0 factors the last panel.  The chain kernel
 // uses them to poll a flag (before), to issue the global loads of its next tiles in waves 2 and 3 (after) and to put
 // what they fetched into LDS (land): the latency hides behind the last panel and no register is held across the leaf.
+#ifndef GPMPC_LEAF_DPP
+#define GPMPC_LEAF_DPP 1
+#endif
+#if GPMPC_LEAF_DPP
+#define GPMPC_INV16 inv16_dpp
+#else
+#define GPMPC_INV16 inv16
+#endif
 struct LeafNoHook {
     __device__ __forceinline__ void before() {}
     __device__ __forceinline__ void after() {}
@@ -220,11 +265,16 @@ __device__ __forceinline__ int leaf_body(double* S, double* T, double* U, double
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             if (wave == 0 && (phases & 1)) {
+#if GPMPC_LEAF_DPP
+                const int b = t == 0 ? panel_potrf_dpp<0, 2>(S, Dr, lane) : t == 1 ? panel_potrf_dpp<1, 2>(S, Dr, lane)
+                            : t == 2 ? panel_potrf_dpp<2, 2>(S, Dr, lane) : panel_potrf_dpp<3, 2>(S, Dr, lane);
+#else
                 const int b = t == 0 ? panel_potrf<0>(S, Dr, lane) : t == 1 ? panel_potrf<1>(S, Dr, lane)
                             : t == 2 ? panel_potrf<2>(S, Dr, lane) : panel_potrf<3>(S, Dr, lane);
+#endif
                 if (b >= 0 && bad < 0) bad = 16 * t + b;
             } else if (wave == 1 && t >= 1 && (phases & 4)) {
-                inv16(S, T, 16 * (t - 1), lane, Dr);   // inverse of the previous diagonal block
+                GPMPC_INV16(S, T, 16 * (t - 1), lane, Dr);   // inverse of the previous diagonal block
             } else if (wave >= 2 && t == 3) {
                 hook.land();                            // waves 2 and 3 have nothing else to do behind the last panel
             }
@@ -243,7 +293,7 @@ __device__ __forceinline__ int leaf_body(double* S, double* T, double* U, double
                     }
             if (t < 3) __syncthreads();
         }
-        if (wave == 1 && (phases & 4)) inv16(S, T, 48, lane, Dr);
+        if (wave == 1 && (phases & 4)) GPMPC_INV16(S, T, 48, lane, Dr);
         __syncthreads();
     } else {
         if (wave < 4) inv16(S, T, 16 * wave, lane, nullptr);

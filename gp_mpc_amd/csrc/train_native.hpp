@@ -3,10 +3,14 @@
 //
 // The reference minimises with scipy SLSQP + finite differences (train_gp_numpy, optimize.py:466-467) or IPOPT on
 // CasADi's AD (train_gp, :236-246); both only see a smooth box-constrained problem in d + 2 (+ mean parameters)
-// variables.  Here: projected L-BFGS.  Variables with a positive lower bound (length scales on the IPOPT-path box, sf,
-// sn) are optimised in log space -- they span up to eight decades (sn in [1e-10, 1e-2]) -- the others raw.  Every step is
-// a projected Armijo backtracking search; a point where K is not positive definite even after the reference's jitter
-// counts as +infinity, exactly like a failed restart in the reference (optimize.py:349-350 would raise).
+// variables.  Here: projected L-BFGS.  Which variables are searched in log space is the caller's choice (BoxProblem::logv);
+// gpmpc_train_multistart runs TWO stages per restart: first with the length scales and sf in log space (their boxes span
+// many decades) and the noise sn LINEAR, as in the reference's optimisers -- the NLL sees sn^2, so its derivative with
+// respect to log sn vanishes at the reference's start sn = 1e-5 and a log-space search never leaves it --, then, if
+// iterations are left, a polish from that end point with sn in log space as well; the better end point is kept.  Every
+// step is a projected Armijo backtracking search that only ever accepts a decrease; the L-BFGS memory is dropped whenever
+// the set of free (not bound-pinned) variables changes; a point where K is not positive definite even after the
+// reference's jitter counts as +infinity, exactly like a failed restart in the reference (optimize.py:349-350 would raise).
 #pragma once
 #include <dlfcn.h>
 
@@ -66,10 +70,10 @@ inline BoxResult minimize_box_lbfgs(const BoxProblem& P, const double* theta0, i
     std::vector<std::vector<double>> Sv, Yv;
     std::vector<double> rho;
     std::vector<double> dir(n), xn(n), gn(n), q(n), al(M);
+    std::vector<char> fr(n), fr_prev;
     for (int it = 0; it < max_iter; ++it) {
         R.iters = it + 1;
         // free variables: not pinned at a bound with the gradient pushing outward
-        std::vector<char> fr(n);
         double pgn = 0.0;
         for (int k = 0; k < n; ++k) {
             const bool at_lo = x[k] <= lo[k] && g[k] > 0.0, at_hi = x[k] >= hi[k] && g[k] < 0.0;
@@ -77,6 +81,9 @@ inline BoxResult minimize_box_lbfgs(const BoxProblem& P, const double* theta0, i
             if (fr[k]) pgn = std::max(pgn, std::fabs(g[k]));
         }
         if (pgn <= tol * std::max(1.0, std::fabs(f))) break;
+        // the curvature pairs describe the problem restricted to the free set they were collected on
+        if (!fr_prev.empty() && fr_prev != fr) { Sv.clear(); Yv.clear(); rho.clear(); }
+        fr_prev = fr;
         // two-loop recursion on the free components
         for (int k = 0; k < n; ++k) q[k] = fr[k] ? g[k] : 0.0;
         const int m = (int)Sv.size();
@@ -128,8 +135,9 @@ inline BoxResult minimize_box_lbfgs(const BoxProblem& P, const double* theta0, i
                 any |= v != x[k];
             }
             if (!any) break;
+            if (!(dec < 0.0)) continue;                         // the clipped step is not a descent step: shorten it
             fn = fun(xn, gn);
-            if (fn <= f + 1e-4 * dec) { moved = true; break; }
+            if (fn <= f + 1e-4 * dec) { moved = true; break; }  // dec < 0: an accepted point is strictly better
         }
         if (!moved) break;                                      // no progress along the projected path
         std::vector<double> s(n), y(n);
@@ -158,6 +166,8 @@ struct RcclApi {
     int (*CommDestroy)(void*) = nullptr;
     int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
+    int (*CommCount)(void*, int*) = nullptr;
+    std::string load_error;                                       // dlerror() text of the first failed dlopen / what is missing
     bool ok() const { return lib && GetUniqueId && CommInitRank && CommDestroy && AllGather; }
 };
 inline RcclApi& rccl_api() {
@@ -183,6 +193,8 @@ inline RcclApi& rccl_api() {
         for (const std::string& name : names) {
             a.lib = dlopen(name.c_str(), RTLD_NOW | RTLD_LOCAL);
             if (a.lib) break;
+            const char* e = dlerror();                            // (reading it clears it: keep the first text)
+            if (a.load_error.empty() && e) a.load_error = e;
         }
         if (a.lib) {
             a.GetUniqueId = (int (*)(RcclId*))dlsym(a.lib, "ncclGetUniqueId");
@@ -190,6 +202,10 @@ inline RcclApi& rccl_api() {
             a.CommDestroy = (int (*)(void*))dlsym(a.lib, "ncclCommDestroy");
             a.AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(a.lib, "ncclAllGather");
             a.GetErrorString = (const char* (*)(int))dlsym(a.lib, "ncclGetErrorString");
+            a.CommCount = (int (*)(void*, int*))dlsym(a.lib, "ncclCommCount");
+            a.load_error = a.ok() ? "" : "librccl is loaded but lacks ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllGather";
+        } else if (a.load_error.empty()) {
+            a.load_error = "no librccl.so found";
         }
         return a;
     }();

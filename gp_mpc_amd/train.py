@@ -96,7 +96,8 @@ def _all_gather_rows(dist, local, world, device=None):
     """all_gather of a fixed-size float64 block per rank (RCCL on GPU boxes, gloo in CPU tests)."""
     import torch
     backend = dist.get_backend()
-    dev = torch.device('cuda', torch.cuda.current_device()) if backend == 'nccl' else torch.device('cpu')
+    dev = (torch.device('cuda', torch.cuda.current_device() if device is None else device) if backend == 'nccl'
+           else torch.device('cpu'))
     t = torch.from_numpy(np.ascontiguousarray(local)).to(dev)
     out = [torch.empty_like(t) for _ in range(world)]
     dist.all_gather(out, t)
@@ -152,24 +153,13 @@ def train_gp(handle, X, Y, multistart=1, hyper_init=None, optimizer_opts=None,
     if optimizer == 'native':
         return _train_native(handle, X, Y, multistart, hyper_init, options, lbk, ubk, nv, h_m, opt_mean, mean_func,
                              predict_adds_mean, random_restarts, seed, dist, rank, world)
+    from ._lib import EINVAL, ENOTPD
+    local = np.full((Ny, multistart, nv + 1), np.inf)        # [a][r][NLL, theta...] of the restarts this rank owns
+    failure = None                                           # a device failure (EHIP / ENOMEM) on this rank
     for a in range(Ny):
-        lb = np.concatenate([lbk, np.full(nv - Nx - 2, -np.inf)])
-        ub = np.concatenate([ubk, np.full(nv - Nx - 2, np.inf)])
-        if opt_mean:
-            mean_param_bounds(lb, ub, mean_func, h_m, np.mean(Y[:, a]))
+        starts, lb, ub = _starts_and_bounds(X, Y, a, multistart, hyper_init, lbk, ubk, nv, h_m, opt_mean, mean_func,
+                                            random_restarts, seed)
         bounds = np.stack([lb, ub], axis=1)
-        if random_restarts:
-            starts = np.zeros((multistart, nv))
-            starts[:, :Nx + 2] = lhs_starts(multistart, lbk, ubk, seed + a)
-            if hyper_init is not None:
-                starts[0] = np.asarray(hyper_init[a], dtype=np.float64)[:nv]
-        else:
-            if hyper_init is None:
-                h0 = np.zeros(nv)                               # optimize.py:215-219: mean parameters start at 0
-                h0[:Nx + 2] = default_init(X, Y[:, a])
-            else:
-                h0 = np.asarray(hyper_init[a], dtype=np.float64)[:nv]
-            starts = np.tile(h0, (multistart, 1))            # optimize.py:462-466: identical restarts
 
         def fun(h):
             nonlocal n_eval
@@ -179,31 +169,62 @@ def train_gp(handle, X, Y, multistart=1, hyper_init=None, optimizer_opts=None,
                 return v, g
             return handle.nll(a, h)
 
-        local = np.full((multistart, nv + 1), np.inf)
         for r in range(multistart):
-            if r % world != rank:
+            if r % world != rank or failure is not None:
                 continue
             try:
                 res = minimize(fun, starts[r], jac=(gradient == 'analytic'), method=method,
                                options=options, bounds=bounds, tol=1e-12)
-                local[r, 0] = res.fun
-                local[r, 1:] = res.x
-            except (np.linalg.LinAlgError, GpmpcError):
-                pass    # this start ran into a non-SPD K twice, or the optimiser stepped onto an unusable point
-                        # (ell = 0, NaN): the restart counts as failed (inf) and every rank still reaches the gather
-        if dist:
-            gathered = _all_gather_rows(dist, local, world)   # [world, multistart, Nx+3]
-            owner = np.arange(multistart) % world
-            local = gathered[owner, np.arange(multistart)]
-        if not np.isfinite(local[:, 0]).any():
+                local[a, r, 0] = res.fun
+                local[a, r, 1:] = res.x
+            except np.linalg.LinAlgError:
+                pass    # this start ran into a non-SPD K twice: the restart counts as failed (inf)
+            except GpmpcError as e:
+                if e.code in (EINVAL, ENOTPD):
+                    pass    # the optimiser stepped onto an unusable point (ell = 0, NaN): a failed restart as well
+                else:
+                    failure = e     # device failure: NOT a failed restart -- reported to every rank below, after the
+                                    # exchange (raising here would leave the peers waiting in the all_gather)
+    local = _merge_restart_tables(dist, world, rank, local, failure)   # ONE exchange for all outputs
+    for a in range(Ny):
+        if not np.isfinite(local[a, :, 0]).any():
             raise np.linalg.LinAlgError('every restart failed for output %d' % a)
-        best = int(np.argmin(local[:, 0]))                    # optimize.py:474
-        hyp_opt[a, :nv] = local[best, 1:]
-        all_obj[a] = local[:, 0]
+        best = int(np.argmin(local[a, :, 0]))                 # optimize.py:474
+        hyp_opt[a, :nv] = local[a, best, 1:]
+        all_obj[a] = local[a, :, 0]
 
     handle.set_mean_func(mean_func, predict_adds_mean)
     info = handle.fit(hyp_opt, want_invK=True)               # optimize.py:476-494 / :264-285 at theta*
     return dict(hyper=hyp_opt, lam_x=0, obj=all_obj, info=info, n_eval=n_eval, rank=rank, world=world)
+
+
+def _merge_restart_tables(dist, world, rank, local, failure=None, status=0, status_text=''):
+    """The exchange step of the restart shard on the host side: ONE all_gather of this rank's table
+    [Ny, multistart, 1 + nv] plus a status word; row r is taken from rank r mod world.  A rank that hit a device failure
+    (`failure`: the exception, or `status` != 0 from gpmpc_train_multistart) still joins the exchange -- with +inf rows --
+    and every rank raises afterwards, so nobody is left waiting in the collective."""
+    from ._lib import GpmpcError, EHIP
+    code = int(getattr(failure, 'code', status) or 0) if (failure is not None or status) else 0
+    if code:
+        local = local.copy()
+        local[..., 0] = np.inf
+    if not (dist and world > 1):
+        if code:
+            raise failure if failure is not None else GpmpcError(code, status_text)
+        return local
+    flat = np.concatenate([local.ravel(), [float(code)]])
+    gathered = _all_gather_rows(dist, flat, world)            # [world, Ny * multistart * (1 + nv) + 1]
+    codes = gathered[:, -1].astype(int)
+    if codes.any():
+        q = int(np.flatnonzero(codes)[0])
+        if q == rank and failure is not None:
+            raise failure
+        raise GpmpcError(int(codes[q]) or EHIP, status_text if q == rank else
+                         'rank %d of the restart shard reported a device failure (code %d)' % (q, codes[q]))
+    tables = gathered[:, :-1].reshape((world,) + local.shape)
+    multistart = local.shape[1]
+    owner = np.arange(multistart) % world
+    return tables[owner, :, np.arange(multistart)].transpose(1, 0, 2)
 
 
 def _starts_and_bounds(X, Y, a, multistart, hyper_init, lbk, ubk, nv, h_m, opt_mean, mean_func, random_restarts, seed):
@@ -240,38 +261,58 @@ def _train_native(handle, X, Y, multistart, hyper_init, options, lbk, ubk, nv, h
     starts = np.stack([t[0] for t in sb])
     lb = np.stack([t[1] for t in sb])
     ub = np.stack([t[2] for t in sb])
+    # Only `maxiter` and `tol` of optimizer_opts reach the native search (include/gpmpc.h): options written for IPOPT or
+    # SLSQP have no counterpart in it.  maxiter >= 10000 is the reference's SLSQP cap (optimize.py:420), not a meaningful
+    # L-BFGS budget: the library default (200) is used instead.
     max_iter = int(options.get('maxiter', 0))
     if max_iter >= 10000:
-        max_iter = 0                      # the reference's SLSQP cap (optimize.py:420) is not a meaningful L-BFGS budget
+        max_iter = 0
     tol = float(options.get('tol', 0.0))
     comm = None
     if dist and world > 1 and dist.get_backend() == 'nccl':
-        import torch
         box = [handle.lib.rccl_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(box, src=0)
-        comm = handle.lib.rccl_comm_create(torch.cuda.current_device(), world, rank, box[0])
+        comm = handle.lib.rccl_comm_create(handle.device, world, rank, box[0])    # on the GPU the model lives on
     try:
-        res = handle.train_multistart(starts, lb, ub, max_iter=max_iter, tol=tol, rank=rank, world=world, comm=comm)
+        res = sharded_multistart(handle, starts, lb, ub, max_iter=max_iter, tol=tol, dist=dist, rank=rank, world=world,
+                                 comm=comm, before_fit=lambda: handle.set_mean_func(mean_func, predict_adds_mean))
     finally:
         if comm is not None:
             handle.lib.rccl_comm_destroy(comm)
+    rccl_ranks = res['rccl_ranks']
     hyp_opt = np.zeros((Ny, Nx + 2 + h_m))
-    if dist and world > 1 and comm is None:                   # gloo: merge the ranks' rows, then fit
-        local = np.concatenate([res['obj'][:, :, None], res['theta']], axis=2)          # [Ny, multistart, 1 + nv]
-        gathered = _all_gather_rows(dist, local, world)                                   # [world, Ny, multistart, 1 + nv]
-        owner = np.arange(multistart) % world
-        merged = gathered[owner, :, np.arange(multistart)].transpose(1, 0, 2)             # [Ny, multistart, 1 + nv]
-        res['obj'] = merged[:, :, 0]
+    hyp_opt[:, :nv] = res['hyper']
+    info = res['info']
+    if nv != hyp_opt.shape[1]:            # numpy-path conventions with a mean function: zero mean parameters appended
+        handle.set_mean_func(mean_func, predict_adds_mean)
+        info = handle.fit(hyp_opt, want_invK=True)
+    return dict(hyper=hyp_opt, lam_x=0, obj=res['obj'], info=info, n_eval=int(res['evaluations']),
+                n_iter=int(res['iterations']), rank=rank, world=world, rccl_ranks=rccl_ranks)
+
+
+def sharded_multistart(handle, starts, lb, ub, max_iter=0, tol=0.0, dist=None, rank=0, world=1, comm=None,
+                       want_invK=True, before_fit=None):
+    """One pass of the restart shard through `gpmpc_train_multistart`: restart r on rank r mod world, ONE
+    exchange of the (NLL, theta) table, the same arg-min on every rank, local fit at the optimum.
+    comm: an RCCL communicator of the library (`rccl_comm_create`) -- the exchange is the library's own ncclAllGather on
+    the model's stream; None with world > 1 (gloo in the CPU tests): the ranks' tables are merged here through `dist`
+    and the fit is issued afterwards.  Returns the library's dictionary (hyper, obj, theta, info, iterations,
+    evaluations) plus rccl_ranks (ncclCommCount, 0 without a communicator)."""
+    res = handle.train_multistart(starts, lb, ub, max_iter=max_iter, tol=tol, rank=rank, world=world, comm=comm,
+                                  want_invK=want_invK)
+    res['rccl_ranks'] = handle.lib.rccl_comm_count(comm) if comm is not None else 0
+    if dist and world > 1 and comm is None:
+        Ny = res['obj'].shape[0]
+        local = np.concatenate([res['obj'][:, :, None], res['theta']], axis=2)          # [Ny, nstart, 1 + nh]
+        merged = _merge_restart_tables(dist, world, rank, local, status=res['status'], status_text=res['status_text'])
+        res['obj'], res['theta'] = merged[:, :, 0], merged[:, :, 1:]
+        hyper = np.zeros_like(res['hyper'])
         for a in range(Ny):
             if not np.isfinite(merged[a, :, 0]).any():
                 raise np.linalg.LinAlgError('every restart failed for output %d' % a)
-            hyp_opt[a, :nv] = merged[a, int(np.argmin(merged[a, :, 0])), 1:]
-        handle.set_mean_func(mean_func, predict_adds_mean)
-        info = handle.fit(hyp_opt, want_invK=True)
-    else:
-        hyp_opt[:, :nv] = res['hyper']
-        info = res['info']
-        if nv != hyp_opt.shape[1]:        # numpy-path conventions with a mean function: zero mean parameters appended
-            handle.set_mean_func(mean_func, predict_adds_mean)
-            info = handle.fit(hyp_opt, want_invK=True)
-    return dict(hyper=hyp_opt, lam_x=0, obj=res['obj'], info=info, n_eval=-1, rank=rank, world=world)
+            hyper[a] = merged[a, int(np.argmin(merged[a, :, 0])), 1:]
+        if before_fit is not None:
+            before_fit()
+        res['hyper'] = hyper
+        res['info'] = handle.fit(hyper, want_invK=want_invK)
+    return res

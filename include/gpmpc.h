@@ -202,7 +202,14 @@ int gpmpc_nll(gpmpc_gp* h, int a, const double* hyper_row, double* nll, double* 
 /* ---- training: a8 ------------------------------------------------------------------------------ */
 /* Multistart hyper-parameter training of all Ny outputs, then the fit at the optimum: train_gp_numpy
  * optimize.py:359-503 (SLSQP + finite differences) / train_gp :100-294 (IPOPT on CasADi AD), here a projected L-BFGS on
- * gpmpc_nll and its analytic gradient, positive-bounded parameters in log space.  starts[Ny x nstart x W] (W =
+ * gpmpc_nll and its analytic gradient, in two stages per restart: (1) length scales and sf -- if their bounds are
+ * positive and finite -- in log space, the noise sn and the mean parameters linear (as in the reference's optimisers;
+ * d NLL / d log sn vanishes at the reference's start sn = 1e-5, a log-space search never leaves it); (2) if stage 1 stops
+ * with iterations to spare, a polish from its end point with sn in log space as well, kept when it ends lower.  An
+ * accepted step always lowers the NLL; the L-BFGS memory is dropped when the set of bound-pinned variables changes.
+ * optimizer_opts written for IPOPT / SLSQP have no counterpart here: only max_iter and tol exist.  Iteration and
+ * evaluation totals of the last call (this rank's restarts, both stages): gpmpc_get_counter "train_iterations" /
+ * "train_evaluations".  starts[Ny x nstart x W] (W =
  * gpmpc_hyper_width): one initial point per restart -- the reference starts every restart from the same point
  * (optimize.py:462-466, its Latin-hypercube line :218 is commented out); lb, ub[Ny x W]: the box (optimize.py:434-443 or
  * :204-229; +-HUGE_VAL for none).  For every output the restart with the smallest NLL wins (first minimum, np.argmin
@@ -213,16 +220,22 @@ int gpmpc_nll(gpmpc_gp* h, int a, const double* hyper_row, double* nll, double* 
  * RCCL communicator (gpmpc_rccl_comm_create, one rank per GPU) the ranks exchange their (NLL, theta) rows with ONE
  * ncclAllGather -- (1 + W) doubles per restart -- take the same arg-min and each fits its own copy; nothing else
  * crosses xGMI.  world > 1 with rccl_comm == NULL: no exchange and no fit; the caller merges the obj / theta_all rows
- * of the ranks (row r is valid on rank r mod world) and calls gpmpc_fit. */
+ * of the ranks (row r is valid on rank r mod world) and calls gpmpc_fit.
+ * Failure of ONE rank (HIP error, out of memory) never strands the others: the rank still joins the exchange with +inf
+ * rows and its error code in a status word of the same all-gather, and EVERY rank returns that code.  Without a
+ * communicator the code is written to *status (may be NULL; 0 = fine) and the call returns GPMPC_OK so that the caller
+ * reaches its own exchange. */
 int gpmpc_train_multistart(gpmpc_gp* h, int nstart, const double* starts, const double* lb, const double* ub,
                            int max_iter, double tol, int rank, int world, void* rccl_comm, int want_invK,
-                           double* hyper_opt, double* obj, double* theta_all, int* info);
+                           double* hyper_opt, double* obj, double* theta_all, int* info, int* status);
 /* RCCL bootstrap for the restart shard (librccl is bound at run time).  Rank 0 obtains the 128-byte id and hands it to
  * the other ranks by any side channel (a file, MPI, torch.distributed's store); every rank then creates its
  * communicator on its own GPU. */
 int gpmpc_rccl_unique_id(char* id128);
 int gpmpc_rccl_comm_create(int device, int world, int rank, const char* id128, void** comm_out);
 int gpmpc_rccl_comm_destroy(void* comm);
+/* Number of ranks the communicator spans (ncclCommCount): what bench.py reports as `rccl_ranks`. */
+int gpmpc_rccl_comm_count(void* comm, int* count);
 
 /* ---- low-level dense ops (host pointers), used by the parity tests ------------------------ */
 /* k(X, Z)[n1 x n2] = sf2 exp(-1/2 sum_d (x_d - z_d)^2 / ell_d^2) for X[n1 x d], Z[n2 x d]: GP.covSEard
@@ -242,7 +255,9 @@ int gpmpc_dgemm(int device, int transa, int transb, int M, int N, int K, double 
  * pins the tile of every GEMM launch of the process, so that small problems reach the large-tile kernels.
  * "cu_count": the number of compute units of device 0 the persistent-kernel factorisation plans with (at most the
  * real count on a GPU; the emulated build accepts up to 64 so that the multi-launch worker schedules can be
- * exercised).  Returns GPMPC_EINVAL for an unknown name or value. */
+ * exercised).  "fail_nll_after": n > 0 makes the n-th gpmpc_nll evaluation from now on return GPMPC_EHIP without touching
+ * the device (fault injection: how the tests reach the failure paths of the restart shard); 0 switches it off.
+ * Returns GPMPC_EINVAL for an unknown name or value. */
 int gpmpc_set_tuning(const char* name, int value);
 
 #ifdef __cplusplus

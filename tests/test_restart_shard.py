@@ -52,3 +52,20 @@ def test_two_rank_shard_native_optimizer(tmp_path):
         assert np.array_equal(one[k], r0[k]), k
         assert np.array_equal(r0[k], r1[k]), k
     assert np.all(np.isfinite(one['obj']))
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize('optimizer', ['native', 'scipy'])
+def test_one_rank_failure_reaches_every_rank(tmp_path, optimizer):
+    """A device failure on ONE rank (injected: its second NLL evaluation returns GPMPC_EHIP) must not strand the other in
+    the exchange: the failing rank still joins it, with +inf rows and its error code, and BOTH raise."""
+    subprocess.check_call([os.path.join(HERE, 'emu', 'build_emu.sh')], stdout=subprocess.DEVNULL)
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(29521 if optimizer == 'native' else 29522), WORLD_SIZE='2')
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, 'dist_worker_fail.py'), str(tmp_path), optimizer],
+                              env=dict(env, RANK=str(r), LOCAL_RANK=str(r))) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=600) == 0          # (a dead-lock shows up as this time-out)
+    v0 = open(tmp_path / f'fail_{optimizer}_rank0.txt').read()
+    v1 = open(tmp_path / f'fail_{optimizer}_rank1.txt').read()
+    assert v1.startswith('GpmpcError -2') and 'injected device failure' in v1, v1
+    assert v0.startswith('GpmpcError -2') and 'rank 1' in v0, v0
