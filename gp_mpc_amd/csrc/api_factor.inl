@@ -309,11 +309,11 @@ static bool factor_twolevel(const Ctx& cx, Workspace& ws, int spin_limit, int W)
 // Returns false if the path is unavailable (no side queue).  A time-out inside the kernels is reported
 // through ws.flags[0] and handled by the caller (fallback to factor_blocked).
 
-static bool factor_chain(const Ctx& cx, Workspace& ws, int spin_limit) {
+static bool factor_chain(const Ctx& cx, Workspace& ws, int spin_limit, bool flags_cleared = false) {
     if (!cx.side || ws.Np < 128) return false;
     const int Np = ws.Np, nb = Np / 64, nf = chain_flag_count(nb);
     const long ld = Np, sM = ws.mat();
-    hipMemsetAsync(ws.flags, 0, (size_t)ws.batch * nf * sizeof(int), cx.stream);
+    if (!flags_cleared) hipMemsetAsync(ws.flags, 0, (size_t)ws.batch * nf * sizeof(int), cx.stream);
     hipEventRecord(cx.fork, cx.stream);
     hipStreamWaitEvent(cx.side, cx.fork, 0);
     // bulk work as tile-owner workers: 7 of 8 CUs run one, the trailing matrix lives in their registers
@@ -411,6 +411,8 @@ static bool factor_chain(const Ctx& cx, Workspace& ws, int spin_limit) {
                            use_workers ? 1 : 0);
     }
     static const bool verbose = getenv("GPMPC_VERBOSE") != nullptr;
+    // (tuning aid) GPMPC_WORKER_LOOKAHEAD=0: the workers turn a panel tile into L(i,k) only at the top of step k
+    static const bool worker_lookahead = !(getenv("GPMPC_WORKER_LOOKAHEAD") && atoi(getenv("GPMPC_WORKER_LOOKAHEAD")) == 0);
     if (verbose)
         fprintf(stderr, "gpmpc: factor Np=%d batch=%d: chain kernel + %s (%d launch%s), inverse %s\n", Np, ws.batch,
                 use_workers ? "tile-owner workers" : "GEMM launches", use_workers ? L : 0, L == 1 ? "" : "es",
@@ -420,7 +422,7 @@ static bool factor_chain(const Ctx& cx, Workspace& ws, int spin_limit) {
             int* ready = i ? ws.flags + chain_ready_index(nb) + 2 * (i - 1) : nullptr;   // arrival counter + flag of launch i
             hipLaunchKernelGGL(chol_worker_kernel, dim3(nws[i], 1, ws.batch), dim3(WORKER_THREADS), WORKER_LDS_BYTES, cx.side,
                                ws.K, ws.L, (const double*)ws.Inv, ld, sM, nb, ws.flags, (long)nf, cx.crow_mode, spin_limit,
-                               r[i] / 64, i + 1 < L ? (r[i + 1] - r[i]) / 64 : nb, ready, g_chain_trace);
+                               r[i] / 64, i + 1 < L ? (r[i + 1] - r[i]) / 64 : nb, ready, g_chain_trace, worker_lookahead ? 1 : 0);
             if (i + 1 == L) break;
             // launch i finished: rows P_i of L are final.  Behind launch i + 1, once it is resident:
             hipEventRecord(cx.seg[i], cx.side);

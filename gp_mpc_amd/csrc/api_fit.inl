@@ -8,12 +8,13 @@ static void gram_and_factor(gpmpc_gp* h, Workspace& ws) {
     const Ctx cx = h->cx();
     {
         PhaseTimer t(h, GPMPC_PH_GRAM);
-        launch_gram(cx.stream, dim3(ws.Np / 64, ws.Np / 64, ws.batch), h->d, h->XT, ws.hyper, ws.jitter, ws.K, h->N, ws.Np);
+        // (the K build also clears the status words and the chain's hand-off flags: no fill kernels in between)
+        launch_gram(cx.stream, dim3(ws.Np / 64, ws.Np / 64, ws.batch), h->d, h->XT, ws.hyper, ws.jitter, ws.K, h->N, ws.Np, 0,
+                    ws.info, ws.batch, ws.flags, ws.batch * chain_flag_count(ws.Np / 64));
     }
     {
         PhaseTimer t(h, GPMPC_PH_FACTOR);
-        hipMemsetAsync(ws.info, 0, ws.batch * sizeof(int), cx.stream);
-        if (!(h->chain_mode && factor_chain(cx, ws, h->spin_limit))) factor_blocked(cx, ws, true);
+        if (!(h->chain_mode && factor_chain(cx, ws, h->spin_limit, true))) factor_blocked(cx, ws, true);
     }
 }
 

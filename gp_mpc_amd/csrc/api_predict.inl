@@ -361,7 +361,9 @@ extern "C" int gpmpc_predict_em_sens(gpmpc_gp* h, int B, const double* Z, const 
     if (!h->fitted) return fail(GPMPC_ENOTFIT, "model has no factors (call gpmpc_fit or gpmpc_set_factors)");
     if (B <= 0 || !Z || !Sigma) return fail(GPMPC_EINVAL, "bad B or NULL Z / Sigma");
     const int d = h->d, Ny = h->Ny, Np = h->Np, N = h->N;
-    if (d > EMK) return fail(GPMPC_EINVAL, "EM: input dimension d=%d exceeds the MFMA cross-term depth %d", d, EMK);
+    if (d > EMK)
+        return fail(GPMPC_EINVAL, "EM derivative outputs: input dimension d=%d exceeds the depth %d of their kernels (the value, "
+                    "gpmpc_predict 'EM', exists up to d=%d: difference it)", d, EMK, DMAX);
     HIPCHK(hipSetDevice(h->device));
     CHK(ensure_scratch(h, 1));
     if (!h->have_invK) {

@@ -51,7 +51,7 @@ __device__ __forceinline__ double& at_byte(double* base, unsigned byte_off) { re
 __global__ void __launch_bounds__(WORKER_THREADS) chol_worker_kernel(double* Kmat, double* L, const double* Inv, long ld,
                                                                      long sBatch, int nb_all, int* flags, long sFlags,
                                                                      int crow_mode, int spin_limit, int kb, int ksteps,
-                                                                     int* ready, long long* trace) {
+                                                                     int* ready, long long* trace, int lookahead) {
     // optional time stamps (100 MHz wall clock) for tools/worker_trace.py: [launch][worker][step][4] from entry 4096 on
 #ifdef GPMPC_EMULATED
 #define WORKER_STAMP(i) ((void)0)
@@ -137,9 +137,18 @@ __global__ void __launch_bounds__(WORKER_THREADS) chol_worker_kernel(double* Kma
         }
     }
 
-    int k = 0;
-    for (; k + 2 < nb && k < ksteps; ++k) {
-        WORKER_STAMP(0);
+    // One panel step = parts 1, 2, 3 below.  Part 3 may leave its update pipeline once ("look-ahead": the panel tiles of
+    // column k + 1 become L(i,k+1) as soon as inv_{k+1} is out) -- that is a second pass through part 1 with
+    // `ahead` = 1, written as a state of this ONE loop so that every heavy block (panel product, update pipeline)
+    // exists once in the kernel (two copies of the panel product pushed the kernel from 197 to 256 VGPRs + 159 spills).
+    int k = 0, ahead = 0;                            // ahead: bit 0 = early panel tiles are due, bit 1 = early hand-off tiles
+    int li[WORKER_MAXT], lj[WORKER_MAXT];            // part 3: coordinates of the resident tiles (scalar registers)
+    unsigned live = 0, urgent = 0, hand = 0, todo = 0;   //     masks: live this step / column k + 1 / next hand-off tiles / not yet updated
+    bool early = false, earlyh = false;              //         tiles of column k + 1 wait for inv_{k+1} / hand-off tiles for row k + 3
+    int peekv = 0, cur = -1, pp = 0;                 //         bit 0: leafdone[k+1], bit 1: row2done[k+1] and pan1[k+1], as last seen
+                                                     //         by thread 0; pipeline state
+    for (; k + 2 < nb && k < ksteps;) {
+        if (!ahead) WORKER_STAMP(0);
         // operand pair of tile (i, j) for this step: blocks L(i,k) and L(j,k) -> pair image `pp` (0 / 1) by DMA,
         // 8 loads per wave; `update`: c -= L(i,k) L(j,k)^T from a landed pair image
         // Issued by ONE wave per SIMD (waves 0-3, two row groups each): the other four go straight on to their
@@ -197,7 +206,7 @@ __global__ void __launch_bounds__(WORKER_THREADS) chol_worker_kernel(double* Kma
         };
         // ---- 1. panel tiles of column k.  Column 0 never receives an update, so its tiles are not kept in
         //         registers: at k = 0 worker w takes rows 2 + w, 2 + w + NW, ... straight from K.
-        for (int i = 2 + w; k == 0 && i < nb; i += NW) {
+        for (int i = 2 + w; k == 0 && !ahead && i < nb; i += NW) {
             if (tid == 0) flag_store(progress, 1 + 4 * k + 1);
             if (!wg_wait2(&leafdone[0], 1, nullptr, 0, err, spin_limit, slot, 2000000 + w)) return;
             request_blocks(Kb + (long)(64 * i) * ld, Ib, 0, true);                  // A(i,0), inv_00
@@ -222,111 +231,170 @@ __global__ void __launch_bounds__(WORKER_THREADS) chol_worker_kernel(double* Kma
             }
             __syncthreads();
         }
+        const int kk = k + (ahead ? 1 : 0);                // the step whose panel / hand-off tiles are due
+        if (!ahead || (ahead & 1)) {
 #pragma unroll
-        for (int n = 0; n < WORKER_MAXT; ++n) {
-            const int i = __builtin_amdgcn_readfirstlane(ti[n]), j = __builtin_amdgcn_readfirstlane(tj[n]);
-            if (i < 0 || j != k) continue;             // (workgroup-uniform)
-            if (tid == 0) flag_store(progress, 1 + 4 * k + 1);
-            if (!wg_wait2(&leafdone[k], 1, nullptr, 0, err, spin_limit, slot, 2000000 + 1000 * k + w)) return;
-            request_blocks(nullptr, Ib + (long)(64 * k) * ld + 64 * k, 0, false);   // inv_kk (zeros above the diagonal)
-            tile_to_image(C[n][0], C[n][1]);
-            dma_wait<0>();
-            __syncthreads();                           // (also waits for the LDS stores of tile_to_image)
-            d4 acc[2] = {d4{0.0, 0.0, 0.0, 0.0}, d4{0.0, 0.0, 0.0, 0.0}};
-            product(0, acc[0], acc[1], false);
-            double* dst = Lb + (long)(64 * i) * ld + 64 * k;
+            for (int n = 0; n < WORKER_MAXT; ++n) {
+                const int i = __builtin_amdgcn_readfirstlane(ti[n]), j = __builtin_amdgcn_readfirstlane(tj[n]);
+                if (i < 0 || j != kk) continue;            // (workgroup-uniform)
+                if (tid == 0) flag_store(progress, 1 + 4 * kk + 1);
+                if (!wg_wait2(&leafdone[kk], 1, nullptr, 0, err, spin_limit, slot, 2000000 + 1000 * kk + w)) return;
+                request_blocks(nullptr, Ib + (long)(64 * kk) * ld + 64 * kk, 0, false);   // inv_kk (zeros above the diagonal)
+                tile_to_image(C[n][0], C[n][1]);
+                dma_wait<0>();
+                __syncthreads();                           // (also waits for the LDS stores of tile_to_image)
+                d4 acc[2] = {d4{0.0, 0.0, 0.0, 0.0}, d4{0.0, 0.0, 0.0, 0.0}};
+                product(0, acc[0], acc[1], false);
+                double* dst = Lb + (long)(64 * i) * ld + 64 * kk;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                at_byte(dst + r * cstep, csub) = acc[0][r];
-                at_byte(dst + r * cstep, csub + 128u) = acc[1][r];
-            }
-            GPMPC_DRAIN_VM();
-            __syncthreads();                           // (also: everybody is done with A and B)
-            if (tid == 0) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                for (int r = 0; r < 4; ++r) {
+                    at_byte(dst + r * cstep, csub) = acc[0][r];
+                    at_byte(dst + r * cstep, csub + 128u) = acc[1][r];
+                }
                 GPMPC_DRAIN_VM();
-                if (i == k + 2) flag_store(&row2done[k], 1);
-                // count the tile; whoever completes the column raises the flag the consumers poll
-                const int before = __hip_atomic_fetch_add(&pancount[k], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (before + 1 == nb - k - 2) flag_store(&colready[k], 1);
-                ti[n] = -1;
+                __syncthreads();                           // (also: everybody is done with A and B)
+                if (tid == 0) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    GPMPC_DRAIN_VM();
+                    if (i == kk + 2) flag_store(&row2done[kk], 1);
+                    // count the tile; whoever completes the column raises the flag the consumers poll
+                    const int before = __hip_atomic_fetch_add(&pancount[kk], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (before + 1 == nb - kk - 2) flag_store(&colready[kk], 1);
+                    ti[n] = -1;
+                }
+                __syncthreads();
             }
-            __syncthreads();
         }
-        // ---- 2. (k+2,k+1), (k+2,k+2) for the chain
+        // ---- 2. (kk+2,kk+1), (kk+2,kk+2) for the chain
+        if (!ahead || (ahead & 2)) {
 #pragma unroll
-        for (int n = 0; n < WORKER_MAXT; ++n) {
-            const int i = __builtin_amdgcn_readfirstlane(ti[n]), j = __builtin_amdgcn_readfirstlane(tj[n]);
-            if (i != k + 2 || j <= k) continue;         // j is k+1 or k+2
-            if (tid == 0) flag_store(progress, 1 + 4 * k + 2);
-            if (!wg_wait2(&row2done[k], 1, j == k + 1 ? &pan1[k] : nullptr, 1, err, spin_limit, slot, 3000000 + 1000 * k + w))
-                return;
-            request(k + 2, j, 0);
-            dma_wait<0>();
-            __syncthreads();
-            double* dst = Kb + (long)(64 * (k + 2)) * ld + 64 * j;
-            update(0, C[n][0], C[n][1]);
+            for (int n = 0; n < WORKER_MAXT; ++n) {
+                const int i = __builtin_amdgcn_readfirstlane(ti[n]), j = __builtin_amdgcn_readfirstlane(tj[n]);
+                if (i != kk + 2 || j <= kk) continue;      // j is kk+1 or kk+2
+                if (tid == 0) flag_store(progress, 1 + 4 * kk + 2);
+                if (!wg_wait2(&row2done[kk], 1, j == kk + 1 ? &pan1[kk] : nullptr, 1, err, spin_limit, slot, 3000000 + 1000 * kk + w))
+                    return;
+                request_blocks(Lb + (long)(64 * (kk + 2)) * ld + 64 * kk, Lb + (long)(64 * j) * ld + 64 * kk, 0, true);
+                dma_wait<0>();
+                __syncthreads();
+                double* dst = Kb + (long)(64 * (kk + 2)) * ld + 64 * j;
+                update(0, C[n][0], C[n][1]);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                at_byte(dst + r * cstep, csub) = C[n][0][r];
-                at_byte(dst + r * cstep, csub + 128u) = C[n][1][r];
+                for (int r = 0; r < 4; ++r) {
+                    at_byte(dst + r * cstep, csub) = C[n][0][r];
+                    at_byte(dst + r * cstep, csub + 128u) = C[n][1][r];
+                }
+                wg_publish(&tdone[2 * kk + (j == kk + 2 ? 1 : 0)], 1);
+                if (tid == 0) ti[n] = -1;
+                __syncthreads();                           // A, B free again; ti[] visible
             }
-            wg_publish(&tdone[2 * k + (j == k + 2 ? 1 : 0)], 1);
-            if (tid == 0) ti[n] = -1;
-            __syncthreads();                           // A, B free again; ti[] visible
         }
-        // ---- 3. all other live tiles, software-pipelined: operands of the next tile travel global -> registers
-        //         while the MFMAs of the current one run from LDS
-        WORKER_STAMP(1);
-        // live tiles of this step, once: coordinates in scalar registers, membership as a bit mask (looking the next
-        // tile up in the LDS table between two tiles cost ~0.7 us per tile: 16 dependent LDS round trips)
-        int li[WORKER_MAXT], lj[WORKER_MAXT];
-        unsigned live = 0;
-#pragma unroll
-        for (int n = 0; n < WORKER_MAXT; ++n) {
-            li[n] = __builtin_amdgcn_readfirstlane(ti[n]);
-            lj[n] = __builtin_amdgcn_readfirstlane(tj[n]);
-            if (li[n] >= 0 && lj[n] > k) live |= 1u << n;
-        }
-        if (live == 0) continue;
-        int cur = __builtin_ctz(live);
         auto coords = [&](int m, int& ci, int& cj) {   // li[m], lj[m] for a run-time m (scalar selects)
             ci = li[0]; cj = lj[0];
 #pragma unroll
             for (int q = 1; q < WORKER_MAXT; ++q)
                 if (q == m) { ci = li[q]; cj = lj[q]; }
         };
+        // order of part 3: panel tiles of the next step, then its hand-off tiles, then by slot
+        auto pick = [&](unsigned t) {
+            return t == 0 ? -1 : __builtin_ctz((t & urgent) ? (t & urgent) : (t & hand) ? (t & hand) : t);
+        };
+        if (ahead) {
+            // back from the early products: the rest of this step's updates, pipeline restarted
+            if (ahead & 1) early = false;
+            if (ahead & 2) earlyh = false;
+            ahead = 0;
+            if (cur >= 0) {
+                int ci, cj;
+                coords(cur, ci, cj);
+                request(ci, cj, 0);
+                pp = 0;
+            }
+        } else {
+        // ---- 3. all other live tiles, software-pipelined: operands of the next tile travel global -> registers
+        //         while the MFMAs of the current one run from LDS
+        WORKER_STAMP(1);
+        // live tiles of this step, once: coordinates in scalar registers, membership as a bit mask (looking the next
+        // tile up in the LDS table between two tiles cost ~0.7 us per tile: 16 dependent LDS round trips)
+        // Look-ahead: the tiles of column k + 1 are updated FIRST; as soon as the chain has published inv_{k+1} (peeked at
+        // once per tile, the load travels behind the matrix instructions) they become L(i,k+1) right here instead of at
+        // the top of step k + 1, where every worker would stand waiting for the slowest one's product (measured before:
+        // 9-11 us of a 38 us step in the first quarter, tools/worker_trace.py).  Never a blocking wait: if the
+        // publication does not come while this worker still updates, part 1 of the next step does it as before.
+        // The two tiles the chain needs after the NEXT leaf, (k+3,k+2) and (k+3,k+3), come second and are handed over as
+        // soon as their operands L(k+3,k+1) [row2done] and L(k+2,k+1) [pan1] exist -- otherwise their owner would reach
+        // them only after its whole part 3, and the chain, one step ahead thanks to the early panel products, would
+        // stand waiting for it every other step (seen in the time stamps: 0.6 / 16 / 0.6 / 22 us).
+        live = 0; urgent = 0; hand = 0;
+        const bool look = lookahead && k + 1 < ksteps && k + 3 < nb;   // the next step belongs to this launch and has panel tiles
+#pragma unroll
+        for (int n = 0; n < WORKER_MAXT; ++n) {
+            li[n] = __builtin_amdgcn_readfirstlane(ti[n]);
+            lj[n] = __builtin_amdgcn_readfirstlane(tj[n]);
+            if (li[n] >= 0 && lj[n] > k) {
+                live |= 1u << n;
+                if (look && lj[n] == k + 1) urgent |= 1u << n;
+                if (look && li[n] == k + 3 && lj[n] >= k + 2) hand |= 1u << n;
+            }
+        }
+        if (live == 0) { ++k; continue; }
         if (tid == 0) flag_store(progress, 1 + 4 * k + 3);
         if (!wg_wait2(&colready[k], 1, &pan1[k], 1, err, spin_limit, slot, 4000000 + 1000 * k + w)) return;
         WORKER_STAMP(2);
+        todo = live;                                   // tiles still to update; order: the urgent ones, then by slot
+        early = urgent != 0;
+        earlyh = hand != 0;
+        peekv = 0;
+        cur = pick(todo);
         {
             int ci, cj;
             coords(cur, ci, cj);
             request(ci, cj, 0);
         }
-        int pp = 0;
+        pp = 0;
+        }   // (!ahead)
+        bool stop = false;                             // leave the pipeline for the early panel product
+#pragma unroll 1
+        while (cur >= 0 && !stop) {
 #pragma unroll
-        for (int n = 0; n < WORKER_MAXT; ++n) {
-            if (n != cur) continue;                    // (slots before the first / between live tiles)
-            const unsigned rest = live & ~((2u << n) - 1u);
-            const int nxt = rest ? __builtin_ctz(rest) : -1;
-            dma_wait<0>();                             // this wave's pieces of the current pair have landed
-            dma_barrier();                             // ... everybody's; the other pair image is free
-            if (nxt >= 0) {
-                int ci, cj;
-                coords(nxt, ci, cj);
-                request(ci, cj, pp ^ 1);
-            }
-            update(pp, C[n][0], C[n][1]);
-            pp ^= 1;
-            cur = nxt;
+            for (int n = 0; n < WORKER_MAXT; ++n) {
+                if (n != cur || stop) continue;        // (slots before the first / between live tiles)
+                todo &= ~(1u << n);
+                const int nxt = pick(todo);
+                // an early product may start once its tiles carry this step's update and its operands are out
+                const bool any_early = early || earlyh;
+                const int ready = ((early && (todo & urgent) == 0) ? 1 : 0) | ((earlyh && (todo & hand) == 0) ? 2 : 0);
+                if (any_early && tid == 0) slot[1 + pp] = peekv & ready;   // (two words in turn: no barrier between a read
+                dma_wait<0>();                         // this wave's pieces of the current pair have landed   and the next write)
+                if (any_early) __syncthreads();        // (orders the word above as well)
+                else dma_barrier();                    // ... everybody's; the other pair image is free
+                if (any_early && ready != 0) {
+                    const int go = slot[1 + pp];
+                    if (go != 0) { stop = true; ahead = go; }
+                }
+                if (nxt >= 0 && !stop) {
+                    int ci, cj;
+                    coords(nxt, ci, cj);
+                    request(ci, cj, pp ^ 1);
+                }
+                update(pp, C[n][0], C[n][1]);
+                if (any_early && tid == 0) {           // consumed at the next tile: the latency hides behind it
+                    peekv = 0;
+                    if (early && flag_load(&leafdone[k + 1]) >= 1) peekv |= 1;
+                    if (earlyh && flag_load(&row2done[k + 1]) >= 1 && flag_load(&pan1[k + 1]) >= 1) peekv |= 2;
+                }
+                pp ^= 1;
+                cur = nxt;
 #ifndef GPMPC_EMULATED
-            if (trace && threadIdx.x == 0 && blockIdx.x < 8 && kb == 0)      // per-tile stamps of the first 8 workers
-                trace[135168 + ((long)blockIdx.x * 64 + k) * 10 + n] = wall_clock64();
+                if (trace && threadIdx.x == 0 && blockIdx.x < 8 && kb == 0)      // per-tile stamps of the first 8 workers
+                    trace[135168 + ((long)blockIdx.x * 64 + k) * 10 + n] = wall_clock64();
 #endif
+            }
         }
-        __syncthreads();                               // the pair images alias A and B of the next step
+        __syncthreads();                               // the pair images alias A and B of the next step / of the early product
+        if (stop) continue;                            // pipeline drained (nothing requested): parts 1 / 2 of step k + 1 as `ahead` says, then back
         WORKER_STAMP(3);
+        ++k;
     }
 #undef WORKER_STAMP
     // a launch that stops before the last step hands its live tiles back through K: the next launch (from block

@@ -182,7 +182,9 @@ __global__ void __launch_bounds__(256) em_mean_finish_kernel(const double* __res
     mean[e] = s;
 }
 
-constexpr int EMK = 8;   // cross-term depth handled by the MFMA path (d <= 8: two 16x16x4 steps)
+// Cross-term depth of the matrix-pipe path: the value kernels below exist for KD = 8 (d <= 8: two 16x16x4 steps per
+// tile) and KD = 16 (d <= 16 = DMAX: four); the derivative kernels further down for depth EMK = 8 only.
+constexpr int em_depth(int d) { return d <= 8 ? 8 : 16; }
 
 // Per-(input, pair, point) operands of the pair kernel.  One thread per (b, p, i); arrays are
 // [b][p][...][Np] so that the pair kernel's loads are contiguous in the point index:
@@ -190,9 +192,11 @@ constexpr int EMK = 8;   // cross-term depth handled by the MFMA path (d <= 8: t
 //   Wt[k][j] = ij_j,k                 (B operand)
 //   La[i] = log_k[i,a] + ii_i S ii_i^T,   Lb[j] = log_k[j,b] + ij_j S ij_j^T
 // (gp_functions.py:394-396, :400-408 with maha expanded as in the header comment).
+template <int KD>
 __global__ void __launch_bounds__(256) em_operands_kernel(const double* __restrict__ XT, const double* __restrict__ Z,
                                                           const double* __restrict__ hyper, const double* __restrict__ prep,
                                                           double* __restrict__ ops, int N, int Np, int d, int Ny) {
+    constexpr int EMK = KD;
     const int P = Ny * (Ny + 1) / 2, stride = d * d + 1;
     const int i = blockIdx.x * 256 + threadIdx.x, p = blockIdx.y, b = blockIdx.z;
     if (i >= Np) return;
@@ -231,10 +235,12 @@ __global__ void __launch_bounds__(256) em_operands_kernel(const double* __restri
 // adds La_i + Lb_j, takes the lean exp and accumulates (beta_ai beta_bj - [a==b] K^-1_ij) Q_ij.  For a == b
 // the summand is symmetric in (i, j): only column tiles up to the diagonal are visited, off-diagonal
 // tiles counted twice.  partial[(b*P + p)*tiles + strip].
-template <bool DIAG>
+template <bool DIAG, int KD>
 __global__ void __launch_bounds__(256) em_pair_kernel(const double* __restrict__ ops, const double* __restrict__ beta,
                                                       const double* __restrict__ invK, double* __restrict__ partial,
                                                       int N, int Np, int Ny, int crow_mode) {
+    constexpr int EMK = KD;                      // cross-term depth: 8 (d <= 8: two matrix instructions per tile) or 16 (four)
+    constexpr int NQ = ((KD + 2) * 64 + 255) / 256;   // staged values per thread and column tile
     const int ti = blockIdx.x, p = blockIdx.y, b = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int P = Ny * (Ny + 1) / 2, tiles = Np / 64;
     int a = 0;
@@ -255,7 +261,9 @@ __global__ void __launch_bounds__(256) em_pair_kernel(const double* __restrict__
     __shared__ double Cs[2][EMK + 2][64];
     const int fr = lane & 15, fk = lane >> 4, i0 = ti * 64 + 16 * wave;
     // A fragments (constant over the sweep) and the row data of this lane's 4 accumulator rows
-    const double a0 = o[(long)fk * Np + i0 + fr], a1 = o[(long)(4 + fk) * Np + i0 + fr];
+    double af[KD / 4];
+#pragma unroll
+    for (int s4 = 0; s4 < KD / 4; ++s4) af[s4] = o[(long)(4 * s4 + fk) * Np + i0 + fr];
     double la[4], bai[4];
     int irow[4];
 #pragma unroll
@@ -266,10 +274,10 @@ __global__ void __launch_bounds__(256) em_pair_kernel(const double* __restrict__
     }
     double acc = 0.0;
     const int jt_end = diag ? ti + 1 : tiles;
-    double st[3];
-    auto fetch = [&](int jt) {   // 640 values / 256 threads: element e = tid + 256 q -> (row e / 64, col e % 64)
+    double st[NQ];
+    auto fetch = [&](int jt) {   // (KD + 2) * 64 values / 256 threads: element e = tid + 256 q -> (row e / 64, col e % 64)
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
+        for (int q = 0; q < NQ; ++q) {
             const int e = tid + 256 * q, rw = e >> 6, cl = e & 63, j = jt * 64 + cl;
             double v = 0.0;
             if (rw < EMK) v = Wt[(long)rw * Np + j];
@@ -280,7 +288,7 @@ __global__ void __launch_bounds__(256) em_pair_kernel(const double* __restrict__
     };
     auto stage = [&](int buf) {
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
+        for (int q = 0; q < NQ; ++q) {
             const int e = tid + 256 * q, rw = e >> 6, cl = e & 63;
             if (rw < EMK + 2) Cs[buf][rw][cl] = st[q];
         }
@@ -303,8 +311,8 @@ __global__ void __launch_bounds__(256) em_pair_kernel(const double* __restrict__
         for (int t = 0; t < 4; ++t) {
             const int cl = 16 * t + fr, j = jt * 64 + cl;
             d4 c = d4{0.0, 0.0, 0.0, 0.0};
-            c = mfma16(a0, Cs[cur][fk][cl], c);
-            c = mfma16(a1, Cs[cur][4 + fk][cl], c);
+#pragma unroll
+            for (int s4 = 0; s4 < KD / 4; ++s4) c = mfma16(af[s4], Cs[cur][4 * s4 + fk][cl], c);
             const double lbj = Cs[cur][EMK][cl];
             const double bj = Cs[cur][EMK + 1][cl];
 #pragma unroll
@@ -348,6 +356,8 @@ __global__ void __launch_bounds__(64) em_finish_kernel(const double* __restrict_
     cov[((long)b * Ny + a) * Ny + bb] = v;
     cov[((long)b * Ny + bb) * Ny + a] = v;
 }
+
+constexpr int EMK = 8;   // cross-term depth of the derivative kernels (d <= 8)
 
 // ---- derivative outputs of the exact moments ---------------------------------------------------
 // d mean / d(mu, Sigma) and d cov / d(mu, Sigma) of gp_exact_moment (what CasADi's AD hands to IPOPT when 'EM' is the

@@ -75,9 +75,17 @@ __device__ __forceinline__ bool recip_is_safe(double b) {
 template <int D>
 __global__ void __launch_bounds__(256) gram_kernel(const double* __restrict__ XT, const double* __restrict__ hyper,
                                                    const double* __restrict__ jitter, double* __restrict__ K,
-                                                   int N, int Np, int tm0) {
+                                                   int N, int Np, int tm0, int* __restrict__ zero_a, int n_zero_a,
+                                                   int* __restrict__ zero_b, int n_zero_b) {
 #pragma clang fp contract(off)
     const int tn = blockIdx.x, tm = (int)(blockIdx.y >> 2) + tm0, rq = blockIdx.y & 3, a = blockIdx.z;   // tm0: first tile row (gpmpc_append)
+    // The hand-off flags and status words of the factorisation that follows are cleared HERE, by the first workgroup
+    // (one above the diagonal if there is one: it has nothing else to do) -- as hipMemsetAsync calls they were three
+    // fill kernels, each behind a dependency gap: 30 us between the K build and the chain's start at C2.
+    if (blockIdx.y == 0 && blockIdx.z == 0 && blockIdx.x == (gridDim.x > 1 ? 1u : 0u)) {
+        for (int i = threadIdx.x; i < n_zero_a; i += 256) zero_a[i] = 0;
+        for (int i = threadIdx.x; i < n_zero_b; i += 256) zero_b[i] = 0;
+    }
     if (tn > tm) return;
     __shared__ double X2r[D][16], Qr[D][16], Cs[2][D];
     __shared__ int safe_s;
@@ -136,8 +144,8 @@ __global__ void __launch_bounds__(256) gram_kernel(const double* __restrict__ XT
 }
 
 inline void launch_gram(hipStream_t st, dim3 grid, int d, const double* XT, const double* hyper, const double* jitter, double* K,
-                        int N, int Np, int tm0 = 0) {
-#define GPMPC_GK(DD) case DD: hipLaunchKernelGGL((gram_kernel<DD>), dim3(grid.x, 4 * grid.y, grid.z), dim3(256), 0, st, XT, hyper, jitter, K, N, Np, tm0); break;
+                        int N, int Np, int tm0 = 0, int* zero_a = nullptr, int n_zero_a = 0, int* zero_b = nullptr, int n_zero_b = 0) {
+#define GPMPC_GK(DD) case DD: hipLaunchKernelGGL((gram_kernel<DD>), dim3(grid.x, 4 * grid.y, grid.z), dim3(256), 0, st, XT, hyper, jitter, K, N, Np, tm0, zero_a, n_zero_a, zero_b, n_zero_b); break;
     switch (d) {
         GPMPC_GK(1) GPMPC_GK(2) GPMPC_GK(3) GPMPC_GK(4) GPMPC_GK(5) GPMPC_GK(6) GPMPC_GK(7) GPMPC_GK(8)
         GPMPC_GK(9) GPMPC_GK(10) GPMPC_GK(11) GPMPC_GK(12) GPMPC_GK(13) GPMPC_GK(14) GPMPC_GK(15) GPMPC_GK(16)

@@ -239,6 +239,8 @@ __device__ __forceinline__ void inv16_dpp(const double* S, double* T, int o, int
 // two thirds into the leaf -- and hook.land() in waves 2 and 3 while wave 0 factors the last panel.  The chain kernel
 // uses them to poll a flag (before), to issue the global loads of its next tiles in waves 2 and 3 (after) and to put
 // what they fetched into LDS (land): the latency hides behind the last panel and no register is held across the leaf.
+// hook.first() runs in waves 1-3 while wave 0 factors the FIRST panel (columns 0-15 of S): the chain kernel finishes the
+// trailing update of the block's columns 16-63 there (only the first 16 columns are needed before the leaf starts).
 #ifndef GPMPC_LEAF_DPP
 #define GPMPC_LEAF_DPP 1
 #endif
@@ -248,6 +250,7 @@ __device__ __forceinline__ void inv16_dpp(const double* S, double* T, int o, int
 #define GPMPC_INV16 inv16
 #endif
 struct LeafNoHook {
+    __device__ __forceinline__ void first() {}
     __device__ __forceinline__ void before() {}
     __device__ __forceinline__ void after() {}
     __device__ __forceinline__ void land() {}
@@ -277,6 +280,8 @@ __device__ __forceinline__ int leaf_body(double* S, double* T, double* U, double
                 GPMPC_INV16(S, T, 16 * (t - 1), lane, Dr);   // inverse of the previous diagonal block
             } else if (wave >= 2 && t == 3) {
                 hook.land();                            // waves 2 and 3 have nothing else to do behind the last panel
+            } else if (wave >= 1 && t == 0) {
+                hook.first();                           // columns 16-63 of S may still be written here (panel 0 owns 0-15)
             }
             if (t == 2) hook.before();
             __syncthreads();

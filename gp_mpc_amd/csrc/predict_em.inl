@@ -32,10 +32,10 @@ static int predict_moments_chunk(gpmpc_gp* h, int method, int B, const double* d
     CHK(ensure_beta(h));
     if (method == GPMPC_EM) {
         PhaseTimer t(h, GPMPC_PH_EM);
-        if (d > EMK) return fail(GPMPC_EINVAL, "EM: input dimension d=%d exceeds the MFMA cross-term depth %d", d, EMK);
+        const int KD = em_depth(d);                           // 8 or 16 (d <= DMAX = 16 is checked at gpmpc_create)
         const int P = Ny * (Ny + 1) / 2, tiles = Np / 64;
         const long prepN = (long)B * (Ny + P) * (d * d + 1), partN = (long)B * P * tiles;
-        const long opsN = (long)B * P * (2 * EMK + 2) * Np, mpartN = (long)B * Ny * EM_MEAN_CHUNKS;
+        const long opsN = (long)B * P * (2 * KD + 2) * Np, mpartN = (long)B * Ny * EM_MEAN_CHUNKS;
         CHK(ensure_em_scratch(h, (prepN + partN + opsN + mpartN) * (long)sizeof(double)));
         double* prep = h->em;
         double* partial = h->em + prepN;
@@ -50,12 +50,21 @@ static int predict_moments_chunk(gpmpc_gp* h, int method, int B, const double* d
             HIPCHK(hipGetLastError());
             return GPMPC_OK;
         }
-        hipLaunchKernelGGL(em_operands_kernel, dim3((Np + 255) / 256, P, B), dim3(256), 0, cx.stream, h->XT, dZ, h->ws.hyper,
-                           prep, ops, N, Np, d, Ny);
-        hipLaunchKernelGGL((em_pair_kernel<false>), dim3(tiles, P, B), dim3(256), 0, cx.stream, ops, h->beta, h->ws.InvK,
-                           partial, N, Np, Ny, cx.crow_mode);
-        hipLaunchKernelGGL((em_pair_kernel<true>), dim3(tiles, P, B), dim3(256), 0, cx.stream, ops, h->beta, h->ws.InvK,
-                           partial, N, Np, Ny, cx.crow_mode);
+        if (KD == 8) {
+            hipLaunchKernelGGL((em_operands_kernel<8>), dim3((Np + 255) / 256, P, B), dim3(256), 0, cx.stream, h->XT, dZ, h->ws.hyper,
+                               prep, ops, N, Np, d, Ny);
+            hipLaunchKernelGGL((em_pair_kernel<false, 8>), dim3(tiles, P, B), dim3(256), 0, cx.stream, ops, h->beta, h->ws.InvK,
+                               partial, N, Np, Ny, cx.crow_mode);
+            hipLaunchKernelGGL((em_pair_kernel<true, 8>), dim3(tiles, P, B), dim3(256), 0, cx.stream, ops, h->beta, h->ws.InvK,
+                               partial, N, Np, Ny, cx.crow_mode);
+        } else {      // d = 9 .. 16: the same kernels with a 16-deep cross term (gp_exact_moment is dimension-generic)
+            hipLaunchKernelGGL((em_operands_kernel<16>), dim3((Np + 255) / 256, P, B), dim3(256), 0, cx.stream, h->XT, dZ, h->ws.hyper,
+                               prep, ops, N, Np, d, Ny);
+            hipLaunchKernelGGL((em_pair_kernel<false, 16>), dim3(tiles, P, B), dim3(256), 0, cx.stream, ops, h->beta, h->ws.InvK,
+                               partial, N, Np, Ny, cx.crow_mode);
+            hipLaunchKernelGGL((em_pair_kernel<true, 16>), dim3(tiles, P, B), dim3(256), 0, cx.stream, ops, h->beta, h->ws.InvK,
+                               partial, N, Np, Ny, cx.crow_mode);
+        }
         hipLaunchKernelGGL(em_finish_kernel, dim3((unsigned)(((long)B * P + 63) / 64)), dim3(64), 0, cx.stream, partial, prep,
                            h->ws.hyper, dMean, dCov, B, Ny, d, tiles);
         HIPCHK(hipGetLastError());

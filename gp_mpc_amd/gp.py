@@ -272,6 +272,48 @@ class GP:
              'dcov_dx': dcz[:, :, :Ny], 'dcov_du': dcz[:, :, Ny:], 'dcov_dcov': dcS}
         return mean.reshape(Ny, 1), c, D
 
+    def predict_derivatives_batch(self, X, U, C, values=True):
+        """`predict_derivatives` for B shooting nodes in ONE device call (the pattern an NLP evaluation produces: IPOPT
+        asks for the Jacobian of all Nt continuity constraints at once, mpc_class.py:361-423).  X[B,Ny], U[B,Nu],
+        C[B,Nx,Nx] -> mean[B,Ny], cov[B,Ny,Ny] (None for 'EM' with values=False) and D as in `predict_derivatives` with
+        a leading node axis.  'ME' / 'TA' / 'EM' only."""
+        if self.__gp_method not in ('ME', 'TA', 'EM'):
+            raise NotImplementedError("analytic derivatives exist for 'ME', 'TA' and 'EM'")
+        Ny, Nx, Nu = self.__Ny, self.__Nx, self.__Nu
+        X = np.asarray(X, dtype=np.float64).reshape(-1, Ny)
+        U = np.asarray(U, dtype=np.float64).reshape(-1, Nu)
+        B = X.shape[0]
+        if self.__normalize:
+            X = self.standardize(X, self.__meanX, self.__stdX)
+            U = self.standardize(U, self.__meanU, self.__stdU)
+        Z = np.concatenate([X, U], axis=1)
+        S = np.asarray(C, dtype=np.float64).reshape(B, Nx, Nx)
+        if self.__gp_method == 'EM':
+            mean, c, dmean, dmS, dcz, dcS = self._h.predict_em_sens(Z, S, want_cov=values)
+        else:
+            mean, var, J, Hm, dvar = self._h.predict_sens(Z)
+            ia = np.arange(Ny)
+            c = np.zeros((B, Ny, Ny))
+            c[:, ia, ia] = var
+            dcz = np.zeros((B, Ny, Ny, Nx))
+            dcz[:, ia, ia] = dvar
+            dcS = np.zeros((B, Ny, Ny, Nx, Nx))
+            dmS = np.zeros((B, Ny, Nx, Nx))
+            if self.__gp_method == 'TA':
+                c = c + np.einsum('bad,bde,bce->bac', J, S, J)
+                dcz += np.einsum('badp,bde,bce->bacp', Hm, S, J) + np.einsum('bad,bde,bcep->bacp', J, S, Hm)
+                dcS = np.einsum('bad,bce->bacde', J, J)
+            dmean = J.copy()
+        if self.__normalize:
+            mean = self.inverse_mean(mean, self.__meanY, self.__stdY)
+            sz = np.concatenate([np.atleast_1d(self.__stdX), np.atleast_1d(self.__stdU)])
+            dmean = dmean * np.atleast_1d(self.__stdY)[None, :, None] / sz[None, None, :]
+            dmS = dmS * np.atleast_1d(self.__stdY)[None, :, None, None]
+            dcz = dcz / sz[None, None, None, :]
+        D = {'dmean_dx': dmean[:, :, :Ny], 'dmean_du': dmean[:, :, Ny:], 'dmean_dcov': dmS,
+             'dcov_dx': dcz[:, :, :, :Ny], 'dcov_du': dcz[:, :, :, Ny:], 'dcov_dcov': dcS}
+        return mean.reshape(B, Ny), c, D
+
     def predict_batch(self, Z, Sigma=None, method=None, standardized=True):
         """All B inputs in one device call (the pattern MPC's Nt shooting nodes want):
         Z[B x Nx] (already standardised unless standardized=False), Sigma[B x Nx x Nx]
@@ -554,9 +596,33 @@ class GP:
             var = var.clip(min=0)
         return (mean, var, controls) if return_controls else (mean, var)
 
-    def predict_compare(self, *args, **kwargs):
-        raise NotImplementedError('predict_compare is the plotting front-end of the rollout loop '
-                                  '(matplotlib UI, out of scope); use GP.rollout for its numeric part')
+    def predict_compare(self, x0, u, model=None, num_cols=2, xnames=None, title=None, feedback=False, x_ref=None,
+                        Q=None, R=None, methods=None):
+        """`predict_compare` (gp_class.py:746-861) without its matplotlib front end: the T-step uncertainty propagation
+        of every method in `methods` (default ['EM', 'TA', 'ME'], :759-760) through `GP.rollout` -- the whole horizon on
+        the device -- next to the simulated trajectory of `model` when one is given (`model.sim(x0, u)`, :819-820;
+        model_class needs casadi + SUNDIALS and is out of scope, so any object with that method -- and
+        `sampling_time()` for the time axis, :756 -- does).  The scripts that call it (van_der_pol.py:83-85,
+        tank_example.py) keep running; instead of figures they get the arrays the figures were drawn from:
+
+            {'t': [Nt+1], 'methods': [...], 'mean': [M, Nt+1, Ny], 'var': [M, Nt+1, Ny] (clipped at 0, :826-827),
+             'y_sim': [Nt+1, Ny] or None}
+
+        num_cols, xnames, title only shaped the plot and are accepted for signature compatibility."""
+        u = np.atleast_2d(np.asarray(u, dtype=np.float64))
+        Nt = u.shape[0]
+        if methods is None:
+            methods = ['EM', 'TA', 'ME']
+        mean, var = self.rollout(x0, u, methods=methods, feedback=feedback, x_ref=x_ref, Q=Q, R=R)
+        y_sim, dt = None, 1.0
+        if model is not None:
+            if hasattr(model, 'sampling_time'):
+                dt = float(model.sampling_time())
+            if hasattr(model, 'sim'):
+                y_sim = np.vstack([np.asarray(x0, dtype=np.float64).reshape(1, -1),
+                                   np.asarray(model.sim(x0, u), dtype=np.float64).reshape(Nt, -1)])   # :819-820
+        return {'t': np.linspace(0.0, Nt * dt, Nt + 1), 'methods': list(methods), 'mean': mean, 'var': var.clip(min=0),
+                'y_sim': y_sim}
 
     def close(self):
         if self._h is not None:

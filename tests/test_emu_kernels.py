@@ -183,7 +183,30 @@ def test_emu_em_sens(emu):
 
 
 def test_emu_callback_blocks(emu):
-    pc.check_callback_blocks(emu)
+    pc.check_callback_blocks(emu, N=60, Ny=2, Nu=1)
+
+
+def test_emu_callback_all_nodes_in_one_call(emu):
+    pc.check_callback_batched(emu, N=50, Ny=2, Nu=1, Nt=3)
+
+
+def test_callback_layout_follows_the_casadi_version():
+    """3.4 / 3.5 (the reference: README.md:18-19) take ONE stacked Jacobian from get_jacobian, >= 3.6 one per pair."""
+    from gp_mpc_amd import casadi_callback as cb
+    assert cb.casadi_version('3.4.5') == (3, 4) and cb.casadi_version('3.5.5') == (3, 5)
+    assert cb.casadi_version('3.6.3+') == (3, 6) and cb.casadi_version('3.7') == (3, 7)
+    assert cb.jacobian_layout('3.4.5') == 'dense' and cb.jacobian_layout('3.5.1') == 'dense'
+    assert cb.jacobian_layout('3.6.0') == 'blocks' and cb.jacobian_layout('3.7.1') == 'blocks'
+    # block-diagonal sparsity of the batched signature, column-major vec layout
+    Ny, Nu, Nx, Nt = 2, 1, 3, 3
+    sp = cb.batched_block_sparsity(Ny, Nu, Nx, Nt)
+    rows, cols, shape = sp[0]                       # d M / d X
+    assert shape == (Ny * Nt, Ny * Nt) and len(rows) == Nt * Ny * Ny
+    assert set(zip(rows // Ny, cols // Ny)) == {(t, t) for t in range(Nt)}                 # node t only sees node t
+    rows, cols, shape = sp[5]                       # d V / d C
+    assert shape == (Ny * Ny * Nt, Nx * Nx * Nt) and len(rows) == Nt * Ny * Ny * Nx * Nx
+    assert set(zip(rows // (Ny * Ny), cols // (Nx * Nx))) == {(t, t) for t in range(Nt)}
+    assert all(len(set(zip(r, c))) == len(r) for r, c, _ in sp)                             # no duplicate entries
 
 
 def test_emu_training_native(emu, train_small):

@@ -169,6 +169,13 @@ def test_callback_blocks(lib):
     pc.check_callback_blocks(lib, N=500, Ny=6, Nu=2, seed=3)
 
 
+def test_callback_all_nodes_in_one_call(lib):
+    """make_batched_predict_callback's numeric core: Nt nodes per call, block-diagonal Jacobian (dense 3.4-style stacking
+    and per-pair triplets) against central differences, all five methods."""
+    pc.check_callback_batched(lib)
+    pc.check_callback_batched(lib, N=400, Ny=4, Nu=2, Nt=6, seed=5)
+
+
 def test_feedback_rollout(lib, tank):
     pc.check_feedback_rollout(lib, tank, T=8)
 
