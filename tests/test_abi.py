@@ -134,3 +134,20 @@ def test_guard_catches_real_uses_and_ignores_comments(tmp_path):
     assert not _native_violations(str(c))
     c.write_text('void* p = dlopen("libgpmpc_emu.so", 2);\n')
     assert _native_violations(str(c))
+
+
+def test_inline_dpp_instructions_respect_the_operand_hazard():
+    """The leaf's v_fmac_f64_dpp statements are inline assembly, invisible to hipcc's hazard recognizer: the generated
+    device code must keep 2 wait states between a VALU write of a register and a DPP read of it (tools/check_dpp_hazards.py
+    compiles the library's device code with the Makefile's flags and walks every kernel)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import check_dpp_hazards as chk
+    # the checker itself: a violation in a hand-written snippet is found, its s_nop-protected twin is not
+    bad = "k1:\n\tv_mul_f64 v[2:3], v[4:5], v[6:7]\n\tv_fmac_f64_dpp v[8:9], -v[2:3], v[10:11] row_newbcast:3 row_mask:0xf bank_mask:0xf\n"
+    good = bad.replace('\tv_fmac', '\ts_nop 1\n\tv_fmac')
+    assert len(chk.check(bad)) == 1 and chk.check(good) == []
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'check_dpp_hazards.py')], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    n = int(re.search(r'(\d+) DPP instructions checked', r.stdout).group(1))
+    assert n >= 1000, r.stdout            # the leaf's panels and 16 x 16 inverses are in there
