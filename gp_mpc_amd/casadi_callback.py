@@ -83,10 +83,8 @@ def _fd_blocks(gp, x, u, S, fd_eps):
 
 
 def _exact_derivatives(gp, Nx):
-    """'ME' / 'TA': always; 'EM': up to 8 inputs (the derivative kernels' cross-term depth; the VALUE exists up to 16 and
-    is differenced above that); legacy methods: never."""
-    m = gp._GP__gp_method
-    return m in ('ME', 'TA') or (m == 'EM' and Nx <= 8)
+    """'ME' / 'TA' / 'EM': one device call (every input dimension the library takes, d <= 16); legacy methods: differenced."""
+    return gp._GP__gp_method in ('ME', 'TA', 'EM')
 
 
 def _blocks_from_D(D, Ny, Nu, Nx):

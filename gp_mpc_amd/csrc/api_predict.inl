@@ -361,9 +361,7 @@ extern "C" int gpmpc_predict_em_sens(gpmpc_gp* h, int B, const double* Z, const 
     if (!h->fitted) return fail(GPMPC_ENOTFIT, "model has no factors (call gpmpc_fit or gpmpc_set_factors)");
     if (B <= 0 || !Z || !Sigma) return fail(GPMPC_EINVAL, "bad B or NULL Z / Sigma");
     const int d = h->d, Ny = h->Ny, Np = h->Np, N = h->N;
-    if (d > EMK)
-        return fail(GPMPC_EINVAL, "EM derivative outputs: input dimension d=%d exceeds the depth %d of their kernels (the value, "
-                    "gpmpc_predict 'EM', exists up to d=%d: difference it)", d, EMK, DMAX);
+    const int KD = em_depth(d), EM_OPS_ORD = em_ops_ord(KD), EM_NSS = em_nss(KD);   // cross-term depth 8 (d <= 8) or 16
     HIPCHK(hipSetDevice(h->device));
     CHK(ensure_scratch(h, 1));
     if (!h->have_invK) {
@@ -420,18 +418,21 @@ extern "C" int gpmpc_predict_em_sens(gpmpc_gp* h, int B, const double* Z, const 
                 hipLaunchKernelGGL(em_prep_kernel, dim3((unsigned)(B * (Ny + P))), dim3(DMAX * GJ_LD), 0, cx.stream, h->ws.hyper, dS,
                                    prep, B, Ny, d);
             }
-            hipLaunchKernelGGL(em_mean_sens_kernel, dim3(Ny, nb), dim3(256), 0, cx.stream, h->XT, dZ, h->beta, prep,
-                               o1 + (size_t)b0 * Ny * d, o2 + (size_t)b0 * Ny * d * d, N, Np, d, Ny, b0);
-            hipLaunchKernelGGL(em_operands_ordered_kernel, dim3((Np + 255) / 256, PO, nb), dim3(256), 0, cx.stream, h->XT, dZ,
-                               h->ws.hyper, prep, h->beta, ops, N, Np, d, Ny, b0);
-            hipLaunchKernelGGL(em_pair_sens_kernel<false>, dim3(tiles, PO, nb), dim3(256), 0, cx.stream, ops, h->ws.InvK, h->XT, dZ,
-                               part, N, Np, Ny, d, b0, cx.crow_mode);
-            hipLaunchKernelGGL(em_pair_sens_kernel<true>, dim3(tiles, PO, nb), dim3(256), 0, cx.stream, ops, h->ws.InvK, h->XT, dZ,
-                               part, N, Np, Ny, d, b0, cx.crow_mode);
-            hipLaunchKernelGGL(em_sens_reduce_kernel, dim3(PO, nb), dim3(256), 0, cx.stream, part, sums, Ny, tiles);
-            hipLaunchKernelGGL(em_sens_finish_kernel, dim3((unsigned)(nb * P)), dim3(DMAX * GJ_LD), 0, cx.stream, sums, prep,
-                               h->ws.hyper, dS, oM, o1 + (size_t)b0 * Ny * d, o2 + (size_t)b0 * Ny * d * d,
+#define GPMPC_EM_SENS(KDV)                                                                                                        \
+            hipLaunchKernelGGL((em_mean_sens_kernel<KDV>), dim3(Ny, nb), dim3(256), 0, cx.stream, h->XT, dZ, h->beta, prep,        \
+                               o1 + (size_t)b0 * Ny * d, o2 + (size_t)b0 * Ny * d * d, N, Np, d, Ny, b0);                            \
+            hipLaunchKernelGGL((em_operands_ordered_kernel<KDV>), dim3((Np + 255) / 256, PO, nb), dim3(256), 0, cx.stream, h->XT, dZ, \
+                               h->ws.hyper, prep, h->beta, ops, N, Np, d, Ny, b0);                                                   \
+            hipLaunchKernelGGL((em_pair_sens_kernel<false, KDV>), dim3(tiles, PO, nb), dim3(256), 0, cx.stream, ops, h->ws.InvK,    \
+                               h->XT, dZ, part, N, Np, Ny, d, b0, cx.crow_mode);                                                     \
+            hipLaunchKernelGGL((em_pair_sens_kernel<true, KDV>), dim3(tiles, PO, nb), dim3(256), 0, cx.stream, ops, h->ws.InvK,     \
+                               h->XT, dZ, part, N, Np, Ny, d, b0, cx.crow_mode);                                                     \
+            hipLaunchKernelGGL((em_sens_reduce_kernel<KDV>), dim3(PO, nb), dim3(256), 0, cx.stream, part, sums, Ny, tiles);          \
+            hipLaunchKernelGGL((em_sens_finish_kernel<KDV>), dim3((unsigned)(nb * P)), dim3(DMAX * GJ_LD), 0, cx.stream, sums, prep, \
+                               h->ws.hyper, dS, oM, o1 + (size_t)b0 * Ny * d, o2 + (size_t)b0 * Ny * d * d,                          \
                                o3 + (size_t)b0 * Ny * Ny * d, o4 + (size_t)b0 * Ny * Ny * d * d, nb, Ny, d, b0);
+            if (KD == 8) { GPMPC_EM_SENS(8) } else { GPMPC_EM_SENS(16) }     // d = 9 .. 16: the 16-deep instantiation
+#undef GPMPC_EM_SENS
             HIPCHK(hipGetLastError());
         }
         if (io.on) {

@@ -357,7 +357,6 @@ __global__ void __launch_bounds__(64) em_finish_kernel(const double* __restrict_
     cov[((long)b * Ny + bb) * Ny + a] = v;
 }
 
-constexpr int EMK = 8;   // cross-term depth of the derivative kernels (d <= 8)
 
 // ---- derivative outputs of the exact moments ---------------------------------------------------
 // d mean / d(mu, Sigma) and d cov / d(mu, Sigma) of gp_exact_moment (what CasADi's AD hands to IPOPT when 'EM' is the
@@ -374,18 +373,20 @@ constexpr int EMK = 8;   // cross-term depth of the derivative kernels (d <= 8)
 // A-operand layout of its transpose, so  [c_j | h_j] += W^T [1 | ii]  costs four v_mfma_f64_16x16x4_f64 per tile on the
 // matrix pipe, which the value kernel leaves two thirds idle, instead of nine VALU fma per entry (the first version: 64
 // accumulator registers per lane, one wave per SIMD, 8.2 ms per input at C3 against 1.5 ms for the value).
-constexpr int EM_NSS = 1 + EMK + 2 * EMK * EMK;     // values per (input, ordered pair, strip)
-// operand rows per (input, ordered pair): row side [U (EMK) | La | beta_a], column side [Wt (EMK) | Lb | beta_c], ii (EMK)
-constexpr int EM_OPS_ORD = 3 * EMK + 4;
-constexpr int EM_ROW0 = 0, EM_COL0 = EMK + 2, EM_II0 = 2 * EMK + 4;
+// (all of it for a cross-term depth KD = 8 or 16 = em_depth(d), as the value kernels)
+constexpr int em_nss(int KD) { return 1 + KD + 2 * KD * KD; }     // values per (input, ordered pair, strip)
+// operand rows per (input, ordered pair): row side [U (KD) | La | beta_a], column side [Wt (KD) | Lb | beta_c], ii (KD)
+constexpr int em_ops_ord(int KD) { return 3 * KD + 4; }
 
 // operands for ORDERED pairs, pair index po = a * Ny + c.  beta rows are copied in (zero in padded points) so that the
 // pair kernel's tile fetch is one branch-free block of rows.
+template <int KD>
 __global__ void __launch_bounds__(256) em_operands_ordered_kernel(const double* __restrict__ XT, const double* __restrict__ Z,
                                                                   const double* __restrict__ hyper,
                                                                   const double* __restrict__ prep,
                                                                   const double* __restrict__ beta, double* __restrict__ ops,
                                                                   int N, int Np, int d, int Ny, int b0) {
+    constexpr int EMK = KD, EM_OPS_ORD = em_ops_ord(KD), EM_ROW0 = 0, EM_COL0 = KD + 2, EM_II0 = 2 * KD + 4;
     const int P = Ny * (Ny + 1) / 2, stride = d * d + 1;
     const int i = blockIdx.x * 256 + threadIdx.x, po = blockIdx.y, bl = blockIdx.z, b = b0 + bl;
     if (i >= Np) return;
@@ -424,11 +425,14 @@ __global__ void __launch_bounds__(256) em_operands_ordered_kernel(const double* 
 // by side in LDS (position pos(il) below), so that La, beta_a and the feature operand of the moment products come
 // in as 128-bit reads.  part[((bl*Ny*Ny + po)*tiles + strip)*EM_NSS + e].  Launched once per kind like
 // em_pair_kernel: only the a == c variant carries the K^-1 registers.
-template <bool DIAG>
+template <bool DIAG, int KD>
 __global__ void __launch_bounds__(256) em_pair_sens_kernel(const double* __restrict__ ops, const double* __restrict__ invK,
                                                            const double* __restrict__ XT, const double* __restrict__ Z,
                                                            double* __restrict__ part, int N, int Np, int Ny, int d, int b0,
                                                            int crow_mode) {
+    constexpr int EMK = KD, EM_OPS_ORD = em_ops_ord(KD), EM_NSS = em_nss(KD), EM_ROW0 = 0, EM_COL0 = KD + 2, EM_II0 = 2 * KD + 4;
+    constexpr int NF = KD == 8 ? 1 : 0;          // KD = 8: feature column 0 is the constant 1 (c_j rides the moment product);
+                                                 // KD = 16: all 16 feature columns are ii, c_j is summed on the VALU
     const int tj = blockIdx.x, po = blockIdx.y, bl = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles = Np / 64, a = po / Ny, cb = po % Ny;
     if ((a == cb) != DIAG) return;
@@ -441,7 +445,9 @@ __global__ void __launch_bounds__(256) em_pair_sens_kernel(const double* __restr
     __shared__ double Vs[64][EMK];                // per strip column: v_j
     const int fr = lane & 15, fk = lane >> 4, n0 = tj * 64, col = n0 + 16 * wave + fr;
     const double* __restrict__ oc = o + (long)EM_COL0 * Np;
-    const double b0f = oc[(long)fk * Np + col], b1f = oc[(long)(4 + fk) * Np + col];     // B fragments: constant over the sweep
+    double bf[KD / 4];                                                                  // B fragments: constant over the sweep
+#pragma unroll
+    for (int s4 = 0; s4 < KD / 4; ++s4) bf[s4] = oc[(long)(4 * s4 + fk) * Np + col];
     const double lbj = oc[(long)EMK * Np + col], bj = oc[(long)(EMK + 1) * Np + col];
     for (int e = tid; e < 64 * EMK; e += 256) {
         const int cl = e / EMK, k = e % EMK, j = n0 + cl;
@@ -449,7 +455,7 @@ __global__ void __launch_bounds__(256) em_pair_sens_kernel(const double* __restr
     }
     for (int e = tid; e < 2 * 16 * 16 * 4; e += 256) {     // constant feature columns of both buffers
         const int f = (e >> 2) & 15;
-        if (f == 0 || f > EMK) (&Fs[0][0][0][0])[e] = f == 0 ? 1.0 : 0.0;
+        if (f < NF || f >= NF + EMK) (&Fs[0][0][0][0])[e] = f < NF ? 1.0 : 0.0;
     }
     // position of row il (0..63) of a tile: sub-tile sb = il / 16, then (lane group g, register r) with crow(g*16, r) == il % 16
     auto pos = [&](int il) {
@@ -457,23 +463,27 @@ __global__ void __launch_bounds__(256) em_pair_sens_kernel(const double* __restr
         return ((il >> 4) * 4 + g) * 4 + r;
     };
     const int scl = tid & 63, srw = tid >> 6, sp = pos(scl), spg = sp >> 2, spr = sp & 3;
-    double st[5];
-    auto fetch = [&](int it) {           // rows 0..9 (U, La, beta_a) and the 8 ii rows of 64 points: 5 coalesced loads per thread
+    constexpr int NG = KD / 4;           // row groups of four: thread (srw, scl) handles rows 4 g + srw of U and of ii
+    double stU[NG], stI[NG], stL;
+    auto fetch = [&](int it) {           // rows U (KD), La, beta_a and the KD ii rows of 64 points: 2 KD / 4 + 1 coalesced loads per thread
         const long i = (long)it * 64 + scl;
-        st[0] = o[(long)(EM_ROW0 + srw) * Np + i];
-        st[1] = o[(long)(EM_ROW0 + 4 + srw) * Np + i];
-        st[2] = o[(long)(EM_ROW0 + 8 + (srw & 1)) * Np + i];
-        st[3] = o[(long)(EM_II0 + srw) * Np + i];
-        st[4] = o[(long)(EM_II0 + 4 + srw) * Np + i];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            stU[g] = o[(long)(EM_ROW0 + 4 * g + srw) * Np + i];
+            stI[g] = o[(long)(EM_II0 + 4 * g + srw) * Np + i];
+        }
+        stL = o[(long)(EM_ROW0 + EMK + (srw & 1)) * Np + i];
     };
     auto stage = [&](int buf) {
-        Us[buf][srw][scl] = st[0];
-        Us[buf][4 + srw][scl] = st[1];
-        if (srw < 2) LBs[buf][sp][srw] = st[2];
-        Fs[buf][spg][1 + srw][spr] = st[3];
-        Fs[buf][spg][5 + srw][spr] = st[4];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            Us[buf][4 * g + srw][scl] = stU[g];
+            Fs[buf][spg][NF + 4 * g + srw][spr] = stI[g];
+        }
+        if (srw < 2) LBs[buf][sp][srw] = stL;
     };
     d4 D0 = d4{0.0, 0.0, 0.0, 0.0}, D1 = D0;   // [c_j | h_j] of this wave's 16 columns: D[j = crow(lane, r)][f = lane & 15]
+    double csum = 0.0;                         // KD = 16: this lane's share of c_j, j = column lane & 15 (rows of its registers)
     fetch(0);
     stage(0);
     __syncthreads();
@@ -493,8 +503,9 @@ __global__ void __launch_bounds__(256) em_pair_sens_kernel(const double* __restr
         d4 c[4];
 #pragma unroll
         for (int sb = 0; sb < 4; ++sb) {                                 // cross terms of the four 16-row sub-tiles
-            c[sb] = mfma16(Us[cur][fk][16 * sb + fr], b0f, d4{0.0, 0.0, 0.0, 0.0});
-            c[sb] = mfma16(Us[cur][4 + fk][16 * sb + fr], b1f, c[sb]);
+            c[sb] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int s4 = 0; s4 < KD / 4; ++s4) c[sb] = mfma16(Us[cur][4 * s4 + fk][16 * sb + fr], bf[s4], c[sb]);
         }
 #pragma unroll
         for (int sb = 0; sb < 4; ++sb) {
@@ -516,51 +527,66 @@ __global__ void __launch_bounds__(256) em_pair_sens_kernel(const double* __restr
             D1 = mfma16(w[1], f4[1], D1);
             D0 = mfma16(w[2], f4[2], D0);
             D1 = mfma16(w[3], f4[3], D1);
+            if (NF == 0) csum += (w[0] + w[1]) + (w[2] + w[3]);
         }
         if (it + 1 < tiles) stage(cur ^ 1);
         __syncthreads();
         cur ^= 1;
     }
+    // Ds[column][0] = c_j, Ds[column][1 + k] = h_j[k]
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-        if (fr <= EMK) Ds[16 * wave + crow(lane, r, crow_mode)][fr] = D0[r] + D1[r];
+        if (fr < NF + EMK) Ds[16 * wave + crow(lane, r, crow_mode)][fr + (1 - NF)] = D0[r] + D1[r];
+    if (NF == 0) {             // the rows of a column are spread over the four lane groups: fixed-order sum across them
+        csum += __shfl_xor(csum, 16);
+        csum += __shfl_xor(csum, 32);
+        if (lane < 16) Ds[16 * wave + lane][0] = csum;
+    }
     __syncthreads();
-    if (tid < EM_NSS) {        // fixed-order sums over the strip's 64 columns
+    for (int t = tid; t < EM_NSS; t += 256) {        // fixed-order sums over the strip's 64 columns
         double s = 0.0;
-        if (tid == 0) {
+        if (t == 0) {
             for (int cl = 0; cl < 64; ++cl) s += Ds[cl][0];
-        } else if (tid < 1 + EMK) {
-            const int k = tid - 1;
+        } else if (t < 1 + EMK) {
+            const int k = t - 1;
             for (int cl = 0; cl < 64; ++cl) s += Ds[cl][0] * Vs[cl][k];
-        } else if (tid < 1 + EMK + EMK * EMK) {
-            const int e = tid - 1 - EMK, k = e / EMK, l = e % EMK;
+        } else if (t < 1 + EMK + EMK * EMK) {
+            const int e = t - 1 - EMK, k = e / EMK, l = e % EMK;
             for (int cl = 0; cl < 64; ++cl) s += Ds[cl][0] * Vs[cl][k] * Vs[cl][l];
         } else {
-            const int e = tid - 1 - EMK - EMK * EMK, k = e / EMK, l = e % EMK;
+            const int e = t - 1 - EMK - EMK * EMK, k = e / EMK, l = e % EMK;
             for (int cl = 0; cl < 64; ++cl) s += Ds[cl][1 + k] * Vs[cl][l];
         }
-        part[(((long)bl * Ny * Ny + po) * tiles + tj) * EM_NSS + tid] = s;
+        part[(((long)bl * Ny * Ny + po) * tiles + tj) * EM_NSS + t] = s;
     }
 }
 
 // sums[(bl*Ny*Ny + po)*EM_NSS + e] = sum over strips (fixed order).  grid (Ny*Ny, Bc), 256 threads.
+template <int KD>
 __global__ void __launch_bounds__(256) em_sens_reduce_kernel(const double* __restrict__ part, double* __restrict__ sums,
                                                              int Ny, int tiles) {
-    const int po = blockIdx.x, bl = blockIdx.y, e = threadIdx.x;
-    if (e >= EM_NSS) return;
-    const double* p = part + (((long)bl * Ny * Ny + po) * tiles) * EM_NSS + e;
-    double s = 0.0;
-    for (int t = 0; t < tiles; ++t) s += p[(long)t * EM_NSS];
-    sums[((long)bl * Ny * Ny + po) * EM_NSS + e] = s;
+    constexpr int EM_NSS = em_nss(KD);
+    const int po = blockIdx.x, bl = blockIdx.y;
+    for (int e = threadIdx.x; e < EM_NSS; e += 256) {
+        const double* p = part + (((long)bl * Ny * Ny + po) * tiles) * EM_NSS + e;
+        double s = 0.0;
+        for (int t = 0; t < tiles; ++t) s += p[(long)t * EM_NSS];
+        sums[((long)bl * Ny * Ny + po) * EM_NSS + e] = s;
+    }
 }
 
 // d mean_a / d mu = P_a M1, d mean_a / d Sigma = -1/2 P_a mean_a + 1/2 P_a M2 P_a with M1 = sum_i w_i v_i,
 // M2 = sum_i w_i v_i v_i^T, w_i = beta_ai q_ai, P_a = (Sigma + Lambda_a)^-1 (prep's iR).  grid (Ny, Bc), 256 threads.
+template <int KD>
 __global__ void __launch_bounds__(256) em_mean_sens_kernel(const double* __restrict__ XT, const double* __restrict__ Z,
                                                            const double* __restrict__ beta, const double* __restrict__ prep,
                                                            double* __restrict__ dm_dz, double* __restrict__ dm_dS, int N,
                                                            int Np, int d, int Ny, int b0) {
-    constexpr int NM = 1 + EMK + EMK * (EMK + 1) / 2;
+    constexpr int EMK = KD, NM = 1 + EMK + EMK * (EMK + 1) / 2;
+    // The moments M0, M1[k], M2[k][l <= k] are gathered in passes of KC rows k (KD = 8: one pass of 45 accumulators per
+    // thread as before; KD = 16: eight passes of 2 + 32 -- 153 at once would not fit the register file, 4 + 64 still spilled); every
+    // pass recomputes the weights w_i, KD^2 flops per point against N x KD x 8 bytes of coordinates: nothing.
+    constexpr int KC = KD == 8 ? 8 : 2;
     const int a = blockIdx.x, b = b0 + blockIdx.y, tid = threadIdx.x;
     const int P = Ny * (Ny + 1) / 2, stride = d * d + 1;
     const double* pr = prep + ((long)b * (Ny + P) + a) * stride;
@@ -569,35 +595,60 @@ __global__ void __launch_bounds__(256) em_mean_sens_kernel(const double* __restr
     if (tid < EMK) mu[tid] = tid < d ? Z[(long)b * d + tid] : 0.0;
     __syncthreads();
     const double c = pr[d * d];
-    double acc[NM];
+#pragma unroll 1
+    for (int k0 = 0; k0 < EMK; k0 += KC) {
+        double a0 = 0.0, a1[KC], a2[KC][EMK];
 #pragma unroll
-    for (int e = 0; e < NM; ++e) acc[e] = 0.0;
-    for (int i = tid; i < N; i += 256) {
-        double v[EMK];
+        for (int kk = 0; kk < KC; ++kk) {
+            a1[kk] = 0.0;
 #pragma unroll
-        for (int k = 0; k < EMK; ++k) v[k] = k < d ? XT[(long)k * Np + i] - mu[k] : 0.0;
-        double qf = 0.0;
-#pragma unroll
-        for (int r = 0; r < EMK; ++r) {
-            double t = 0.0;
-#pragma unroll
-            for (int k = 0; k < EMK; ++k) t += v[k] * iR[k * EMK + r];
-            qf += t * v[r];
+            for (int l = 0; l < EMK; ++l) a2[kk][l] = 0.0;
         }
-        const double w = c * exp(-0.5 * qf) * beta[(long)a * Np + i];
-        acc[0] += w;
-        int e = 1 + EMK;
+        for (int i = tid; i < N; i += 256) {
+            double v[EMK];
 #pragma unroll
-        for (int k = 0; k < EMK; ++k) {
-            acc[1 + k] += w * v[k];
+            for (int k = 0; k < EMK; ++k) v[k] = k < d ? XT[(long)k * Np + i] - mu[k] : 0.0;
+            // qf = v^T iR v = sum_k v_k (iR v)_k (iR is symmetric): the row index k stays a loop variable at KD = 16 -- fully
+            // unrolled, the 256 LDS operands were hoisted into registers and the kernel spilled 290 of them
+            double qf = 0.0;
+#pragma unroll(KD == 8 ? 8 : 1)
+            for (int k = 0; k < EMK; ++k) {
+                double t = 0.0;
 #pragma unroll
-            for (int l = 0; l <= k; ++l, ++e) acc[e] += w * v[k] * v[l];
+                for (int r = 0; r < EMK; ++r) t += iR[k * EMK + r] * v[r];
+                double vk = 0.0;
+#pragma unroll
+                for (int q = 0; q < EMK; ++q) vk = (q == k) ? v[q] : vk;
+                qf += t * vk;
+            }
+            const double w = c * exp(-0.5 * qf) * beta[(long)a * Np + i];
+            a0 += w;
+#pragma unroll
+            for (int kk = 0; kk < KC; ++kk) {
+                double vk = 0.0;                       // v[k0 + kk] without a run-time register index
+#pragma unroll
+                for (int q = 0; q < EMK; ++q) vk = (q == k0 + kk) ? v[q] : vk;
+                a1[kk] += w * vk;
+#pragma unroll
+                for (int l = 0; l < EMK; ++l) a2[kk][l] += w * vk * v[l];      // (entries l > k are formed and not used)
+            }
         }
-    }
+        // wave sums -> red, for the entries of this pass
+        {
+            const double t = wave_sum(a0);
+            if ((tid & 63) == 0 && k0 == 0) red[tid >> 6][0] = t;
+        }
 #pragma unroll
-    for (int e = 0; e < NM; ++e) {
-        const double t = wave_sum(acc[e]);
-        if ((tid & 63) == 0) red[tid >> 6][e] = t;
+        for (int kk = 0; kk < KC; ++kk) {
+            const int k = k0 + kk;
+            const double t = wave_sum(a1[kk]);
+            if ((tid & 63) == 0) red[tid >> 6][1 + k] = t;
+#pragma unroll
+            for (int l = 0; l < EMK; ++l) {
+                const double t2 = wave_sum(a2[kk][l]);
+                if ((tid & 63) == 0 && l <= k) red[tid >> 6][1 + EMK + k * (k + 1) / 2 + l] = t2;
+            }
+        }
     }
     __syncthreads();
     if (tid < NM) M[tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
@@ -625,11 +676,13 @@ __global__ void __launch_bounds__(256) em_mean_sens_kernel(const double* __restr
 
 // assembly per (input, unordered pair a >= c).  grid (Bc * P), DMAX * GJ_LD threads: one workgroup per item, its d x d
 // algebra in LDS with a thread per entry (one THREAD per item with the matrices in scratch memory took 0.31 ms at C3).
+template <int KD>
 __global__ void __launch_bounds__(DMAX * GJ_LD) em_sens_finish_kernel(const double* __restrict__ sums, const double* __restrict__ prep,
                                                                       const double* __restrict__ hyper, const double* __restrict__ Sigma,
                                                                       const double* __restrict__ mean, const double* __restrict__ dm_dz,
                                                                       const double* __restrict__ dm_dS, double* __restrict__ dc_dz,
                                                                       double* __restrict__ dc_dS, int Bc, int Ny, int d, int b0) {
+    constexpr int EMK = KD, EM_NSS = em_nss(KD);
     const int P = Ny * (Ny + 1) / 2, stride = d * d + 1;
     const int tid = threadIdx.x, r = tid / GJ_LD, q = tid % GJ_LD;
     const int bl = (int)blockIdx.x / P, p = (int)blockIdx.x % P, b = b0 + bl;

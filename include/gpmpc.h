@@ -158,7 +158,7 @@ int gpmpc_predict_sens(gpmpc_gp* h, int B, const double* Z, double* mean, double
  * jacobian(..., covar_s) which the reference relies on inside IPOPT).  Sigma must be symmetric: like gpmpc_predict's
  * 'EM' value path, which visits each pair (i, j) of training points once, the formulas use Sigma = Sigma^T.  Any output
  * may be NULL; with cov == NULL the value kernels' pair sums are not formed (a Jacobian callback: 3.9 instead of 5.6 ms
- * per input at N = 8192, Ny = 6).  d <= 8. */
+ * per input at N = 8192, Ny = 6).  Every d the library takes (<= 16): d <= 8 on an 8-deep, d = 9..16 on a 16-deep cross term. */
 int gpmpc_predict_em_sens(gpmpc_gp* h, int B, const double* Z, const double* Sigma, double* mean, double* cov,
                           double* dmean_dz, double* dmean_dS, double* dcov_dz, double* dcov_dS);
 /* GP.__predict (gp_class.py:212-235) batched over B input distributions:

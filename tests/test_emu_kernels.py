@@ -180,6 +180,8 @@ def test_emu_em_sens(emu):
     pc.check_em_sens(emu, N=70, d=8, Ny=1, B=1, seed=3)
     pc.check_em_sens(emu, N=100, d=1, Ny=3, B=2, seed=7)      # one input dimension
     pc.check_em_sens(emu, N=47, d=7, Ny=4, B=1, seed=8)       # ragged, nearly the full cross-term depth
+    pc.check_em_sens(emu, N=60, d=9, Ny=2, B=1, seed=9)       # d > 8: the 16-deep instantiation of the kernels
+    pc.check_em_sens(emu, N=40, d=16, Ny=1, B=1, seed=10)
 
 
 def test_emu_callback_blocks(emu):

@@ -162,6 +162,9 @@ def test_em_sens(lib):
     pc.check_em_sens(lib, N=600, d=8, Ny=6, B=3, seed=4)          # C3's output / input dimensions
     pc.check_em_sens(lib, N=100, d=1, Ny=3, B=2, seed=7)          # one input dimension
     pc.check_em_sens(lib, N=47, d=7, Ny=4, B=1, seed=8)           # ragged, nearly the full cross-term depth
+    pc.check_em_sens(lib, N=150, d=9, Ny=2, B=2, seed=9)          # d > 8: the 16-deep instantiation of the kernels
+    pc.check_em_sens(lib, N=200, d=16, Ny=3, B=1, seed=10)        # the largest input dimension the library takes
+    pc.check_em_sens(lib, N=90, d=12, Ny=1, B=2, seed=11)
 
 
 def test_callback_blocks(lib):
