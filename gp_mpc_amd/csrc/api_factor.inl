@@ -404,6 +404,7 @@ static bool factor_chain(const Ctx& cx, Workspace& ws, int spin_limit, bool flag
     // inverse pipelined segment by segment behind the chain: next to GEMM launches only
     const bool pipelined = !use_workers && cx.aux && cx.seg && Np >= 4 * SEGR;
     int seg_done = 0;
+    bool s_ready_recorded = false;
     {   // the chain kernel ends with the last leaf, i.e. when L is complete: its duration is the Cholesky's
         ProfScope t(cx.prof, cx.stream, GPMPC_PH_CHAIN);
         hipLaunchKernelGGL(chol_chain_kernel, dim3(1, 1, ws.batch), dim3(256), CHAIN_LDS_BYTES, cx.stream, (const double*)ws.K,
@@ -426,12 +427,24 @@ static bool factor_chain(const Ctx& cx, Workspace& ws, int spin_limit, bool flag
             if (i + 1 == L) break;
             // launch i finished: rows P_i of L are final.  Behind launch i + 1, once it is resident:
             hipEventRecord(cx.seg[i], cx.side);
-            hipStreamWaitEvent(cx.aux, cx.seg[i], 0);
-            hipLaunchKernelGGL(flag_gate_kernel, dim3(ws.batch), dim3(64), 0, cx.aux, ws.flags, (long)nf,
-                               chain_ready_index(nb) + 2 * i + 1, 1, -1, 0, spin_limit);
             const int ri = r[i], a = r[i + 1] - r[i];
-            trtri_range(cx, ws, cx.aux, ri, a);                                    // I_i
-            if (i + 2 == L) hipEventRecord(cx.seg[cx.n_seg - 2], cx.aux);         // the side queue's last use of the level scratch
+            // I_i is eight latency-bound launches (~90 us) that need nothing of panel i-1's products, which still occupy
+            // the inverse queue when launch i ends (r03 timeline: they ran until 0.19 ms after launch 2's end): they go to
+            // a queue of their own from the second panel on (the low-priority one: a HIGH-priority queue for them made every
+            // launch 5 x slower and the fit 2.67 ms), the products wait for them through an event.
+            static const bool trtri_own_queue = !(getenv("GPMPC_TRTRI_QUEUE") && atoi(getenv("GPMPC_TRTRI_QUEUE")) == 0);
+            hipStream_t tq = (i >= 1 && cx.bulk && trtri_own_queue && 2 * L + 1 < cx.n_seg - 2) ? cx.bulk : cx.aux;
+            hipStreamWaitEvent(tq, cx.seg[i], 0);
+            // (all I_i share ONE level scratch: the previous one must be through with it -- an explicit event, not "it
+            //  finished long ago": with several handles alive HIP multiplexes their streams onto a few hardware queues and
+            //  the inverse queue of this handle can sit behind another handle's work for any length of time)
+            if (tq != cx.aux && i >= 1) hipStreamWaitEvent(tq, cx.seg[L + i - 1], 0);
+            hipLaunchKernelGGL(flag_gate_kernel, dim3(ws.batch), dim3(64), 0, tq, ws.flags, (long)nf,
+                               chain_ready_index(nb) + 2 * i + 1, 1, -1, 0, spin_limit);
+            trtri_range(cx, ws, tq, ri, a);                                        // I_i
+            if (i + 2 == L) hipEventRecord(cx.seg[cx.n_seg - 2], tq);             // the side queues' last use of the level scratch
+            hipEventRecord(cx.seg[L + i], tq);                                     // I_i done (events L .. 2L-2: free, the launches use 0 .. L-2)
+            if (tq != cx.aux) hipStreamWaitEvent(cx.aux, cx.seg[L + i], 0);
             const double* Ii = ws.Inv + (long)ri * ld + ri;
             const double* Si = i ? ws.W + wofs[i] : nullptr;                       // a x ri
             for (int jj = i + 1; jj < L; ++jj) {
@@ -440,6 +453,9 @@ static bool factor_chain(const Ctx& cx, Workspace& ws, int spin_limit, bool flag
                 product(cx.aux, ws.L + (long)rj * ld + ri, ld, KB_GE_N, Ii, ld, Sj + ri, rj, hj, a, a, 1.0, 0.0);        // W_j
                 if (i) product(cx.aux, Sj + ri, rj, 0, Si, ri, Sj, rj, hj, ri, a, -1.0, 1.0);                            // S_j -= W_j S_i
             }
+            // (the last panel's S is complete here: the final product after the chain waits for THIS point, not for the
+            //  rows of L^-1 that follow -- nobody reads them before the factorisation is over)
+            if (i + 2 == L && 2 * L + 1 < cx.n_seg - 2) { hipEventRecord(cx.seg[cx.n_seg - 1], cx.aux); s_ready_recorded = true; }
             if (i) product(cx.aux, Ii, ld, KA_LE_M, Si, ri, ws.Inv + (long)ri * ld, ld, a, ri, a, -1.0, 0.0);             // L^-1[P_i, <r_i]
         }
     } else {
@@ -492,10 +508,14 @@ static bool factor_chain(const Ctx& cx, Workspace& ws, int spin_limit, bool flag
         hipStreamWaitEvent(cx.stream, cx.seg[cx.n_seg - 2], 0);
         const int rl = r[L - 1], h = Np - rl;
         trtri_range(cx, ws, cx.stream, rl, h);
-        hipEventRecord(cx.seg[cx.n_seg - 1], cx.aux);
+        if (!s_ready_recorded) hipEventRecord(cx.seg[cx.n_seg - 1], cx.aux);
         hipStreamWaitEvent(cx.stream, cx.seg[cx.n_seg - 1], 0);
         product(cx.stream, ws.Inv + (long)rl * ld + rl, ld, KA_LE_M, ws.W + wofs[L - 1], rl, ws.Inv + (long)rl * ld, ld,
                 h, rl, h, -1.0, 0.0);
+        if (s_ready_recorded) {                             // ... and for whatever the inverse queue still had to do
+            hipEventRecord(cx.seg[2 * L + 1], cx.aux);
+            hipStreamWaitEvent(cx.stream, cx.seg[2 * L + 1], 0);
+        }
         return true;
     }
     if (!pipelined) { trtri_levels(cx, ws); return true; }
