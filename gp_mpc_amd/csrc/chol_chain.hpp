@@ -22,7 +22,8 @@
 
 namespace gpmpc {
 
-constexpr int CHAIN_LDS_BYTES = 150400;   // S, T, U, P (64 x LS each), the packed lower triangle Qp, Dr, slot
+constexpr int CHAIN_LDS_BYTES = 152576;   // S, T, U, P (64 x LS each), the packed lower triangle Qp, Dr, slot, the store table
+constexpr int CHAIN_TRI_PAIRS = 1056;     // 16-byte column pairs (r, 2c), 2c <= r, of a 64 x 64 lower triangle
 
 // flag layout per matrix (ints): [0] error, [1 .. nb] leafdone, [1+nb .. 2nb] pan1, [1+2nb .. 1+4nb) tdone[k][2],
 // and for the tile-owner workers (chol_worker.hpp): [1+4nb .. 1+5nb) pancount, [1+5nb .. 1+6nb) row2done,
@@ -92,6 +93,16 @@ __global__ void __launch_bounds__(256) chol_chain_kernel(const double* Kmat, dou
     int* slot = (int*)(Dr + 64);
     double* P = Dr + 64 + 2;            // prefetched A(k+1,k), row stride LS
     double* Qp = P + 64 * LS;           // prefetched lower triangle of A(k+1,k+1), packed: (r, c) at r (r + 1) / 2 + c
+    // The diagonal blocks of L and L^-1 go to memory as the 1056 column pairs that touch the lower triangle -- the rest
+    // of those 64 x 64 blocks is zero from the workspace's allocation and nobody writes there (api_core.inl ws_alloc;
+    // leaf64_kernel writes zeros) -- dealt evenly: 4-5 16-byte stores per thread and matrix instead of 8, a third less
+    // traffic on the chain's critical path.  tri[e] = (r << 6) | 2c, built once.
+    unsigned short* tri = (unsigned short*)(Qp + 2080);
+    for (int e = threadIdx.x; e < CHAIN_TRI_PAIRS; e += 256) {
+        int r = 0, m = e;
+        while (m >= r / 2 + 1) { m -= r / 2 + 1; ++r; }
+        tri[e] = (unsigned short)((r << 6) | (2 * m));
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const long mb = (long)blockIdx.z * sBatch;
     const double* __restrict__ Kb = Kmat + mb;
@@ -167,12 +178,12 @@ __global__ void __launch_bounds__(256) chol_chain_kernel(const double* Kmat, dou
         const int bad = leaf_body(S, T, U, Dr, 1, 15, crow_mode, pf);
         CHAIN_STAMP(1);
         if (tid == 0 && bad >= 0) atomicCAS(&info[blockIdx.z], 0, 64 * k + bad + 1);
-        for (int idx = tid; idx < 2048; idx += 256) {     // two columns per thread: 16-byte global stores
-            const int rr = idx >> 5, cc = (idx & 31) * 2;
+        for (int e = tid; e < CHAIN_TRI_PAIRS; e += 256) {   // two columns per thread: 16-byte global stores
+            const int rc = tri[e], rr = rc >> 6, cc = rc & 63;    // cc <= rr; the second column may lie above the diagonal
             double2 l, v;
-            l.x = (cc <= rr) ? S[rr * LS + cc] : 0.0;
+            l.x = S[rr * LS + cc];
             l.y = (cc + 1 <= rr) ? S[rr * LS + cc + 1] : 0.0;
-            v.x = (cc <= rr) ? T[rr * LS + cc] : 0.0;
+            v.x = T[rr * LS + cc];
             v.y = (cc + 1 <= rr) ? T[rr * LS + cc + 1] : 0.0;
             *reinterpret_cast<double2*>(&Lb[o + (long)rr * ld + cc]) = l;
             *reinterpret_cast<double2*>(&Ib[o + (long)rr * ld + cc]) = v;
