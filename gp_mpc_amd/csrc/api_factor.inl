@@ -405,11 +405,12 @@ static bool factor_chain(const Ctx& cx, Workspace& ws, int spin_limit, bool flag
     const bool pipelined = !use_workers && cx.aux && cx.seg && Np >= 4 * SEGR;
     int seg_done = 0;
     bool s_ready_recorded = false;
+    static const int late_polls = getenv("GPMPC_LATE_POLLS") ? atoi(getenv("GPMPC_LATE_POLLS")) : 3;   // (tuning aid, chol_chain.hpp land())
     {   // the chain kernel ends with the last leaf, i.e. when L is complete: its duration is the Cholesky's
         ProfScope t(cx.prof, cx.stream, GPMPC_PH_CHAIN);
         hipLaunchKernelGGL(chol_chain_kernel, dim3(1, 1, ws.batch), dim3(256), CHAIN_LDS_BYTES, cx.stream, (const double*)ws.K,
                            ws.L, ws.Inv, ld, sM, nb, ws.flags, (long)nf, ws.info, cx.crow_mode, spin_limit, g_chain_trace,
-                           use_workers ? 1 : 0);
+                           use_workers ? 1 : 0, 0, -1, late_polls);
     }
     static const bool verbose = getenv("GPMPC_VERBOSE") != nullptr;
     // (tuning aid) GPMPC_WORKER_LOOKAHEAD=0: the workers turn a panel tile into L(i,k) only at the top of step k

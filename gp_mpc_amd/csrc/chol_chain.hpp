@@ -75,7 +75,7 @@ __device__ __forceinline__ void chain_diag_tiles(double* S, const double* U, con
 __global__ void __launch_bounds__(256) chol_chain_kernel(const double* Kmat, double* L, double* Inv, long ld, long sBatch,
                                                          int nb, int* flags, long sFlags, int* info, int crow_mode,
                                                          int spin_limit, long long* trace, int merge_publish,
-                                                         int kb = 0, int ke = -1) {
+                                                         int kb = 0, int ke = -1, int late_polls = 3) {
     // [kb, ke): the block columns this launch factors (two-level execution: one launch per super-panel; the tiles of
     // block kb then carry every earlier update by stream order, no flag).  Default: the whole matrix.
     if (ke < 0) ke = nb;
@@ -135,6 +135,7 @@ __global__ void __launch_bounds__(256) chol_chain_kernel(const double* Kmat, dou
             const double* Kb; long o10, o11, ld; const int* f0; const int* f1; int* slot; int tid, wave; bool active;
             bool* pre; double* P; double* Qp;
             double* S; const double* U; int defer, crow_mode;     // defer: 0 none, 1 = S holds A(k,k), 2 = Qp does
+            int late_polls;
             // the six tiles of columns 16-63 of A(k,k) -= L(k,k-1) L(k,k-1)^T that the previous step left for now
             __device__ __forceinline__ void first() {
                 if (defer) chain_diag_tiles(S, U, Qp, defer == 2, wave - 1, 3, 1, tid & 63, crow_mode);
@@ -153,7 +154,25 @@ __global__ void __launch_bounds__(256) chol_chain_kernel(const double* Kmat, dou
             // takes slots u + 128 i = (row 4 i + u / 32, columns 2 (u % 32) ..).  Loads and LDS stores sit in ONE region
             // without a barrier in between: nothing fetched is live across the leaf's synchronisation points.
             __device__ __forceinline__ void land() {
-                if (*pre) {
+                // Second chance: the tiles often arrive a microsecond or two after the check in before() (hand-off latency
+                // ~9 us against ~8 us from the publication to that check).  Waves 2 and 3 have nothing to do behind this
+                // barrier anyway: each polls a little longer; what a wave decides is recorded in LDS (slot[2], slot[3])
+                // and counts only if both agree -- the caller turns it into `pre` after the leaf.
+                bool go = *pre;
+                if (!go && active && f0) {
+                    int ok = 0;
+                    if ((tid & 63) == 0) {
+                        for (int it = 0; it < late_polls && !ok; ++it) {
+                            ok = flag_load(f0) >= 1 && flag_load(f1) >= 1;
+                            if (!ok) __builtin_amdgcn_s_sleep(4);
+                        }
+                    }
+                    ok = __builtin_amdgcn_readfirstlane(ok);
+                    if (ok) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    if ((tid & 63) == 0) slot[wave] = ok;       // wave is 2 or 3
+                    go = ok != 0;
+                }
+                if (go) {
                     const int u = tid - 128, r0 = u >> 5, c = (u & 31) * 2;
                     double2 pu[16], ps[16];
 #pragma unroll
@@ -173,9 +192,11 @@ __global__ void __launch_bounds__(256) chol_chain_kernel(const double* Kmat, dou
                 }
             }
         } pf{Kb, o10, o11, ld, k > kb ? &tdone[2 * (k - 1)] : nullptr, k > kb ? &tdone[2 * (k - 1) + 1] : nullptr, slot, tid, wave,
-             k + 1 < ke, &pre, P, Qp, S, U, defer, crow_mode};
+             k + 1 < ke, &pre, P, Qp, S, U, defer, crow_mode, late_polls};
         defer = 0;
+        if (tid == 0) { slot[2] = 0; slot[3] = 0; }       // (read after the leaf's barriers, written behind its third one)
         const int bad = leaf_body(S, T, U, Dr, 1, 15, crow_mode, pf);
+        if (!pre && slot[2] != 0 && slot[3] != 0) pre = true;   // both loader waves saw the tiles late and landed them
         CHAIN_STAMP(1);
         if (tid == 0 && bad >= 0) atomicCAS(&info[blockIdx.z], 0, 64 * k + bad + 1);
         for (int e = tid; e < CHAIN_TRI_PAIRS; e += 256) {   // two columns per thread: 16-byte global stores
