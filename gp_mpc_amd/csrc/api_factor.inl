@@ -324,8 +324,13 @@ static bool factor_chain(const Ctx& cx, Workspace& ws, int spin_limit, bool flag
     // polls had timed out.  So: 7 workers per engine, nothing else in flight but the chain (one matrix only).
     const int ntiles = (nb - 1) * nb / 2 - 1;            // tiles kept in registers (chol_worker.hpp)
     int NW = ws.batch == 1 ? cx.workers - cx.workers / 8 : 0;
-    if (NW > ntiles) NW = ntiles;
-    const bool use_workers = NW >= 1 && nb >= 3 && (ntiles + NW - 1) / NW <= WORKER_MAXT;
+    // the last workgroup of every worker launch is the chain's courier (chol_worker.hpp), no tile owner; GPMPC_COURIER=0:
+    // tile owners only (r03 A/B on one box: factor 1.675 -> 1.630 ms at C2 with the courier)
+    static const bool worker_courier = !(getenv("GPMPC_COURIER") && atoi(getenv("GPMPC_COURIER")) == 0);
+    const int ncour = worker_courier ? 1 : 0;
+    const int worker_maxt = worker_courier ? WORKER_MAXT_COURIER : WORKER_MAXT;
+    if (NW > ntiles + ncour) NW = ntiles + ncour;
+    const bool use_workers = NW >= 1 + ncour && nb >= 3 && (ntiles + (NW - ncour) - 1) / (NW - ncour) <= worker_maxt;
     // what the workers do not take: two-level panels (GPMPC_TWOLEVEL=<block columns per super-panel>, 0/1 = off)
 #ifdef GPMPC_EMULATED
     static const int twolevel_W = getenv("GPMPC_TWOLEVEL") ? atoi(getenv("GPMPC_TWOLEVEL")) : 2;
@@ -372,8 +377,8 @@ static bool factor_chain(const Ctx& cx, Workspace& ws, int spin_limit, bool flag
             const int a = start - r[L - 1];                 // rows of the panel the new cut closes
             const int nbr = (Np - start) / 64, nt = (nbr - 1) * nbr / 2 - 1;
             int nw = nw_rule[L];
-            if (nt > 0 && nw > nt) nw = nt;
-            if (a < SEGR || nbr < 3 || nt < 1 || (nt + nw - 1) / nw > WORKER_MAXT) break;
+            if (nt > 0 && nw > nt + ncour) nw = nt + ncour;
+            if (a < SEGR || nbr < 3 || nt < 1 || nw < 1 + ncour || (nt + (nw - ncour) - 1) / (nw - ncour) > worker_maxt) break;
             r[L] = start; nws[L] = nw; ++L;
             int nxt = 64;                                   // next cut: the left child of what remains
             while (2 * nxt < Np - start) nxt *= 2;
@@ -419,44 +424,84 @@ static bool factor_chain(const Ctx& cx, Workspace& ws, int spin_limit, bool flag
         fprintf(stderr, "gpmpc: factor Np=%d batch=%d: chain kernel + %s (%d launch%s), inverse %s\n", Np, ws.batch,
                 use_workers ? "tile-owner workers" : "GEMM launches", use_workers ? L : 0, L == 1 ? "" : "es",
                 split ? "by row panels behind the worker launches" : pipelined ? "pipelined" : "at the end");
+    // Row panels of the inverse: the worker launches' panels; GPMPC_TAIL_CUTS="8,12" (tuning aid) cuts the LAST launch's panel
+    // again at those blocks (counted from that launch's first block).  A panel that ends with a worker launch is handed
+    // over by that launch's end (event), one inside the last launch by the chain's own flags: pan1[e] and colready[e] of
+    // its last block column e say that rows <= e of L and the whole block column e (row e + 1: the chain's, below: the
+    // workers') are final.  That leaves less to invert after the chain (two levels at 256 rows instead of four), but every
+    // extra panel adds ~10 dependent launches across three queues to the side work, and that -- not the last panel's
+    // inverse -- is what ends last: measured at C2 (r03) factor 1.65 ms without, 1.80 / 1.97 / 2.18 ms with 1 / 2 / 3 cuts.
+    int pcut[12] = {0}, P = 0;                              // panel starts pcut[0..P], pcut[P] = Np
+    for (int i = 0; i < L; ++i) pcut[P++] = r[i];
+    if (split) {
+        static const char* tail_env = getenv("GPMPC_TAIL_CUTS");
+        const char* tc = tail_env ? tail_env : "";
+        const int b0 = r[L - 1] / 64;
+        while (*tc && P < 10) {
+            char* e2 = nullptr;
+            const long c = strtol(tc, &e2, 10);
+            if (e2 == tc) break;
+            tc = (*e2 == ',') ? e2 + 1 : e2;
+            const int row = 64 * (b0 + (int)c);
+            if (c > 0 && row > pcut[P - 1] && row + 128 <= Np) pcut[P++] = row;
+        }
+    }
+    long sofs[12] = {0};                                    // S_j of panel j (1 <= j < P) inside ws.W, ld = pcut[j]
+    for (;;) {
+        pcut[P] = Np;
+        long need = ws.hw() * ws.hw();
+        for (int jj = 1; jj < P; ++jj) { sofs[jj] = need; need += (long)(pcut[jj + 1] - pcut[jj]) * pcut[jj]; }
+        if (P == L || need <= ws.wstride()) break;
+        P = L;                                              // (the refined S_j are a little larger than the coarse ones)
+    }
+    const int ev0 = L;                                      // events: 0 .. L-2 the launches, ev0 + i: I_i done
     if (use_workers) {
         for (int i = 0; i < L; ++i) {
             int* ready = i ? ws.flags + chain_ready_index(nb) + 2 * (i - 1) : nullptr;   // arrival counter + flag of launch i
-            hipLaunchKernelGGL(chol_worker_kernel, dim3(nws[i], 1, ws.batch), dim3(WORKER_THREADS), WORKER_LDS_BYTES, cx.side,
+            auto* worker = worker_courier ? chol_worker_kernel<WORKER_MAXT_COURIER, true> : chol_worker_kernel<WORKER_MAXT, false>;
+            hipLaunchKernelGGL(worker, dim3(nws[i], 1, ws.batch), dim3(WORKER_THREADS), WORKER_LDS_BYTES, cx.side,
                                ws.K, ws.L, (const double*)ws.Inv, ld, sM, nb, ws.flags, (long)nf, cx.crow_mode, spin_limit,
                                r[i] / 64, i + 1 < L ? (r[i + 1] - r[i]) / 64 : nb, ready, g_chain_trace, worker_lookahead ? 1 : 0);
-            if (i + 1 == L) break;
-            // launch i finished: rows P_i of L are final.  Behind launch i + 1, once it is resident:
-            hipEventRecord(cx.seg[i], cx.side);
-            const int ri = r[i], a = r[i + 1] - r[i];
+            if (i + 1 < L) hipEventRecord(cx.seg[i], cx.side);        // launch i finished: rows P_i of L are final
+        }
+        const bool own_events = ev0 + P + 2 < cx.n_seg - 2;
+        for (int i = 0; split && i + 1 < P; ++i) {
+            const int ri = pcut[i], a = pcut[i + 1] - pcut[i];
             // I_i is eight latency-bound launches (~90 us) that need nothing of panel i-1's products, which still occupy
             // the inverse queue when launch i ends (r03 timeline: they ran until 0.19 ms after launch 2's end): they go to
             // a queue of their own from the second panel on (the low-priority one: a HIGH-priority queue for them made every
             // launch 5 x slower and the fit 2.67 ms), the products wait for them through an event.
             static const bool trtri_own_queue = !(getenv("GPMPC_TRTRI_QUEUE") && atoi(getenv("GPMPC_TRTRI_QUEUE")) == 0);
-            hipStream_t tq = (i >= 1 && cx.bulk && trtri_own_queue && 2 * L + 1 < cx.n_seg - 2) ? cx.bulk : cx.aux;
-            hipStreamWaitEvent(tq, cx.seg[i], 0);
+            hipStream_t tq = (i >= 1 && cx.bulk && trtri_own_queue && own_events) ? cx.bulk : cx.aux;
             // (all I_i share ONE level scratch: the previous one must be through with it -- an explicit event, not "it
             //  finished long ago": with several handles alive HIP multiplexes their streams onto a few hardware queues and
             //  the inverse queue of this handle can sit behind another handle's work for any length of time)
-            if (tq != cx.aux && i >= 1) hipStreamWaitEvent(tq, cx.seg[L + i - 1], 0);
-            hipLaunchKernelGGL(flag_gate_kernel, dim3(ws.batch), dim3(64), 0, tq, ws.flags, (long)nf,
-                               chain_ready_index(nb) + 2 * i + 1, 1, -1, 0, spin_limit);
+            if (tq != cx.aux && i >= 1) hipStreamWaitEvent(tq, cx.seg[ev0 + i - 1], 0);
+            if (i + 1 < L) {
+                // behind launch i + 1, once it is resident (its workgroups need whole CUs)
+                hipStreamWaitEvent(tq, cx.seg[i], 0);
+                hipLaunchKernelGGL(flag_gate_kernel, dim3(ws.batch), dim3(64), 0, tq, ws.flags, (long)nf,
+                                   chain_ready_index(nb) + 2 * i + 1, 1, -1, 0, spin_limit);
+            } else {
+                const int e = pcut[i + 1] / 64 - 1;         // (e + 2 < nb: the cuts leave >= 128 rows)
+                hipLaunchKernelGGL(flag_gate_kernel, dim3(ws.batch), dim3(64), 0, tq, ws.flags, (long)nf,
+                                   chain_pan1_index(nb, e), 1, chain_colready_index(nb, e), 1, spin_limit);
+            }
             trtri_range(cx, ws, tq, ri, a);                                        // I_i
-            if (i + 2 == L) hipEventRecord(cx.seg[cx.n_seg - 2], tq);             // the side queues' last use of the level scratch
-            hipEventRecord(cx.seg[L + i], tq);                                     // I_i done (events L .. 2L-2: free, the launches use 0 .. L-2)
-            if (tq != cx.aux) hipStreamWaitEvent(cx.aux, cx.seg[L + i], 0);
+            if (i + 2 == P) hipEventRecord(cx.seg[cx.n_seg - 2], tq);             // the side queues' last use of the level scratch
+            hipEventRecord(cx.seg[ev0 + i], tq);                                   // I_i done
+            if (tq != cx.aux) hipStreamWaitEvent(cx.aux, cx.seg[ev0 + i], 0);
             const double* Ii = ws.Inv + (long)ri * ld + ri;
-            const double* Si = i ? ws.W + wofs[i] : nullptr;                       // a x ri
-            for (int jj = i + 1; jj < L; ++jj) {
-                const int rj = r[jj], hj = r[jj + 1] - r[jj];
-                double* Sj = ws.W + wofs[jj];
+            const double* Si = i ? ws.W + sofs[i] : nullptr;                       // a x ri
+            for (int jj = i + 1; jj < P; ++jj) {
+                const int rj = pcut[jj], hj = pcut[jj + 1] - pcut[jj];
+                double* Sj = ws.W + sofs[jj];
                 product(cx.aux, ws.L + (long)rj * ld + ri, ld, KB_GE_N, Ii, ld, Sj + ri, rj, hj, a, a, 1.0, 0.0);        // W_j
                 if (i) product(cx.aux, Sj + ri, rj, 0, Si, ri, Sj, rj, hj, ri, a, -1.0, 1.0);                            // S_j -= W_j S_i
             }
             // (the last panel's S is complete here: the final product after the chain waits for THIS point, not for the
             //  rows of L^-1 that follow -- nobody reads them before the factorisation is over)
-            if (i + 2 == L && 2 * L + 1 < cx.n_seg - 2) { hipEventRecord(cx.seg[cx.n_seg - 1], cx.aux); s_ready_recorded = true; }
+            if (i + 2 == P && own_events) { hipEventRecord(cx.seg[cx.n_seg - 1], cx.aux); s_ready_recorded = true; }
             if (i) product(cx.aux, Ii, ld, KA_LE_M, Si, ri, ws.Inv + (long)ri * ld, ld, a, ri, a, -1.0, 0.0);             // L^-1[P_i, <r_i]
         }
     } else {
@@ -507,15 +552,15 @@ static bool factor_chain(const Ctx& cx, Workspace& ws, int spin_limit, bool flag
         // whole side queue first put its last product, which ends ~50 us after the chain, in front of these eight
         // latency-bound launches.)
         hipStreamWaitEvent(cx.stream, cx.seg[cx.n_seg - 2], 0);
-        const int rl = r[L - 1], h = Np - rl;
+        const int rl = pcut[P - 1], h = Np - rl;
         trtri_range(cx, ws, cx.stream, rl, h);
         if (!s_ready_recorded) hipEventRecord(cx.seg[cx.n_seg - 1], cx.aux);
         hipStreamWaitEvent(cx.stream, cx.seg[cx.n_seg - 1], 0);
-        product(cx.stream, ws.Inv + (long)rl * ld + rl, ld, KA_LE_M, ws.W + wofs[L - 1], rl, ws.Inv + (long)rl * ld, ld,
+        product(cx.stream, ws.Inv + (long)rl * ld + rl, ld, KA_LE_M, ws.W + sofs[P - 1], rl, ws.Inv + (long)rl * ld, ld,
                 h, rl, h, -1.0, 0.0);
         if (s_ready_recorded) {                             // ... and for whatever the inverse queue still had to do
-            hipEventRecord(cx.seg[2 * L + 1], cx.aux);
-            hipStreamWaitEvent(cx.stream, cx.seg[2 * L + 1], 0);
+            hipEventRecord(cx.seg[ev0 + P], cx.aux);
+            hipStreamWaitEvent(cx.stream, cx.seg[ev0 + P], 0);
         }
         return true;
     }

@@ -171,7 +171,10 @@ static int create_impl(gpmpc_gp* h, const double* X, const double* Y) {
     }
     // the persistent kernels ask for more than the default 64 KB of dynamic LDS (per device: set for every handle)
     HIPCHK(hipFuncSetAttribute((const void*)chol_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CHAIN_LDS_BYTES));
-    HIPCHK(hipFuncSetAttribute((const void*)chol_worker_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WORKER_LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void*)chol_worker_kernel<WORKER_MAXT, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               WORKER_LDS_BYTES));
+    HIPCHK(hipFuncSetAttribute((const void*)chol_worker_kernel<WORKER_MAXT_COURIER, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               WORKER_LDS_BYTES));
     const size_t nseg = seg_event_count(round_up(N, 64));
     for (size_t i = 0; i < nseg; ++i) {
         hipEvent_t e;

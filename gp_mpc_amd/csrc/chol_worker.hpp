@@ -34,7 +34,8 @@
 
 namespace gpmpc {
 
-constexpr int WORKER_MAXT = 9;
+constexpr int WORKER_MAXT = 9;            // 9 tiles x 224 workers hold the 2015 tiles of Np = 4096
+constexpr int WORKER_MAXT_COURIER = 10;   // ... with one workgroup as courier it is 10 x 223 (the larger kernel is slower per tile)
 constexpr int WORKER_THREADS = 512;
 // LDS: two operand pairs of the trailing update (2 x 2 x 32 KB, DMA images); the two padded 64 x 65 blocks of the
 // panel / hand-off products alias the first of them; then the slot table.  > 80 KB also keeps one worker per CU.
@@ -48,6 +49,7 @@ __device__ __forceinline__ const double& at_byte(const double* base, unsigned by
 }
 __device__ __forceinline__ double& at_byte(double* base, unsigned byte_off) { return *(double*)((char*)base + byte_off); }
 
+template <int MAXT, bool COURIER>
 __global__ void __launch_bounds__(WORKER_THREADS) chol_worker_kernel(double* Kmat, double* L, const double* Inv, long ld,
                                                                      long sBatch, int nb_all, int* flags, long sFlags,
                                                                      int crow_mode, int spin_limit, int kb, int ksteps,
@@ -62,7 +64,11 @@ __global__ void __launch_bounds__(WORKER_THREADS) chol_worker_kernel(double* Kma
     int* slot = (int*)((char*)smem + 2 * WORKER_PAIR_BYTES);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;                 // this wave's 16 x 32 piece: rows 16 wr, columns 32 wc
-    const int w = blockIdx.x, NW = gridDim.x;
+    // With `courier` the LAST workgroup of the launch is not a tile owner but the courier of the chain (see below); the
+    // others are the NW regular workers.
+    constexpr bool has_courier = COURIER;              // (the launch has >= 2 workgroups then: host)
+    const int w = blockIdx.x, NW = has_courier ? (int)gridDim.x - 1 : (int)gridDim.x;
+    const bool is_courier = has_courier && w == NW;
     // A launch works on the trailing matrix from block kb on, for `ksteps` panel steps: everything below is
     // written for kb = 0 and made relative by shifting the base pointers and the flag arrays by kb.
     const int nb = nb_all - kb;
@@ -79,10 +85,11 @@ __global__ void __launch_bounds__(WORKER_THREADS) chol_worker_kernel(double* Kma
     int* row2done = fl + 1 + 5 * nb_all + kb;
     int* colready = fl + 1 + 6 * nb_all + kb;
     int* progress = fl + 1 + 7 * nb_all + (w & 255);
+    int* handed = fl + chain_handed_index(nb_all) + kb;
     if (tid == 0) flag_store(progress, 1);
     if (ready && tid == 0) {                       // "all workgroups of this launch are resident" for the host's gates
         int* rd = ready + (long)blockIdx.z * sFlags;
-        if (__hip_atomic_fetch_add(rd, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 == NW) flag_store(rd + 1, 1);
+        if (__hip_atomic_fetch_add(rd, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 == (int)gridDim.x) flag_store(rd + 1, 1);
     }
 #ifndef GPMPC_EMULATED
     if (tid == 0) flag_store(progress + 256, (int)((wall_clock64() / 100) & 0x3fffffff));   // start time, us
@@ -109,12 +116,12 @@ __global__ void __launch_bounds__(WORKER_THREADS) chol_worker_kernel(double* Kma
     // registers C[n].  The slot index is a run-time value: the code that touches a tile is
     // addressed through a switch over compile-time indices so that C[] never becomes an indexed (scratch) array.
     int* ti = slot + 4;
-    int* tj = ti + WORKER_MAXT;
-    d4 C[WORKER_MAXT][2];
-    if (tid < WORKER_MAXT) {
+    int* tj = ti + MAXT;
+    d4 C[MAXT][2];
+    if (tid < MAXT) {
         const int t = w + tid * NW;
         int i = -1, j = 0;
-        if (t < ntiles) {
+        if (t < ntiles && !is_courier) {
             // t + 1 enumerates the triangle (r, c) = (i-1, j-1), c <= r, COLUMN by column (column c holds rows c .. nb-2).
             // The tiles live at step k are those of the columns > k -- a suffix of this numbering -- so dealing them round
             // robin leaves every worker ceil(live / NW) of them at EVERY step.  (r01-r02 numbered row by row: the same
@@ -124,12 +131,13 @@ __global__ void __launch_bounds__(WORKER_THREADS) chol_worker_kernel(double* Kma
             while (m >= nb - 1 - c) { m -= nb - 1 - c; ++c; }
             i = c + m + 1;
             j = c + 1;
+            if (has_courier && i == 2) i = -1;        // row 2 is the courier's first row: it takes (2,1), (2,2) from K
         }
         ti[tid] = i; tj[tid] = j;
     }
     __syncthreads();
 #pragma unroll
-    for (int n = 0; n < WORKER_MAXT; ++n) {
+    for (int n = 0; n < MAXT; ++n) {
         const int i = __builtin_amdgcn_readfirstlane(ti[n]), j = __builtin_amdgcn_readfirstlane(tj[n]);
         C[n][0] = C[n][1] = d4{0.0, 0.0, 0.0, 0.0};
         if (i >= 0) {
@@ -142,76 +150,153 @@ __global__ void __launch_bounds__(WORKER_THREADS) chol_worker_kernel(double* Kma
         }
     }
 
-    // One panel step = parts 1, 2, 3 below.  Part 3 may leave its update pipeline once ("look-ahead": the panel tiles of
-    // column k + 1 become L(i,k+1) as soon as inv_{k+1} is out) -- that is a second pass through part 1 with
-    // `ahead` = 1, written as a state of this ONE loop so that every heavy block (panel product, update pipeline)
-    // exists once in the kernel (two copies of the panel product pushed the kernel from 197 to 256 VGPRs + 159 spills).
-    int k = 0, ahead = 0;                            // ahead: bit 0 = early panel tiles are due, bit 1 = early hand-off tiles
-    int li[WORKER_MAXT], lj[WORKER_MAXT];            // part 3: coordinates of the resident tiles (scalar registers)
-    unsigned live = 0, urgent = 0, hand = 0, todo = 0;   //     masks: live this step / column k + 1 / next hand-off tiles / not yet updated
-    bool early = false, earlyh = false;              //         tiles of column k + 1 wait for inv_{k+1} / hand-off tiles for row k + 3
-    int peekv = 0, cur = -1, pp = 0;                 //         bit 0: leafdone[k+1], bit 1: row2done[k+1] and pan1[k+1], as last seen
-                                                     //         by thread 0; pipeline state
-    for (; k + 2 < nb && k < ksteps;) {
-        if (!ahead) WORKER_STAMP(0);
-        // operand pair of tile (i, j) for this step: blocks L(i,k) and L(j,k) -> pair image `pp` (0 / 1) by DMA,
-        // 8 loads per wave; `update`: c -= L(i,k) L(j,k)^T from a landed pair image
-        // Issued by ONE wave per SIMD (waves 0-3, two row groups each): the other four go straight on to their
-        // matrix instructions, so the ~150 scalar instructions of a request do not idle the matrix pipes.
-        auto request_blocks = [&](const double* pa, const double* pb, int pp, bool with_a) {
-            if (swave >= 4) return;
-            char* img = (char*)smem + pp * WORKER_PAIR_BYTES + 1024 * swave;
-            const unsigned half = (unsigned)(32 * ld * 8);        // rows 8 (wave + 4) .. : 32 rows further down
-            if (with_a) {
-                const dma_rsrc_t ra = dma_make_rsrc(pa, (unsigned)(64 * ld * 8));
+    // k-independent building blocks (used by the step loop and by the courier)
+    // operand pair of tile (i, j) for this step: blocks L(i,k) and L(j,k) -> pair image `pp` (0 / 1) by DMA,
+    // 8 loads per wave; `update`: c -= L(i,k) L(j,k)^T from a landed pair image
+    // Issued by ONE wave per SIMD (waves 0-3, two row groups each): the other four go straight on to their
+    // matrix instructions, so the ~150 scalar instructions of a request do not idle the matrix pipes.
+    auto request_blocks = [&](const double* pa, const double* pb, int pp, bool with_a, bool with_b = true) {
+        if (swave >= 4) return;
+        char* img = (char*)smem + pp * WORKER_PAIR_BYTES + 1024 * swave;
+        const unsigned half = (unsigned)(32 * ld * 8);        // rows 8 (wave + 4) .. : 32 rows further down
+        if (with_a) {
+            const dma_rsrc_t ra = dma_make_rsrc(pa, (unsigned)(64 * ld * 8));
 #pragma unroll
-                for (int sl = 0; sl < 4; ++sl) {
-                    dma_load16(ra, img + 8192 * sl, dvo, 128u * sl);
-                    dma_load16(ra, img + 8192 * sl + 4096, dvo, 128u * sl + half);
-                }
+            for (int sl = 0; sl < 4; ++sl) {
+                dma_load16(ra, img + 8192 * sl, dvo, 128u * sl);
+                dma_load16(ra, img + 8192 * sl + 4096, dvo, 128u * sl + half);
             }
+        }
+        if (with_b) {
             const dma_rsrc_t rb = dma_make_rsrc(pb, (unsigned)(64 * ld * 8));
 #pragma unroll
             for (int sl = 0; sl < 4; ++sl) {
                 dma_load16(rb, img + 32768 + 8192 * sl, dvo, 128u * sl);
                 dma_load16(rb, img + 32768 + 8192 * sl + 4096, dvo, 128u * sl + half);
             }
-        };
+        }
+    };
+    // c0, c1 += sgn * A B^T on this wave's 16 x 32 piece, operands from the landed pair image pp
+    // (imgA / imgB: block images of the A and the B operand -- any landed 32 KB image serves as either)
+    auto product_ab = [&](const char* imgA, const char* imgB, d4& c0, d4& c1, bool negate) {
+        const char* img = imgA;
+        const long boff = (imgB - imgA) - 32768;       // fb0 / fb1 carry the B part's offset inside a pair image
+#pragma unroll 1
+        for (int sl = 0; sl < 4; ++sl)             // (fully unrolled, the 24 fragment loads are hoisted and spill)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                double2 a = *reinterpret_cast<const double2*>(img + 8192 * sl + (h ? fa1 : fa0));
+                const double2 b0 = *reinterpret_cast<const double2*>(img + boff + 8192 * sl + (h ? fb1 : fb0));
+                const double2 b1 = *reinterpret_cast<const double2*>(img + boff + 8192 * sl + 2048 + (h ? fb1 : fb0));
+                if (negate) { a.x = -a.x; a.y = -a.y; }
+                c0 = mfma16(a.x, b0.x, c0);
+                c1 = mfma16(a.x, b1.x, c1);
+                c0 = mfma16(a.y, b0.y, c0);
+                c1 = mfma16(a.y, b1.y, c1);
+            }
+    };
+    auto product = [&](int pp, d4& c0, d4& c1, bool negate) {
+        const char* img = (const char*)smem + pp * WORKER_PAIR_BYTES;
+        product_ab(img, img + 32768, c0, c1, negate);
+    };
+    auto update = [&](int pp, d4& c0, d4& c1) { product(pp, c0, c1, true); };
+    // a resident tile (this wave's two accumulators) as the A operand of pair image 0, in the slab layout
+    auto tile_to_image = [&](const d4& c0, const d4& c1, int img_off = 0) {
+        char* img = (char*)smem + img_off;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * wr + crow(lane, r, crow_mode), cc = lane & 15;
+            const unsigned o = (unsigned)(row * 128) + ((unsigned)((cc >> 1) ^ ((row >> 1) & 7)) << 4) + 8u * (cc & 1);
+            *reinterpret_cast<double*>(img + 8192 * (2 * wc) + o) = c0[r];
+            *reinterpret_cast<double*>(img + 8192 * (2 * wc + 1) + o) = c1[r];
+        }
+    };
+
+    // ---- the courier (last workgroup of the launch): row k + 2 of every panel step k ------------------------------------
+    // The chain needs, after its NEXT leaf, the tiles (k+2,k+1) and (k+2,k+2) with the update of column k; that update
+    // needs L(k+2,k) = A(k+2,k) inv_kk^T.  Tile owners reach those three products one flag hop apart (panel tile's owner
+    // -> hand-off tiles' owners), ~9 us after the chain's publication even when they stand waiting for it -- a microsecond
+    // after the chain looks for the tiles (8 us, two thirds into its next leaf), so that it fetches them after the leaf
+    // instead of behind its last panel (+1.3 us of load latency) and often waits for them as well.  The courier does
+    // nothing else: the owners hand it the three tiles of row k + 2 one step EARLY (with the updates of columns < k,
+    // stored to K behind their update of step k - 1; handed[k] counts them), it spins on the chain's publication and runs
+    // the three products back to back (~6 us).
+    if (is_courier) {
+        d4 c1[2], c2[2];
+        for (int k = 0; k + 2 < nb && k < ksteps; ++k) {
+            const int i = k + 2;
+            if (tid == 0) flag_store(progress, 1 + 4 * k);
+            // the three tiles with the updates of columns < k: at k = 0 they are in K (K build / previous launch)
+            if (k > 0 && !wg_wait2(&handed[k], 3, nullptr, 0, err, spin_limit, slot, 6000000 + 1000 * k)) return;
+            const double* s1 = Kb + (long)(64 * i) * ld + 64 * (k + 1);
+            const double* s2 = Kb + (long)(64 * i) * ld + 64 * i;
+            request_blocks(Kb + (long)(64 * i) * ld + 64 * k, nullptr, 0, true, false);          // A(i,k) -> image 0, A part
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                c1[0][r] = at_byte(s1 + r * cstep, csub); c1[1][r] = at_byte(s1 + r * cstep, csub + 128u);
+                c2[0][r] = at_byte(s2 + r * cstep, csub); c2[1][r] = at_byte(s2 + r * cstep, csub + 128u);
+            }
+            if (!wg_wait2(&leafdone[k], 1, &pan1[k], 1, err, spin_limit, slot, 6500000 + 1000 * k)) return;
+            request_blocks(nullptr, Ib + (long)(64 * k) * ld + 64 * k, 0, false);                   // inv_kk -> image 0, B part
+            request_blocks(nullptr, Lb + (long)(64 * (k + 1)) * ld + 64 * k, 1, false);            // L(k+1,k) -> image 1, B part
+            dma_wait<0>();
+            __syncthreads();
+            d4 acc[2] = {d4{0.0, 0.0, 0.0, 0.0}, d4{0.0, 0.0, 0.0, 0.0}};
+            product(0, acc[0], acc[1], false);                                                     // L(i,k)
+            double* dl = Lb + (long)(64 * i) * ld + 64 * k;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                at_byte(dl + r * cstep, csub) = acc[0][r];
+                at_byte(dl + r * cstep, csub + 128u) = acc[1][r];
+            }
+            tile_to_image(acc[0], acc[1], WORKER_PAIR_BYTES);                                      // ... -> image 1, A part
+            __syncthreads();
+            const char* img1 = (const char*)smem + WORKER_PAIR_BYTES;
+            product_ab(img1, img1 + 32768, c1[0], c1[1], true);                                    // (i,k+1) -= L(i,k) L(k+1,k)^T
+            product_ab(img1, img1, c2[0], c2[1], true);                                            // (i,i)   -= L(i,k) L(i,k)^T
+            double* d1 = Kb + (long)(64 * i) * ld + 64 * (k + 1);
+            double* d2 = Kb + (long)(64 * i) * ld + 64 * i;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                at_byte(d1 + r * cstep, csub) = c1[0][r]; at_byte(d1 + r * cstep, csub + 128u) = c1[1][r];
+                at_byte(d2 + r * cstep, csub) = c2[0][r]; at_byte(d2 + r * cstep, csub + 128u) = c2[1][r];
+            }
+            GPMPC_DRAIN_VM();
+            __syncthreads();
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                GPMPC_DRAIN_VM();
+                flag_store(&tdone[2 * k], 1);
+                flag_store(&tdone[2 * k + 1], 1);
+                flag_store(&row2done[k], 1);
+                const int before = __hip_atomic_fetch_add(&pancount[k], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (before + 1 == nb - k - 2) flag_store(&colready[k], 1);
+            }
+            __syncthreads();
+        }
+        return;
+    }
+
+    // One panel step = parts 1, 2, 3 below.  Part 3 may leave its update pipeline once ("look-ahead": the panel tiles of
+    // column k + 1 become L(i,k+1) as soon as inv_{k+1} is out) -- that is a second pass through part 1 with
+    // `ahead` = 1, written as a state of this ONE loop so that every heavy block (panel product, update pipeline)
+    // exists once in the kernel (two copies of the panel product pushed the kernel from 197 to 256 VGPRs + 159 spills).
+    int k = 0, ahead = 0;                            // ahead: bit 0 = early panel tiles are due, bit 1 = early hand-off tiles
+    int li[MAXT], lj[MAXT];            // part 3: coordinates of the resident tiles (scalar registers)
+    unsigned live = 0, urgent = 0, hand = 0, todo = 0;   //     masks: live this step / column k + 1 / next hand-off tiles / not yet updated
+    bool early = false, earlyh = false;              //         tiles of column k + 1 wait for inv_{k+1} / hand-off tiles for row k + 3
+    bool give = false;                               //         this step hands the tiles of row k + 3 to the courier
+    int givepend = 0;                                //         tiles stored for the courier whose count is not yet published
+    int peekv = 0, cur = -1, pp = 0;                 //         bit 0: leafdone[k+1], bit 1: row2done[k+1] and pan1[k+1], as last seen
+                                                     //         by thread 0; pipeline state
+    for (; k + 2 < nb && k < ksteps;) {
+        if (!ahead) WORKER_STAMP(0);
         auto request = [&](int i, int j, int pp) {
             request_blocks(Lb + (long)(64 * i) * ld + 64 * k, Lb + (long)(64 * j) * ld + 64 * k, pp, true);
         };
-        // c0, c1 += sgn * A B^T on this wave's 16 x 32 piece, operands from the landed pair image pp
-        auto product = [&](int pp, d4& c0, d4& c1, bool negate) {
-            const char* img = (const char*)smem + pp * WORKER_PAIR_BYTES;
-#pragma unroll 1
-            for (int sl = 0; sl < 4; ++sl)             // (fully unrolled, the 24 fragment loads are hoisted and spill)
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    double2 a = *reinterpret_cast<const double2*>(img + 8192 * sl + (h ? fa1 : fa0));
-                    const double2 b0 = *reinterpret_cast<const double2*>(img + 8192 * sl + (h ? fb1 : fb0));
-                    const double2 b1 = *reinterpret_cast<const double2*>(img + 8192 * sl + 2048 + (h ? fb1 : fb0));
-                    if (negate) { a.x = -a.x; a.y = -a.y; }
-                    c0 = mfma16(a.x, b0.x, c0);
-                    c1 = mfma16(a.x, b1.x, c1);
-                    c0 = mfma16(a.y, b0.y, c0);
-                    c1 = mfma16(a.y, b1.y, c1);
-                }
-        };
-        auto update = [&](int pp, d4& c0, d4& c1) { product(pp, c0, c1, true); };
-        // a resident tile (this wave's two accumulators) as the A operand of pair image 0, in the slab layout
-        auto tile_to_image = [&](const d4& c0, const d4& c1) {
-            char* img = (char*)smem;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = 16 * wr + crow(lane, r, crow_mode), cc = lane & 15;
-                const unsigned o = (unsigned)(row * 128) + ((unsigned)((cc >> 1) ^ ((row >> 1) & 7)) << 4) + 8u * (cc & 1);
-                *reinterpret_cast<double*>(img + 8192 * (2 * wc) + o) = c0[r];
-                *reinterpret_cast<double*>(img + 8192 * (2 * wc + 1) + o) = c1[r];
-            }
-        };
         // ---- 1. panel tiles of column k.  Column 0 never receives an update, so its tiles are not kept in
         //         registers: at k = 0 worker w takes rows 2 + w, 2 + w + NW, ... straight from K.
-        for (int i = 2 + w; k == 0 && !ahead && i < nb; i += NW) {
+        for (int i = (has_courier ? 3 : 2) + w; k == 0 && !ahead && i < nb; i += NW) {      // (row 2: the courier's)
             if (tid == 0) flag_store(progress, 1 + 4 * k + 1);
             if (!wg_wait2(&leafdone[0], 1, nullptr, 0, err, spin_limit, slot, 2000000 + w)) return;
             request_blocks(Kb + (long)(64 * i) * ld, Ib, 0, true);                  // A(i,0), inv_00
@@ -239,7 +324,7 @@ __global__ void __launch_bounds__(WORKER_THREADS) chol_worker_kernel(double* Kma
         const int kk = k + (ahead ? 1 : 0);                // the step whose panel / hand-off tiles are due
         if (!ahead || (ahead & 1)) {
 #pragma unroll
-            for (int n = 0; n < WORKER_MAXT; ++n) {
+            for (int n = 0; n < MAXT; ++n) {
                 const int i = __builtin_amdgcn_readfirstlane(ti[n]), j = __builtin_amdgcn_readfirstlane(tj[n]);
                 if (i < 0 || j != kk) continue;            // (workgroup-uniform)
                 if (tid == 0) flag_store(progress, 1 + 4 * kk + 1);
@@ -270,10 +355,10 @@ __global__ void __launch_bounds__(WORKER_THREADS) chol_worker_kernel(double* Kma
                 __syncthreads();
             }
         }
-        // ---- 2. (kk+2,kk+1), (kk+2,kk+2) for the chain
-        if (!ahead || (ahead & 2)) {
+        // ---- 2. (kk+2,kk+1), (kk+2,kk+2) for the chain (with a courier: its job, the tiles were handed to it a step ago)
+        if (!has_courier && (!ahead || (ahead & 2))) {
 #pragma unroll
-            for (int n = 0; n < WORKER_MAXT; ++n) {
+            for (int n = 0; n < MAXT; ++n) {
                 const int i = __builtin_amdgcn_readfirstlane(ti[n]), j = __builtin_amdgcn_readfirstlane(tj[n]);
                 if (i != kk + 2 || j <= kk) continue;      // j is kk+1 or kk+2
                 if (tid == 0) flag_store(progress, 1 + 4 * kk + 2);
@@ -297,12 +382,14 @@ __global__ void __launch_bounds__(WORKER_THREADS) chol_worker_kernel(double* Kma
         auto coords = [&](int m, int& ci, int& cj) {   // li[m], lj[m] for a run-time m (scalar selects)
             ci = li[0]; cj = lj[0];
 #pragma unroll
-            for (int q = 1; q < WORKER_MAXT; ++q)
+            for (int q = 1; q < MAXT; ++q)
                 if (q == m) { ci = li[q]; cj = lj[q]; }
         };
         // order of part 3: panel tiles of the next step, then its hand-off tiles, then by slot
         auto pick = [&](unsigned t) {
-            return t == 0 ? -1 : __builtin_ctz((t & urgent) ? (t & urgent) : (t & hand) ? (t & hand) : t);
+            if (t == 0) return -1;
+            if (has_courier) return (int)__builtin_ctz((t & hand) ? (t & hand) : (t & urgent) ? (t & urgent) : t);
+            return (int)__builtin_ctz((t & urgent) ? (t & urgent) : (t & hand) ? (t & hand) : t);
         };
         if (ahead) {
             // back from the early products: the rest of this step's updates, pipeline restarted
@@ -331,15 +418,20 @@ __global__ void __launch_bounds__(WORKER_THREADS) chol_worker_kernel(double* Kma
         // them only after its whole part 3, and the chain, one step ahead thanks to the early panel products, would
         // stand waiting for it every other step (seen in the time stamps: 0.6 / 16 / 0.6 / 22 us).
         live = 0; urgent = 0; hand = 0;
-        const bool look = lookahead && k + 1 < ksteps && k + 3 < nb;   // the next step belongs to this launch and has panel tiles
+        const bool next_here = k + 1 < ksteps && k + 3 < nb;           // the next step belongs to this launch and has panel tiles
+        const bool look = lookahead && next_here;
+        // with a courier: the three tiles of row k + 3 go to it behind this step's update (stored to K, handed[k+1]);
+        // they come first, no product of step k + 1 is this worker's any more
+        give = has_courier && next_here;
 #pragma unroll
-        for (int n = 0; n < WORKER_MAXT; ++n) {
+        for (int n = 0; n < MAXT; ++n) {
             li[n] = __builtin_amdgcn_readfirstlane(ti[n]);
             lj[n] = __builtin_amdgcn_readfirstlane(tj[n]);
             if (li[n] >= 0 && lj[n] > k) {
                 live |= 1u << n;
-                if (look && lj[n] == k + 1) urgent |= 1u << n;
-                if (look && li[n] == k + 3 && lj[n] >= k + 2) hand |= 1u << n;
+                if (give && li[n] == k + 3) hand |= 1u << n;
+                else if (look && lj[n] == k + 1) urgent |= 1u << n;
+                else if (look && !has_courier && li[n] == k + 3 && lj[n] >= k + 2) hand |= 1u << n;
             }
         }
         if (live == 0) { ++k; continue; }
@@ -348,8 +440,9 @@ __global__ void __launch_bounds__(WORKER_THREADS) chol_worker_kernel(double* Kma
         WORKER_STAMP(2);
         todo = live;                                   // tiles still to update; order: the urgent ones, then by slot
         early = urgent != 0;
-        earlyh = hand != 0;
+        earlyh = hand != 0 && !has_courier;
         peekv = 0;
+        givepend = 0;
         cur = pick(todo);
         {
             int ci, cj;
@@ -362,7 +455,7 @@ __global__ void __launch_bounds__(WORKER_THREADS) chol_worker_kernel(double* Kma
 #pragma unroll 1
         while (cur >= 0 && !stop) {
 #pragma unroll
-            for (int n = 0; n < WORKER_MAXT; ++n) {
+            for (int n = 0; n < MAXT; ++n) {
                 if (n != cur || stop) continue;        // (slots before the first / between live tiles)
                 todo &= ~(1u << n);
                 const int nxt = pick(todo);
@@ -377,12 +470,30 @@ __global__ void __launch_bounds__(WORKER_THREADS) chol_worker_kernel(double* Kma
                     const int go = slot[1 + pp];
                     if (go != 0) { stop = true; ahead = go; }
                 }
+                if (givepend) {                        // the stores of the tiles given away have drained (dma_wait<0> above
+                    if (tid == 0) {                    // is vmcnt(0)) in every wave: barrier passed -> publish the count
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                        GPMPC_DRAIN_VM();
+                        __hip_atomic_fetch_add(&handed[k + 1], givepend, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    givepend = 0;
+                }
                 if (nxt >= 0 && !stop) {
                     int ci, cj;
                     coords(nxt, ci, cj);
                     request(ci, cj, pp ^ 1);
                 }
                 update(pp, C[n][0], C[n][1]);
+                if (give && ((hand >> n) & 1u)) {      // a tile of row k + 3: to K for the courier, retired here
+                    double* dst = Kb + (long)(64 * li[n]) * ld + 64 * lj[n];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        at_byte(dst + r * cstep, csub) = C[n][0][r];
+                        at_byte(dst + r * cstep, csub + 128u) = C[n][1][r];
+                    }
+                    if (tid == 0) ti[n] = -1;
+                    ++givepend;
+                }
                 if (any_early && tid == 0) {           // consumed at the next tile: the latency hides behind it
                     peekv = 0;
                     if (early && flag_load(&leafdone[k + 1]) >= 1) peekv |= 1;
@@ -396,7 +507,16 @@ __global__ void __launch_bounds__(WORKER_THREADS) chol_worker_kernel(double* Kma
 #endif
             }
         }
+        if (givepend) GPMPC_DRAIN_VM();                // (a tile given away by the last iteration: its stores)
         __syncthreads();                               // the pair images alias A and B of the next step / of the early product
+        if (givepend) {
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                GPMPC_DRAIN_VM();
+                __hip_atomic_fetch_add(&handed[k + 1], givepend, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            givepend = 0;
+        }
         if (stop) continue;                            // pipeline drained (nothing requested): parts 1 / 2 of step k + 1 as `ahead` says, then back
         WORKER_STAMP(3);
         ++k;
@@ -406,7 +526,7 @@ __global__ void __launch_bounds__(WORKER_THREADS) chol_worker_kernel(double* Kma
     // kb + ksteps on, with fewer workers -- the freed CUs take the inverse pipeline) reloads them
     if (k + 2 < nb) {
 #pragma unroll
-        for (int n = 0; n < WORKER_MAXT; ++n) {
+        for (int n = 0; n < MAXT; ++n) {
             const int i = __builtin_amdgcn_readfirstlane(ti[n]), j = __builtin_amdgcn_readfirstlane(tj[n]);
             if (i < 0) continue;
             double* dst = Kb + (long)(64 * i) * ld + 64 * j;
