@@ -2,7 +2,7 @@
 # round-3 refresh of the judged artefacts: GPU tests, smoke, bench lines (C2 with CPU baseline, C3), kernel trace,
 # PMC passes of the bench step (one counter group per run), secondary configs.  Everything lands in gpurun_out/r03_*.
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out
-timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -3
+timeout 1200 python -m pytest tests -m gpu -q > gpurun_out/r03_gpu_tests.txt 2>&1; grep -E "passed|failed|error" gpurun_out/r03_gpu_tests.txt | tail -3
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
 timeout 600 python bench.py > gpurun_out/r03_bench.json 2> gpurun_out/r03_bench.err; tail -c 600 gpurun_out/r03_bench.json; echo
 timeout 600 python bench.py --config C3 > gpurun_out/r03_bench_c3.json 2> gpurun_out/r03_bench_c3.err; cut -c1-900 gpurun_out/r03_bench_c3.json
