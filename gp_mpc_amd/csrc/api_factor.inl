@@ -9,6 +9,8 @@ static GemmP gemm_base(const Ctx& cx) {
     return p;
 }
 
+static int g_worker_courier = -1;   // gpmpc_set_tuning("worker_courier", 0 / 1): tile owners only / with the courier; -1: GPMPC_COURIER or default
+
 // Fit factorisation = right-looking blocked Cholesky (NB = 64) + level-by-level batched triangular
 // inverse.  K is consumed (trailing updates in place), L and Inv = L^-1 are written; [batch][Np x Np].
 //
@@ -326,7 +328,8 @@ static bool factor_chain(const Ctx& cx, Workspace& ws, int spin_limit, bool flag
     int NW = ws.batch == 1 ? cx.workers - cx.workers / 8 : 0;
     // the last workgroup of every worker launch is the chain's courier (chol_worker.hpp), no tile owner; GPMPC_COURIER=0:
     // tile owners only (r03 A/B on one box: factor 1.675 -> 1.630 ms at C2 with the courier)
-    static const bool worker_courier = !(getenv("GPMPC_COURIER") && atoi(getenv("GPMPC_COURIER")) == 0);
+    static const bool worker_courier_env = !(getenv("GPMPC_COURIER") && atoi(getenv("GPMPC_COURIER")) == 0);
+    const bool worker_courier = g_worker_courier >= 0 ? g_worker_courier != 0 : worker_courier_env;   // (gpmpc_set_tuning("worker_courier", ..))
     const int ncour = worker_courier ? 1 : 0;
     const int worker_maxt = worker_courier ? WORKER_MAXT_COURIER : WORKER_MAXT;
     if (NW > ntiles + ncour) NW = ntiles + ncour;

@@ -86,6 +86,11 @@ extern "C" int gpmpc_set_tuning(const char* name, int value) {
         g_cu_count[0] = value;
         return GPMPC_OK;
     }
+    if (std::strcmp(name, "worker_courier") == 0) {      // which worker kernel the chained factorisation launches (chol_worker.hpp)
+        if (value < -1 || value > 1) return fail(GPMPC_EINVAL, "worker_courier must be -1 (default), 0 or 1");
+        g_worker_courier = value;
+        return GPMPC_OK;
+    }
     if (std::strcmp(name, "fail_nll_after") == 0) {      // fault injection for the tests of the restart shard's failure paths
         if (value < 0) return fail(GPMPC_EINVAL, "fail_nll_after must be >= 0");
         g_fail_nll_after = value;

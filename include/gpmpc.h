@@ -257,6 +257,8 @@ int gpmpc_dgemm(int device, int transa, int transb, int M, int N, int K, double 
  * real count on a GPU; the emulated build accepts up to 64 so that the multi-launch worker schedules can be
  * exercised).  "fail_nll_after": n > 0 makes the n-th gpmpc_nll evaluation from now on return GPMPC_EHIP without touching
  * the device (fault injection: how the tests reach the failure paths of the restart shard); 0 switches it off.
+ * "worker_courier": 1 / 0 = the tile-owner worker launches of the chained factorisation run with / without the courier
+ * workgroup (two instantiations of one kernel; default 1, or GPMPC_COURIER), -1 back to the default.
  * Returns GPMPC_EINVAL for an unknown name or value. */
 int gpmpc_set_tuning(const char* name, int value);
 

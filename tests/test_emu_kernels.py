@@ -71,6 +71,16 @@ def test_emu_tile_owner_workers(emu):
     pc.check_synthetic(emu, N=700, d=3, Ny=1, B=10, sn=0.1, strict_rel=True)
 
 
+def test_emu_tile_owner_workers_without_courier(emu):
+    # the same schedules with the nine-slot kernel: tile owners make the chain's hand-off tiles themselves
+    emu.set_tuning('worker_courier', 0)
+    try:
+        pc.check_synthetic(emu, N=560, d=4, Ny=1, B=30, sn=0.1, strict_rel=True)
+        pc.check_synthetic(emu, N=700, d=3, Ny=1, B=10, sn=0.1, strict_rel=True)
+    finally:
+        emu.set_tuning('worker_courier', -1)
+
+
 def test_emu_three_worker_launches(emu):
     # Np = 960 with 14 emulated workers: blocks 0-7, 8-11 and 12-14 as three worker launches, the inverse of the
     # left half behind the second and of the third quarter behind the third (factor_chain, split3)

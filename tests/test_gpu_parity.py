@@ -114,8 +114,20 @@ def test_moment_methods(lib, tank):
 def test_worker_path_odd_size(lib):
     # Np = 4032 = 63 blocks: tile-owner workers in two launches (32 + 31 blocks), tree with an unbalanced root
     pc.check_synthetic(lib, N=4000, d=6, Ny=1, B=200, sn=1e-2, strict_rel=False)
-    # Np = 4160 = 65 blocks: one tile too many for the workers' registers -> chain kernel + flagged GEMM launches
+    # Np = 4160 = 65 blocks: 2079 tiles, ten slots of 223 owners hold them (r03; the nine-slot kernel below does not:
+    # chain kernel + flagged GEMM launches)
     pc.check_synthetic(lib, N=4100, d=6, Ny=1, B=50, sn=1e-2, strict_rel=False)
+
+
+def test_worker_path_without_courier(lib):
+    # the nine-slot instantiation of the worker kernel (tile owners make the chain's hand-off tiles themselves)
+    lib.set_tuning('worker_courier', 0)
+    try:
+        pc.check_synthetic(lib, N=4096, d=6, Ny=1, B=100, sn=1e-2, strict_rel=False)
+        pc.check_synthetic(lib, N=4000, d=6, Ny=1, B=50, sn=1e-2, strict_rel=False)
+        pc.check_synthetic(lib, N=4100, d=6, Ny=1, B=50, sn=1e-2, strict_rel=False)
+    finally:
+        lib.set_tuning('worker_courier', -1)
 
 
 def test_small_batch_chunks(lib):
