@@ -413,12 +413,16 @@ static bool factor_chain(const Ctx& cx, Workspace& ws, int spin_limit, bool flag
     const bool pipelined = !use_workers && cx.aux && cx.seg && Np >= 4 * SEGR;
     int seg_done = 0;
     bool s_ready_recorded = false;
+    // leafdone[k] together with pan1[k] (one release less on the chain's path; r01-r02 default next to workers) or on its own
+    // right behind the leaf: since the courier and the workers' look-ahead start from inv_kk, the early publication wins
+    // (r03 A/B: chain 1.310 -> 1.302 ms).  GPMPC_MERGE_PUBLISH=1: the old way.
+    static const bool merge_publish = getenv("GPMPC_MERGE_PUBLISH") && atoi(getenv("GPMPC_MERGE_PUBLISH")) != 0;
     static const int late_polls = getenv("GPMPC_LATE_POLLS") ? atoi(getenv("GPMPC_LATE_POLLS")) : 3;   // (tuning aid, chol_chain.hpp land())
     {   // the chain kernel ends with the last leaf, i.e. when L is complete: its duration is the Cholesky's
         ProfScope t(cx.prof, cx.stream, GPMPC_PH_CHAIN);
         hipLaunchKernelGGL(chol_chain_kernel, dim3(1, 1, ws.batch), dim3(256), CHAIN_LDS_BYTES, cx.stream, (const double*)ws.K,
                            ws.L, ws.Inv, ld, sM, nb, ws.flags, (long)nf, ws.info, cx.crow_mode, spin_limit, g_chain_trace,
-                           use_workers ? 1 : 0, 0, -1, late_polls);
+                           use_workers && merge_publish ? 1 : 0, 0, -1, late_polls);
     }
     static const bool verbose = getenv("GPMPC_VERBOSE") != nullptr;
     // (tuning aid) GPMPC_WORKER_LOOKAHEAD=0: the workers turn a panel tile into L(i,k) only at the top of step k

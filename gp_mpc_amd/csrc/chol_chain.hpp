@@ -59,19 +59,29 @@ __global__ void __launch_bounds__(64) flag_gate_kernel(int* flags, long sFlags, 
 // r (r + 1) / 2 + c; entries above the diagonal do not exist there and are not needed: nothing reads S above it).
 __device__ __forceinline__ void chain_diag_tiles(double* S, const double* U, const double* Qp, bool from_q, int who, int nwho,
                                                  int part, int lane, int crow_mode) {
-    int cnt = 0;
-    for (int i = part; i < 4; ++i)
-        for (int j = part; j <= (part ? i : 0); ++j, ++cnt) {
-            if (cnt % nwho != who) continue;
-            d4 acc = d4{0.0, 0.0, 0.0, 0.0};
-            acc = lds_mm16<true>(U, 16 * i, 0, U, 16 * j, 0, 64, lane, acc);
+    auto subtract = [&](int i, int j, const d4& acc) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int rr = 16 * i + crow(lane, r, crow_mode), cc = 16 * j + (lane & 15);
-                const double a = from_q ? (cc <= rr ? Qp[rr * (rr + 1) / 2 + cc] : 0.0) : S[rr * LS + cc];
-                S[rr * LS + cc] = a - acc[r];
-            }
+        for (int r = 0; r < 4; ++r) {
+            const int rr = 16 * i + crow(lane, r, crow_mode), cc = 16 * j + (lane & 15);
+            const double a = from_q ? (cc <= rr ? Qp[rr * (rr + 1) / 2 + cc] : 0.0) : S[rr * LS + cc];
+            S[rr * LS + cc] = a - acc[r];
         }
+    };
+    // this caller's tiles: at most two (part 1: six tiles over three waves); their products run interleaved
+    int cnt = 0, mine = 0, ti[2] = {0, 0}, tj[2] = {0, 0};
+    for (int i = part; i < 4; ++i)
+        for (int j = part; j <= (part ? i : 0); ++j, ++cnt)
+            if (cnt % nwho == who && mine < 2) { ti[mine] = i; tj[mine] = j; ++mine; }
+    if (mine == 2) {
+        d4 a0 = d4{0.0, 0.0, 0.0, 0.0}, a1 = a0;
+        lds_mm16k_x2<true, 64>(U, 16 * ti[0], 16 * ti[1], 0, U, 16 * tj[0], 16 * tj[1], 0, lane, a0, a1);
+        subtract(ti[0], tj[0], a0);
+        subtract(ti[1], tj[1], a1);
+    } else if (mine == 1) {
+        d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+        acc = lds_mm16<true>(U, 16 * ti[0], 0, U, 16 * tj[0], 0, 64, lane, acc);
+        subtract(ti[0], tj[0], acc);
+    }
 }
 
 __global__ void __launch_bounds__(256) chol_chain_kernel(const double* Kmat, double* L, double* Inv, long ld, long sBatch,
@@ -138,13 +148,28 @@ __global__ void __launch_bounds__(256) chol_chain_kernel(const double* Kmat, dou
             bool* pre; double* P; double* Qp;
             double* S; const double* U; int defer, crow_mode;     // defer: 0 none, 1 = S holds A(k,k), 2 = Qp does
             int late_polls;
+            long long* trace; int k;                 // (developer aid: the leaf's own time stamps, tools/chain_trace.py)
+            __device__ __forceinline__ void stamp(int i) {
+#ifndef GPMPC_EMULATED
+                if (trace && tid == 0) trace[200000 + k * 16 + i] = wall_clock64();
+#endif
+            }
             // the six tiles of columns 16-63 of A(k,k) -= L(k,k-1) L(k,k-1)^T that the previous step left for now
             __device__ __forceinline__ void first() {
                 if (defer) chain_diag_tiles(S, U, Qp, defer == 2, wave - 1, 3, 1, tid & 63, crow_mode);
             }
+            // Called by every wave in front of the barrier behind the third panel -- which waves 2 and 3 reach right after
+            // the barrier behind the second one, having nothing to do in between: the look at the hand-off flags is wave 3's
+            // (thread 192), next to wave 0's third panel.  (r01-r03 had thread 0 do it: two dependent flag loads and the
+            // acquire, 2-3 us, on the one wave every other wave of the leaf waits for.)  A few polls: the look comes a
+            // panel earlier than it did.
             __device__ __forceinline__ void before() {
-                if (active && tid == 0) {
-                    const int ok = !f0 || (flag_load(f0) >= 1 && flag_load(f1) >= 1);
+                if (active && tid == 192) {
+                    int ok = !f0;
+                    for (int it = 0; it < 3 && !ok; ++it) {
+                        ok = flag_load(f0) >= 1 && flag_load(f1) >= 1;
+                        if (!ok) __builtin_amdgcn_s_sleep(4);
+                    }
                     if (ok && f0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                     *slot = ok;
                 }
@@ -194,7 +219,7 @@ __global__ void __launch_bounds__(256) chol_chain_kernel(const double* Kmat, dou
                 }
             }
         } pf{Kb, o10, o11, ld, k > kb ? &tdone[2 * (k - 1)] : nullptr, k > kb ? &tdone[2 * (k - 1) + 1] : nullptr, slot, tid, wave,
-             k + 1 < ke, &pre, P, Qp, S, U, defer, crow_mode, late_polls};
+             k + 1 < ke, &pre, P, Qp, S, U, defer, crow_mode, late_polls, blockIdx.z == 0 ? trace : nullptr, k};
         defer = 0;
         if (tid == 0) { slot[2] = 0; slot[3] = 0; }       // (read after the leaf's barriers, written behind its third one)
         const int bad = leaf_body(S, T, U, Dr, 1, 15, crow_mode, pf);
@@ -211,8 +236,8 @@ __global__ void __launch_bounds__(256) chol_chain_kernel(const double* Kmat, dou
             *reinterpret_cast<double2*>(&Lb[o + (long)rr * ld + cc]) = l;
             *reinterpret_cast<double2*>(&Ib[o + (long)rr * ld + cc]) = v;
         }
-        // merge_publish (tile-owner workers, which have slack): leafdone[k] goes out together with pan1[k]
-        // a few microseconds later, saving one L2 write-back per step on this critical path
+        // merge_publish: leafdone[k] goes out together with pan1[k] a few microseconds later, saving one L2 write-back per
+        // step on this critical path (off by default since r03: the courier and the workers' look-ahead want inv_kk early)
         if (!merge_publish || k + 1 == ke) wg_publish(&leafdone[k], 1);
         CHAIN_STAMP(2);
         if (k + 1 == ke) break;

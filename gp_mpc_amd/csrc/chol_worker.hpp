@@ -57,7 +57,9 @@ __global__ void __launch_bounds__(WORKER_THREADS) chol_worker_kernel(double* Kma
     // optional time stamps (100 MHz wall clock) for tools/worker_trace.py: [launch][worker][step][4] from entry 4096 on
 #ifdef GPMPC_EMULATED
 #define WORKER_STAMP(i) ((void)0)
+#define COURIER_STAMP(i) ((void)0)
 #else
+#define COURIER_STAMP(i) do { if (trace && threadIdx.x == 0) trace[300000 + (kb + k) * 8 + (i)] = wall_clock64(); } while (0)
 #define WORKER_STAMP(i) do { if (trace && threadIdx.x == 0) trace[4096 + ((((kb ? 1L : 0L) * 256 + blockIdx.x) * 64 + (kb + k)) * 4) + (i)] = wall_clock64(); } while (0)
 #endif
     double* smem = GPMPC_DYN_SMEM();
@@ -219,26 +221,29 @@ __global__ void __launch_bounds__(WORKER_THREADS) chol_worker_kernel(double* Kma
     // after the chain looks for the tiles (8 us, two thirds into its next leaf), so that it fetches them after the leaf
     // instead of behind its last panel (+1.3 us of load latency) and often waits for them as well.  The courier does
     // nothing else: the owners hand it the three tiles of row k + 2 one step EARLY (with the updates of columns < k,
-    // stored to K behind their update of step k - 1; handed[k] counts them), it spins on the chain's publication and runs
-    // the three products back to back (~6 us).
+    // stored to K behind their update of step k - 1; handed[k] counts them), it spins on the chain's publications and runs
+    // the products as their operands appear: L(k+2,k) and the diagonal tile behind inv_kk, the other tile behind the panel row.
     if (is_courier) {
         d4 c1[2], c2[2];
         for (int k = 0; k + 2 < nb && k < ksteps; ++k) {
             const int i = k + 2;
             if (tid == 0) flag_store(progress, 1 + 4 * k);
-            // the three tiles with the updates of columns < k: at k = 0 they are in K (K build / previous launch)
-            if (k > 0 && !wg_wait2(&handed[k], 3, nullptr, 0, err, spin_limit, slot, 6000000 + 1000 * k)) return;
+            // the three tiles with the updates of columns < k: at k = 0 they are in K (K build / previous launch).  They arrive
+            // with or after inv_kk (time stamps, tools/courier_trace.py), so both are awaited together and everything is
+            // requested at once -- a flag poll BEHIND the tile loads would wait for them (in-order return), 3-4 us.
+            if (!wg_wait2(&leafdone[k], 1, k > 0 ? &handed[k] : nullptr, 3, err, spin_limit, slot, 6000000 + 1000 * k)) return;
+            COURIER_STAMP(0);
             const double* s1 = Kb + (long)(64 * i) * ld + 64 * (k + 1);
             const double* s2 = Kb + (long)(64 * i) * ld + 64 * i;
-            request_blocks(Kb + (long)(64 * i) * ld + 64 * k, nullptr, 0, true, false);          // A(i,k) -> image 0, A part
+            // stage 1: L(i,k) like every other tile of the panel column -- the workers' step k waits for the whole column
+            // (colready) -- and the diagonal tile
+            request_blocks(Kb + (long)(64 * i) * ld + 64 * k, Ib + (long)(64 * k) * ld + 64 * k, 0, true);   // A(i,k), inv_kk -> image 0
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 c1[0][r] = at_byte(s1 + r * cstep, csub); c1[1][r] = at_byte(s1 + r * cstep, csub + 128u);
                 c2[0][r] = at_byte(s2 + r * cstep, csub); c2[1][r] = at_byte(s2 + r * cstep, csub + 128u);
             }
-            if (!wg_wait2(&leafdone[k], 1, &pan1[k], 1, err, spin_limit, slot, 6500000 + 1000 * k)) return;
-            request_blocks(nullptr, Ib + (long)(64 * k) * ld + 64 * k, 0, false);                   // inv_kk -> image 0, B part
-            request_blocks(nullptr, Lb + (long)(64 * (k + 1)) * ld + 64 * k, 1, false);            // L(k+1,k) -> image 1, B part
+            COURIER_STAMP(1);
             dma_wait<0>();
             __syncthreads();
             d4 acc[2] = {d4{0.0, 0.0, 0.0, 0.0}, d4{0.0, 0.0, 0.0, 0.0}};
@@ -249,13 +254,28 @@ __global__ void __launch_bounds__(WORKER_THREADS) chol_worker_kernel(double* Kma
                 at_byte(dl + r * cstep, csub) = acc[0][r];
                 at_byte(dl + r * cstep, csub + 128u) = acc[1][r];
             }
+            GPMPC_DRAIN_VM();                                                                      // L(i,k) is out: the column count
             tile_to_image(acc[0], acc[1], WORKER_PAIR_BYTES);                                      // ... -> image 1, A part
             __syncthreads();
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                GPMPC_DRAIN_VM();
+                flag_store(&row2done[k], 1);
+                const int before = __hip_atomic_fetch_add(&pancount[k], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (before + 1 == nb - k - 2) flag_store(&colready[k], 1);
+            }
             const char* img1 = (const char*)smem + WORKER_PAIR_BYTES;
-            product_ab(img1, img1 + 32768, c1[0], c1[1], true);                                    // (i,k+1) -= L(i,k) L(k+1,k)^T
             product_ab(img1, img1, c2[0], c2[1], true);                                            // (i,i)   -= L(i,k) L(i,k)^T
             double* d1 = Kb + (long)(64 * i) * ld + 64 * (k + 1);
             double* d2 = Kb + (long)(64 * i) * ld + 64 * i;
+            COURIER_STAMP(2);                       // (its stores wait until the end: a flag poll behind stores waits for them)
+            // stage 2, behind the chain's panel row: the off-diagonal tile, then both go to the chain
+            if (!wg_wait2(&pan1[k], 1, nullptr, 0, err, spin_limit, slot, 6600000 + 1000 * k)) return;
+            COURIER_STAMP(3);
+            request_blocks(nullptr, Lb + (long)(64 * (k + 1)) * ld + 64 * k, 1, false);            // L(k+1,k) -> image 1, B part
+            dma_wait<0>();
+            __syncthreads();
+            product_ab(img1, img1 + 32768, c1[0], c1[1], true);                                    // (i,k+1) -= L(i,k) L(k+1,k)^T
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 at_byte(d1 + r * cstep, csub) = c1[0][r]; at_byte(d1 + r * cstep, csub + 128u) = c1[1][r];
@@ -268,10 +288,8 @@ __global__ void __launch_bounds__(WORKER_THREADS) chol_worker_kernel(double* Kma
                 GPMPC_DRAIN_VM();
                 flag_store(&tdone[2 * k], 1);
                 flag_store(&tdone[2 * k + 1], 1);
-                flag_store(&row2done[k], 1);
-                const int before = __hip_atomic_fetch_add(&pancount[k], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (before + 1 == nb - k - 2) flag_store(&colready[k], 1);
             }
+            COURIER_STAMP(4);
             __syncthreads();
         }
         return;

@@ -31,6 +31,30 @@ __device__ __forceinline__ d4 lds_mm16(const double* Sa, int ar, int ac, const d
     return acc;
 }
 
+// Two independent products of one wave, K known at compile time: all fragments are fetched first, then the matrix
+// instructions of the two dependency chains alternate.  lds_mm16's loop is "two LDS reads, wait, one matrix instruction that
+// depends on the previous one", ~200 cycles per step of 4 in K of which the instruction itself is 64 (in-kernel stamps, r03:
+// the chain's two K = 64 diagonal-update tiles per wave took 3.0 us, 2.2 us this way; for ONE chain, and for the K = 16
+// products of the leaf, fetching first measured slower).  Same order of the summation per product: bit-identical results.
+template <bool BT, int K>
+__device__ __forceinline__ void lds_mm16k_x2(const double* Sa, int ar0, int ar1, int ac, const double* Sb, int br0, int br1,
+                                             int bc, int lane, d4& acc0, d4& acc1) {
+    const int fr = lane & 15, fk = lane >> 4;
+    double a0[K / 4], b0[K / 4], a1[K / 4], b1[K / 4];
+#pragma unroll
+    for (int q = 0; q < K / 4; ++q) {
+        a0[q] = Sa[(ar0 + fr) * LS + ac + 4 * q + fk];
+        b0[q] = BT ? Sb[(br0 + fr) * LS + bc + 4 * q + fk] : Sb[(br0 + 4 * q + fk) * LS + bc + fr];
+        a1[q] = Sa[(ar1 + fr) * LS + ac + 4 * q + fk];
+        b1[q] = BT ? Sb[(br1 + fr) * LS + bc + 4 * q + fk] : Sb[(br1 + 4 * q + fk) * LS + bc + fr];
+    }
+#pragma unroll
+    for (int q = 0; q < K / 4; ++q) {
+        acc0 = mfma16(a0[q], b0[q], acc0);
+        acc1 = mfma16(a1[q], b1[q], acc1);
+    }
+}
+
 __device__ __forceinline__ void lds_put16(double* S, int r0, int c0, d4 v, double scale, int lane, int mode) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) S[(r0 + crow(lane, r, mode)) * LS + c0 + (lane & 15)] = scale * v[r];
@@ -149,9 +173,11 @@ __device__ __forceinline__ double rsqrt_newton(double x) {
 // No per-column test of the pivot: a non-positive or NaN pivot makes y NaN (rsq of a negative; 0 x inf in the
 // correction), the NaN spreads to every later column, so ONE test of the last y decides, and only then the stored
 // reciprocals are scanned for the first bad column (same `info` as the per-column test of panel_potrf).
-template <int TT, int MODE>
-__device__ __forceinline__ int panel_potrf_dpp(double* S, double* Drinv, int lane) {
-    constexpr int o = 16 * TT;
+// o = 16 x panel index at RUN time: the leaf then holds this code once, not four times (the chain kernel's 55 KB of
+// straight-line code do not stay in the 64 KB instruction cache it shares with a neighbour CU, and refetching them through
+// a busy L2 cost the leaf ~3 us per call: tools/ubench/leaf_icache_bench.hip).
+template <int MODE>
+__device__ __forceinline__ int panel_potrf_dpp_at(double* S, double* Drinv, int lane, const int o) {
     const int r = lane, i = lane & 15;
     double a[16], d[16];
 #pragma unroll
@@ -196,6 +222,11 @@ __device__ __forceinline__ int panel_potrf_dpp(double* S, double* Drinv, int lan
         }
     }
     return bad;
+}
+
+template <int TT, int MODE>
+__device__ __forceinline__ int panel_potrf_dpp(double* S, double* Drinv, int lane) {
+    return panel_potrf_dpp_at<MODE>(S, Drinv, lane, 16 * TT);
 }
 
 // One wave: inverse of the 16 x 16 lower-triangular block at (o,o) of S into T, DPP form of inv16: lane (q, r) owns row r of
@@ -254,6 +285,7 @@ struct LeafNoHook {
     __device__ __forceinline__ void before() {}
     __device__ __forceinline__ void after() {}
     __device__ __forceinline__ void land() {}
+    __device__ __forceinline__ void stamp(int) {}
 };
 
 template <class Hook>
@@ -264,13 +296,17 @@ __device__ __forceinline__ int leaf_body(double* S, double* T, double* U, double
     //  one role keeps in registers -- the chain kernel's prefetch in waves 2 and 3 -- is not live in the others' code)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int bad = -1;
+    hook.stamp(0);
     if (do_chol) {
+#if GPMPC_LEAF_DPP
+#pragma unroll 1
+#else
 #pragma unroll
+#endif
         for (int t = 0; t < 4; ++t) {
             if (wave == 0 && (phases & 1)) {
 #if GPMPC_LEAF_DPP
-                const int b = t == 0 ? panel_potrf_dpp<0, 2>(S, Dr, lane) : t == 1 ? panel_potrf_dpp<1, 2>(S, Dr, lane)
-                            : t == 2 ? panel_potrf_dpp<2, 2>(S, Dr, lane) : panel_potrf_dpp<3, 2>(S, Dr, lane);
+                const int b = panel_potrf_dpp_at<2>(S, Dr, lane, 16 * t);
 #else
                 const int b = t == 0 ? panel_potrf<0>(S, Dr, lane) : t == 1 ? panel_potrf<1>(S, Dr, lane)
                             : t == 2 ? panel_potrf<2>(S, Dr, lane) : panel_potrf<3>(S, Dr, lane);
@@ -283,8 +319,10 @@ __device__ __forceinline__ int leaf_body(double* S, double* T, double* U, double
             } else if (wave >= 1 && t == 0) {
                 hook.first();                           // columns 16-63 of S may still be written here (panel 0 owns 0-15)
             }
+            hook.stamp(1 + 3 * t);
             if (t == 2) hook.before();
             __syncthreads();
+            hook.stamp(2 + 3 * t);
             if (t == 2) hook.after();
             // rank-16 update of the remaining lower tiles: A_ij -= L_it L_jt^T, t < j <= i <= 3
             const int o = 16 * t;
@@ -297,9 +335,11 @@ __device__ __forceinline__ int leaf_body(double* S, double* T, double* U, double
                         lds_sub16(S, 16 * i, 16 * j, pacc, lane, crow_mode);
                     }
             if (t < 3) __syncthreads();
+            if (t < 3) hook.stamp(3 + 3 * t);
         }
         if (wave == 1 && (phases & 4)) GPMPC_INV16(S, T, 48, lane, Dr);
         __syncthreads();
+        hook.stamp(12);
     } else {
         if (wave < 4) inv16(S, T, 16 * wave, lane, nullptr);
         __syncthreads();
@@ -316,6 +356,7 @@ __device__ __forceinline__ int leaf_body(double* S, double* T, double* U, double
         if (wave < 2) acc = lds_mm16<false>(T, r2, r2, U, r2, c1, 16, lane, acc);
         if (wave < 2) lds_put16(T, r2, c1, acc, -1.0, lane, crow_mode);
         __syncthreads();
+        hook.stamp(13);
     }
     if (phases & 8) {
         const int pi = (wave >> 1) & 1, pj = wave & 1;
@@ -328,6 +369,7 @@ __device__ __forceinline__ int leaf_body(double* S, double* T, double* U, double
         __syncthreads();
         lds_put16(T, 32 + 16 * pi, 16 * pj, acc, -1.0, lane, crow_mode);
         __syncthreads();
+        hook.stamp(14);
     }
     return bad;
 }

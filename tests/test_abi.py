@@ -150,4 +150,4 @@ def test_inline_dpp_instructions_respect_the_operand_hazard():
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'check_dpp_hazards.py')], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout + r.stderr
     n = int(re.search(r'(\d+) DPP instructions checked', r.stdout).group(1))
-    assert n >= 1000, r.stdout            # the leaf's panels and 16 x 16 inverses are in there
+    assert n >= 800, r.stdout             # the leaf's panel (one copy per kernel since r03) and 16 x 16 inverses are in there

@@ -36,6 +36,13 @@ __global__ void __launch_bounds__(256) loop_kernel(const double* A, long long* s
     }
     if (tid == 0) { stamps[0] = acc; stamps[1] = bad; }
 }
+__global__ void __launch_bounds__(512) k_stream(double* p, long n, int reps) {
+    extern __shared__ double sm[];
+    double s = 0;
+    for (int r = 0; r < reps; ++r)
+        for (long i = (long)blockIdx.x * 512 + threadIdx.x; i < n; i += (long)gridDim.x * 512) s += p[i];
+    if (s == 12345.678) p[0] = s;
+}
 int main() {
     const int n = 64;
     std::vector<double> h(n * n);
@@ -43,14 +50,21 @@ int main() {
     double* A; long long* st;
     hipMalloc(&A, n * n * 8); hipMalloc(&st, 64);
     hipMemcpy(A, h.data(), n * n * 8, hipMemcpyHostToDevice);
-    for (int junk = 0; junk <= 6; ++junk) {
+    const long nbig = 1L << 27;
+    double* big; hipMalloc(&big, nbig * 8); hipMemset(big, 0, nbig * 8);
+    hipFuncSetAttribute((const void*)k_stream, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+    hipStream_t sa, sb;
+    hipStreamCreateWithFlags(&sa, hipStreamNonBlocking); hipStreamCreateWithFlags(&sb, hipStreamNonBlocking);
+    for (int load = 0; load < 2; ++load)
+    for (int junk = 0; junk <= 6; junk += 2) {
         long long s[2];
         for (int rep = 0; rep < 2; ++rep) {
-            hipLaunchKernelGGL(loop_kernel, dim3(1), dim3(256), 0, 0, (const double*)A, st, 200, junk);
+            hipLaunchKernelGGL(loop_kernel, dim3(1), dim3(256), 0, sa, (const double*)A, st, 2000, junk);
+            if (load) hipLaunchKernelGGL(k_stream, dim3(224), dim3(512), 100 * 1024, sb, big, nbig, 150);   // HBM stream on 224 other CUs
             hipDeviceSynchronize();
         }
         hipMemcpy(s, st, 16, hipMemcpyDeviceToHost);
-        printf("%2d KB of other code between two leaves: %7.2f us per leaf\n", 16 * junk, s[0] / 100.0 / 200);
+        printf("%s, %2d KB of other code between two leaves: %7.2f us per leaf\n", load ? "224 CUs stream HBM" : "chip idle         ", 16 * junk, s[0] / 100.0 / 2000);
     }
     return 0;
 }
