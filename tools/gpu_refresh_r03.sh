@@ -54,3 +54,5 @@ python tools/worker_trace.py gpurun_out/chain_trace_r03.bin 64 2>&1 | grep -v "^
 python tools/step_timeline.py gpurun_out/prof_r03/t_results.db > gpurun_out/r03_step_timeline.txt 2>&1; head -5 gpurun_out/r03_step_timeline.txt
 { tools/ubench/panel_dpp_bench; echo "--- leaf, readlane form (-DGPMPC_LEAF_DPP=0)"; tools/ubench/leaf_loop_bench_old; echo "--- leaf, DPP form"; tools/ubench/leaf_loop_bench; } > gpurun_out/r03_ubench_leaf_dpp.txt 2>&1; tail -8 gpurun_out/r03_ubench_leaf_dpp.txt
 tools/ubench/mfma_burst_bench > gpurun_out/r03_ubench_mfma_burst.txt 2>&1; head -4 gpurun_out/r03_ubench_mfma_burst.txt
+tools/ubench/leaf_icache_bench > gpurun_out/r03_ubench_leaf_icache.txt 2>&1; tail -4 gpurun_out/r03_ubench_leaf_icache.txt
+tools/ubench/leaf_underload_bench > gpurun_out/r03_ubench_leaf_underload.txt 2>&1; tail -4 gpurun_out/r03_ubench_leaf_underload.txt
