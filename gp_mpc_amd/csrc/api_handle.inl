@@ -29,6 +29,8 @@ struct gpmpc_gp {
     int chain_strikes = 0, chain_parked = 0;
     long n_timeouts = 0, n_chained = 0, n_single = 0;   // gpmpc_get_counter
     long train_iters = 0, train_evals = 0;              // of the last gpmpc_train_multistart (this rank's restarts)
+    int nll_last_a = -1;                                 // the training workspace holds the factors of this output ...
+    std::vector<double> nll_last_row;                    // ... at these hyper-parameters (gpmpc_nll; nll_grad_last reuses them)
 #ifdef GPMPC_EMULATED
     int spin_limit = 1 << 30;   // the emulator's polls are scheduler passes, not time
 #else

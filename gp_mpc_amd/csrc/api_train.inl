@@ -7,6 +7,75 @@
 // (GPMPC_EHIP) without touching the device -- how the tests reach the failure paths of the restart shard (0 = off).
 static int g_fail_nll_after = 0;
 
+// K^-1 (lower triangle) from the L^-1 in `ws`, then the gradient reductions into h->gradOut: what gpmpc_nll adds for a
+// gradient, enqueued on the handle's stream
+static void enqueue_nll_grad(gpmpc_gp* h, Workspace& ws, const Ctx& cx, int nmean) {
+    const int d = h->d, Np = h->Np;
+    {
+        PhaseTimer t(h, GPMPC_PH_INVK);
+        GemmP p = gemm_base(cx);  // lower triangle of K^-1 = L^-T L^-1 is all the gradient pass reads
+        p.A = ws.Inv; p.lda = Np; p.sA = ws.mat(); p.a_mc = 1;
+        p.B = ws.Inv; p.ldb = Np; p.sB = ws.mat(); p.b_nc = 1;
+        p.kflags = KA_GE_M | KB_GE_N;
+        p.C = ws.InvK; p.ldc = Np; p.sC = ws.mat();
+        p.M = Np; p.N = Np; p.K = Np; p.lower = 1;
+        launch_gemm(p, 1, cx.stream);
+    }
+    PhaseTimer t(h, GPMPC_PH_NLL);
+    hipLaunchKernelGGL(nll_grad_kernel, dim3(Np / 64, Np / 64), dim3(256), 0, cx.stream, h->XT, ws.hyper, ws.InvK,
+                       ws.alpha, h->gradPartial, h->N, Np, d);
+    hipLaunchKernelGGL(nll_grad_finish_kernel, dim3(1), dim3(256), 0, cx.stream, h->gradPartial, ws.hyper,
+                       h->gradOut, Np, d);
+    if (nmean)
+        hipLaunchKernelGGL(mean_grad_kernel, dim3(1), dim3(256), 0, cx.stream, h->XT, ws.alpha, h->gradOut + d + 2,
+                           h->mean_kind, h->N, Np, d);
+}
+
+// calc_NLL optimize.py:77-97, literally: `return NLL(...) + log_prior` with log_prior the sum of the Gaussian
+// log-densities prior_gauss(theta, mu, s^2) = -(theta - mu)^2 / (2 s^2) - 1/2 log(2 pi s^2) of every ell_i and of
+// sf^2 and sn^2 (the SQUARED hyper-parameters, :90-91).  (The log-prior is ADDED to the negative log-likelihood
+// there, not subtracted; the reference never enables it, prior = None :157.)  Either output may be NULL.
+static void add_log_prior(const gpmpc_gp* h, const double* hyper_row, double* nll, double* grad) {
+    if (!h->have_prior) return;
+    const int d = h->d;
+    const double two_pi = 6.283185307179586476925286766559;
+    auto lg = [&](double th, double mu, double sd) { return -(th - mu) * (th - mu) / (2.0 * sd * sd) - 0.5 * std::log(two_pi * sd * sd); };
+    auto dlg = [&](double th, double mu, double sd) { return -(th - mu) / (sd * sd); };
+    double lp = 0.0;
+    for (int k = 0; k < d; ++k) {
+        lp += lg(hyper_row[k], h->prior[0], h->prior[1]);
+        if (grad) grad[k] += dlg(hyper_row[k], h->prior[0], h->prior[1]);
+    }
+    const double sf = hyper_row[d], sn = hyper_row[d + 1];
+    lp += lg(sf * sf, h->prior[2], h->prior[3]) + lg(sn * sn, h->prior[4], h->prior[5]);
+    if (grad) {
+        grad[d] += dlg(sf * sf, h->prior[2], h->prior[3]) * 2.0 * sf;
+        grad[d + 1] += dlg(sn * sn, h->prior[4], h->prior[5]) * 2.0 * sn;
+    }
+    if (nll) *nll += lp;
+}
+
+// The gradient at the point gpmpc_nll evaluated LAST (value only) on this handle: the factors are still in the training
+// workspace, so this is the K^-1 product and the reductions, not a second factorisation.  GPMPC_EINVAL if the workspace
+// holds something else.  (A line search evaluates values until a step is accepted and asks for one gradient then: a
+// rejected trial point costs 1.7 instead of 2.5 ms at N = 4096; same numbers as gpmpc_nll with a gradient, same kernels.)
+static int nll_grad_last(gpmpc_gp* h, int a, const double* hyper_row, double* grad) {
+    const int d = h->d, nh = h->nh();
+    if (!h->tws.K || h->nll_last_a != a || (int)h->nll_last_row.size() != nh ||
+        std::memcmp(h->nll_last_row.data(), hyper_row, nh * sizeof(double)) != 0)
+        return fail(GPMPC_EINVAL, "the training workspace does not hold this point");
+    HIPCHK(hipSetDevice(h->device));
+    Workspace& ws = h->tws;
+    CHK(ws_need_invK(ws));
+    const int nmean = mean_param_count(h->mean_kind, d);
+    enqueue_nll_grad(h, ws, h->cx(), nmean);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(grad, h->gradOut, (d + 2 + nmean) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    add_log_prior(h, hyper_row, nullptr, grad);
+    return GPMPC_OK;
+}
+
 extern "C" int gpmpc_nll(gpmpc_gp* h, int a, const double* hyper_row, double* nll, double* grad, int* jitter_out) {
     if (!h || !hyper_row || !nll || a < 0 || a >= h->Ny) return fail(GPMPC_EINVAL, "bad arguments");
     if (g_fail_nll_after > 0 && --g_fail_nll_after == 0) return fail(GPMPC_EHIP, "injected device failure (fail_nll_after)");
@@ -23,6 +92,7 @@ extern "C" int gpmpc_nll(gpmpc_gp* h, int a, const double* hyper_row, double* nl
     Workspace& ws = h->tws;
     int info = 0;
     const Ctx cx = h->cx();
+    h->nll_last_a = -1;                       // (set again when this evaluation has succeeded)
     if (grad) CHK(ws_need_invK(ws));
     // prior mean: the objective is evaluated on y - m(X) (calc_NLL optimize.py:43,75,96)
     std::vector<double> kpart;
@@ -39,53 +109,16 @@ extern "C" int gpmpc_nll(gpmpc_gp* h, int a, const double* hyper_row, double* nl
             PhaseTimer t(h, GPMPC_PH_NLL);
             hipLaunchKernelGGL(nll_reduce_kernel, dim3(1), dim3(256), 0, cx.stream, ws.L, ws.w, ws.nll, h->N, Np);
         }
-        if (grad) {
-            {
-                PhaseTimer t(h, GPMPC_PH_INVK);
-                GemmP p = gemm_base(cx);  // lower triangle of K^-1 = L^-T L^-1 is all the gradient pass reads
-                p.A = ws.Inv; p.lda = Np; p.sA = ws.mat(); p.a_mc = 1;
-                p.B = ws.Inv; p.ldb = Np; p.sB = ws.mat(); p.b_nc = 1;
-                p.kflags = KA_GE_M | KB_GE_N;
-                p.C = ws.InvK; p.ldc = Np; p.sC = ws.mat();
-                p.M = Np; p.N = Np; p.K = Np; p.lower = 1;
-                launch_gemm(p, 1, cx.stream);
-            }
-            PhaseTimer t(h, GPMPC_PH_NLL);
-            hipLaunchKernelGGL(nll_grad_kernel, dim3(Np / 64, Np / 64), dim3(256), 0, cx.stream, h->XT, ws.hyper, ws.InvK,
-                               ws.alpha, h->gradPartial, h->N, Np, d);
-            hipLaunchKernelGGL(nll_grad_finish_kernel, dim3(1), dim3(256), 0, cx.stream, h->gradPartial, ws.hyper,
-                               h->gradOut, Np, d);
-            if (nmean)
-                hipLaunchKernelGGL(mean_grad_kernel, dim3(1), dim3(256), 0, cx.stream, h->XT, ws.alpha, h->gradOut + d + 2,
-                                   h->mean_kind, h->N, Np, d);
-        }
+        if (grad) enqueue_nll_grad(h, ws, cx, nmean);
     }));
     if (jitter_out) *jitter_out = info;
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(nll, ws.nll, sizeof(double), hipMemcpyDeviceToHost, h->stream));
     if (grad) HIPCHK(hipMemcpyAsync(grad, h->gradOut, (d + 2 + nmean) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
-    if (h->have_prior) {
-        // calc_NLL optimize.py:77-97, literally: `return NLL(...) + log_prior` with log_prior the sum of the Gaussian
-        // log-densities prior_gauss(theta, mu, s^2) = -(theta - mu)^2 / (2 s^2) - 1/2 log(2 pi s^2) of every ell_i and of
-        // sf^2 and sn^2 (the SQUARED hyper-parameters, :90-91).  (The log-prior is ADDED to the negative log-likelihood
-        // there, not subtracted; the reference never enables it, prior = None :157.)
-        const double two_pi = 6.283185307179586476925286766559;
-        auto lg = [&](double th, double mu, double sd) { return -(th - mu) * (th - mu) / (2.0 * sd * sd) - 0.5 * std::log(two_pi * sd * sd); };
-        auto dlg = [&](double th, double mu, double sd) { return -(th - mu) / (sd * sd); };
-        double lp = 0.0;
-        for (int k = 0; k < d; ++k) {
-            lp += lg(hyper_row[k], h->prior[0], h->prior[1]);
-            if (grad) grad[k] += dlg(hyper_row[k], h->prior[0], h->prior[1]);
-        }
-        const double sf = hyper_row[d], sn = hyper_row[d + 1];
-        lp += lg(sf * sf, h->prior[2], h->prior[3]) + lg(sn * sn, h->prior[4], h->prior[5]);
-        if (grad) {
-            grad[d] += dlg(sf * sf, h->prior[2], h->prior[3]) * 2.0 * sf;
-            grad[d + 1] += dlg(sn * sn, h->prior[4], h->prior[5]) * 2.0 * sn;
-        }
-        *nll += lp;
-    }
+    add_log_prior(h, hyper_row, nll, grad);
+    h->nll_last_a = a;
+    h->nll_last_row.assign(hyper_row, hyper_row + h->nh());
     return GPMPC_OK;
 }
 
@@ -167,6 +200,12 @@ extern "C" int gpmpc_train_multistart(gpmpc_gp* h, int nstart, const double* sta
         P.eval = [&](const double* th, double* f, double* g) -> bool {
             if (local_rc != GPMPC_OK) return false;              // after a device failure: every point is unusable
             const int rc = gpmpc_nll(h, a, th, f, g, nullptr);
+            if (rc == GPMPC_EHIP || rc == GPMPC_ENOMEM) { local_rc = rc; local_err = g_err; }
+            return rc == GPMPC_OK;
+        };
+        P.grad_last = [&](const double* th, double* g) -> bool {
+            if (local_rc != GPMPC_OK) return false;
+            const int rc = nll_grad_last(h, a, th, g);
             if (rc == GPMPC_EHIP || rc == GPMPC_ENOMEM) { local_rc = rc; local_err = g_err; }
             return rc == GPMPC_OK;
         };

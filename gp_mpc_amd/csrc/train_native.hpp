@@ -27,7 +27,10 @@ struct BoxProblem {
     std::vector<double> lb, ub;          // in the ORIGINAL variables
     std::vector<char> logv;              // optimise log(theta_k)?
     // f(theta, grad) -> value; returns false if the point is unusable (value treated as +inf)
-    std::function<bool(const double*, double*, double*)> eval;
+    std::function<bool(const double*, double*, double*)> eval;   // (grad may be NULL: value only)
+    // optional: the gradient at the point `eval` saw LAST (value only), cheaper than a second full evaluation; false if
+    // it cannot be had (the search then evaluates the point again, with a gradient)
+    std::function<bool(const double*, double*)> grad_last;
 };
 
 struct BoxResult {
@@ -60,6 +63,23 @@ inline BoxResult minimize_box_lbfgs(const BoxProblem& P, const double* theta0, i
             if (!(gx[k] == gx[k])) return inf;
         }
         return f;
+    };
+    // a trial point of the line search: the value alone; its gradient only once the step is accepted
+    auto fun_value = [&](const std::vector<double>& xx) -> double {
+        for (int k = 0; k < n; ++k) th[k] = P.logv[k] ? std::exp(xx[k]) : xx[k];
+        double f = inf;
+        ++R.evals;
+        if (!P.eval(th.data(), &f, nullptr) || !(f == f)) return inf;
+        return f;
+    };
+    auto grad_of_last = [&](const std::vector<double>& xx, std::vector<double>& gx) -> bool {
+        for (int k = 0; k < n; ++k) th[k] = P.logv[k] ? std::exp(xx[k]) : xx[k];
+        if (!P.grad_last(th.data(), gt.data())) return false;
+        for (int k = 0; k < n; ++k) {
+            gx[k] = P.logv[k] ? gt[k] * th[k] : gt[k];
+            if (!(gx[k] == gx[k])) return false;
+        }
+        return true;
     };
     double f = fun(x, g);
     R.theta.assign(n, 0.0);
@@ -136,8 +156,13 @@ inline BoxResult minimize_box_lbfgs(const BoxProblem& P, const double* theta0, i
             }
             if (!any) break;
             if (!(dec < 0.0)) continue;                         // the clipped step is not a descent step: shorten it
-            fn = fun(xn, gn);
-            if (fn <= f + 1e-4 * dec) { moved = true; break; }  // dec < 0: an accepted point is strictly better
+            fn = P.grad_last ? fun_value(xn) : fun(xn, gn);
+            if (fn <= f + 1e-4 * dec) {                         // dec < 0: an accepted point is strictly better
+                // (value-only trial: now its gradient -- from the factors of that evaluation, or by evaluating again)
+                if (P.grad_last && !grad_of_last(xn, gn)) fn = fun(xn, gn);
+                moved = fn <= f + 1e-4 * dec;
+                break;
+            }
         }
         if (!moved) break;                                      // no progress along the projected path
         std::vector<double> s(n), y(n);
