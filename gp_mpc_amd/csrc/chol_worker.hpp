@@ -20,6 +20,11 @@
 //      MFMA pipe issuing every ~104 cycles; one wave per SIMD manages one per ~142; four would reach ~75
 //      but leave only 128 registers per thread, less than the resident tiles need).
 // Tiles (0,0), (1,0), (1,1) and, after their hand-off, (k+1,k) / (k+1,k+1) belong to the chain.
+// With a courier (template argument; the default since r03) step 2 is not the owners' any more: the last workgroup of
+// the launch owns no tiles, receives the three tiles of row k+3 from their owners behind the update of step k (they come
+// first in part 3; stored to K, counted in handed[k+1]) and makes L(k+2,k) and the two hand-off tiles as the chain's
+// publications appear -- see the courier's loop below.  Part 3 also looks one panel ahead: the tiles of column k+1 are
+// updated first and turned into L(i,k+1) as soon as the chain has published inv_{k+1} (no blocking wait).
 // Dead-lock freedom: a wait only ever targets work of an earlier step or a panel tile of the same step,
 // and every worker does its panel tiles first; all NW workers plus the chain must be co-resident (one
 // workgroup per CU: the LDS request below is > 80 KB), which the host guarantees by sizing NW to the CU
