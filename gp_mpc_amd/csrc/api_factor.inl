@@ -360,6 +360,7 @@ static bool factor_chain(const Ctx& cx, Workspace& ws, int spin_limit, bool flag
     //  polling kernels instead of launch boundaries were slower)
     int s_top = 64;                                         // rows of the left child of the inverse tree's root
     while (2 * s_top < Np) s_top *= 2;
+    if (s_top >= 256 && Np - s_top < s_top / 4) s_top /= 2;   // (Np a little above a power of two: not "everything, then a sliver")
     static const bool split_ok = !(getenv("GPMPC_WORKER_SPLIT") && atoi(getenv("GPMPC_WORKER_SPLIT")) == 0);
     static const int max_launches = getenv("GPMPC_MAX_LAUNCHES") ? atoi(getenv("GPMPC_MAX_LAUNCHES")) : 3;
     static const int nw2_env = getenv("GPMPC_NW2") ? atoi(getenv("GPMPC_NW2")) : 0;   // (tuning aids)
@@ -385,6 +386,7 @@ static bool factor_chain(const Ctx& cx, Workspace& ws, int spin_limit, bool flag
             r[L] = start; nws[L] = nw; ++L;
             int nxt = 64;                                   // next cut: the left child of what remains
             while (2 * nxt < Np - start) nxt *= 2;
+            if (nxt >= 256 && Np - start - nxt < nxt / 4) nxt /= 2;
             static const int cut2 = getenv("GPMPC_CUT2") ? atoi(getenv("GPMPC_CUT2")) : 0;   // (tuning aid: block of the second cut)
             if (L == 2 && cut2 > 0 && 64 * cut2 > start && 64 * cut2 < Np) nxt = 64 * cut2 - start;
             start += nxt;

@@ -117,6 +117,9 @@ def test_worker_path_odd_size(lib):
     # Np = 4160 = 65 blocks: 2079 tiles, ten slots of 223 owners hold them (r03; the nine-slot kernel below does not:
     # chain kernel + flagged GEMM launches)
     pc.check_synthetic(lib, N=4100, d=6, Ny=1, B=50, sn=1e-2, strict_rel=False)
+    # Np = 4288 = 67 blocks: 2210 tiles, the most 223 owners hold (ten each); Np = 4352: one block more -> GEMM launches
+    pc.check_synthetic(lib, N=4280, d=6, Ny=1, B=50, sn=1e-2, strict_rel=False)
+    pc.check_synthetic(lib, N=4300, d=6, Ny=1, B=50, sn=1e-2, strict_rel=False)
 
 
 def test_worker_path_without_courier(lib):
