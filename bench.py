@@ -199,13 +199,14 @@ class Ranks:
             self.dist.destroy_process_group()
 
 
-def timed(rk, h, step, steps, warmup, profile=True):
-    """`warmup` untimed steps, then exactly `steps` steps between (barrier + synchronize) pairs; max over the ranks."""
+def timed(rk, h, step, steps, warmup, profile=True, phases=None):
+    """`warmup` untimed steps, then exactly `steps` steps between (barrier + synchronize) pairs; max over the ranks.
+    profile: HIP-event brackets inside the library during the timed steps -- of the phases named, or of all."""
     for _ in range(warmup):
         step()
     rk.sync(h)
     if profile:
-        h.profile_enable(True)
+        h.profile_enable(True, phases)
         h.profile_read(reset=True)
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -371,7 +372,14 @@ def main():
         h.fit(hyper)                                                    # K build + Cholesky + L^-1 + alpha
         h.predict_mean_var_dev(B, z.data_ptr(), mean.data_ptr(), var.data_ptr())   # 10k mean+var
 
-    elapsed, prof = timed(rk, h, step, args.steps, args.warmup)
+    # Timed region: only the dominant kernel is bracketed by events (the roofline needs its launch durations from THIS region);
+    # bracketing all seven phases costs 65 us per step (tools/bench_noprof.py), so the phase split comes from a second,
+    # untimed pass with all brackets on.
+    elapsed, prof_timed = timed(rk, h, step, args.steps, args.warmup, phases=('vargemm',))
+    phase_steps = max(5, min(args.steps, 20))
+    _, prof = timed(rk, h, step, phase_steps, 0)
+    prof = {k: (v[0] * args.steps / phase_steps, int(round(v[1] * args.steps / phase_steps))) for k, v in prof.items()}   # as if over `steps` steps
+    prof['vargemm'] = prof_timed['vargemm']
 
     # HBM traffic of the dominant kernel: NOT measured in this run (rocprofv3 --pmc serialises dispatches); it is read
     # from the committed PMC passes under profiles/ and labelled as such
@@ -405,6 +413,7 @@ def main():
                          'avg_launch_ms': gemm_ms / max(gemm_n, 1), 'launches': gemm_n,
                          'peak_measured_mfma_only_ubench': mfma_rate},
             'phases_ms_per_step': {k: v[0] / args.steps for k, v in prof.items() if v[1] > 0},
+            'phases_source': 'second, untimed pass of %d steps with every phase bracketed by events (all brackets on cost ~65 us per step); vargemm and the roofline: from the timed region, the only bracket there' % phase_steps,
             'cholesky': (lambda ms, n: {'kernel': 'chol_chain_kernel (+ chol_worker_kernel x3, concurrent)', 'bound': 'mfma',
                                         'achieved': (N ** 3 / 3.0) / (ms / max(n, 1) * 1e-3) * 1e-12 if ms > 0 else 0.0,
                                         'peak': FP64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',

@@ -250,8 +250,15 @@ class Handle:
         self.lib.check(self.lib.dll.gpmpc_get_counter(self.h, name.encode(), ctypes.byref(v)))
         return v.value
 
-    def profile_enable(self, on=True):
-        self.lib.check(self.lib.dll.gpmpc_profile_enable(self.h, int(on)))
+    def profile_enable(self, on=True, phases=None):
+        """HIP-event brackets per phase; `phases` (names from PHASES) restricts them -- every bracket costs stream time."""
+        code = int(bool(on))
+        if on and phases is not None:
+            mask = 0
+            for name in phases:
+                mask |= 1 << PHASES.index(name)
+            code = 1 | (mask << 1)
+        self.lib.check(self.lib.dll.gpmpc_profile_enable(self.h, code))
 
     def profile_read(self, reset=True):
         out = {}

@@ -284,6 +284,7 @@ static int ws_need_invK(Workspace& ws) {
 
 struct Prof {
     bool on = false;
+    unsigned mask = ~0u;            // phases that are bracketed while `on` (bit = phase index)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[GPMPC_PH_COUNT];
     std::vector<hipEvent_t> pool;
     double total[GPMPC_PH_COUNT] = {0};
@@ -297,7 +298,7 @@ struct ProfScope {
     int phase;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     ProfScope(Prof* pr_, hipStream_t st_, int ph) : pr(pr_), st(st_), phase(ph) {
-        if (!pr || !pr->on) return;
+        if (!pr || !pr->on || !((pr->mask >> ph) & 1u)) return;
         auto get = [&]() {
             hipEvent_t e;
             if (!pr->pool.empty()) { e = pr->pool.back(); pr->pool.pop_back(); }

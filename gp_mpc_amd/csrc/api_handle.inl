@@ -360,6 +360,7 @@ int gpmpc_get_counter(gpmpc_gp* h, const char* name, long* value) {
 int gpmpc_profile_enable(gpmpc_gp* h, int enable) {
     if (!h) return fail(GPMPC_EINVAL, "NULL handle");
     h->prof.on = enable != 0;
+    h->prof.mask = enable > 1 ? (unsigned)enable >> 1 : ~0u;     // enable = 1 | mask << 1: only the phases of `mask`
     return GPMPC_OK;
 }
 
