@@ -309,10 +309,37 @@ struct ProfScope {
         e1 = get();
         hipEventRecord(e0, st);
     }
+    void end_on(hipStream_t s) { st = s; }     // the bracket closes on another queue (a phase that spans two)
     ~ProfScope() {
         if (!e0) return;
         hipEventRecord(e1, st);
         pr->ev[phase].push_back({e0, e1});
+    }
+};
+
+// What a chained factorisation leaves for its caller and for the first prediction behind it.
+//  * Early status: `info` and the hand-off words are final when the chain kernel ends, ~0.3 ms before the last rows of
+//    L^-1.  factor_chain copies them to the host on the workers' queue (idle by then) and records `ev_info` there; the
+//    fit returns on that event with the tail of the inverse still in flight on the main queue.
+//  * alpha off the main queue: gpmpc_fit then forms alpha on the workers' queue behind the tail (ev_alpha); the main
+//    queue waits for it in front of the next consumer (alpha_ready), so a variance product that does not read alpha
+//    follows the tail directly.
+//  * The first prediction behind such a fit (`armed`) forms its cross-covariances on the low-priority queue while the
+//    tail runs, and its mean (which needs alpha) next to the variance product (predict_chunk).
+struct TailState {
+    bool armed = false;          // set by gpmpc_fit, consumed (or dropped) by the next call that touches the predict scratch
+    bool alpha_pending = false;  // alpha of the model workspace is being formed on the workers' queue: wait for ev_alpha
+    hipEvent_t ev_chain = nullptr, ev_tail = nullptr, ev_alpha = nullptr, ev_ks = nullptr, ev_mean = nullptr;
+    // early status (set up by factor_with_jitter per attempt)
+    int* pin_info = nullptr;
+    int* cerr = nullptr;
+    size_t nflag = 0;
+    int nb = 0;
+    hipEvent_t ev_info = nullptr;
+    bool want_early = false, early_done = false;
+    static hipEvent_t get(hipEvent_t& e) {
+        if (!e) hipEventCreateWithFlags(&e, hipEventDisableTiming);
+        return e;
     }
 };
 
@@ -327,4 +354,5 @@ struct Ctx {
     int workers = 0;                // > 0: tile-owner worker kernel with this many CUs to share (chain mode 3)
     Prof* prof = nullptr;           // the handle's profile (phase brackets inside the factorisation)
     hipStream_t bulk = nullptr;     // fourth queue (low priority): look-ahead part of the two-level trailing updates
+    TailState* tail = nullptr;      // early status + row-panel events of the chained factorisation (may be null)
 };

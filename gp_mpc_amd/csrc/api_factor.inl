@@ -555,6 +555,18 @@ static bool factor_chain(const Ctx& cx, Workspace& ws, int spin_limit, bool flag
     }
     hipEventRecord(cx.join, cx.side);
     hipStreamWaitEvent(cx.stream, cx.join, 0);
+    if (cx.tail && cx.tail->want_early && use_workers && split) {
+        // Early status: the pivot word and the hand-off words are final when the chain kernel ends (the chain cannot
+        // finish unless every worker launch became resident and delivered; nothing behind it polls).  The workers'
+        // queue is idle by then: it waits for the chain kernel and copies them, the caller waits on ev_info.
+        TailState& ts = *cx.tail;
+        hipEventRecord(TailState::get(ts.ev_chain), cx.stream);          // (the chain kernel is the main queue's last entry here)
+        hipStreamWaitEvent(cx.side, ts.ev_chain, 0);
+        hipMemcpyAsync(ts.pin_info, ws.info, ts.nb * sizeof(int), hipMemcpyDeviceToHost, cx.side);
+        hipMemcpyAsync(ts.cerr, ws.flags, ts.nflag * sizeof(int), hipMemcpyDeviceToHost, cx.side);
+        hipEventRecord(ts.ev_info, cx.side);
+        ts.early_done = true;
+    }
     if (split) {                                            // the last panel: its own inverse, then -I S
         // The inverse of the last panel needs nothing from the side queue but the level scratch, which that queue left
         // long ago (event recorded behind its last trtri_range); only the product waits for its S.  (Waiting for the

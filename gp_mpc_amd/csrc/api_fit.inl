@@ -49,12 +49,21 @@ static int factor_with_jitter(gpmpc_gp* h, Workspace& ws, const double* hyper_ho
     if (h->chain_mode) turn.lock();               // held until the status words are back, i.e. the factorisation is done
     for (int attempt = 0; attempt < 2; ++attempt) {
         HIPCHK(hipMemcpyAsync(ws.jitter, jit.data(), nb * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        // (TailState) with the tile-owner workers the status words come back when the chain kernel ends, on the workers'
+        // queue: this call then returns with the tail of the inverse (and `post`) still in flight on the main queue
+        static const bool early_status = !(getenv("GPMPC_EARLY_STATUS") && atoi(getenv("GPMPC_EARLY_STATUS")) == 0);
+        h->tail.pin_info = pin_info; h->tail.cerr = cerr; h->tail.nflag = nflag; h->tail.nb = nb;
+        h->tail.ev_info = h->ev_info;
+        h->tail.want_early = early_status && !g_chain_trace;
+        h->tail.early_done = false;
         gram_and_factor(h, ws);
         HIPCHK(hipGetLastError());
         const bool check_chain = h->chain_mode && h->side_stream && ws.Np >= 128;
-        HIPCHK(hipMemcpyAsync(pin_info, ws.info, nb * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-        if (check_chain) HIPCHK(hipMemcpyAsync(cerr, ws.flags, nflag * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipEventRecord(h->ev_info, h->stream));
+        if (!h->tail.early_done) {
+            HIPCHK(hipMemcpyAsync(pin_info, ws.info, nb * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+            if (check_chain) HIPCHK(hipMemcpyAsync(cerr, ws.flags, nflag * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipEventRecord(h->ev_info, h->stream));
+        }
         static const bool post_early = !(getenv("GPMPC_POST_EARLY") && atoi(getenv("GPMPC_POST_EARLY")) == 0);
         if (post && post_early) post();
         HIPCHK(hipEventSynchronize(h->ev_info));
@@ -94,6 +103,8 @@ static int factor_with_jitter(gpmpc_gp* h, Workspace& ws, const double* hyper_ho
                 ++h->n_timeouts;
                 if (++h->chain_strikes >= gpmpc_gp::CHAIN_STRIKES) h->chain_parked = gpmpc_gp::CHAIN_REARM;
                 h->chain_mode = 0;                  // for the rest of THIS call (restored on return)
+                h->tail.want_early = false;
+                h->tail.early_done = false;
                 HIPCHK(hipStreamSynchronize(h->stream));
                 HIPCHK(hipStreamSynchronize(h->side_stream));
                 if (h->aux_stream) HIPCHK(hipStreamSynchronize(h->aux_stream));
@@ -140,11 +151,26 @@ extern "C" int gpmpc_fit(gpmpc_gp* h, const double* hyper, int want_invK, int* i
     h->fitted = false;
     h->have_invK = false;
     h->have_beta = false;
+    h->tail.armed = false;
     int post_rc = GPMPC_OK;
     std::vector<double> kpart;           // [Ny][d+2]; y - m(X) goes to h->Yc (optimize.py:285,494)
     CHK(upload_mean_and_residual(h, hyper, h->Ny, kpart, &h->mpar, h->Y, &h->Yc));
+    alpha_ready(h);                      // (a previous fit's alpha launches on the workers' queue: ordered before this fit's)
+    bool alpha_on_side = false;
     CHK(factor_with_jitter(h, h->ws, kpart.data(), info, [&]() {
-        {
+        static const bool alpha_side_env = !(getenv("GPMPC_ALPHA_SIDE") && atoi(getenv("GPMPC_ALPHA_SIDE")) == 0);
+        alpha_on_side = h->tail.early_done && alpha_side_env && !want_invK && h->side_stream;
+        if (alpha_on_side) {
+            // the fit returns at the end of the chain kernel: alpha goes to the workers' queue, behind the inverse's tail,
+            // so that what the caller enqueues next on the main queue -- a variance product -- follows the tail directly
+            Ctx cs = h->cx();
+            hipEventRecord(TailState::get(h->tail.ev_tail), h->stream);
+            hipStreamWaitEvent(h->side_stream, h->tail.ev_tail, 0);
+            cs.stream = h->side_stream;
+            ProfScope t(&h->prof, h->side_stream, GPMPC_PH_SOLVE);
+            solve_alpha(cs, h->ws, h->y_model(), h->Np);
+            hipEventRecord(TailState::get(h->tail.ev_alpha), h->side_stream);
+        } else {
             PhaseTimer t(h, GPMPC_PH_SOLVE);
             solve_alpha(h->cx(), h->ws, h->y_model(), h->Np);
         }
@@ -158,6 +184,9 @@ extern "C" int gpmpc_fit(gpmpc_gp* h, const double* hyper, int want_invK, int* i
     HIPCHK(hipGetLastError());
     h->hyper.assign(hyper, hyper + (size_t)h->Ny * nh);
     h->fitted = true;
+    // the first large prediction behind this fit may start next to the inverse's tail (predict_chunk)
+    h->tail.alpha_pending = alpha_on_side;
+    h->tail.armed = h->tail.early_done && !want_invK;
     return GPMPC_OK;
 }
 
@@ -193,6 +222,8 @@ extern "C" int gpmpc_append(gpmpc_gp* h, int n, const double* Xnew, const double
     if (!h || n <= 0 || !Xnew || !Ynew) return fail(GPMPC_EINVAL, "NULL handle/data or n <= 0");
     if (!h->fitted) return fail(GPMPC_ENOTFIT, "model has no factors (call gpmpc_fit or gpmpc_set_factors)");
     HIPCHK(hipSetDevice(h->device));
+    alpha_ready(h);
+    h->tail.armed = false;
     HIPCHK(hipStreamSynchronize(h->stream));
     const int N0 = h->N, N1 = N0 + n, d = h->d, Ny = h->Ny, Np0 = h->Np, Np1 = round_up(N1, 64);
     const int R0 = (N0 / 64) * 64, m = Np1 - R0;
@@ -364,6 +395,7 @@ extern "C" int gpmpc_get_factors(gpmpc_gp* h, double* hyper, double* chol, doubl
     if (!h) return fail(GPMPC_EINVAL, "NULL handle");
     if (!h->fitted) return fail(GPMPC_ENOTFIT, "model has no factors (call gpmpc_fit or gpmpc_set_factors)");
     HIPCHK(hipSetDevice(h->device));
+    alpha_ready(h);
     HIPCHK(hipStreamSynchronize(h->stream));
     if (hyper) std::memcpy(hyper, h->hyper.data(), h->hyper.size() * sizeof(double));
     if (chol) CHK(export_mats(h, h->ws.L, chol));
@@ -387,6 +419,8 @@ extern "C" int gpmpc_set_factors(gpmpc_gp* h, const double* hyper, const double*
                                  const double* invK) {
     if (!h || !hyper || !chol) return fail(GPMPC_EINVAL, "hyper and chol are required");
     HIPCHK(hipSetDevice(h->device));
+    alpha_ready(h);
+    h->tail.armed = false;
     HIPCHK(hipStreamSynchronize(h->stream));
     h->fitted = false;
     h->have_invK = false;

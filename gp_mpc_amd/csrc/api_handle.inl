@@ -28,6 +28,7 @@ struct gpmpc_gp {
     static constexpr int CHAIN_STRIKES = 3, CHAIN_REARM = 64;
     int chain_strikes = 0, chain_parked = 0;
     long n_timeouts = 0, n_chained = 0, n_single = 0;   // gpmpc_get_counter
+    long n_behind_tail = 0;                              // predictions that started next to a fit's tail (predict_behind_tail)
     long train_iters = 0, train_evals = 0;              // of the last gpmpc_train_multistart (this rank's restarts)
     int nll_last_a = -1;                                 // the training workspace holds the factors of this output ...
     std::vector<double> nll_last_row;                    // ... at these hyper-parameters (gpmpc_nll; nll_grad_last reuses them)
@@ -72,10 +73,11 @@ struct gpmpc_gp {
     double* ccpart = nullptr;                    // chunk partials of the small-batch cross-covariance kernel
     bool have_beta = false;
     Prof prof;
+    TailState tail;
     Ctx cx() {
         return Ctx{stream, crow_mode, side_stream, ev_fork, ev_join, chain_mode >= 2 ? aux_stream : nullptr,
                    seg_events.data(), (int)seg_events.size(), chain_mode >= 3 ? g_cu_count[device] : 0, &prof,
-                   chain_mode >= 2 ? bulk_stream : nullptr};
+                   chain_mode >= 2 ? bulk_stream : nullptr, chain_mode >= 3 ? &tail : nullptr};
     }
 };
 
@@ -83,8 +85,17 @@ struct PhaseTimer : ProfScope {
     PhaseTimer(gpmpc_gp* h, int ph) : ProfScope(&h->prof, h->stream, ph) {}
 };
 
+// alpha of the model workspace may still be in the making on the workers' queue (TailState): order the main queue behind it
+static void alpha_ready(gpmpc_gp* h) {
+    if (!h->tail.alpha_pending) return;
+    hipStreamWaitEvent(h->stream, h->tail.ev_alpha, 0);
+    h->tail.alpha_pending = false;
+}
+
 static int prof_collect(gpmpc_gp* h) {
     HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->side_stream) HIPCHK(hipStreamSynchronize(h->side_stream));   // (brackets of alpha / the cross-covariances next to a fit's tail)
+    if (h->bulk_stream) HIPCHK(hipStreamSynchronize(h->bulk_stream));
     for (int ph = 0; ph < GPMPC_PH_COUNT; ++ph) {
         for (auto& pr : h->prof.ev[ph]) {
             float ms = 0.f;
@@ -247,6 +258,8 @@ int gpmpc_destroy(gpmpc_gp* h) {
     if (!h) return GPMPC_OK;
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
+    if (h->side_stream) hipStreamSynchronize(h->side_stream);
+    if (h->bulk_stream) hipStreamSynchronize(h->bulk_stream);
     ws_free(h->ws);
     ws_free(h->tws);
     hipFree(h->XT); hipFree(h->Y); hipFree(h->gradPartial); hipFree(h->gradOut);
@@ -258,6 +271,8 @@ int gpmpc_destroy(gpmpc_gp* h) {
         for (auto& pr : h->prof.ev[ph]) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     for (auto e : h->prof.pool) hipEventDestroy(e);
     if (h->ev_info) hipEventDestroy(h->ev_info);
+    for (hipEvent_t e : {h->tail.ev_chain, h->tail.ev_tail, h->tail.ev_alpha, h->tail.ev_ks, h->tail.ev_mean})
+        if (e) hipEventDestroy(e);
     if (h->pin) hipHostFree(h->pin);
     if (h->io_pin) hipHostFree(h->io_pin);
     hipFree(h->io_dev);
@@ -347,6 +362,7 @@ int gpmpc_get_counter(gpmpc_gp* h, const char* name, long* value) {
     if (std::strcmp(name, "handoff_timeouts") == 0) *value = h->n_timeouts;
     else if (std::strcmp(name, "chained_factorisations") == 0) *value = h->n_chained;
     else if (std::strcmp(name, "single_queue_factorisations") == 0) *value = h->n_single;
+    else if (std::strcmp(name, "predictions_behind_tail") == 0) *value = h->n_behind_tail;
     else if (std::strcmp(name, "train_iterations") == 0) *value = h->train_iters;
     else if (std::strcmp(name, "train_evaluations") == 0) *value = h->train_evals;
     else if (std::strcmp(name, "workspace_blocks_reused") == 0 || std::strcmp(name, "workspace_blocks_fresh") == 0) {

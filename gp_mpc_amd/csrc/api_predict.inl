@@ -59,7 +59,10 @@ struct IoPack {
     }
 };
 
-static int ensure_scratch(gpmpc_gp* h, int B) {
+// keep_tail: the caller is the first prediction behind a fit and orders itself against the fit's tail and alpha (predict_chunk)
+static int ensure_scratch(gpmpc_gp* h, int B, bool keep_tail = false) {
+    h->tail.armed = false;      // whoever comes here is about to use the predict scratch on the main queue (TailState)
+    if (!keep_tail) alpha_ready(h);
     const int need = round_up(B < chunk_size(h) ? B : chunk_size(h), 64);
     if (need <= h->Bcap) return GPMPC_OK;
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -86,17 +89,52 @@ static int ensure_scratch(gpmpc_gp* h, int B) {
 
 // One chunk (B <= Bcap) with device pointers: mean/var (either may be NULL), optional J.
 // VT (optional, with dVar): also keep V^T = (L^-1 Ks)^T, [Ny][Bp][Np], for the sensitivities
-static int predict_chunk(gpmpc_gp* h, int B, const double* dZ, double* dMean, double* dVar, double* dJ, double* VT = nullptr) {
+// behind_tail: this is the first use of the predict scratch behind a gpmpc_fit that returned at the end of its chain
+// kernel (TailState, api_core.inl): the last row panel of L^-1 (eight latency-bound level launches
+// and one product, ~0.3 ms in which the chip is nearly idle) is still in flight on the main queue and alpha follows it
+// on the workers' queue.  The cross-covariances need neither: they are formed on the low-priority queue NOW, next to the
+// tail, by a grid of one workgroup per CU (the tail's small launches keep finding room), the variance product follows
+// the tail directly on the main queue, and the mean Ks^T alpha is formed on the workers' queue behind alpha, next to
+// the variance product.  Only with device pointers on the handle's own queue (the inputs are ready when the call is
+// made) and without the Jacobian (its sums are fused with alpha into the cross-covariance kernel).
+static int predict_chunk(gpmpc_gp* h, int B, const double* dZ, double* dMean, double* dVar, double* dJ, double* VT = nullptr,
+                         bool behind_tail = false) {
     const Ctx cx = h->cx();
     const int Bp = round_up(B, 32), Np = h->Np, Ny = h->Ny;
-    {
+    int tilesM = 0;
+    static const int overlap_env = getenv("GPMPC_PREDICT_OVERLAP") ? atoi(getenv("GPMPC_PREDICT_OVERLAP")) : 1;
+    const bool overlapped = behind_tail && overlap_env && dVar && !dJ && !VT && B > 64 && cx.bulk && cx.side &&
+                            h->stream == h->own_stream;
+    TailState& ts = h->tail;
+    if (overlapped) {
+        // (GPMPC_CROSSCOV_WGS: workgroups of the throttled launch; 0 = one per block of test points, i.e. not throttled)
+        static const int cc_wgs = getenv("GPMPC_CROSSCOV_WGS") ? atoi(getenv("GPMPC_CROSSCOV_WGS")) : g_cu_count[h->device];
+        {
+            ProfScope t(&h->prof, cx.bulk, GPMPC_PH_CROSSCOV);
+            launch_crosscov(cx.bulk, h->d, h->XT, h->ws.hyper, nullptr, dZ, h->KsT, h->meanT, nullptr, h->N, Np, B, Bp, Ny, nullptr,
+                            1, cc_wgs);
+        }
+        hipEventRecord(TailState::get(ts.ev_ks), cx.bulk);
+        hipStreamWaitEvent(cx.stream, ts.ev_ks, 0);
+        if (dMean) {                                    // behind alpha (same queue), next to the variance product
+            hipStreamWaitEvent(cx.side, ts.ev_ks, 0);
+            if (!ts.alpha_pending) {                    // (alpha was formed on the main queue: behind the tail then)
+                hipEventRecord(TailState::get(ts.ev_tail), cx.stream);
+                hipStreamWaitEvent(cx.side, ts.ev_tail, 0);
+            }
+            hipLaunchKernelGGL((mean_dot_kernel<CROSSCOV_JT>), dim3(Bp / CROSSCOV_JT, Ny), dim3(256), 0, cx.side, h->KsT,
+                               h->ws.alpha, h->meanT, Np, Bp);
+            hipEventRecord(TailState::get(ts.ev_mean), cx.side);
+        }
+        ++h->n_behind_tail;
+    } else {
+        alpha_ready(h);                                 // (a caller that kept the tail state and did not qualify after all)
         PhaseTimer t(h, GPMPC_PH_CROSSCOV);
         // few test points (an MPC's shooting nodes): cut the training points in chunks so that the launch fills the chip
         const int nch = (Bp <= CROSSCOV_SMALL_B && Np >= CROSSCOV_CHUNK_MIN_NP) ? CROSSCOV_CHUNKS : 1;
         launch_crosscov(cx.stream, h->d, h->XT, h->ws.hyper, h->ws.alpha, dZ, h->KsT, h->meanT, dJ, h->N, Np, B, Bp, Ny,
                         h->ccpart, nch);
     }
-    int tilesM = 0;
     // One point: a dedicated kernel streams L^-1 once at 5.6 TB/s (C3 size).  Measured at N = 8192, Ny = 6
     // (tools/bench_smallb.py), its multi-column versions fall off quickly (B = 2 / 4 / 8: 0.41 / 0.52 / 0.82 ms)
     // while the DMA-staged GEMM below does any B <= 32 in 0.30-0.32 ms: GPMPC_VARSMALL_MAX (default 1) is the switch.
@@ -142,10 +180,14 @@ static int predict_chunk(gpmpc_gp* h, int B, const double* dZ, double* dMean, do
         p.M = Np; p.N = Bp; p.K = Np;
         p.epi = EPI_COLSUMSQ; p.part = h->part; p.ldpart = Bp;
         p.Ct = VT; p.ldct = Np; p.sCt = (long)Bp * Np;
-        const int tile = gemm_pick_tile(p, Ny);
+        const int tile = g_gemm_force_tile ? g_gemm_force_tile : gemm_pick_tile(p, Ny);
         tilesM = (Np + tile - 1) / tile;
         p.sPart = (long)tilesM * Bp;
         launch_gemm(p, Ny, cx.stream, tile);
+    }
+    if (overlapped && dMean) {
+        hipStreamWaitEvent(cx.stream, ts.ev_mean, 0);
+        ts.alpha_pending = false;                       // (the main queue is now ordered behind alpha as well)
     }
     {
         PhaseTimer t(h, GPMPC_PH_FINISH);
@@ -173,9 +215,11 @@ static int predict_driver(gpmpc_gp* h, int method, int B, const double* Z, const
     const bool need_sigma = (method == GPMPC_TA || method == GPMPC_EM || method == GPMPC_OLD_TA);
     if (cov && need_sigma && !Sigma) return fail(GPMPC_EINVAL, "this method needs the input covariance Sigma");
     HIPCHK(hipSetDevice(h->device));
-    CHK(ensure_scratch(h, B));
     const int d = h->d, Ny = h->Ny;
     const bool host = h->ptr_mode == GPMPC_PTR_HOST;
+    // (ensure_scratch drops `armed`: only the first scratch user behind a fit may take the route next to the fit's tail)
+    const bool behind_tail = h->tail.armed && !host && !cov && !J && var && B <= chunk_size(h) && B > 64;
+    CHK(ensure_scratch(h, B, behind_tail));
     const bool moments = cov && (method == GPMPC_EM || method == GPMPC_OLD_ME || method == GPMPC_OLD_TA);
     if (moments && !h->have_invK) {
         PhaseTimer t(h, GPMPC_PH_INVK);
@@ -220,7 +264,7 @@ static int predict_driver(gpmpc_gp* h, int method, int B, const double* Z, const
             const bool ta = cov && method == GPMPC_TA;
             double* jbuf = oJ ? oJ : (ta ? h->J : nullptr);
             double* vbuf = oVar ? oVar : (cov ? h->var : nullptr);
-            CHK(predict_chunk(h, nb, dZ, oMean, vbuf, jbuf));
+            CHK(predict_chunk(h, nb, dZ, oMean, vbuf, jbuf, nullptr, behind_tail));
             if (cov) {
                 PhaseTimer t(h, GPMPC_PH_FINISH);
                 const long ne = (long)nb * Ny * Ny;

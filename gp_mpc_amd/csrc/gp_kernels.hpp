@@ -187,18 +187,24 @@ __global__ void __launch_bounds__(256) crosscov_kernel(const double* __restrict_
     // gridDim.z > 1 (small batches, the MPC's shooting nodes): the training points are cut into gridDim.z
     // chunks so that more than Bp/JT x Ny workgroups exist; the partial sums go to cpart[chunk][a][j][1 + D]
     // and crosscov_finish_kernel adds them in a fixed order.
-    const int j0 = blockIdx.x * JT, a = blockIdx.y, tid = threadIdx.x;
+    // gridDim.x < Bp/JT (the launch next to a fit's tail, api_predict.inl): a workgroup walks the blocks of test points
+    // blockIdx.x, blockIdx.x + gridDim.x, ... so that the launch occupies a few waves per CU only.
+    const int a = blockIdx.y, tid = threadIdx.x;
     const int nch = gridDim.z, clen = ((Np + nch - 1) / nch + 255) / 256 * 256;
     const int ibeg = blockIdx.z * clen, iend = min(Np, ibeg + clen);
     constexpr int NR = JAC ? JT * (D + 1) : JT;
     __shared__ double Zs[JT][D], w[D], red[4][NR];
     const double* hy = hyper + (long)a * (D + 2);
+    if (tid < D) w[tid] = 1.0 / (hy[tid] * hy[tid]);
+    const double sf2 = hy[D] * hy[D];
+    // alpha == nullptr (JAC == false only): the cross-covariances alone; mean_dot_kernel forms the mean later, once alpha
+    // exists (the first prediction behind a fit runs next to the fit's tail, api_predict.inl)
+    const double* __restrict__ al = alpha ? alpha + (long)a * Np : nullptr;
+    for (int j0 = blockIdx.x * JT; j0 < Bp; j0 += gridDim.x * JT) {
     if (tid < JT * D) {
         const int jj = tid / D, dd = tid % D;
         Zs[jj][dd] = (j0 + jj < B) ? Z[(long)(j0 + jj) * D + dd] : 0.0;
     }
-    if (tid < D) w[tid] = 1.0 / (hy[tid] * hy[tid]);
-    const double sf2 = hy[D] * hy[D];
     __syncthreads();
     double macc[JT], jacc[JAC ? JT : 1][D];
 #pragma unroll
@@ -209,13 +215,12 @@ __global__ void __launch_bounds__(256) crosscov_kernel(const double* __restrict_
 #pragma unroll
             for (int dd = 0; dd < D; ++dd) jacc[jj][dd] = 0.0;
     }
-    const double* __restrict__ al = alpha + (long)a * Np;
     double* __restrict__ out = KsT + ((long)a * Bp + j0) * Np;
     for (int i = ibeg + tid; i < iend; i += 256) {
         double x[D];
 #pragma unroll
         for (int dd = 0; dd < D; ++dd) x[dd] = XT[(long)dd * Np + i];
-        const double ai = al[i];
+        const double ai = al ? al[i] : 0.0;
         const bool live = i < N;
 #pragma unroll
         for (int jj = 0; jj < JT; ++jj) {
@@ -255,13 +260,15 @@ __global__ void __launch_bounds__(256) crosscov_kernel(const double* __restrict_
             const int jj = tid < JT ? tid : (tid - JT) / D, e = tid < JT ? 0 : 1 + (tid - JT) % D;
             cpart[(((long)blockIdx.z * Ny + a) * Bp + j0 + jj) * (D + 1) + e] = e ? v * w[e - 1] : v;
         }
-        return;
+    } else {
+        if (tid < JT && al) meanT[(long)a * Bp + j0 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+        if (JAC && tid >= JT && tid < NR) {
+            const int e = tid - JT, jj = e / D, dd = e % D;
+            if (j0 + jj < B)
+                J[((long)(j0 + jj) * Ny + a) * D + dd] = ((red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid])) * w[dd];
+        }
     }
-    if (tid < JT) meanT[(long)a * Bp + j0 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
-    if (JAC && tid >= JT && tid < NR) {
-        const int e = tid - JT, jj = e / D, dd = e % D;
-        if (j0 + jj < B)
-            J[((long)(j0 + jj) * Ny + a) * D + dd] = ((red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid])) * w[dd];
+    __syncthreads();          // Zs / red are rewritten by the next block of test points
     }
 }
 
@@ -280,6 +287,33 @@ __global__ void __launch_bounds__(256) crosscov_finish_kernel(const double* __re
     else if (j < B) J[((long)j * Ny + a) * D + e - 1] = s;
 }
 
+// mean_a(z_j) = ks^T alpha_a from the stored cross-covariances, for a crosscov_kernel launch that ran without alpha: the
+// same thread -> training point mapping and the same reduction order as the fused sum, so both routes give the same bits.
+// grid (Bp / JT, Ny), 256 threads.
+template <int JT>
+__global__ void __launch_bounds__(256) mean_dot_kernel(const double* __restrict__ KsT, const double* __restrict__ alpha,
+                                                       double* __restrict__ meanT, int Np, int Bp) {
+    const int j0 = blockIdx.x * JT, a = blockIdx.y, tid = threadIdx.x;
+    __shared__ double red[4][JT];
+    const double* __restrict__ al = alpha + (long)a * Np;
+    const double* __restrict__ ks = KsT + ((long)a * Bp + j0) * Np;
+    double macc[JT];
+#pragma unroll
+    for (int jj = 0; jj < JT; ++jj) macc[jj] = 0.0;
+    for (int i = tid; i < Np; i += 256) {
+        const double ai = al[i];
+#pragma unroll
+        for (int jj = 0; jj < JT; ++jj) macc[jj] += ks[(long)jj * Np + i] * ai;
+    }
+#pragma unroll
+    for (int jj = 0; jj < JT; ++jj) {
+        const double s = wave_sum(macc[jj]);
+        if ((tid & 63) == 0) red[tid >> 6][jj] = s;
+    }
+    __syncthreads();
+    if (tid < JT) meanT[(long)a * Bp + j0 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+}
+
 constexpr int CROSSCOV_JT = 8;       // test points per workgroup (4 when the Jacobian is accumulated as well)
 constexpr int CROSSCOV_SMALL_B = 64; // up to this many (padded) test points the training points are chunked ...
 constexpr int CROSSCOV_CHUNKS = 8;   // ... into this many pieces (gridDim.z)
@@ -292,13 +326,14 @@ constexpr int CROSSCOV_CHUNK_MIN_NP = 2048;
 template <int D>
 inline void launch_crosscov_d(hipStream_t st, const double* XT, const double* hyper, const double* alpha,
                               const double* Z, double* KsT, double* meanT, double* J, int N, int Np, int B, int Bp,
-                              int Ny, double* cpart, int nch) {
+                              int Ny, double* cpart, int nch, int max_wgs) {
     if (!cpart) nch = 1;
+    auto gx = [&](int blocks) { return max_wgs > 0 && max_wgs < blocks ? max_wgs : blocks; };   // (throttled: see the kernel)
     if (J)
-        hipLaunchKernelGGL((crosscov_kernel<D, 4, true>), dim3(Bp / 4, Ny, nch), dim3(256), 0, st, XT, hyper, alpha, Z, KsT,
+        hipLaunchKernelGGL((crosscov_kernel<D, 4, true>), dim3(gx(Bp / 4), Ny, nch), dim3(256), 0, st, XT, hyper, alpha, Z, KsT,
                            meanT, J, N, Np, B, Bp, Ny, cpart);
     else
-        hipLaunchKernelGGL((crosscov_kernel<D, CROSSCOV_JT, false>), dim3(Bp / CROSSCOV_JT, Ny, nch), dim3(256), 0, st, XT,
+        hipLaunchKernelGGL((crosscov_kernel<D, CROSSCOV_JT, false>), dim3(gx(Bp / CROSSCOV_JT), Ny, nch), dim3(256), 0, st, XT,
                            hyper, alpha, Z, KsT, meanT, J, N, Np, B, Bp, Ny, cpart);
     if (nch > 1) {
         const long items = (long)Ny * Bp * (D + 1);
@@ -309,8 +344,8 @@ inline void launch_crosscov_d(hipStream_t st, const double* XT, const double* hy
 
 inline void launch_crosscov(hipStream_t st, int d, const double* XT, const double* hyper, const double* alpha,
                             const double* Z, double* KsT, double* meanT, double* J, int N, int Np, int B, int Bp,
-                            int Ny, double* cpart = nullptr, int nch = 1) {
-#define GPMPC_CC(DD) case DD: launch_crosscov_d<DD>(st, XT, hyper, alpha, Z, KsT, meanT, J, N, Np, B, Bp, Ny, cpart, nch); break;
+                            int Ny, double* cpart = nullptr, int nch = 1, int max_wgs = 0) {
+#define GPMPC_CC(DD) case DD: launch_crosscov_d<DD>(st, XT, hyper, alpha, Z, KsT, meanT, J, N, Np, B, Bp, Ny, cpart, nch, max_wgs); break;
     switch (d) {
         GPMPC_CC(1) GPMPC_CC(2) GPMPC_CC(3) GPMPC_CC(4) GPMPC_CC(5) GPMPC_CC(6) GPMPC_CC(7) GPMPC_CC(8)
         GPMPC_CC(9) GPMPC_CC(10) GPMPC_CC(11) GPMPC_CC(12) GPMPC_CC(13) GPMPC_CC(14) GPMPC_CC(15) GPMPC_CC(16)

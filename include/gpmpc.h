@@ -108,7 +108,7 @@ int gpmpc_synchronize(gpmpc_gp* h);
  * in which case THAT factorisation is repeated on the single-queue path (same result) and the next call tries again;
  * after three consecutive time-outs the handle stays on the single-queue path for 64 fits.  Handles of one process
  * take turns for the factorisation itself.  Counters: "handoff_timeouts", "chained_factorisations",
- * "single_queue_factorisations"; process-wide: "workspace_blocks_fresh" / "workspace_blocks_reused" (the N x N blocks
+ * "single_queue_factorisations", "predictions_behind_tail" (see gpmpc_fit); process-wide: "workspace_blocks_fresh" / "workspace_blocks_reused" (the N x N blocks
  * of a workspace, >= 64 MB, come from size classes and return to a free list: gpmpc_append at large N re-uses what the
  * previous append gave back instead of paying for fresh multi-GB allocations). */
 int gpmpc_get_counter(gpmpc_gp* h, const char* name, long* value);
@@ -123,7 +123,12 @@ int gpmpc_profile_read(gpmpc_gp* h, int phase, double* total_ms, long* launches,
  * rule (optimize.py:345-350, :483-488; gp_class.py:524-529): info[a] = 0 ok, 1 = 1e-8*I was added
  * once, and the call returns GPMPC_ENOTPD (info[a] = -(first bad pivot index, 1-based)) if that
  * also fails.  alpha = K^-1 y (optimize.py:494), and if want_invK: K^-1 (optimize.py:489-490).
- * hyper is [Ny x gpmpc_hyper_width()] (= d+2 for the zero mean); info may be NULL. */
+ * hyper is [Ny x gpmpc_hyper_width()] (= d+2 for the zero mean); info may be NULL.
+ * The call returns when `info` is known -- with the persistent-kernel factorisation that is when L is complete; the
+ * last rows of L^-1 and alpha may still be in flight, and everything this API does afterwards is ordered behind them.
+ * The first gpmpc_predict_mean_var with more than 64 points behind a fit (device pointers, the handle's own stream)
+ * uses that window: its cross-covariances are formed on a second queue while the last row panel of L^-1 is inverted,
+ * its mean next to the variance product (counter "predictions_behind_tail"; same results as any later call). */
 int gpmpc_fit(gpmpc_gp* h, const double* hyper, int want_invK, int* info);
 /* Export in the reference's save_model layout (gp_class.py:693-704): hyper[Ny x gpmpc_hyper_width()],
  * chol[Ny x N x N] (lower, zeros above), alpha[Ny x N], invK[Ny x N x N]; any pointer may be NULL. */

@@ -12,6 +12,9 @@ Tolerances: fp64 throughout.
   var:  |dvar| / sf^2 <= 1e-10   (plain relative 1e-10 in addition on the sn=0.1 synthetic set)
   NLL:  |dNLL| / (|NLL| + N) <= 1e-10 on well-conditioned data
 """
+import ctypes
+import os
+
 import numpy as np
 
 import gp_oracle as go
@@ -180,6 +183,83 @@ def check_synthetic(lib, N, d, Ny, B, sn, strict_rel):
             assert abs(v - ref) / (abs(ref) + N) <= 1e-10
     h.close()
     return dict(X=X, Y=Y, H=H, Z=Z, mean=mean, var=var)
+
+
+class DevArray:
+    """A double array in device memory for the device-pointer entry points: hipMalloc / hipMemcpy through the HIP runtime
+    the library is linked against (ctypes, no torch: one HIP runtime per process); under the emulator device memory is
+    host memory and the array is a numpy array."""
+
+    def __init__(self, lib, src=None, shape=None):
+        self.emulated = 'emu' in os.path.basename(lib.path)
+        self.shape = tuple(np.shape(src)) if src is not None else tuple(shape)
+        self.nbytes = int(np.prod(self.shape)) * 8
+        if self.emulated:
+            self.host = np.ascontiguousarray(src, dtype=np.float64).copy() if src is not None else np.zeros(self.shape)
+            self.ptr = self.host.ctypes.data
+            return
+        self.hip = ctypes.CDLL('libamdhip64.so')
+        p = ctypes.c_void_p()
+        assert self.hip.hipMalloc(ctypes.byref(p), ctypes.c_size_t(self.nbytes)) == 0
+        self.ptr = p.value
+        if src is not None:
+            a = np.ascontiguousarray(src, dtype=np.float64)
+            assert self.hip.hipMemcpy(ctypes.c_void_p(self.ptr), a.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(self.nbytes), 1) == 0
+
+    def numpy(self):
+        if self.emulated:
+            return self.host.copy()
+        out = np.empty(self.shape)
+        assert self.hip.hipMemcpy(out.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(self.ptr), ctypes.c_size_t(self.nbytes), 2) == 0
+        return out
+
+    def free(self):
+        if not self.emulated and self.ptr:
+            self.hip.hipFree(ctypes.c_void_p(self.ptr))
+            self.ptr = None
+
+
+def check_predict_behind_tail(lib, N, d, B, sn=0.1, seed=77, strict=True, expect_overlap=True, repeats=2, mean_only_second=False):
+    """The first large mean + variance prediction behind a fit runs next to the tail of the triangular inverse
+    (api_predict.inl predict_chunk, `behind_tail`: the fit returns when its chain kernel ends; cross-covariances on the
+    low-priority queue, alpha and the mean on the workers' queue, the variance product right behind the tail).  Device
+    pointers, one output.  Against the oracle, and against the same library's plain route (a second prediction without
+    a fit in between runs entirely on the main queue): the same bits for the variance (same tiles, same per-tile partial
+    sums) and the mean (same summation order).  mean_only_second: the follow-up call asks for the mean alone -- it must
+    order itself behind alpha, which the first call (variance only) left pending on the workers' queue."""
+    p = go.synthetic_problem(N, d, 1, B, seed=seed, sn=sn)
+    X, Y, H, Z = p['X'], p['Y'], p['hyper'], p['Z']
+    h = Handle(lib, X, Y)
+    h.set_pointer_mode(True)
+    z = DevArray(lib, Z)
+    m1, v1 = DevArray(lib, shape=(B, 1)), DevArray(lib, shape=(B, 1))
+    m2, v2 = DevArray(lib, shape=(B, 1)), DevArray(lib, shape=(B, 1))
+    o = go.fit(X, Y, H, want_invK=False)
+    om, ov, _ = go.mean_var_jac(Z, X, H, o['alpha'], o['chol'], False)
+    for rep in range(repeats):
+        assert np.all(h.fit(H) == 0)
+        if mean_only_second:
+            h.predict_mean_var_dev(B, z.ptr, None, v1.ptr)        # behind the tail, variance only: alpha stays pending
+            h.predict_mean_var_dev(B, z.ptr, m1.ptr, None)        # plain route, reads alpha
+        else:
+            h.predict_mean_var_dev(B, z.ptr, m1.ptr, v1.ptr)      # behind the tail
+        h.predict_mean_var_dev(B, z.ptr, m2.ptr, v2.ptr)          # plain route
+        h.synchronize()
+        mean, var, mean2, var2 = m1.numpy(), v1.numpy(), m2.numpy(), v2.numpy()
+        assert np.max(np.abs(mean - om) / mean_scale(X, Z, H, o['alpha'])) <= 1e-10
+        assert np.max(np.abs(var - ov) / H[:, d] ** 2) <= 1e-10
+        if strict:
+            assert np.max(np.abs(var - ov) / np.abs(ov)) <= 1e-10
+        assert np.array_equal(var, var2), np.abs(var - var2).max()
+        assert np.max(np.abs(mean - mean2)) <= 1e-13 * np.abs(om).max()
+    if expect_overlap is not None:
+        assert (h.counter('predictions_behind_tail') == repeats) == bool(expect_overlap), h.counter('predictions_behind_tail')
+    f = h.get_factors()
+    assert relF(f['chol'][0], o['chol'][0]) <= 1e-10
+    assert np.max(np.abs(f['alpha'][0] - o['alpha'][0])) <= 1e-9 * np.abs(o["alpha"][0]).max() * (0.1 / sn) ** 2
+    for a in (z, m1, v1, m2, v2):
+        a.free()
+    h.close()
 
 
 def check_jitter_rule(lib, t):
@@ -1307,6 +1387,160 @@ def check_callback_batched(lib, N=120, Ny=3, Nu=2, Nt=4, seed=23):
             mask[rows + roff[kk // 3], cols + coff[kk % 3]] = True
         assert np.all(Jd[~mask] == 0.0)
     gp.close()
+
+
+def _callback_model(lib, N, Ny, Nu, seed):
+    """A standardised GP (so the chain rule through GP.predict's scaling is exercised) and its oracle twin."""
+    from gp_mpc_amd.gp import GP
+    Nx = Ny + Nu
+    p = go.synthetic_problem(N, Nx, Ny, 2, seed=seed, sn=0.1)
+    rng = np.random.default_rng(seed)
+    meta = dict(meanY=rng.standard_normal(Ny), stdY=rng.uniform(0.5, 2.0, Ny), meanZ=rng.standard_normal(Nx),
+                stdZ=rng.uniform(0.5, 2.0, Nx))
+    meta.update(meanX=meta['meanZ'][:Ny], stdX=meta['stdZ'][:Ny], meanU=meta['meanZ'][Ny:], stdU=meta['stdZ'][Ny:])
+    o = go.fit(p['X'], p['Y'], p['hyper'])
+    gp = GP(p['X'], p['Y'], hyper=dict(hyper=p['hyper'], chol=o['chol'], alpha=o['alpha'], invK=o['invK']), normalize=True,
+            meta=meta, xlb=np.zeros(Ny), xub=np.ones(Ny), ulb=np.zeros(Nu), uub=np.ones(Nu), lib=lib)
+    og = go.OracleGP(p['X'], p['Y'], p['hyper'], o['chol'], o['alpha'], o['invK'], normalize=True, meta=meta)
+    return gp, og, meta, rng
+
+
+def _oracle_vec(og, x, u, S):
+    m, c = og.predict(x, u, S)
+    return np.concatenate([np.asarray(m).reshape(-1), np.asarray(c).reshape(-1, order='F')])     # CasADi's column-major vec
+
+
+def _oracle_jacobian(og, x, u, S, Ny, Nu, h=1e-5):
+    """d [mean; vec(cov)] / d [x; u; vec(covar)] of the ORACLE's predict by central differences; the input covariance is
+    perturbed symmetrically (the only perturbation the value path is defined for, see check_callback_blocks), so the
+    columns of the covariance block are to be compared folded: col(p, q) + col(q, p)."""
+    Nx = Ny + Nu
+    z = np.concatenate([x, u])
+    J = np.zeros((Ny + Ny * Ny, Nx + Nx * Nx))
+    for k in range(Nx):
+        e = np.zeros(Nx)
+        e[k] = h
+        J[:, k] = (_oracle_vec(og, (z + e)[:Ny], (z + e)[Ny:], S) - _oracle_vec(og, (z - e)[:Ny], (z - e)[Ny:], S)) / (2 * h)
+    for qq in range(Nx):
+        for pp in range(Nx):
+            E = np.zeros((Nx, Nx))
+            E[pp, qq] = E[qq, pp] = h
+            J[:, Nx + pp + Nx * qq] = (_oracle_vec(og, x, u, S + E) - _oracle_vec(og, x, u, S - E)) / (2 * h)
+    return J
+
+
+def _fold_cov_columns(J, Nx, off):
+    """columns off + p + Nx q of a Jacobian w.r.t. vec(covar): add the mirror column (what a symmetric perturbation moves)"""
+    out = J.copy()
+    for qq in range(Nx):
+        for pp in range(Nx):
+            if pp != qq:
+                out[:, off + pp + Nx * qq] = J[:, off + pp + Nx * qq] + J[:, off + qq + Nx * pp]
+    return out
+
+
+def check_callback_classes(lib, ca, version, N=60, Ny=2, Nu=1, Nt=3, seed=31, methods=('ME', 'TA', 'EM', 'old_ME', 'old_TA')):
+    """The casadi.Callback classes of gp_mpc_amd/casadi_callback.py EXECUTED through the Callback protocol (`ca`: a module
+    with CasADi's API -- tests/stub_casadi.py here, casadi itself where it is installed), for the Jacobian convention of
+    CasADi `version` (3.4 / 3.5: one stacked Jacobian, the reference's version README.md:18-19; >= 3.6: one block per
+    (output, input) pair): construct, evaluate with CasADi-ordered arguments, ask for the Jacobian function and evaluate
+    it.  Values against OracleGP.predict (gp_class.py:245-263, the call MPC makes at mpc_class.py:412-413), Jacobians
+    against central differences of the ORACLE (not of the HIP path)."""
+    from gp_mpc_amd import casadi_callback as cb
+    Nx = Ny + Nu
+    ca.set_version(version) if hasattr(ca, 'set_version') else None
+    keep = cb.ca
+    cb.ca = ca
+    gp, og, meta, rng = _callback_model(lib, N, Ny, Nu, seed)
+    try:
+        layout = cb.jacobian_layout()
+        assert layout == ('dense' if cb.casadi_version(version) < (3, 6) else 'blocks')
+        Zn = meta['meanZ'][None, :] + 0.4 * meta['stdZ'][None, :] * rng.standard_normal((Nt, Nx))
+        Cs = []
+        for t in range(Nt):
+            A = rng.standard_normal((Nx, Nx)) * 0.15
+            Cs.append(A @ A.T + 1e-3 * np.eye(Nx))
+        for method in methods:
+            gp.set_method(method)
+            og.set_method(method)
+            vtol = 1e-9 if method in ('ME', 'TA') else 1e-7
+            # ---- one node per call: the signature of GP.__predict (gp_class.py:212-224) ----
+            f = cb.make_predict_callback(gp, name='gp_hip_' + method)
+            assert (f.n_in(), f.n_out()) == (3, 2)
+            assert [f.size_in(i) for i in range(3)] == [(Ny, 1), (Nu, 1), (Nx, Nx)] and [f.size_out(i) for i in range(2)] == [(Ny, 1), (Ny, Ny)]
+            x, u, S = Zn[0, :Ny], Zn[0, Ny:], Cs[0]
+            mean, cov = f(ca.DM(x), ca.DM(u), ca.DM(S))
+            om, oc = og.predict(x, u, S)
+            assert np.array(mean).shape == (Ny, 1) and np.array(cov).shape == (Ny, Ny)
+            assert np.allclose(np.array(mean), om, rtol=vtol, atol=vtol), (method, np.abs(np.array(mean) - om).max())
+            assert np.allclose(np.array(cov), oc, rtol=0, atol=vtol * max(1.0, np.abs(oc).max())), (method, np.abs(np.array(cov) - oc).max())
+            Jf = f.jacobian()
+            assert Jf.n_in() == 5 and Jf.n_out() == (1 if layout == 'dense' else 6)
+            res = Jf(ca.DM(x), ca.DM(u), ca.DM(S), mean, cov)
+            if layout == 'dense':
+                Jd = np.array(res)
+            else:
+                b = [np.array(r) for r in res]
+                assert [r.shape for r in b] == [(Ny, Ny), (Ny, Nu), (Ny, Nx * Nx), (Ny * Ny, Ny), (Ny * Ny, Nu), (Ny * Ny, Nx * Nx)]
+                Jd = np.block([[b[0], b[1], b[2]], [b[3], b[4], b[5]]])
+            assert Jd.shape == (Ny + Ny * Ny, Nx + Nx * Nx)
+            ref = _oracle_jacobian(og, x, u, S, Ny, Nu)
+            got = _fold_cov_columns(Jd, Nx, Nx)
+            assert np.allclose(got, ref, rtol=2e-5, atol=2e-6 * max(1.0, np.abs(ref).max())), (method, layout, np.abs(got - ref).max())
+            # ---- all shooting nodes of mpc_class.py:361-423 in one call ----
+            g = cb.make_batched_predict_callback(gp, Nt, name='gp_hip_nodes_' + method)
+            X, U, C = Zn[:, :Ny].T.copy(), Zn[:, Ny:].T.copy(), np.concatenate(Cs, axis=1)
+            assert [g.size_in(i) for i in range(3)] == [(Ny, Nt), (Nu, Nt), (Nx, Nx * Nt)]
+            M, V = g(ca.DM(X), ca.DM(U), ca.DM(C))
+            M, V = np.array(M), np.array(V)
+            assert M.shape == (Ny, Nt) and V.shape == (Ny, Ny * Nt)
+            for t in range(Nt):
+                om, oc = og.predict(X[:, t], U[:, t], Cs[t])
+                assert np.allclose(M[:, t:t + 1], om, rtol=vtol, atol=vtol), (method, t)
+                assert np.allclose(V[:, Ny * t:Ny * (t + 1)], oc, rtol=0, atol=vtol * max(1.0, np.abs(oc).max())), (method, t)
+            Jg = g.jacobian()
+            res = Jg(ca.DM(X), ca.DM(U), ca.DM(C), ca.DM(M), ca.DM(V))
+            nin, nout = [Ny * Nt, Nu * Nt, Nx * Nx * Nt], [Ny * Nt, Ny * Ny * Nt]
+            if layout == 'dense':
+                assert res.sparsity().nnz() == Nt * (Ny + Ny * Ny) * (Nx + Nx * Nx)          # declared block diagonal
+                Jb = np.array(res)
+            else:
+                bb = [np.array(r) for r in res]
+                assert [r.shape for r in bb] == [(r_, c_) for r_ in nout for c_ in nin]
+                assert sum(r.sparsity().nnz() for r in res) == Nt * (Ny + Ny * Ny) * (Nx + Nx * Nx)
+                Jb = np.block([[bb[0], bb[1], bb[2]], [bb[3], bb[4], bb[5]]])
+            assert Jb.shape == (sum(nout), sum(nin))
+            # node t's block against the oracle's single-node Jacobian; everything off the block diagonal is exactly zero
+            seen = np.zeros_like(Jb, dtype=bool)
+            for t in range(Nt):
+                ref = _oracle_jacobian(og, X[:, t], U[:, t], Cs[t], Ny, Nu)
+                rows = np.concatenate([Ny * t + np.arange(Ny), nout[0] + Ny * Ny * t + np.arange(Ny * Ny)])
+                cols = np.concatenate([Ny * t + np.arange(Ny), nin[0] + Nu * t + np.arange(Nu),
+                                       nin[0] + nin[1] + Nx * Nx * t + np.arange(Nx * Nx)])
+                blk = Jb[np.ix_(rows, cols)]
+                got = _fold_cov_columns(blk, Nx, Nx)
+                assert np.allclose(got, ref, rtol=2e-5, atol=2e-6 * max(1.0, np.abs(ref).max())), (method, layout, t, np.abs(got - ref).max())
+                seen[np.ix_(rows, cols)] = True
+            assert np.all(Jb[~seen] == 0.0)
+            assert f.n_eval >= 1 and Jf.n_eval == 1 and g.n_eval == 1 and Jg.n_eval == 1 if hasattr(f, 'n_eval') else True
+        # the Callback refuses what CasADi would refuse: wrong argument shapes
+        bad = False
+        try:
+            f(ca.DM(np.zeros(Ny + 1)), ca.DM(u), ca.DM(S))
+        except RuntimeError:
+            bad = True
+        assert bad
+        cb.ca = None                       # without casadi the factories say so (the GP itself keeps working)
+        for make in (lambda: cb.make_predict_callback(gp), lambda: cb.make_batched_predict_callback(gp, Nt)):
+            try:
+                make()
+                raised = False
+            except ImportError:
+                raised = True
+            assert raised
+    finally:
+        cb.ca = keep
+        gp.close()
 
 
 def check_training_active_bound(lib, t):

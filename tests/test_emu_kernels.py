@@ -91,6 +91,19 @@ def test_emu_three_worker_launches(emu):
         emu.set_tuning('cu_count', 8)
 
 
+def test_emu_predict_behind_tail(emu):
+    # Np = 768 with 14 emulated workers: two worker launches, so the fit returns at the end of the chain kernel with the
+    # last row panel of L^-1 and alpha (workers' queue) in flight; the first prediction forms its cross-covariances on the
+    # low-priority queue (throttled grid: 16 workgroups walk the blocks of test points) and its mean next to the
+    # variance product; device pointers (host memory under the emulator)
+    emu.set_tuning('cu_count', 16)
+    try:
+        pc.check_predict_behind_tail(emu, N=760, d=3, B=150)
+        pc.check_predict_behind_tail(emu, N=700, d=3, B=70, mean_only_second=True)
+    finally:
+        emu.set_tuning('cu_count', 8)
+
+
 def test_emu_jitter_rule(emu, train_small):
     pc.check_jitter_rule(emu, train_small)
 
@@ -200,6 +213,14 @@ def test_emu_callback_blocks(emu):
 
 def test_emu_callback_all_nodes_in_one_call(emu):
     pc.check_callback_batched(emu, N=50, Ny=2, Nu=1, Nt=3)
+
+
+@pytest.mark.parametrize('version', ['3.4.5', '3.6.3'])
+def test_emu_callback_classes_execute_under_stub_casadi(emu, version):
+    """casadi_callback.py's four Callback subclasses run through CasADi's Callback protocol (tests/stub_casadi.py), both
+    Jacobian conventions; values against OracleGP.predict, Jacobians against differences of the oracle."""
+    import stub_casadi
+    pc.check_callback_classes(emu, stub_casadi, version, N=50, Ny=2, Nu=1, Nt=2)
 
 
 def test_callback_layout_follows_the_casadi_version():

@@ -77,6 +77,27 @@ def test_synthetic_default_noise(lib):
     pc.check_synthetic(lib, N=1500, d=8, Ny=3, B=1000, sn=1e-2, strict_rel=False)
 
 
+def test_predict_behind_tail_c2_size(lib):
+    """The first large prediction behind a fit runs next to the tail of L^-1 (cross-covariances on a second queue while the
+    last row panel is inverted, alpha and the mean on the workers' queue next to the variance product): same bits as the
+    plain route, oracle bars; at the C2 size and around it."""
+    pc.check_predict_behind_tail(lib, N=4096, d=6, B=10000, sn=0.1, strict=True, repeats=3)
+    pc.check_predict_behind_tail(lib, N=4096, d=6, B=1000, sn=1e-2, strict=False, seed=1234)
+    pc.check_predict_behind_tail(lib, N=2048, d=4, B=700, sn=0.1, mean_only_second=True)
+    pc.check_predict_behind_tail(lib, N=3000, d=5, B=900, sn=0.1)
+    pc.check_predict_behind_tail(lib, N=4100, d=6, B=600, sn=0.1)
+    pc.check_predict_behind_tail(lib, N=500, d=6, B=200, sn=0.1, expect_overlap=None)
+
+
+@pytest.mark.parametrize('version', ['3.4.5', '3.6.3'])
+def test_callback_classes_execute_under_stub_casadi(lib, version):
+    """the casadi.Callback subclasses (single node = GP.__predict's signature gp_class.py:212-224, and all
+    shooting nodes of mpc_class.py:361-423 in one call) driven through CasADi's Callback protocol by tests/stub_casadi.py,
+    both Jacobian conventions; values vs OracleGP.predict, Jacobians vs central differences of the oracle."""
+    import stub_casadi
+    pc.check_callback_classes(lib, stub_casadi, version, N=200, Ny=3, Nu=2, Nt=4)
+
+
 def test_jitter_rule(lib, train_small):
     pc.check_jitter_rule(lib, train_small)
 
