@@ -31,6 +31,8 @@ _vp = ctypes.c_void_p
 # name -> (restype, argtypes); must list every symbol gpmpc.h declares (tests/test_abi.py checks)
 SIGNATURES = {
     'gpmpc_abi_version': (ctypes.c_int, []),
+    'gpmpc_runtime_info': (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int]),
+    'gpmpc_profile_set_mask': (ctypes.c_int, [_vp, ctypes.c_uint]),
     'gpmpc_last_error': (ctypes.c_char_p, []),
     'gpmpc_device_count': (ctypes.c_int, [_ip]),
     'gpmpc_device_name': (ctypes.c_int, [ctypes.c_int, ctypes.c_char_p, ctypes.c_int]),
@@ -138,6 +140,12 @@ class GpmpcLib:
         tf = ctypes.c_double(0.0)
         self.check(self.dll.gpmpc_mfma_selftest(device, ctypes.byref(layout), ctypes.byref(tf)))
         return layout.value, tf.value
+
+    def runtime_info(self):
+        """{'hip_runtime', 'hip_path', 'rccl', 'rccl_path'}: the HIP runtime and RCCL build this process runs the library on."""
+        buf = ctypes.create_string_buffer(1024)
+        self.check(self.dll.gpmpc_runtime_info(buf, 1024))
+        return dict(kv.split('=', 1) for kv in buf.value.decode().split(' ') if '=' in kv)
 
     def set_tuning(self, name, value):
         """Diagnostic knob, e.g. set_tuning('gemm_tile', 64) pins the GEMM tile (0 = automatic)."""
@@ -252,13 +260,12 @@ class Handle:
 
     def profile_enable(self, on=True, phases=None):
         """HIP-event brackets per phase; `phases` (names from PHASES) restricts them -- every bracket costs stream time."""
-        code = int(bool(on))
+        mask = 0
         if on and phases is not None:
-            mask = 0
             for name in phases:
                 mask |= 1 << PHASES.index(name)
-            code = 1 | (mask << 1)
-        self.lib.check(self.lib.dll.gpmpc_profile_enable(self.h, code))
+        self.lib.check(self.lib.dll.gpmpc_profile_set_mask(self.h, mask))
+        self.lib.check(self.lib.dll.gpmpc_profile_enable(self.h, int(bool(on))))
 
     def profile_read(self, reset=True):
         out = {}

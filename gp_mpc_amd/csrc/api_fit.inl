@@ -251,6 +251,7 @@ extern "C" int gpmpc_append(gpmpc_gp* h, int n, const double* Xnew, const double
     HIPCHK(hipMemcpy(ws1.jitter, h->ws.jitter, (size_t)Ny * sizeof(double), hipMemcpyDeviceToDevice));
     const long slot_cap = ws1.wstride() - ws1.hw() * ws1.hw();
     const bool strip = R0 >= 64 && m <= Np1 / 4 && (long)m * R0 <= slot_cap;
+    h->nll_last_a = -1;                                     // (the training workspace's factors belong to the old data)
     auto install = [&]() {                                  // the handle takes the new data set
         hipFree(h->XT); hipFree(h->Y);
         ws_free(h->ws);

@@ -311,6 +311,7 @@ int gpmpc_set_mean_func(gpmpc_gp* h, int kind, int add_to_prediction) {
     HIPCHK(hipStreamSynchronize(h->stream));
     h->mean_kind = kind;
     h->mean_add = add_to_prediction != 0;
+    h->nll_last_a = -1;                                  // (the training workspace's factors belong to the old objective)
     h->hyper.assign((size_t)h->Ny * h->nh(), 0.0);     // rows change width: the model has to be fitted / loaded again
     h->fitted = false;
     h->have_invK = false;
@@ -321,6 +322,7 @@ int gpmpc_set_mean_func(gpmpc_gp* h, int kind, int add_to_prediction) {
 int gpmpc_set_hyper_prior(gpmpc_gp* h, const double* prior6) {
     if (!h) return fail(GPMPC_EINVAL, "NULL handle");
     h->have_prior = prior6 != nullptr;
+    h->nll_last_a = -1;                                  // (nll_grad_last adds the prior's gradient of the point gpmpc_nll saw)
     if (prior6) {
         for (int k = 0; k < 6; ++k) {
             if (!(prior6[k] == prior6[k]) || ((k & 1) && !(prior6[k] > 0.0)))
@@ -375,8 +377,13 @@ int gpmpc_get_counter(gpmpc_gp* h, const char* name, long* value) {
 
 int gpmpc_profile_enable(gpmpc_gp* h, int enable) {
     if (!h) return fail(GPMPC_EINVAL, "NULL handle");
-    h->prof.on = enable != 0;
-    h->prof.mask = enable > 1 ? (unsigned)enable >> 1 : ~0u;     // enable = 1 | mask << 1: only the phases of `mask`
+    h->prof.on = enable != 0;                  // (any nonzero value: on; which phases: gpmpc_profile_set_mask)
+    return GPMPC_OK;
+}
+
+int gpmpc_profile_set_mask(gpmpc_gp* h, unsigned mask) {
+    if (!h) return fail(GPMPC_EINVAL, "NULL handle");
+    h->prof.mask = mask ? mask : ~0u;
     return GPMPC_OK;
 }
 

@@ -93,7 +93,9 @@ extern "C" int gpmpc_set_tuning(const char* name, int value) {
     }
     if (std::strcmp(name, "fail_nll_after") == 0) {      // fault injection for the tests of the restart shard's failure paths
         if (value < 0) return fail(GPMPC_EINVAL, "fail_nll_after must be >= 0");
-        g_fail_nll_after = value;
+        static const bool testing = getenv("GPMPC_TESTING") && atoi(getenv("GPMPC_TESTING")) != 0;
+        if (!testing) return fail(GPMPC_EINVAL, "fail_nll_after is a test knob: start the process with GPMPC_TESTING=1");
+        g_fail_nll_after.store(value);
         return GPMPC_OK;
     }
     return fail(GPMPC_EINVAL, "unknown tuning knob '%s'", name);

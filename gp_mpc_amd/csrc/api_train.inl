@@ -5,7 +5,8 @@
 // ------------------------------------------------------------------------------------------------
 // gpmpc_set_tuning("fail_nll_after", n): the n-th NLL evaluation of the process from now on reports a device failure
 // (GPMPC_EHIP) without touching the device -- how the tests reach the failure paths of the restart shard (0 = off).
-static int g_fail_nll_after = 0;
+// Only in a process started with GPMPC_TESTING=1 (the knob is refused otherwise): production code cannot arm it.
+static std::atomic<int> g_fail_nll_after{0};
 
 // K^-1 (lower triangle) from the L^-1 in `ws`, then the gradient reductions into h->gradOut: what gpmpc_nll adds for a
 // gradient, enqueued on the handle's stream
@@ -78,7 +79,8 @@ static int nll_grad_last(gpmpc_gp* h, int a, const double* hyper_row, double* gr
 
 extern "C" int gpmpc_nll(gpmpc_gp* h, int a, const double* hyper_row, double* nll, double* grad, int* jitter_out) {
     if (!h || !hyper_row || !nll || a < 0 || a >= h->Ny) return fail(GPMPC_EINVAL, "bad arguments");
-    if (g_fail_nll_after > 0 && --g_fail_nll_after == 0) return fail(GPMPC_EHIP, "injected device failure (fail_nll_after)");
+    if (g_fail_nll_after.load(std::memory_order_relaxed) > 0 && g_fail_nll_after.fetch_sub(1) == 1)
+        return fail(GPMPC_EHIP, "injected device failure (fail_nll_after)");
     HIPCHK(hipSetDevice(h->device));
     const int d = h->d, Np = h->Np;
     for (int k = 0; k < d + 1; ++k)
@@ -164,6 +166,31 @@ extern "C" int gpmpc_rccl_comm_count(void* comm, int* count) {
     if (!R.ok() || !R.CommCount) return fail(GPMPC_EHIP, "librccl.so could not be loaded: %s", R.load_error.c_str());
     const int rc = R.CommCount(comm, count);
     return rc == 0 ? GPMPC_OK : fail(GPMPC_EHIP, "ncclCommCount failed: %s", R.GetErrorString ? R.GetErrorString(rc) : "?");
+}
+
+// Which HIP runtime and which RCCL this process runs the library on (one of each per process: the library is linked
+// against libamdhip64.so.N by soname and takes whichever the process mapped first -- PyTorch's bundled copy when torch
+// was imported first, /opt/rocm's otherwise; RCCL is bound at run time to the image the process already maps or, failing
+// that, to the one next to that HIP runtime, train_native.hpp).  Text: "hip_runtime=<version> hip_path=<file>
+// rccl=<version|unavailable> rccl_path=<file>".
+extern "C" int gpmpc_runtime_info(char* buf, int buflen) {
+    if (!buf || buflen <= 0) return fail(GPMPC_EINVAL, "bad buffer");
+    int hv = 0;
+    std::string hip_path = "?";
+#ifndef GPMPC_EMULATED
+    (void)hipRuntimeGetVersion(&hv);
+    Dl_info di;
+    if (dladdr((void*)&hipGetDeviceCount, &di) && di.dli_fname) hip_path = di.dli_fname;
+#else
+    hip_path = "emulator";
+#endif
+    RcclApi& R = rccl_api();
+    int rv = 0;
+    if (R.ok() && R.GetVersion) (void)R.GetVersion(&rv);
+    char rver[32];
+    if (R.ok()) snprintf(rver, sizeof(rver), "%d", rv); else snprintf(rver, sizeof(rver), "unavailable");
+    snprintf(buf, buflen, "hip_runtime=%d hip_path=%s rccl=%s rccl_path=%s", hv, hip_path.c_str(), rver, R.ok() ? R.path.c_str() : "-");
+    return GPMPC_OK;
 }
 
 extern "C" int gpmpc_train_multistart(gpmpc_gp* h, int nstart, const double* starts, const double* lb, const double* ub,

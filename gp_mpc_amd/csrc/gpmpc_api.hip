@@ -3,6 +3,7 @@
 // The host code is split by concern into the api_*.inl files included below, in dependency order.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>

@@ -192,6 +192,8 @@ struct RcclApi {
     int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
     int (*CommCount)(void*, int*) = nullptr;
+    int (*GetVersion)(int*) = nullptr;
+    std::string path;                                             // file the symbols come from (dladdr)
     std::string load_error;                                       // dlerror() text of the first failed dlopen / what is missing
     bool ok() const { return lib && GetUniqueId && CommInitRank && CommDestroy && AllGather; }
 };
@@ -202,6 +204,14 @@ inline RcclApi& rccl_api() {
         // PyTorch first runs on the copies bundled in torch/lib, one that loaded this library first on /opt/rocm, and an
         // RCCL from the other tree opens a second, uninitialised HSA runtime ("no ROCm-capable device is detected").
         // So: the librccl next to the libamdhip64 that hipGetDeviceCount resolves to, with local symbol scope.
+        // ONE RCCL build per process: if the process already maps an RCCL (PyTorch links its own; torch.distributed's
+        // "nccl" backend runs on it) that very image is bound -- RTLD_NOLOAD never loads a second one; otherwise the
+        // librccl next to the live HIP runtime.
+        for (const char* soname : {"librccl.so.1", "librccl.so"}) {
+            a.lib = dlopen(soname, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
+            if (a.lib) break;
+        }
+        (void)dlerror();
         std::vector<std::string> names;
         Dl_info di;
         if (dladdr((void*)&hipGetDeviceCount, &di) && di.dli_fname) {
@@ -216,6 +226,7 @@ inline RcclApi& rccl_api() {
         names.push_back("librccl.so.1");
         names.push_back("librccl.so");
         for (const std::string& name : names) {
+            if (a.lib) break;
             a.lib = dlopen(name.c_str(), RTLD_NOW | RTLD_LOCAL);
             if (a.lib) break;
             const char* e = dlerror();                            // (reading it clears it: keep the first text)
@@ -228,6 +239,9 @@ inline RcclApi& rccl_api() {
             a.AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(a.lib, "ncclAllGather");
             a.GetErrorString = (const char* (*)(int))dlsym(a.lib, "ncclGetErrorString");
             a.CommCount = (int (*)(void*, int*))dlsym(a.lib, "ncclCommCount");
+            a.GetVersion = (int (*)(int*))dlsym(a.lib, "ncclGetVersion");
+            Dl_info dr;
+            if (a.AllGather && dladdr((void*)a.AllGather, &dr) && dr.dli_fname) a.path = dr.dli_fname;
             a.load_error = a.ok() ? "" : "librccl is loaded but lacks ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllGather";
         } else if (a.load_error.empty()) {
             a.load_error = "no librccl.so found";

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GPMPC_ABI_VERSION 1
+#define GPMPC_ABI_VERSION 2   /* 2 (r04): + gpmpc_profile_set_mask, gpmpc_runtime_info; gpmpc_profile_enable: nonzero = all phases again */
 
 /* status codes */
 #define GPMPC_OK 0
@@ -112,10 +112,11 @@ int gpmpc_synchronize(gpmpc_gp* h);
  * of a workspace, >= 64 MB, come from size classes and return to a free list: gpmpc_append at large N re-uses what the
  * previous append gave back instead of paying for fresh multi-GB allocations). */
 int gpmpc_get_counter(gpmpc_gp* h, const char* name, long* value);
-/* HIP-event brackets per phase on the handle's stream.  enable: 0 off, 1 every phase, 1 | (mask << 1) only the phases whose
- * bit (the GPMPC_PH_* index) is set in mask -- each bracket is two timing events, ~5 us of the stream's time: with all seven
- * phases of a fit + predict step bracketed the step takes 65 us longer at N = 4096 (r03 measurement). */
+/* HIP-event brackets per phase on the handle's stream.  enable: 0 off, nonzero on.  gpmpc_profile_set_mask restricts the
+ * brackets to the phases whose bit (the GPMPC_PH_* index) is set (0 = all) -- each bracket is two timing events, ~5 us of the
+ * stream's time: with all seven phases of a fit + predict step bracketed the step takes 65 us longer at N = 4096 (r03). */
 int gpmpc_profile_enable(gpmpc_gp* h, int enable);
+int gpmpc_profile_set_mask(gpmpc_gp* h, unsigned mask);
 int gpmpc_profile_read(gpmpc_gp* h, int phase, double* total_ms, long* launches, int reset);
 
 /* ---- fit: a1,a3-a6 ----------------------------------------------------------------------- */
@@ -244,6 +245,11 @@ int gpmpc_rccl_comm_create(int device, int world, int rank, const char* id128, v
 int gpmpc_rccl_comm_destroy(void* comm);
 /* Number of ranks the communicator spans (ncclCommCount): what bench.py reports as `rccl_ranks`. */
 int gpmpc_rccl_comm_count(void* comm, int* count);
+/* The HIP runtime and the RCCL build this process runs the library on, as text "hip_runtime=<version> hip_path=<file>
+ * rccl=<version|unavailable> rccl_path=<file>".  One of each per process: the library takes the libamdhip64 the process
+ * mapped first and binds, at run time, the RCCL image the process already maps (PyTorch's, if torch was imported) or
+ * else the one next to that HIP runtime -- so the library's ncclAllGather and torch.distributed's share one RCCL. */
+int gpmpc_runtime_info(char* buf, int buflen);
 
 /* ---- low-level dense ops (host pointers), used by the parity tests ------------------------ */
 /* k(X, Z)[n1 x n2] = sf2 exp(-1/2 sum_d (x_d - z_d)^2 / ell_d^2) for X[n1 x d], Z[n2 x d]: GP.covSEard

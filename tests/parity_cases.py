@@ -973,6 +973,42 @@ def check_rollout_vs_oracle(lib, N, Ny, d, T, seed=77, uscale=0.3):
     gp.close()
 
 
+def check_c3_size_step(h, p, outs=(1, 4), node=3):
+    """One propagation step at the full C3 size against the ORACLE's own factors: the oracle
+    fits `outs` of the model's outputs from scratch (expanded-form K, LAPACK Cholesky, LU solves: optimize.py:303-356,
+    :483-494) and evaluates ME / TA / EM at one node (gp_functions.py:72-173, :344-418); the device predicts all outputs
+    from its own fit.  EM's covariance between two outputs only involves those two outputs, so the sub-model is exact.
+    Bars as at the small sizes: mean 1e-10 of sum |ks alpha|, variances 1e-10 sf^2 (ME), 1e-9 of the largest entry (TA),
+    1e-9 of the cancellation scale (EM)."""
+    X, Y, H = p['X'], p['Y'], p['hyper']
+    d = X.shape[1]
+    outs = list(outs)
+    Xs, Ys, Hs = X, Y[:, outs], H[outs]
+    o = go.fit(Xs, Ys, Hs)                                   # with K^-1 (EM)
+    z, S = p['Z'][node], p['Sigma'][node]
+    sf2 = Hs[:, d] ** 2
+    ms = mean_scale(Xs, z[None], Hs, o['alpha'])[0]
+    om, ov, oJ = go.mean_var_jac(z[None], Xs, Hs, o['alpha'], o['chol'])
+    # ME
+    m, c = h.predict('ME', z[None], S[None])
+    assert np.max(np.abs(m[0][outs] - om[0]) / ms) <= 1e-10, np.max(np.abs(m[0][outs] - om[0]) / ms)
+    assert np.max(np.abs(np.diag(c[0])[outs] - ov[0]) / sf2) <= 1e-10, np.max(np.abs(np.diag(c[0])[outs] - ov[0]) / sf2)
+    # TA
+    m, c = h.predict('TA', z[None], S[None])
+    oc = go.ta_cov(ov, oJ, S[None])[0]
+    got = c[0][np.ix_(outs, outs)]
+    assert np.max(np.abs(m[0][outs] - om[0]) / ms) <= 1e-10
+    assert np.max(np.abs(got - oc)) <= 1e-9 * max(np.abs(oc).max(), sf2.max()), np.max(np.abs(got - oc))
+    # EM
+    m, c = h.predict('EM', z[None], S[None])
+    em, ec = go.exact_moment(o['invK'], Xs, Ys, Hs, z, S)
+    got = c[0][np.ix_(outs, outs)]
+    bar = 1e-9 * (_em_scale(o['invK'], Xs, Ys, Hs, z, S).max() + sf2.max())
+    assert np.max(np.abs(m[0][outs] - em.reshape(-1))) <= 1e-10 * max(1.0, ms.max()), np.max(np.abs(m[0][outs] - em.reshape(-1)))
+    assert np.max(np.abs(got - ec)) <= bar, (np.max(np.abs(got - ec)), bar)
+    return dict(ms=ms, bar_em=bar)
+
+
 def check_callback_pattern(h, X, H, alpha, chol, Z, S, repeats=5):
     """One NLP-callback evaluation: Nt nodes, value + mean Jacobian + TA covariance from one `gpmpc_predict_jac` call,
     against the oracle evaluated on the given factors."""

@@ -34,7 +34,7 @@ def test_header_binding_and_exports_agree(built):
 
 def test_library_loads_and_reports_without_gpu(built):
     lib = _lib.GpmpcLib(built)          # resolves every declared symbol or raises AttributeError
-    assert lib.dll.gpmpc_abi_version() == 1
+    assert lib.dll.gpmpc_abi_version() == 2
     n = lib.device_count()
     if n == 0:                           # build container: creating a model must fail loudly, not fall back
         import numpy as np

@@ -49,6 +49,15 @@ def test_c3_rollout_vs_oracle_n1024(lib):
     pc.check_rollout_vs_oracle(lib, N=1024, Ny=6, d=8, T=30)
 
 
+def test_c3_full_size_step_vs_oracle(c3):
+    """N = 8192, d = 8: outputs 1 and 4 of the six, one node, ME / TA / EM against the oracle's own fit of those outputs."""
+    import time
+    p, h = c3
+    t0 = time.time()
+    r = pc.check_c3_size_step(h, p, outs=(1, 4), node=3)
+    print(f'\n[C3] full-size oracle step took {time.time() - t0:.1f} s; EM bar {r["bar_em"]:.2e}')
+
+
 def test_c5_pattern_car_fixture(lib, car):
     """Nt = 30 nodes per call on the reference's own car model (N = 200, Ny = 3, d = 5)."""
     from gp_mpc_amd._lib import Handle

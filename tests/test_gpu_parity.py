@@ -127,6 +127,14 @@ def test_c2_full_size_vs_oracle_and_properties(lib):
     h.close()
 
 
+def test_c2_full_size_strict_relative_bars(lib):
+    """SURVEY 8c / north_star "within 1e-10 rel": the C2 size with sn = 0.1 (well conditioned) at PLAIN relative 1e-10 on
+    L, the mean, the variance and the NLL (check_synthetic strict_rel) -- next to the cond-scaled bars of the sn = 1e-2 set."""
+    t0 = time.time()
+    pc.check_synthetic(lib, N=4096, d=6, Ny=1, B=10000, sn=0.1, strict_rel=True)
+    print(f'\n[C2 strict] took {time.time() - t0:.1f} s')
+
+
 def test_moment_methods(lib, tank):
     pc.check_moment_methods(lib)
     pc.check_moment_methods(lib, tank)

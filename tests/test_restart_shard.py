@@ -60,7 +60,8 @@ def test_one_rank_failure_reaches_every_rank(tmp_path, optimizer):
     """A device failure on ONE rank (injected: its second NLL evaluation returns GPMPC_EHIP) must not strand the other in
     the exchange: the failing rank still joins it, with +inf rows and its error code, and BOTH raise."""
     subprocess.check_call([os.path.join(HERE, 'emu', 'build_emu.sh')], stdout=subprocess.DEVNULL)
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(29521 if optimizer == 'native' else 29522), WORLD_SIZE='2')
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(29521 if optimizer == 'native' else 29522), WORLD_SIZE='2',
+               GPMPC_TESTING='1')          # (arms the fault-injection knob: refused in a process without it)
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, 'dist_worker_fail.py'), str(tmp_path), optimizer],
                               env=dict(env, RANK=str(r), LOCAL_RANK=str(r))) for r in range(2)]
     for p in procs:
