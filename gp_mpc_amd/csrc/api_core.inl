@@ -229,12 +229,14 @@ static void block_list_release() {
 struct Workspace {
     int batch = 0, Np = 0, d = 0;
     double *K = nullptr, *L = nullptr, *Inv = nullptr, *InvK = nullptr, *W = nullptr;
+    double* Wl = nullptr;   // level scratch of the diagonal-block inverses of the two-level factorisation (batches of matrices)
     double *w = nullptr, *alpha = nullptr, *hyper = nullptr, *jitter = nullptr, *nll = nullptr;
     int* info = nullptr;
     int* flags = nullptr;   // hand-off words of the chain kernel, [batch][chain_flag_count(Np/64)]
     long mat() const { return (long)Np * Np; }
     // scratch of the triangular inverse per matrix: [0, hw^2) level scratch, then one slot per high-level node
     long hw() const { return Np / 2 + 64; }
+    static long wl_stride() { return 512L * 512L; }     // super-panels of up to 16 block columns: (32 W)^2 doubles per matrix
     long wstride() const {
         long slots = 0;                 // sum of h2 * s over the nodes above the segment level (trtri_segment)
         for (long s = SEGR; s < Np; s *= 2)
@@ -252,6 +254,7 @@ static int ws_alloc(Workspace& ws, int batch, int Np, int d) {
     HIPCHK(block_alloc(&ws.L, mb));
     HIPCHK(block_alloc(&ws.Inv, mb));
     HIPCHK(block_alloc(&ws.W, (size_t)batch * ws.wstride() * sizeof(double)));
+    HIPCHK(hipMalloc(&ws.Wl, (size_t)batch * Workspace::wl_stride() * sizeof(double)));
     HIPCHK(hipMalloc(&ws.w, (size_t)batch * Np * sizeof(double)));
     HIPCHK(hipMalloc(&ws.alpha, (size_t)batch * Np * sizeof(double)));
     HIPCHK(hipMalloc(&ws.hyper, (size_t)batch * (d + 2) * sizeof(double)));
@@ -273,6 +276,7 @@ static int ws_alloc(Workspace& ws, int batch, int Np, int d) {
 
 static void ws_free(Workspace& ws) {
     block_free(ws.K); block_free(ws.L); block_free(ws.Inv); block_free(ws.InvK); block_free(ws.W);
+    hipFree(ws.Wl);
     hipFree(ws.w); hipFree(ws.alpha); hipFree(ws.hyper); hipFree(ws.jitter); hipFree(ws.nll); hipFree(ws.info); hipFree(ws.flags);
     ws = Workspace();
 }
@@ -355,4 +359,6 @@ struct Ctx {
     Prof* prof = nullptr;           // the handle's profile (phase brackets inside the factorisation)
     hipStream_t bulk = nullptr;     // fourth queue (low priority): look-ahead part of the two-level trailing updates
     TailState* tail = nullptr;      // early status + row-panel events of the chained factorisation (may be null)
+    bool no_workers = false;        // never the tile-owner workers: the choice of execution must not depend on the batch size
+                                    // (lock-step restart search: a point's value may not depend on what else is in its batch)
 };

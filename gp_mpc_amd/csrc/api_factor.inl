@@ -33,8 +33,12 @@ static int g_worker_courier = -1;   // gpmpc_set_tuning("worker_courier", 0 / 1)
 // single-queue version did not pay because the leaf slows down 3-8x when it shares a CU with MFMA waves.)
 
 // level-by-level batched inverse of the diagonal range [base, base + n) (rows), given its 64-blocks
-static void trtri_range(const Ctx& cx, Workspace& ws, hipStream_t stream, long base0, int n) {
-    const long ld = ws.Np, sM = ws.mat(), sW = ws.wstride();
+// (scratch / sScratch: the W = L21 inv11 products of a level go there instead of to the head of ws.W -- a caller whose
+//  other queues use ws.W at the same time, factor_twolevel)
+static void trtri_range(const Ctx& cx, Workspace& ws, hipStream_t stream, long base0, int n, double* scratch = nullptr,
+                        long sScratch = 0) {
+    const long ld = ws.Np, sM = ws.mat(), sW = scratch ? sScratch : ws.wstride();
+    double* Wl = scratch ? scratch : ws.W;
     for (int s = 64; s < n; s *= 2) {
         const int nfull = n / (2 * s);                  // nodes with a full right child
         const int rem = n - nfull * 2 * s;              // tail: a partial node exists if rem > s
@@ -49,13 +53,13 @@ static void trtri_range(const Ctx& cx, Workspace& ws, hipStream_t stream, long b
             GemmP t = gemm_base(cx);                    // W = L21 inv11
             t.A = ws.L + o21; t.lda = ld; t.a_mc = 0;
             t.B = ws.Inv + o11; t.ldb = ld; t.b_nc = 1; t.kflags = KB_GE_N;
-            t.C = ws.W; t.ldc = s;
+            t.C = Wl; t.ldc = s;
             t.M = h2; t.N = s; t.K = s;
             t.zdiv = nodes; t.sA = snode; t.sB = snode; t.sC = (long)s * s; t.sA2 = sM; t.sB2 = sM; t.sC2 = sW;
             launch_gemm(t, nodes * ws.batch, stream);
             GemmP u = gemm_base(cx);                    // inv21 = -inv22 W
             u.A = ws.Inv + o22; u.lda = ld; u.a_mc = 0; u.kflags = KA_LE_M;
-            u.B = ws.W; u.ldb = s; u.b_nc = 1;
+            u.B = Wl; u.ldb = s; u.b_nc = 1;
             u.C = ws.Inv + o21; u.ldc = ld;
             u.M = h2; u.N = s; u.K = h2; u.alpha = -1.0;
             u.zdiv = nodes; u.sA = snode; u.sB = (long)s * s; u.sC = snode; u.sA2 = sM; u.sB2 = sW; u.sC2 = sM;
@@ -152,12 +156,26 @@ static long long* g_chain_trace = nullptr;   // developer aid: GPMPC_CHAIN_TRACE
 //                                      then ONE product A22 -= L21 L21^T with K = 64 W on everything to the right.
 // C traffic of the big updates falls by W and they run at the GEMM's MFMA rate; the inverse of a finished 512-row
 // segment runs on the third queue while the big update occupies the second.
-static bool factor_twolevel(const Ctx& cx, Workspace& ws, int spin_limit, int W) {
+// Blocked super-panels (r04).  The first version carried EVERY row below a super-panel through its K = 64 in-panel
+// steps: per step the panel product and a trailing update over (all rows below) x (the super-panel's remaining columns),
+// flag-coupled to the chain -- at a batch of 16 matrices of 4096^2 each of those launches moves ~0.5 GB and takes 0.1-0.5 ms,
+// eight of them pace every super-panel (2.4 of the 2.5 ms a super-panel took; profiles/r04_batchfit_trace_before.txt).  Now
+// the in-panel steps stay INSIDE the super-panel's diagonal block (64 W rows: L2-resident, latency only), and the rows
+// below follow in one product with the block's explicit inverse, which the panel-wise triangular inverse needs anyway:
+//     chain + flagged K = 64 launches on rows / columns [r_i, r_i+1)          ->  L11 = chol(A11)
+//     I_i = L11^-1 (level-batched, own scratch)                               ->  trtri_range
+//     L21 = A21 I_i^T   (rows below, K = 64 W, triangular)                    ->  one MFMA-rate product
+//     A22 -= L21 L21^T  (K = 64 W; look-ahead split as before)
+// want_inverse = false (value-only NLL evaluations of the restart search): L and the diagonal blocks' inverses I_i only.
+static bool factor_twolevel(const Ctx& cx, Workspace& ws, int spin_limit, int W, bool want_inverse = true) {
     const int Np = ws.Np, nb = Np / 64, nf = chain_flag_count(nb);
     const long ld = Np, sM = ws.mat(), sW = ws.wstride();
     int* leafdone = ws.flags + 1;
     int* pan1 = ws.flags + 1 + nb;
     int* tdone = ws.flags + 1 + 2 * nb;
+    static const bool blocked_env = !(getenv("GPMPC_TWOLEVEL_BLOCKED") && atoi(getenv("GPMPC_TWOLEVEL_BLOCKED")) == 0);
+    const int nsp = (nb + W - 1) / W;
+    const bool blocked = blocked_env && ws.Wl && (long)(32 * W) * (32 * W) <= ws.wl_stride() && cx.seg && cx.n_seg >= 5 * nsp + 4;
     // The inverse follows panel by panel on the third queue -- right-looking blocked inversion of the row panels
     // P_i = super-panel i: with S = sum over finished panels m of L[., P_m] X[P_m, .] accumulated IN the not yet final
     // rows of Inv,
@@ -166,10 +184,10 @@ static bool factor_twolevel(const Ctx& cx, Workspace& ws, int spin_limit, int W)
     // so every step only needs rows P_i of L -- final as soon as super-panel i is factored -- and after the last
     // super-panel just its own inverse and one 64 W-row product remain (the tree-shaped inverse left the two products of
     // its root, a third of the fit, for the end).  Needs a 64 W x Np scratch panel in ws.W and the event pool.
-    const bool panel_inv = cx.aux && cx.seg && cx.n_seg >= 3 && (long)64 * W * Np <= sW;
-    auto inverse_panel = [&](hipStream_t st, int k0, int k1) {
+    const bool panel_inv = want_inverse && cx.aux && cx.seg && cx.n_seg >= 3 && (long)64 * W * Np <= sW;
+    auto inverse_panel = [&](hipStream_t st, int k0, int k1, bool have_I) {
         const int ri = 64 * k0, a = 64 * (k1 - k0), rn = 64 * k1, Mb = Np - rn;
-        trtri_range(cx, ws, st, ri, a);                                        // I_i
+        if (!have_I) trtri_range(cx, ws, st, ri, a, blocked ? ws.Wl : nullptr, blocked ? ws.wl_stride() : 0);   // I_i
         if (ri > 0) {
             GemmP u = gemm_base(cx);                                           // T = -I_i S_i, then back into Inv[P_i, < r_i]
             u.A = ws.Inv + (long)ri * ld + ri; u.lda = ld; u.sA = sM; u.a_mc = 0; u.kflags = KA_LE_M;
@@ -177,9 +195,8 @@ static bool factor_twolevel(const Ctx& cx, Workspace& ws, int spin_limit, int W)
             u.C = ws.W; u.ldc = ri; u.sC = sW;
             u.M = a; u.N = ri; u.K = a; u.alpha = -1.0;
             launch_gemm(u, ws.batch, st);
-            for (int b = 0; b < ws.batch; ++b)
-                hipMemcpy2DAsync(ws.Inv + b * sM + (long)ri * ld, ld * sizeof(double), ws.W + b * sW, (size_t)ri * sizeof(double),
-                                 (size_t)ri * sizeof(double), a, hipMemcpyDeviceToDevice, st);
+            hipLaunchKernelGGL(copy_rect_kernel, dim3((ri / 2 + 255) / 256, a, ws.batch), dim3(256), 0, st, (const double*)ws.W,
+                               (long)ri, sW, ws.Inv + (long)ri * ld, ld, sM, ri);   // (ri is a multiple of 64: pairs)
         }
         if (Mb > 0) {
             GemmP t = gemm_base(cx);                                           // new columns of S: L[> P_i, P_i] I_i
@@ -205,7 +222,7 @@ static bool factor_twolevel(const Ctx& cx, Workspace& ws, int spin_limit, int W)
     // the latency-bound factorisation of super-panel s+1.  Order on shared tiles: A(s) after B(s-1) (event), B(s) after
     // the panels of s (event) and after B(s-1) (queue order).
     static const bool lookahead_on = !(getenv("GPMPC_LOOKAHEAD") && atoi(getenv("GPMPC_LOOKAHEAD")) == 0);
-    const bool lookahead = lookahead_on && cx.bulk && cx.seg && cx.n_seg >= 4 * ((nb + W - 1) / W) + 2;
+    const bool lookahead = lookahead_on && cx.bulk && cx.seg && cx.n_seg >= 5 * nsp + 4;
     hipEvent_t evB_prev = nullptr;
     if (lookahead) {
         hipEventRecord(cx.join, cx.stream);                    // the fourth queue starts behind everything enqueued so far
@@ -213,6 +230,7 @@ static bool factor_twolevel(const Ctx& cx, Workspace& ws, int spin_limit, int W)
     }
     for (int k0 = 0; k0 < nb; k0 += W) {
         const int k1 = std::min(nb, k0 + W), k2 = std::min(nb, k1 + W);
+        const int rows_end = blocked ? 64 * k1 : Np;           // in-panel steps: inside the diagonal block / every row below
         // the chain of this super-panel starts when the update of its columns (second queue) is complete
         hipEventRecord(cx.join, cx.side);
         hipStreamWaitEvent(cx.stream, cx.join, 0);
@@ -225,7 +243,7 @@ static bool factor_twolevel(const Ctx& cx, Workspace& ws, int spin_limit, int W)
             const int off = 64 * k;
             const long o11 = (long)off * ld + off;
             const bool last = k + 1 == k1;                     // the chain stops after this leaf: row k+1 is the panel product's
-            const int r0 = off + (last ? 64 : 128), M2 = Np - r0;
+            const int r0 = off + (last ? 64 : 128), M2 = rows_end - r0;
             if (M2 > 0) {
                 GemmP p = gemm_base(cx);                       // panel: L(i,k) = A(i,k) inv_kk^T
                 p.A = ws.K + (long)r0 * ld + off; p.lda = ld; p.sA = sM; p.a_mc = 0;
@@ -235,7 +253,7 @@ static bool factor_twolevel(const Ctx& cx, Workspace& ws, int spin_limit, int W)
                 p.wait_flag = leafdone + k; p.err = ws.flags; p.spin_limit = spin_limit; p.sFlags = nf;
                 launch_gemm(p, ws.batch, cx.side);
             }
-            const int M1 = Np - off - 64, N1 = 64 * (k1 - k - 1);   // trailing update inside the super-panel's columns
+            const int M1 = rows_end - off - 64, N1 = 64 * (k1 - k - 1);   // trailing update inside the super-panel's columns
             if (!last && M1 > 64) {
                 const long o1 = (long)(off + 64) * ld;
                 GemmP q = gemm_base(cx);
@@ -248,6 +266,23 @@ static bool factor_twolevel(const Ctx& cx, Workspace& ws, int spin_limit, int W)
                 launch_gemm(q, ws.batch, cx.side, 64);         // flags are defined on 64 x 64 tiles
             }
         }
+        bool have_I = false;
+        if (blocked && k1 < nb) {
+            // the diagonal block is factored when the chain launch ends (its last leaf has no flagged consumer): its inverse,
+            // then every row below in one product
+            const int ri = 64 * k0, a = 64 * (k1 - k0), rn = 64 * k1;
+            hipEventRecord(cx.seg[ev], cx.stream);
+            hipStreamWaitEvent(cx.side, cx.seg[ev], 0);
+            ++ev;
+            trtri_range(cx, ws, cx.side, ri, a, ws.Wl, ws.wl_stride());                   // I_i
+            GemmP p = gemm_base(cx);                                                       // L21 = A21 I_i^T
+            p.A = ws.K + (long)rn * ld + ri; p.lda = ld; p.sA = sM; p.a_mc = 0;
+            p.B = ws.Inv + (long)ri * ld + ri; p.ldb = ld; p.sB = sM; p.b_nc = 0; p.kflags = KB_LE_N;
+            p.C = ws.L + (long)rn * ld + ri; p.ldc = ld; p.sC = sM;
+            p.M = Np - rn; p.N = a; p.K = a;
+            launch_gemm(p, ws.batch, cx.side);
+            have_I = true;
+        }
         // rows < 64 k1 of L are final: the inverse of this row panel goes to the third queue, next to the big update
         if (panel_inv && k1 < nb && ev + 2 < cx.n_seg) {
             hipEventRecord(cx.seg[ev], cx.side);
@@ -256,8 +291,8 @@ static bool factor_twolevel(const Ctx& cx, Workspace& ws, int spin_limit, int W)
             hipEventRecord(cx.seg[ev], cx.stream);            // (the leaf's own stores: the chain launch has to be complete)
             hipStreamWaitEvent(cx.aux, cx.seg[ev], 0);
             ++ev;
-            if (inv_done < k0) inverse_panel(cx.aux, inv_done, k0);   // (panels skipped for want of events: as one)
-            inverse_panel(cx.aux, k0, k1);
+            if (inv_done < k0) inverse_panel(cx.aux, inv_done, k0, false);   // (panels skipped for want of events: as one)
+            inverse_panel(cx.aux, k0, k1, have_I && inv_done <= k0);
             inv_done = k1;
         }
         if (k1 < nb) {                                         // A22 -= L21 L21^T, K = 64 (k1 - k0)
@@ -284,6 +319,15 @@ static bool factor_twolevel(const Ctx& cx, Workspace& ws, int spin_limit, int W)
                 gb.C = ws.K + r2 * ld + r2;
                 gb.M = Np - (int)r2; gb.N = Np - (int)r2;
                 hipStreamWaitEvent(cx.bulk, evP, 0);
+                // B(s) fills every CU for milliseconds, and the next super-panel's chain workgroups need a CU's whole LDS
+                // each: launched into that, they waited until B(s) had nothing left to dispatch (r04 trace, 16 matrices of
+                // 4096^2: 1.2 ms between the chain launch and its first leaf, per super-panel).  So B(s) starts only once that
+                // chain is resident -- its first leaf is out -- i.e. behind A(s) instead of next to it; what it then overlaps
+                // is the latency-bound part of super-panel s+1 (chain, diagonal-block inverse), which is the point.
+                static const bool gate_bulk = !(getenv("GPMPC_GATE_BULK") && atoi(getenv("GPMPC_GATE_BULK")) == 0);
+                if (gate_bulk)
+                    hipLaunchKernelGGL(flag_gate_kernel, dim3(ws.batch), dim3(64), 0, cx.bulk, ws.flags, (long)nf, 1 + k1, 1, -1, 0,
+                                       spin_limit);
                 launch_gemm(gb, ws.batch, cx.bulk);
                 hipEventRecord(evB, cx.bulk);
                 evB_prev = evB;
@@ -300,8 +344,13 @@ static bool factor_twolevel(const Ctx& cx, Workspace& ws, int spin_limit, int W)
         hipEventRecord(cx.seg[cx.n_seg - 1], cx.aux);
         hipStreamWaitEvent(cx.stream, cx.seg[cx.n_seg - 1], 0);
     }
+    if (!want_inverse) {
+        // value only: the last diagonal block's inverse completes the set I_0 .. I_last (forward substitution by blocks)
+        if (blocked) trtri_range(cx, ws, cx.stream, 64 * ((nb - 1) / W * W), Np - 64 * ((nb - 1) / W * W), ws.Wl, ws.wl_stride());
+        return true;
+    }
     if (!panel_inv) { trtri_levels(cx, ws); return true; }
-    inverse_panel(cx.stream, inv_done, nb);                    // what is left: the last panel (or everything not handed over)
+    inverse_panel(cx.stream, inv_done, nb, false);             // what is left: the last panel (or everything not handed over)
     return true;
 }
 
@@ -325,7 +374,7 @@ static bool factor_chain(const Ctx& cx, Workspace& ws, int spin_limit, bool flag
     // -- with 8 workers on the engine that also got the chain, the 8th started 234 ms late, after the others'
     // polls had timed out.  So: 7 workers per engine, nothing else in flight but the chain (one matrix only).
     const int ntiles = (nb - 1) * nb / 2 - 1;            // tiles kept in registers (chol_worker.hpp)
-    int NW = ws.batch == 1 ? cx.workers - cx.workers / 8 : 0;
+    int NW = ws.batch == 1 && !cx.no_workers ? cx.workers - cx.workers / 8 : 0;
     // the last workgroup of every worker launch is the chain's courier (chol_worker.hpp), no tile owner; GPMPC_COURIER=0:
     // tile owners only (r03 A/B on one box: factor 1.675 -> 1.630 ms at C2 with the courier)
     static const bool worker_courier_env = !(getenv("GPMPC_COURIER") && atoi(getenv("GPMPC_COURIER")) == 0);

@@ -4,8 +4,9 @@
 // fit
 // ------------------------------------------------------------------------------------------------
 // gram + factor on a workspace whose hyper/jitter buffers are already on the device.
-static void gram_and_factor(gpmpc_gp* h, Workspace& ws) {
-    const Ctx cx = h->cx();
+static void gram_and_factor(gpmpc_gp* h, Workspace& ws, bool no_workers = false) {
+    Ctx cx = h->cx();
+    cx.no_workers = no_workers;
     {
         PhaseTimer t(h, GPMPC_PH_GRAM);
         // (the K build also clears the status words and the chain's hand-off flags: no fill kernels in between)
@@ -25,10 +26,13 @@ static void gram_and_factor(gpmpc_gp* h, Workspace& ws) {
 // between the two -- so the host's round trip (wake up, inspect, return to the caller, next launches: ~50 us)
 // overlaps with that work instead of leaving the device idle.  If the attempt turns out to have failed (jitter rule,
 // hand-off time-out) the next attempt overwrites what `post` produced.
+// max_attempts / jit_init (the lock-step restart search): ONE attempt with the given jitter on every matrix -- the caller
+// repeats only the matrices that failed (info_out[b] < 0), as a batch of their own, instead of the whole batch.
 static int factor_with_jitter(gpmpc_gp* h, Workspace& ws, const double* hyper_host, int* info_out,
-                              const std::function<void()>& post = std::function<void()>()) {
+                              const std::function<void()>& post = std::function<void()>(), int max_attempts = 2,
+                              double jit_init = 0.0, bool no_workers = false) {
     const int nb = ws.batch;
-    std::vector<double> jit(nb, 0.0);
+    std::vector<double> jit(nb, jit_init);
     std::vector<int> info(nb, 0), res(nb, 0);
     const size_t nflag = (size_t)nb * chain_flag_count(ws.Np / 64);
     if (!h->ev_info) HIPCHK(hipEventCreateWithFlags(&h->ev_info, hipEventDisableTiming));
@@ -47,7 +51,7 @@ static int factor_with_jitter(gpmpc_gp* h, Workspace& ws, const double* hyper_ho
     struct Restore { gpmpc_gp* h; int m; ~Restore() { h->chain_mode = m; } } restore{h, mode_configured};
     std::unique_lock<std::mutex> turn(g_factor_mutex[h->device], std::defer_lock);
     if (h->chain_mode) turn.lock();               // held until the status words are back, i.e. the factorisation is done
-    for (int attempt = 0; attempt < 2; ++attempt) {
+    for (int attempt = 0; attempt < max_attempts; ++attempt) {
         HIPCHK(hipMemcpyAsync(ws.jitter, jit.data(), nb * sizeof(double), hipMemcpyHostToDevice, h->stream));
         // (TailState) with the tile-owner workers the status words come back when the chain kernel ends, on the workers'
         // queue: this call then returns with the tail of the inverse (and `post`) still in flight on the main queue
@@ -56,7 +60,7 @@ static int factor_with_jitter(gpmpc_gp* h, Workspace& ws, const double* hyper_ho
         h->tail.ev_info = h->ev_info;
         h->tail.want_early = early_status && !g_chain_trace;
         h->tail.early_done = false;
-        gram_and_factor(h, ws);
+        gram_and_factor(h, ws, no_workers);
         HIPCHK(hipGetLastError());
         const bool check_chain = h->chain_mode && h->side_stream && ws.Np >= 128;
         if (!h->tail.early_done) {
@@ -109,7 +113,7 @@ static int factor_with_jitter(gpmpc_gp* h, Workspace& ws, const double* hyper_ho
                 HIPCHK(hipStreamSynchronize(h->side_stream));
                 if (h->aux_stream) HIPCHK(hipStreamSynchronize(h->aux_stream));
                 if (h->bulk_stream) HIPCHK(hipStreamSynchronize(h->bulk_stream));
-                gram_and_factor(h, ws);
+                gram_and_factor(h, ws, no_workers);
                 HIPCHK(hipMemcpyAsync(pin_info, ws.info, nb * sizeof(int), hipMemcpyDeviceToHost, h->stream));
                 HIPCHK(hipEventRecord(h->ev_info, h->stream));
                 if (post) post();
@@ -124,8 +128,10 @@ static int factor_with_jitter(gpmpc_gp* h, Workspace& ws, const double* hyper_ho
         for (int b = 0; b < nb; ++b)
             if (info[b] != 0) {
                 any = true;
-                if (attempt == 0) { jit[b] = 1e-8; res[b] = 1; }
+                if (attempt + 1 < max_attempts) { jit[b] = 1e-8; res[b] = 1; }
                 else res[b] = -info[b];
+            } else if (attempt == 0 && jit_init > 0.0) {
+                res[b] = 1;                                 // (factored with the caller's jitter)
             }
         if (!any) break;
     }
@@ -209,6 +215,9 @@ static void free_predict_scratch(gpmpc_gp* h) {
     h->emBytes = h->emsBytes = 0;
     h->have_beta = false;
     ws_free(h->tws);
+    ws_free(h->bws);
+    hipFree(h->bYc); hipFree(h->bmpar); hipFree(h->bgradPartial); hipFree(h->bgradOut);
+    h->bYc = h->bmpar = h->bgradPartial = h->bgradOut = nullptr;
 }
 
 // y - m(X) of the model's current data and stored mean parameters (after the data changed)

@@ -44,6 +44,8 @@ struct gpmpc_gp {
     double *XT = nullptr, *Y = nullptr;  // [d][Np], [Ny][Np]
     Workspace ws;                        // model factors, batch = Ny
     Workspace tws;                       // training workspace, batch = 1 (lazy)
+    Workspace bws;                       // lock-step restart search: batch = up to TRAIN_BATCH_CAP points of one output (lazy)
+    double *bYc = nullptr, *bmpar = nullptr, *bgradPartial = nullptr, *bgradOut = nullptr;
     double* gradPartial = nullptr;
     double* gradOut = nullptr;
     std::vector<double> hyper;           // host copy [Ny][nh()]: [ell.., sf, sn, mean parameters]
@@ -165,8 +167,8 @@ int gpmpc_destroy(gpmpc_gp* h);
 }  // extern "C"
 
 // events for hand-overs between the queues of the factorisation: segments of the pipelined inverse, or two per
-// super-panel of the two-level execution (>= 2 block columns each; two more each with the look-ahead)
-static size_t seg_event_count(int Np) { return (size_t)std::max(3, std::max(Np / SEGR + 2, 2 * (Np / 64) + 8)); }
+// super-panel of the two-level execution (>= 2 block columns each; two more each with the look-ahead, one for the blocked rows below)
+static size_t seg_event_count(int Np) { return (size_t)std::max(3, std::max(Np / SEGR + 2, 3 * (Np / 64) + 8)); }
 
 static int create_impl(gpmpc_gp* h, const double* X, const double* Y) {
     const int device = h->device, N = h->N, d = h->d, Ny = h->Ny;
@@ -262,6 +264,8 @@ int gpmpc_destroy(gpmpc_gp* h) {
     if (h->bulk_stream) hipStreamSynchronize(h->bulk_stream);
     ws_free(h->ws);
     ws_free(h->tws);
+    ws_free(h->bws);
+    hipFree(h->bYc); hipFree(h->bmpar); hipFree(h->bgradPartial); hipFree(h->bgradOut);
     hipFree(h->XT); hipFree(h->Y); hipFree(h->gradPartial); hipFree(h->gradOut);
     hipFree(h->mpar); hipFree(h->Yc); hipFree(h->tmpar); hipFree(h->tYc);
     hipFree(h->Z); hipFree(h->Sigma); hipFree(h->KsT); hipFree(h->part); hipFree(h->meanT);

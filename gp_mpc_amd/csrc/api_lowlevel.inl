@@ -91,6 +91,11 @@ extern "C" int gpmpc_set_tuning(const char* name, int value) {
         g_worker_courier = value;
         return GPMPC_OK;
     }
+    if (std::strcmp(name, "train_batch_cap") == 0) {     // lock-step restart search: points per batch (0 = automatic, 1 = one at a time)
+        if (value < 0 || value > TRAIN_BATCH_CAP_MAX) return fail(GPMPC_EINVAL, "train_batch_cap must be in [0, %d]", TRAIN_BATCH_CAP_MAX);
+        g_train_batch_cap = value;
+        return GPMPC_OK;
+    }
     if (std::strcmp(name, "fail_nll_after") == 0) {      // fault injection for the tests of the restart shard's failure paths
         if (value < 0) return fail(GPMPC_EINVAL, "fail_nll_after must be >= 0");
         static const bool testing = getenv("GPMPC_TESTING") && atoi(getenv("GPMPC_TESTING")) != 0;

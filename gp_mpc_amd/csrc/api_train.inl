@@ -168,10 +168,221 @@ extern "C" int gpmpc_rccl_comm_count(void* comm, int* count) {
     return rc == 0 ? GPMPC_OK : fail(GPMPC_EHIP, "ncclCommCount failed: %s", R.GetErrorString ? R.GetErrorString(rc) : "?");
 }
 
-// Which HIP runtime and which RCCL this process runs the library on (one of each per process: the library is linked
-// against libamdhip64.so.N by soname and takes whichever the process mapped first -- PyTorch's bundled copy when torch
-// was imported first, /opt/rocm's otherwise; RCCL is bound at run time to the image the process already maps or, failing
-// that, to the one next to that HIP runtime, train_native.hpp).  Text: "hip_runtime=<version> hip_path=<file>
+// ------------------------------------------------------------------------------------------------
+// Lock-step restart search (r04): many hyper-parameter points of ONE output evaluated as one batch
+// ------------------------------------------------------------------------------------------------
+// A restart's search evaluates the NLL at one point at a time, and one 4096^2 factorisation is latency-bound (64
+// sequential leaves: 0.35 of the fp64 MFMA peak for value + gradient, r03).  The restarts of a rank are independent, so
+// they advance in lock-step: every live restart runs its unchanged projected L-BFGS in a thread of its own, an
+// evaluation request parks the thread, and when all live restarts are parked the points they ask for go through the
+// device as ONE batch -- K build, two-level factorisation (factor_twolevel: the execution that gives 0.6 of peak on
+// batches), alpha, log det, and for the points that want it the K^-1 product and the gradient pass, all with a batch
+// dimension.  A point's result does not depend on what else is in its batch (no tile-owner workers here: the execution is
+// chosen without looking at the batch size; every batched kernel treats its matrices independently), so the search of a
+// restart is the same whether it runs alone or next to 63 others -- bitwise: the restart shard stays world-size invariant.
+constexpr int TRAIN_BATCH_CAP_MAX = 64;
+static int g_train_batch_cap = 0;            // gpmpc_set_tuning("train_batch_cap", n): 0 = automatic (memory), 1 = one point at a time
+static constexpr int BGS = DMAX + 2 + MPW;   // stride of a point's gradient in bgradOut
+
+struct NllReq {
+    const double* theta = nullptr;           // [nh]
+    bool want_grad = false;
+    double f = std::numeric_limits<double>::infinity();
+    double* g = nullptr;                     // [nh], want_grad
+    int rc = GPMPC_OK;                       // GPMPC_OK, GPMPC_ENOTPD (unusable point), GPMPC_EINVAL, or a device failure
+};
+
+static int ensure_batch_ws(gpmpc_gp* h, int want) {
+    const int Np = h->Np, d = h->d;
+    // per point: K, L, L^-1, K^-1 and the inverse's scratch
+    Workspace probe;
+    probe.Np = Np;
+    const double per_point = (4.0 * Np * Np + (double)probe.wstride()) * 8.0;
+    int cap = (int)std::min<double>(TRAIN_BATCH_CAP_MAX, std::max(1.0, 64.0e9 / per_point));
+    if (g_train_batch_cap > 0) cap = std::min(cap, g_train_batch_cap);
+    want = std::max(1, std::min(want, cap));
+    if (h->bws.K && h->bws.batch >= want) return GPMPC_OK;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    ws_free(h->bws);
+    hipFree(h->bYc); hipFree(h->bmpar); hipFree(h->bgradPartial); hipFree(h->bgradOut);
+    h->bYc = h->bmpar = h->bgradPartial = h->bgradOut = nullptr;
+    CHK(ws_alloc(h->bws, want, Np, d));
+    CHK(ws_need_invK(h->bws));
+    HIPCHK(hipMalloc(&h->bgradPartial, (size_t)want * (Np / 64) * (Np / 64) * (DMAX + 2) * sizeof(double)));
+    HIPCHK(hipMalloc(&h->bgradOut, (size_t)want * BGS * sizeof(double)));
+    HIPCHK(hipMalloc(&h->bYc, (size_t)want * Np * sizeof(double)));
+    HIPCHK(hipMalloc(&h->bmpar, (size_t)want * MPW * sizeof(double)));
+    const size_t need = seg_event_count(Np);
+    while (h->seg_events.size() < need) {
+        hipEvent_t e;
+        HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        h->seg_events.push_back(e);
+    }
+    return GPMPC_OK;
+}
+
+// n <= h->bws.batch points of output a, all with or all without the gradient; jit: the jitter added to every K of this
+// call (0, or 1e-8 for the repeat of the points whose first factorisation failed: optimize.py:345-350 per point).
+static int nll_batch_core(gpmpc_gp* h, int a, int n, NllReq* const* req, bool want_grad, double jit, std::vector<int>& failed) {
+    const int d = h->d, Np = h->Np, nh = h->nh(), nmean = mean_param_count(h->mean_kind, d);
+    Workspace ws = h->bws;                       // a view: the first n matrices
+    ws.batch = n;
+    Ctx cx = h->cx();
+    cx.no_workers = true;
+    std::vector<double> kpart((size_t)n * (d + 2));
+    for (int i = 0; i < n; ++i) std::memcpy(&kpart[(size_t)i * (d + 2)], req[i]->theta, (d + 2) * sizeof(double));
+    const double* ytrain = h->Y + (size_t)a * Np;
+    long sy = 0;                                 // every point shares the output's targets ...
+    if (h->mean_kind) {                          // ... unless a prior mean is trained: y - m(X) per point (calc_NLL optimize.py:43,75,96)
+        std::vector<double> mp((size_t)n * MPW, 0.0);
+        for (int i = 0; i < n; ++i)
+            for (int k = 0; k < nmean; ++k) mp[(size_t)i * MPW + k] = req[i]->theta[d + 2 + k];
+        HIPCHK(hipStreamSynchronize(h->stream));
+        HIPCHK(hipMemcpy(h->bmpar, mp.data(), mp.size() * sizeof(double), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(mean_resid_kernel, dim3((Np + 255) / 256, n), dim3(256), 0, h->stream, h->XT, ytrain, h->bmpar, h->bYc,
+                           h->mean_kind, h->N, Np, d, 0L);
+        ytrain = h->bYc;
+        sy = Np;
+    }
+    std::vector<int> info(n, 0);
+    const int frc = factor_with_jitter(h, ws, kpart.data(), info.data(), [&]() {
+        {
+            PhaseTimer t(h, GPMPC_PH_SOLVE);
+            solve_alpha(cx, ws, ytrain, sy);
+        }
+        {
+            PhaseTimer t(h, GPMPC_PH_NLL);
+            hipLaunchKernelGGL(nll_reduce_kernel, dim3(n), dim3(256), 0, cx.stream, ws.L, ws.w, ws.nll, h->N, Np);
+        }
+        if (want_grad) {
+            {
+                PhaseTimer t(h, GPMPC_PH_INVK);
+                GemmP p = gemm_base(cx);      // lower triangle of K^-1 = L^-T L^-1 is all the gradient pass reads
+                p.A = ws.Inv; p.lda = Np; p.sA = ws.mat(); p.a_mc = 1;
+                p.B = ws.Inv; p.ldb = Np; p.sB = ws.mat(); p.b_nc = 1;
+                p.kflags = KA_GE_M | KB_GE_N;
+                p.C = ws.InvK; p.ldc = Np; p.sC = ws.mat();
+                p.M = Np; p.N = Np; p.K = Np; p.lower = 1;
+                // (64-row tiles: what one matrix gets at this size; the tile the launcher picks for 64 matrices -- 128 rows,
+                //  whose heaviest tile is the duration of the launch for this doubly triangular product -- was measured
+                //  slower: 2.2 against 1.8 ms per point)
+                launch_gemm(p, n, cx.stream, 64);
+            }
+            PhaseTimer t(h, GPMPC_PH_NLL);
+            hipLaunchKernelGGL(nll_grad_kernel, dim3(Np / 64, Np / 64, n), dim3(256), 0, cx.stream, h->XT, ws.hyper, ws.InvK,
+                               ws.alpha, h->bgradPartial, h->N, Np, d);
+            hipLaunchKernelGGL(nll_grad_finish_kernel, dim3(n), dim3(256), 0, cx.stream, h->bgradPartial, ws.hyper, h->bgradOut,
+                               Np, d, BGS);
+            if (nmean)
+                hipLaunchKernelGGL(mean_grad_kernel, dim3(n), dim3(256), 0, cx.stream, h->XT, ws.alpha, h->bgradOut + d + 2,
+                                   h->mean_kind, h->N, Np, d, BGS);
+        }
+    }, 1, jit, true);
+    if (frc != GPMPC_OK && frc != GPMPC_ENOTPD) return frc;
+    HIPCHK(hipGetLastError());
+    std::vector<double> fv(n), gv(want_grad ? (size_t)n * BGS : 0);
+    HIPCHK(hipMemcpyAsync(fv.data(), ws.nll, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (want_grad) HIPCHK(hipMemcpyAsync(gv.data(), h->bgradOut, gv.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (int i = 0; i < n; ++i) {
+        if (info[i] < 0) { failed.push_back(i); continue; }
+        req[i]->rc = GPMPC_OK;
+        req[i]->f = fv[i];
+        if (want_grad) std::memcpy(req[i]->g, &gv[(size_t)i * BGS], nh * sizeof(double));
+    }
+    return GPMPC_OK;
+}
+
+// Evaluates every request (any number, mixed).  Device failures are returned; unusable points are marked in their request.
+static int nll_batch(gpmpc_gp* h, int a, std::vector<NllReq*>& reqs) {
+    const int d = h->d;
+    std::vector<NllReq*> group[2];
+    for (NllReq* r : reqs) {
+        bool usable = true;
+        for (int k = 0; k < d + 1; ++k) usable &= (r->theta[k] == r->theta[k]) && r->theta[k] != 0.0;
+        for (int k = d + 1; k < h->nh(); ++k) usable &= r->theta[k] == r->theta[k];
+        if (!usable) { r->rc = GPMPC_EINVAL; continue; }
+        if (g_fail_nll_after.load(std::memory_order_relaxed) > 0 && g_fail_nll_after.fetch_sub(1) == 1)
+            return fail(GPMPC_EHIP, "injected device failure (fail_nll_after)");
+        r->rc = GPMPC_ENOTPD;                    // until an evaluation succeeds
+        group[r->want_grad ? 1 : 0].push_back(r);
+    }
+    const size_t total = group[0].size() + group[1].size();
+    if (total == 0) return GPMPC_OK;
+    CHK(ensure_batch_ws(h, (int)std::max(group[0].size(), group[1].size())));
+    const int cap = h->bws.batch;
+    for (int wg = 1; wg >= 0; --wg) {
+        std::vector<NllReq*>& G = group[wg];
+        for (size_t b0 = 0; b0 < G.size(); b0 += cap) {
+            const int n = (int)std::min<size_t>(cap, G.size() - b0);
+            std::vector<int> failed;
+            static const bool verbose = getenv("GPMPC_VERBOSE") != nullptr;
+            const auto t0 = std::chrono::steady_clock::now();
+            CHK(nll_batch_core(h, a, n, &G[b0], wg == 1, 0.0, failed));
+            if (verbose)
+                fprintf(stderr, "gpmpc: lock-step batch of %d point%s (%s): %.3f ms, %d to repeat with jitter\n", n, n == 1 ? "" : "s",
+                        wg ? "value + gradient" : "value", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(),
+                        (int)failed.size());
+            if (!failed.empty()) {                // the reference's one-shot jitter, for the points that need it
+                std::vector<NllReq*> again;
+                for (int i : failed) again.push_back(G[b0 + i]);
+                std::vector<int> failed2;
+                CHK(nll_batch_core(h, a, (int)again.size(), again.data(), wg == 1, 1e-8, failed2));
+            }
+        }
+    }
+    // completion on the host, as gpmpc_nll does: the hyper-priors (calc_NLL has no N/2 log 2 pi term)
+    for (NllReq* r : reqs)
+        if (r->rc == GPMPC_OK) add_log_prior(h, r->theta, &r->f, r->want_grad ? r->g : nullptr);
+    h->nll_last_a = -1;
+    return GPMPC_OK;
+}
+
+// One restart's search as a thread that parks at every evaluation; the driver runs the parked requests as batches.
+struct LockstepPool {
+    std::mutex m;
+    std::condition_variable cv_driver, cv_worker;
+    int n_threads = 0, n_parked = 0, n_done = 0;
+    long epoch = 0;
+    bool abort = false;                          // a device failure: every further evaluation is refused
+    struct Slot {
+        NllReq req;
+        std::vector<double> theta, grad;
+        bool posted = false;
+        long served_epoch = -1;
+    };
+    std::vector<Slot> slots;
+    // worker side: evaluate `theta` (value, or value + gradient into g); false = unusable point / failure
+    bool evaluate(int id, const double* theta, int nh, double* f, double* g) {
+        std::unique_lock<std::mutex> lk(m);
+        if (abort) return false;
+        Slot& s = slots[id];
+        s.theta.assign(theta, theta + nh);
+        s.grad.assign(nh, 0.0);
+        s.req = NllReq();
+        s.req.theta = s.theta.data();
+        s.req.want_grad = g != nullptr;
+        s.req.g = s.grad.data();
+        s.posted = true;
+        ++n_parked;
+        const long my_epoch = epoch;
+        cv_driver.notify_one();
+        cv_worker.wait(lk, [&] { return s.served_epoch >= my_epoch && !s.posted; });
+        if (s.req.rc != GPMPC_OK) return false;
+        *f = s.req.f;
+        if (g) std::memcpy(g, s.grad.data(), nh * sizeof(double));
+        return true;
+    }
+    void finished() {
+        std::lock_guard<std::mutex> lk(m);
+        ++n_done;
+        cv_driver.notify_one();
+    }
+};
+
+// Which HIP runtime and which RCCL this process runs the library on (the library is linked against libamdhip64.so.N by
+// soname and takes whichever the process mapped first -- PyTorch's bundled copy when torch was imported first, /opt/rocm's
+// otherwise; RCCL is bound at run time to the librccl next to that HIP runtime, train_native.hpp).  Text: "hip_runtime=<version> hip_path=<file>
 // rccl=<version|unavailable> rccl_path=<file>".
 extern "C" int gpmpc_runtime_info(char* buf, int buflen) {
     if (!buf || buflen <= 0) return fail(GPMPC_EINVAL, "bad buffer");
@@ -236,25 +447,87 @@ extern "C" int gpmpc_train_multistart(gpmpc_gp* h, int nstart, const double* sta
             if (rc == GPMPC_EHIP || rc == GPMPC_ENOMEM) { local_rc = rc; local_err = g_err; }
             return rc == GPMPC_OK;
         };
-        for (int r = 0; r < nstart; ++r) {
-            double* out = &table[((size_t)a * nstart + r) * row];
-            out[0] = inf;
-            if (r % world != rank || local_rc != GPMPC_OK) continue;
-            BoxResult res = minimize_box_lbfgs(P, starts + ((size_t)a * nstart + r) * nh, max_iter, tol);
-            iters_total += res.iters; evals_total += res.evals;
+        // one restart: the two-stage search (train_native.hpp) from its start; counts go to the totals
+        auto run_restart = [&](const BoxProblem& Pr, int r, long& iters, long& evals) -> BoxResult {
+            BoxResult res = minimize_box_lbfgs(Pr, starts + ((size_t)a * nstart + r) * nh, max_iter, tol);
+            iters += res.iters; evals += res.evals;
             // The linear noise variable is badly scaled against the log variables (its whole box is 1e-2 wide): once the
             // first search has stopped with iterations to spare, a second one from there with sn in log space -- where its
             // gradient no longer vanishes -- polishes the optimum (third reference-made fixture: -95.7 -> the -197.7 that
             // SLSQP with the analytic gradient finds; the reference's own run stops at -80.3).
-            if (res.ok && res.iters < max_iter && P.lb[d + 1] > 0.0 && P.ub[d + 1] < inf && local_rc == GPMPC_OK) {
-                BoxProblem P2 = P;
+            if (res.ok && res.iters < max_iter && Pr.lb[d + 1] > 0.0 && Pr.ub[d + 1] < inf && local_rc == GPMPC_OK) {
+                BoxProblem P2 = Pr;
                 P2.logv[d + 1] = 1;
                 const BoxResult res2 = minimize_box_lbfgs(P2, res.theta.data(), max_iter - res.iters, tol);
-                iters_total += res2.iters; evals_total += res2.evals;
+                iters += res2.iters; evals += res2.evals;
                 if (res2.ok && res2.f < res.f) res = res2;
             }
-            std::memcpy(out + 1, res.theta.data(), nh * sizeof(double));
-            if (res.ok && local_rc == GPMPC_OK) out[0] = res.f;
+            return res;
+        };
+        std::vector<int> mine;
+        for (int r = 0; r < nstart; ++r) {
+            table[((size_t)a * nstart + r) * row] = inf;
+            if (r % world == rank) mine.push_back(r);
+        }
+        // Lock-step: the restarts of this rank advance together and their evaluation points form batches (above).  `nstart`
+        // is the same on every rank, so the choice is too.  GPMPC_TRAIN_LOCKSTEP=0 / a single restart: one after the other.
+        static const bool lockstep_env = !(getenv("GPMPC_TRAIN_LOCKSTEP") && atoi(getenv("GPMPC_TRAIN_LOCKSTEP")) == 0);
+        if (lockstep_env && nstart > 1 && !mine.empty() && local_rc == GPMPC_OK) {
+            LockstepPool pool;
+            pool.n_threads = (int)mine.size();
+            pool.slots.resize(mine.size());
+            std::vector<BoxResult> results(mine.size());
+            std::vector<long> it_each(mine.size(), 0), ev_each(mine.size(), 0);
+            std::vector<std::thread> threads;
+            for (int id = 0; id < (int)mine.size(); ++id)
+                threads.emplace_back([&, id]() {
+                    BoxProblem Pt = P;                          // (value + gradient at every trial point: one kind of batch)
+                    Pt.eval = [&pool, id, nh](const double* th, double* f, double* g) -> bool {
+                        std::vector<double> gtmp(nh);
+                        return pool.evaluate(id, th, nh, f, g ? g : gtmp.data());
+                    };
+                    Pt.grad_last = nullptr;
+                    results[id] = run_restart(Pt, mine[id], it_each[id], ev_each[id]);
+                    pool.finished();
+                });
+            {
+                std::unique_lock<std::mutex> lk(pool.m);
+                for (;;) {
+                    pool.cv_driver.wait(lk, [&] { return pool.n_parked + pool.n_done == pool.n_threads; });
+                    if (pool.n_done == pool.n_threads) break;
+                    std::vector<NllReq*> reqs;
+                    for (auto& sl : pool.slots)
+                        if (sl.posted) reqs.push_back(&sl.req);
+                    lk.unlock();
+                    int rc = local_rc == GPMPC_OK ? nll_batch(h, a, reqs) : local_rc;
+                    lk.lock();
+                    if (rc != GPMPC_OK && local_rc == GPMPC_OK) { local_rc = rc; local_err = g_err; }
+                    if (local_rc != GPMPC_OK) {
+                        pool.abort = true;                      // (every parked and every later evaluation is refused)
+                        for (NllReq* rq : reqs) rq->rc = local_rc;
+                    }
+                    for (auto& sl : pool.slots)
+                        if (sl.posted) { sl.posted = false; sl.served_epoch = pool.epoch; }
+                    pool.n_parked = 0;
+                    ++pool.epoch;
+                    pool.cv_worker.notify_all();
+                }
+            }
+            for (auto& t : threads) t.join();
+            for (int id = 0; id < (int)mine.size(); ++id) {
+                double* out = &table[((size_t)a * nstart + mine[id]) * row];
+                iters_total += it_each[id]; evals_total += ev_each[id];
+                std::memcpy(out + 1, results[id].theta.data(), nh * sizeof(double));
+                if (results[id].ok && local_rc == GPMPC_OK) out[0] = results[id].f;
+            }
+        } else {
+            for (int r : mine) {
+                double* out = &table[((size_t)a * nstart + r) * row];
+                if (local_rc != GPMPC_OK) continue;
+                BoxResult res = run_restart(P, r, iters_total, evals_total);
+                std::memcpy(out + 1, res.theta.data(), nh * sizeof(double));
+                if (res.ok && local_rc == GPMPC_OK) out[0] = res.f;
+            }
         }
     }
     h->train_iters = iters_total;

@@ -287,6 +287,16 @@ __global__ void __launch_bounds__(256) crosscov_finish_kernel(const double* __re
     else if (j < B) J[((long)j * Ny + a) * D + e - 1] = s;
 }
 
+// dst[b][r][0 .. cols) = src[b][r][0 .. cols) for a batch of row-major rectangles (cols even, 16-byte aligned rows);
+// grid (ceil(cols / 2 / 256), rows, batch)
+__global__ void __launch_bounds__(256) copy_rect_kernel(const double* __restrict__ src, long lds_, long sS,
+                                                        double* __restrict__ dst, long ldd, long sD, int cols) {
+    const int c = 2 * ((int)blockIdx.x * 256 + (int)threadIdx.x);
+    if (c >= cols) return;
+    const double2 v = *reinterpret_cast<const double2*>(src + (long)blockIdx.z * sS + (long)blockIdx.y * lds_ + c);
+    *reinterpret_cast<double2*>(dst + (long)blockIdx.z * sD + (long)blockIdx.y * ldd + c) = v;
+}
+
 // mean_a(z_j) = ks^T alpha_a from the stored cross-covariances, for a crosscov_kernel launch that ran without alpha: the
 // same thread -> training point mapping and the same reduction order as the fused sum, so both routes give the same bits.
 // grid (Bp / JT, Ny), 256 threads.
@@ -562,8 +572,10 @@ __global__ void __launch_bounds__(256) mean_resid_kernel(const double* __restric
 // const: -sum alpha; linear a_k: -sum alpha_i x_ik; polynomial a_k: -sum alpha_i x_ik^2, b_k: -sum alpha_i x_ik.
 // One workgroup, one wave per parameter in turn, fixed order.  out[count].
 __global__ void __launch_bounds__(256) mean_grad_kernel(const double* __restrict__ XT, const double* __restrict__ alpha,
-                                                        double* __restrict__ out, int kind, int N, int Np, int d) {
+                                                        double* __restrict__ out, int kind, int N, int Np, int d, int gstride = 0) {
     const int count = mean_param_count(kind, d), lane = threadIdx.x & 63;
+    alpha += (long)blockIdx.x * Np;              // grid (batch): alpha number b, out + b * gstride
+    out += (long)blockIdx.x * gstride;
     for (int e = threadIdx.x >> 6; e < count; e += 4) {
         const bool is_c = e == count - 1;
         const int k = (kind == MEAN_POLY && e >= d) ? e - d : e;
@@ -748,13 +760,17 @@ __global__ void __launch_bounds__(256) nll_reduce_kernel(const double* __restric
 //   dK/d ell_dd = Kse_ij (x_id - x_jd)^2 / ell_dd^3,  dK/d sf = 2 Kse / sf,  dK/d sn = 2 sn I.
 // One pass over the lower triangle of K^-1 with Kse recomputed on the fly (HBM-read bound:
 // 4 N^2 bytes); per-tile partial sums are written out and reduced in a fixed order.
-// grid (Np/64, Np/64), 256 threads; partial[tile][d+2].
+// grid (Np/64, Np/64, batch), 256 threads; partial[b][tile][d+2]; batch element b: hyper row b, K^-1 and alpha number b
+// (the lock-step restart search evaluates many hyper-parameter points of ONE data set at once).
 __global__ void __launch_bounds__(256) nll_grad_kernel(const double* __restrict__ XT, const double* __restrict__ hyper,
                                                        const double* __restrict__ invK, const double* __restrict__ alpha,
                                                        double* __restrict__ partial, int N, int Np, int d) {
     const int tn = blockIdx.x, tm = blockIdx.y, tid = threadIdx.x;
     const int tiles = Np / 64;
-    double* out = partial + ((long)tm * tiles + tn) * (DMAX + 2);
+    hyper += (long)blockIdx.z * (d + 2);
+    invK += (long)blockIdx.z * Np * Np;
+    alpha += (long)blockIdx.z * Np;
+    double* out = partial + ((long)blockIdx.z * tiles * tiles + (long)tm * tiles + tn) * (DMAX + 2);
     if (tn > tm) return;
     __shared__ double Xr[DMAX][64], Xc[DMAX][64], w[DMAX], ar[64], ac[64], red[4][DMAX + 2];
     const int m0 = tm * 64, n0 = tn * 64;
@@ -805,11 +821,15 @@ __global__ void __launch_bounds__(256) nll_grad_kernel(const double* __restrict_
 // final reduction of the gradient partials -> grad[d+2]: one wave per parameter in turn, lanes stride the lower tiles,
 // butterfly sum (a fixed order: deterministic).  (The first version let d + 2 threads walk all (Np/64)^2 / 2 partials one
 // after the other: 0.47 ms of dependent loads at N = 4096, a fifth of an NLL + gradient evaluation.)
+// grid (batch): element b reads partial[b], hyper row b and writes grad + b * gstride
 __global__ void __launch_bounds__(256) nll_grad_finish_kernel(const double* __restrict__ partial,
                                                               const double* __restrict__ hyper,
-                                                              double* __restrict__ grad, int Np, int d) {
+                                                              double* __restrict__ grad, int Np, int d, int gstride = 0) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tiles = Np / 64;
     const long nt = (long)tiles * tiles;
+    partial += (long)blockIdx.x * nt * (DMAX + 2);
+    hyper += (long)blockIdx.x * (d + 2);
+    grad += (long)blockIdx.x * gstride;
     for (int e = wave; e < d + 2; e += 4) {
         const int col = e < d ? e : (e == d ? DMAX : DMAX + 1);
         double s = 0.0;

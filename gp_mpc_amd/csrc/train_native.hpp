@@ -204,14 +204,10 @@ inline RcclApi& rccl_api() {
         // PyTorch first runs on the copies bundled in torch/lib, one that loaded this library first on /opt/rocm, and an
         // RCCL from the other tree opens a second, uninitialised HSA runtime ("no ROCm-capable device is detected").
         // So: the librccl next to the libamdhip64 that hipGetDeviceCount resolves to, with local symbol scope.
-        // ONE RCCL build per process: if the process already maps an RCCL (PyTorch links its own; torch.distributed's
-        // "nccl" backend runs on it) that very image is bound -- RTLD_NOLOAD never loads a second one; otherwise the
-        // librccl next to the live HIP runtime.
-        for (const char* soname : {"librccl.so.1", "librccl.so"}) {
-            a.lib = dlopen(soname, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
-            if (a.lib) break;
-        }
-        (void)dlerror();
+        // (r04: binding whatever RCCL image the process already maps -- RTLD_NOLOAD -- was tried and is wrong: a process that
+        //  imports PyTorch AFTER this library maps torch's RCCL next to torch's own HIP runtime while this library's
+        //  kernels run on /opt/rocm's; ncclCommInitRank then fails as described above.  The rule stays: next to MY runtime.
+        //  gpmpc_runtime_info reports which files that resolved to.)
         std::vector<std::string> names;
         Dl_info di;
         if (dladdr((void*)&hipGetDeviceCount, &di) && di.dli_fname) {
@@ -226,7 +222,6 @@ inline RcclApi& rccl_api() {
         names.push_back("librccl.so.1");
         names.push_back("librccl.so");
         for (const std::string& name : names) {
-            if (a.lib) break;
             a.lib = dlopen(name.c_str(), RTLD_NOW | RTLD_LOCAL);
             if (a.lib) break;
             const char* e = dlerror();                            // (reading it clears it: keep the first text)

@@ -246,9 +246,9 @@ int gpmpc_rccl_comm_destroy(void* comm);
 /* Number of ranks the communicator spans (ncclCommCount): what bench.py reports as `rccl_ranks`. */
 int gpmpc_rccl_comm_count(void* comm, int* count);
 /* The HIP runtime and the RCCL build this process runs the library on, as text "hip_runtime=<version> hip_path=<file>
- * rccl=<version|unavailable> rccl_path=<file>".  One of each per process: the library takes the libamdhip64 the process
- * mapped first and binds, at run time, the RCCL image the process already maps (PyTorch's, if torch was imported) or
- * else the one next to that HIP runtime -- so the library's ncclAllGather and torch.distributed's share one RCCL. */
+ * rccl=<version|unavailable> rccl_path=<file>".  The library runs on the libamdhip64 the process mapped first (PyTorch's
+ * bundled copy if torch was imported before the library, /opt/rocm's otherwise) and binds, at run time, the librccl that
+ * sits NEXT TO that runtime -- in a process that imported torch first that is the RCCL torch.distributed runs on. */
 int gpmpc_runtime_info(char* buf, int buflen);
 
 /* ---- low-level dense ops (host pointers), used by the parity tests ------------------------ */

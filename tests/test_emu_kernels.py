@@ -242,6 +242,11 @@ def test_callback_layout_follows_the_casadi_version():
     assert all(len(set(zip(r, c))) == len(r) for r, c, _ in sp)                             # no duplicate entries
 
 
+def test_emu_training_lockstep_batches_are_composition_independent(emu):
+    pc.check_train_lockstep_invariance(emu, N=300, d=3, nstart=5, max_iter=3)                  # two-level execution (Np = 320)
+    pc.check_train_lockstep_invariance(emu, N=100, d=2, nstart=4, max_iter=3, mean_func='linear')   # flagged-GEMM execution, trained mean
+
+
 def test_emu_training_native(emu, train_small):
     pc.check_training_native(emu, train_small)
 

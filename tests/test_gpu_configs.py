@@ -92,6 +92,11 @@ def test_c4_random_restarts_world1(lib):
     pc.check_random_restarts(lib, p['X'], p['Y'], multistart=16, maxiter=3)
 
 
+def test_c4_lockstep_batches_are_composition_independent(lib):
+    """C4 size: 8 seeded restarts x 3 iterations as batches of 8, of 3 and one point at a time: the same table bit for bit."""
+    pc.check_train_lockstep_invariance(lib, N=4096, d=6, nstart=8, max_iter=3, seed=1234)
+
+
 @pytest.mark.parametrize('optimizer', ['scipy', 'native'])
 def test_c4_restart_shard_rccl_two_gpus(lib, tmp_path, optimizer):
     """The RCCL branches of the restart shard -- train.py `_all_gather_rows` on backend nccl ('scipy') and the
@@ -141,7 +146,7 @@ def test_c4_native_training_with_rccl_self_gather(lib):
             ref = go.nll(th, X, Y[:, 0])
             tol = max(1e-10, 50 * np.finfo(float).eps * N * (th[d] ** 2 + th[d + 1] ** 2) / th[d + 1] ** 2)
             assert abs(best - ref) <= tol * (abs(ref) + N), (best, ref, tol)
-            assert abs(h.nll(0, th) - best) <= 1e-12 * (abs(best) + N)
+            assert abs(h.nll(0, th) - best) <= 0.1 * tol * (abs(best) + N)    # (gpmpc_nll: single-matrix execution; the search: batched)
         h.close()
     for k in ('hyper', 'obj', 'theta'):
         assert np.array_equal(res[0][k], res[1][k]), k
