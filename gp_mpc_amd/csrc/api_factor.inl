@@ -9,6 +9,7 @@ static GemmP gemm_base(const Ctx& cx) {
     return p;
 }
 
+static int g_vargemm_persist = -1;  // gpmpc_set_tuning("vargemm_persist", 0 / 1 / 2): dispatcher order / static schedule / ... at any size; -1: GPMPC_VARGEMM_PERSIST or default
 static int g_worker_courier = -1;   // gpmpc_set_tuning("worker_courier", 0 / 1): tile owners only / with the courier; -1: GPMPC_COURIER or default
 
 // Fit factorisation = right-looking blocked Cholesky (NB = 64) + level-by-level batched triangular

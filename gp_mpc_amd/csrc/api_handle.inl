@@ -28,6 +28,7 @@ struct gpmpc_gp {
     static constexpr int CHAIN_STRIKES = 3, CHAIN_REARM = 64;
     int chain_strikes = 0, chain_parked = 0;
     long n_timeouts = 0, n_chained = 0, n_single = 0;   // gpmpc_get_counter
+    long n_var_persist = 0;                              // variance products through the persistent static-schedule kernel
     long n_behind_tail = 0;                              // predictions that started next to a fit's tail (predict_behind_tail)
     long train_iters = 0, train_evals = 0;              // of the last gpmpc_train_multistart (this rank's restarts)
     int nll_last_a = -1;                                 // the training workspace holds the factors of this output ...
@@ -73,6 +74,7 @@ struct gpmpc_gp {
     double* VT = nullptr;    // L^-1 ks per test point (sensitivities: K^-1 ks = L^-T (L^-1 ks) without K^-1)
     double *sensH = nullptr, *sensV = nullptr;   // staging of gpmpc_predict_sens outputs in host-pointer mode
     double* ccpart = nullptr;                    // chunk partials of the small-batch cross-covariance kernel
+    VarSchedDev vsched;                          // tile lists of the persistent variance product (vargemm_persist.hpp)
     bool have_beta = false;
     Prof prof;
     TailState tail;
@@ -271,6 +273,7 @@ int gpmpc_destroy(gpmpc_gp* h) {
     hipFree(h->Z); hipFree(h->Sigma); hipFree(h->KsT); hipFree(h->part); hipFree(h->meanT);
     hipFree(h->mean); hipFree(h->var); hipFree(h->J); hipFree(h->cov); hipFree(h->em); hipFree(h->ems);
     hipFree(h->beta); hipFree(h->UT); hipFree(h->VT); hipFree(h->sensH); hipFree(h->sensV); hipFree(h->ccpart);
+    hipFree(h->vsched.list); hipFree(h->vsched.off);
     for (int ph = 0; ph < GPMPC_PH_COUNT; ++ph)
         for (auto& pr : h->prof.ev[ph]) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     for (auto e : h->prof.pool) hipEventDestroy(e);
@@ -369,6 +372,7 @@ int gpmpc_get_counter(gpmpc_gp* h, const char* name, long* value) {
     else if (std::strcmp(name, "chained_factorisations") == 0) *value = h->n_chained;
     else if (std::strcmp(name, "single_queue_factorisations") == 0) *value = h->n_single;
     else if (std::strcmp(name, "predictions_behind_tail") == 0) *value = h->n_behind_tail;
+    else if (std::strcmp(name, "persistent_variance_products") == 0) *value = h->n_var_persist;
     else if (std::strcmp(name, "train_iterations") == 0) *value = h->train_iters;
     else if (std::strcmp(name, "train_evaluations") == 0) *value = h->train_evals;
     else if (std::strcmp(name, "workspace_blocks_reused") == 0 || std::strcmp(name, "workspace_blocks_fresh") == 0) {

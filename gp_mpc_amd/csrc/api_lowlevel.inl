@@ -91,6 +91,11 @@ extern "C" int gpmpc_set_tuning(const char* name, int value) {
         g_worker_courier = value;
         return GPMPC_OK;
     }
+    if (std::strcmp(name, "vargemm_persist") == 0) {     // variance product: 0 one tile per workgroup, 1 persistent static schedule, 2 ... at any size
+        if (value < -1 || value > 2) return fail(GPMPC_EINVAL, "vargemm_persist must be -1 (default), 0, 1 or 2");
+        g_vargemm_persist = value;
+        return GPMPC_OK;
+    }
     if (std::strcmp(name, "train_batch_cap") == 0) {     // lock-step restart search: points per batch (0 = automatic, 1 = one at a time)
         if (value < 0 || value > TRAIN_BATCH_CAP_MAX) return fail(GPMPC_EINVAL, "train_batch_cap must be in [0, %d]", TRAIN_BATCH_CAP_MAX);
         g_train_batch_cap = value;

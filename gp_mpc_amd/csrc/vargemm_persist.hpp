@@ -1,0 +1,276 @@
+// Predictive variance as ONE persistent launch over a static tile schedule  (a9, gp_functions.py:122-126:
+// var_j = sf2 - sum_i (L^-1 ks_j)_i^2 for every test point j; GP.covar gp_class.py:377-380).
+//
+// Same arithmetic, tiles and LDS images as gemm_f64_dma_kernel<128,128,2,4,2,4> with A = L^-1 (lower triangular, K
+// contiguous), B = KsT (K contiguous) and the column-sum-of-squares epilogue -- the per-tile results are bit-identical
+// to that kernel's -- but the 128 x 128 tiles are not handed out by the hardware dispatcher:
+//   * The tile in block row tm is tm + 1 K-units long, so the 2528 tiles of C2 (32 x 79) carry 1 ... 32 units and the
+//     512 workgroup slots of the chip get ~5 tiles each.  Workgroups are dealt to the 8 XCDs round-robin whatever
+//     their load, and 79 columns on 8 XCDs leave one XCD with nine tenths of the others' work: in-order dispatch ends
+//     4.3 % above the mean slot load (simulation of the dispatcher, heavy rows first), i.e. the last 0.1 ms of the
+//     kernel run on a draining chip.  Here 2 x CUs workgroups stay resident and walk lists made on the host
+//     (var_schedule: longest tile first to the least loaded slot of the column's home XCD, overflow to the globally
+//     least loaded slot, then moves / swaps off the heaviest slot): 0.7 % above the mean, 89 % of the tiles on the XCD
+//     that also holds the rest of their Ks panel.
+//   * The slabs of a workgroup's tiles form one stream through the two-image ring: the first slab of the next tile is
+//     requested behind the barrier of the current tile's last step, so a tile boundary costs the epilogue and nothing
+//     else (the one-tile kernel drains its ring, writes its sums, exits, and its successor starts with an empty ring).
+//     The epilogue's scratch has its own 2 KB of LDS for that reason, and its barrier waits for LDS traffic only.
+#pragma once
+#include <algorithm>
+#include <vector>
+#include "gemm_f64_dma.hpp"
+
+namespace gpmpc {
+
+// tile word: batch index z (8 bits) | block row tm (12 bits) | block column tn (12 bits)
+constexpr int VAR_TILE = 128;
+// amdgpu_num_vgpr counts halves of the unified 512-entry file of gfx90a+ (the backend doubles the request): 56 = a budget of
+// 112 registers (109 used, no spills), so that four waves per SIMD leave 64 per lane and the alpha / mean kernels of the
+// workers' queue (<= 48 registers), which run NEXT TO the variance product, still find room on the persistent kernel's CUs
+constexpr int VAR_VGPRS = 56;
+__host__ __device__ inline int var_tile_word(int z, int tm, int tn) { return (z << 24) | (tm << 12) | tn; }
+
+template <int WPS>
+__global__ void __launch_bounds__(512, WPS) __attribute__((amdgpu_num_vgpr(VAR_VGPRS))) vargemm_persist_kernel(GemmP p, const int* __restrict__ list,
+                                                                     const int* __restrict__ off) {
+    constexpr int BM = VAR_TILE, BN = VAR_TILE, BK = 16, WGM = 2, WGN = 4, NW = WGM * WGN;
+    constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 16, TN = WN / 16;
+    constexpr int LA = BM / 8, LB = BN / 8, LPW = (LA + LB) / NW;
+    constexpr int IMG_A = BM * 128, SLAB = (BM + BN) * 128;
+    char* smem = (char*)GPMPC_DYN_SMEM();
+    double* red = reinterpret_cast<double*>(smem + 2 * SLAB);      // [WGM][BN], not part of the ring
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int beg = off[blockIdx.x], end = off[blockIdx.x + 1];
+    if (beg >= end) return;
+
+    const int fr = lane & 15, fq = lane >> 4;
+    const unsigned sw = (unsigned)((fr >> 1) & 7);
+    unsigned fa[2], fb[2];                                         // fragment offsets inside an image (gemm_f64_dma.hpp)
+    fa[0] = (unsigned)((wm * WM + fr) * 128) + (((unsigned)fq ^ sw) << 4);
+    fa[1] = fa[0] ^ 64u;
+    fb[0] = (unsigned)(IMG_A + (wn * WN + fr) * 128) + (((unsigned)fq ^ sw) << 4);
+    fb[1] = fb[0] ^ 64u;
+
+    // ---- request cursor: tile ri of the list, its next slab rt of rnk
+    int ri = beg, rt = 0, rnk = 0;
+    unsigned vo[LPW];
+    dma_rsrc_t rsA, rsB;
+    auto open_request = [&](int word) {
+        const int z = word >> 24, m0 = ((word >> 12) & 4095) * BM, n0 = (word & 4095) * BN;
+        rnk = (min(p.K, m0 + BM) + BK - 1) / BK;
+        rsA = dma_make_rsrc(p.A + (long)z * p.sA, (unsigned)((long)p.M * p.lda * 8));
+        rsB = dma_make_rsrc(p.B + (long)z * p.sB, (unsigned)((long)p.N * p.ldb * 8));
+#pragma unroll
+        for (int i = 0; i < LPW; ++i) {
+            const int j = wave + NW * i;                           // [0, LA): piece j of the A image, else of the B image
+            const bool isA = j < LA;
+            const int row = 8 * (isA ? j : j - LA) + (lane >> 3);
+            const unsigned piece = (unsigned)(lane & 7) ^ (unsigned)((row >> 1) & 7);
+            const long grow = isA ? (long)min(m0 + row, p.M - 1) * p.lda : (long)min(n0 + row, p.N - 1) * p.ldb;
+            vo[i] = (unsigned)(grow * 8) + (piece << 4);
+        }
+    };
+    auto request_next = [&](int g) {                               // next slab of the stream -> image g & 1
+        if (ri >= end) return;
+        char* img = smem + (g & 1) * SLAB;
+        const unsigned k0 = (unsigned)(rt * BK) * 8u;
+#pragma unroll
+        for (int i = 0; i < LPW; ++i) {
+            const int j = wave + NW * i;
+            if (j < LA) dma_load16(rsA, img + 1024 * j, vo[i], k0);
+            else dma_load16(rsB, img + 1024 * j, vo[i], k0);
+        }
+        if (++rt == rnk) {
+            rt = 0;
+            if (++ri < end) open_request(list[ri]);
+        }
+    };
+
+    // ---- compute cursor
+    int ci = beg, ct = 0, cword = list[beg];
+    int cnk = (min(p.K, ((cword >> 12) & 4095) * BM + BM) + BK - 1) / BK;
+    // a wave whose 64 rows lie entirely above a slab's K range multiplies exact zeros there: it sits the slab out
+    int kskip = (((cword >> 12) & 4095) * BM + (wm + 1) * WM + BK - 1) / BK;
+
+    d4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
+
+    open_request(cword);
+    request_next(0);
+    for (int g = 0;; ++g) {
+        dma_wait<0>();                                             // slab g has landed (this wave's pieces)
+        dma_barrier();                                             // ... everybody's, and image (g + 1) & 1 is free
+        request_next(g + 1);
+        if (ct < kskip) {
+            const char* img = smem + (g & 1) * SLAB;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                double2 a[TM], b[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const double2*>(img + fa[h] + i * 2048);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const double2*>(img + fb[h] + j * 2048);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = mfma16(a[i].x, b[j].x, acc[i][j]);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = mfma16(a[i].y, b[j].y, acc[i][j]);
+            }
+        }
+        if (++ct < cnk) continue;
+
+        // ---- tile finished: column sums of squares over its rows < M, then the next tile of the list
+        const int z = cword >> 24, tm = (cword >> 12) & 4095, m0 = tm * BM, n0 = (cword & 4095) * BN;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            double s = 0.0;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = m0 + wm * WM + i * 16 + crow(lane, r, p.crow_mode);
+                    const double v = (m < p.M) ? acc[i][j][r] : 0.0;
+                    s += v * v;
+                    acc[i][j][r] = 0.0;
+                }
+            s += __shfl_xor(s, 16);
+            s += __shfl_xor(s, 32);
+            if (lane < 16) red[wm * BN + wn * WN + j * 16 + lane] = s;
+        }
+        lds_barrier();                                             // (the slab in flight is not waited for)
+        if (tid < BN && n0 + tid < p.N) {
+            double t = 0.0;
+#pragma unroll
+            for (int w = 0; w < WGM; ++w) t += red[w * BN + tid];
+            p.part[(long)z * p.sPart + (long)tm * p.ldpart + n0 + tid] = t;
+        }
+        if (++ci >= end) break;
+        cword = list[ci];
+        ct = 0;
+        cnk = (min(p.K, ((cword >> 12) & 4095) * BM + BM) + BK - 1) / BK;
+        kskip = (((cword >> 12) & 4095) * BM + (wm + 1) * WM + BK - 1) / BK;
+        // (`red` is written again after >= 8 more ring barriers: no barrier needed behind its readers)
+    }
+}
+
+// ---- host side: the schedule ------------------------------------------------------------------------
+// Slots are the workgroups of the launch; slot s runs on XCD s % nx.  Cost of a tile in half slabs: 2 nk + 1 (the
+// epilogue).  Returns the slot lists concatenated (tile words) and their offsets [slots + 1].
+struct VarSchedule {
+    std::vector<int> list, off;
+    double mean_load = 0.0, max_load = 0.0;
+    int home = 0;                                                  // tiles on their column's home XCD
+};
+
+inline VarSchedule var_schedule(int tilesM, int tilesN, int batch, int K, int slots, int nx = 8) {
+    struct T { int cost, word, x; };
+    std::vector<T> tiles;
+    tiles.reserve((size_t)tilesM * tilesN * batch);
+    for (int z = 0; z < batch; ++z)
+        for (int tm = 0; tm < tilesM; ++tm) {
+            const int nk = (std::min(K, (tm + 1) * VAR_TILE) + 15) / 16;
+            for (int tn = 0; tn < tilesN; ++tn) tiles.push_back(T{2 * nk + 1, var_tile_word(z, tm, tn), (tn + z) % nx});
+        }
+    std::stable_sort(tiles.begin(), tiles.end(), [](const T& a, const T& b) { return a.cost > b.cost; });
+    long total = 0;
+    for (const T& t : tiles) total += t.cost;
+    const double target = (double)total / slots;
+    std::vector<long> load(slots, 0);
+    std::vector<std::vector<T>> lists(slots);
+    if (nx > slots) nx = 1;
+    for (const T& t : tiles) {
+        int s = t.x % nx;
+        for (int c = s; c < slots; c += nx)
+            if (load[c] < load[s]) s = c;
+        if (load[s] + t.cost > target) {
+            const int g = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+            if (load[g] < load[s]) s = g;
+        }
+        load[s] += t.cost;
+        lists[s].push_back(t);
+    }
+    // moves / swaps off the heaviest slot while they lower it (partners: the 32 lightest slots)
+    for (int it = 0; it < 4 * slots; ++it) {
+        const int smax = (int)(std::max_element(load.begin(), load.end()) - load.begin());
+        std::vector<int> light(slots);
+        for (int s = 0; s < slots; ++s) light[s] = s;
+        const int nl = std::min(slots, 32);
+        std::partial_sort(light.begin(), light.begin() + nl, light.end(), [&](int a, int b) { return load[a] < load[b]; });
+        long best = 0;
+        int bi = -1, bs = -1, bj = -1;
+        for (int li = 0; li < nl; ++li) {
+            const int s2 = light[li];
+            if (s2 == smax) continue;
+            for (int i = 0; i < (int)lists[smax].size(); ++i) {
+                const long c = lists[smax][i].cost;
+                if (load[s2] + c < load[smax]) {                   // move
+                    const long gain = load[smax] - std::max(load[smax] - c, load[s2] + c);
+                    if (gain > best) { best = gain; bi = i; bs = s2; bj = -1; }
+                }
+                for (int j = 0; j < (int)lists[s2].size(); ++j) {  // swap
+                    const long dlt = c - lists[s2][j].cost;
+                    if (dlt > 0 && load[s2] + dlt < load[smax]) {
+                        const long gain = load[smax] - std::max(load[smax] - dlt, load[s2] + dlt);
+                        if (gain > best) { best = gain; bi = i; bs = s2; bj = j; }
+                    }
+                }
+            }
+        }
+        if (bi < 0) break;
+        if (bj < 0) {
+            const T t = lists[smax][bi];
+            lists[smax].erase(lists[smax].begin() + bi);
+            lists[bs].push_back(t);
+            load[smax] -= t.cost;
+            load[bs] += t.cost;
+        } else {
+            std::swap(lists[smax][bi], lists[bs][bj]);
+            const long dlt = lists[bs][bj].cost - lists[smax][bi].cost;
+            load[smax] -= dlt;
+            load[bs] += dlt;
+        }
+    }
+    VarSchedule r;
+    r.off.resize(slots + 1);
+    r.mean_load = target;
+    for (int s = 0; s < slots; ++s) {
+        std::stable_sort(lists[s].begin(), lists[s].end(), [](const T& a, const T& b) { return a.cost > b.cost; });
+        r.off[s] = (int)r.list.size();
+        for (const T& t : lists[s]) {
+            r.list.push_back(t.word);
+            if (t.x % nx == s % nx) ++r.home;
+        }
+        r.max_load = std::max(r.max_load, (double)load[s]);
+    }
+    r.off[slots] = (int)r.list.size();
+    return r;
+}
+
+// the device copy of a schedule, cached on the model handle (one shape at a time)
+struct VarSchedDev {
+    int tilesM = 0, tilesN = 0, batch = 0, K = 0, slots = 0;
+    int* list = nullptr;
+    int* off = nullptr;
+};
+
+inline void launch_vargemm_persist(const GemmP& p, const VarSchedDev& s, hipStream_t stream) {
+    constexpr int lds = 2 * (VAR_TILE + VAR_TILE) * 128 + 2 * VAR_TILE * 8 + 16;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&vargemm_persist_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((vargemm_persist_kernel<4>), dim3(s.slots), dim3(512), lds, stream, p, (const int*)s.list, (const int*)s.off);
+}
+
+}  // namespace gpmpc

@@ -108,7 +108,8 @@ int gpmpc_synchronize(gpmpc_gp* h);
  * in which case THAT factorisation is repeated on the single-queue path (same result) and the next call tries again;
  * after three consecutive time-outs the handle stays on the single-queue path for 64 fits.  Handles of one process
  * take turns for the factorisation itself.  Counters: "handoff_timeouts", "chained_factorisations",
- * "single_queue_factorisations", "predictions_behind_tail" (see gpmpc_fit); process-wide: "workspace_blocks_fresh" / "workspace_blocks_reused" (the N x N blocks
+ * "single_queue_factorisations", "predictions_behind_tail" (see gpmpc_fit), "persistent_variance_products" (variance products
+ * of gpmpc_predict_mean_var that ran as one persistent launch over a static tile schedule, vargemm_persist.hpp); process-wide: "workspace_blocks_fresh" / "workspace_blocks_reused" (the N x N blocks
  * of a workspace, >= 64 MB, come from size classes and return to a free list: gpmpc_append at large N re-uses what the
  * previous append gave back instead of paying for fresh multi-GB allocations). */
 int gpmpc_get_counter(gpmpc_gp* h, const char* name, long* value);
@@ -273,6 +274,9 @@ int gpmpc_dgemm(int device, int transa, int transb, int M, int N, int K, double 
  * the device (fault injection: how the tests reach the failure paths of the restart shard); 0 switches it off.
  * "worker_courier": 1 / 0 = the tile-owner worker launches of the chained factorisation run with / without the courier
  * workgroup (two instantiations of one kernel; default 1, or GPMPC_COURIER), -1 back to the default.
+ * "vargemm_persist": the large-batch variance product (gp_functions.py:122-126) as 0 = one 128 x 128 tile per workgroup in
+ * the dispatcher's order, 1 = one persistent launch over a static schedule when there are at least two tiles per workgroup
+ * slot (default, or GPMPC_VARGEMM_PERSIST), 2 = ... at any size (tests), -1 back to the default; same bits either way.
  * Returns GPMPC_EINVAL for an unknown name or value. */
 int gpmpc_set_tuning(const char* name, int value);
 

@@ -185,6 +185,36 @@ def check_synthetic(lib, N, d, Ny, B, sn, strict_rel):
     return dict(X=X, Y=Y, H=H, Z=Z, mean=mean, var=var)
 
 
+def check_variance_persistent(lib, N, d, Ny, B, sn=0.1, seed=4321):
+    """The persistent variance product (vargemm_persist.hpp: resident workgroups walking a static tile schedule, the
+    slabs of a workgroup's tiles as one stream) against the one-tile-per-workgroup launch of the same tiles: the same bits
+    (same per-tile arithmetic, same per-tile partial sums), and against the oracle's variance (gp_functions.py:122-126)."""
+    p = go.synthetic_problem(N, d, Ny, B, seed=seed, sn=sn)
+    X, Y, H, Z = p['X'], p['Y'], p['hyper'], p['Z']
+    sf2 = H[:, d] ** 2
+    h = Handle(lib, X, Y)
+    try:
+        lib.set_tuning('gemm_tile', 128)
+        assert np.all(h.fit(H) == 0)
+        lib.set_tuning('vargemm_persist', 0)
+        m0, v0 = h.predict_mean_var(Z)
+        assert h.counter('persistent_variance_products') == 0
+        lib.set_tuning('vargemm_persist', 2)
+        m1, v1 = h.predict_mean_var(Z)
+        assert h.counter('persistent_variance_products') >= 1
+        m2, v2 = h.predict_mean_var(Z[: max(1, B // 2) + 70])      # another shape: the schedule is rebuilt
+        assert np.array_equal(v0, v1) and np.array_equal(m0, m1)
+        assert np.array_equal(v2, v0[: len(v2)])
+        o = go.fit(X, Y, H, want_invK=False)
+        om, ov, _ = go.mean_var_jac(Z, X, H, o['alpha'], o['chol'], False)
+        assert np.max(np.abs(v1 - ov) / sf2) <= 1e-10
+        assert np.max(np.abs(v1 - ov) / np.abs(ov)) <= 1e-10
+    finally:
+        lib.set_tuning('gemm_tile', 0)
+        lib.set_tuning('vargemm_persist', -1)
+        h.close()
+
+
 class DevArray:
     """A double array in device memory for the device-pointer entry points: hipMalloc / hipMemcpy through the HIP runtime
     the library is linked against (ctypes, no torch: one HIP runtime per process); under the emulator device memory is
@@ -198,7 +228,10 @@ class DevArray:
             self.host = np.ascontiguousarray(src, dtype=np.float64).copy() if src is not None else np.zeros(self.shape)
             self.ptr = self.host.ctypes.data
             return
-        self.hip = ctypes.CDLL('libamdhip64.so')
+        # the runtime the LIBRARY runs on (gpmpc_runtime_info), not whatever 'libamdhip64.so' resolves to: in a process
+        # that imported torch earlier (an earlier test of the same pytest run) the library lives on torch's bundled
+        # runtime and the bare name would open /opt/rocm's as a second, uninitialised one (hipMalloc fails there)
+        self.hip = ctypes.CDLL(lib.runtime_info().get('hip_path', 'libamdhip64.so'))
         p = ctypes.c_void_p()
         assert self.hip.hipMalloc(ctypes.byref(p), ctypes.c_size_t(self.nbytes)) == 0
         self.ptr = p.value
@@ -1448,22 +1481,28 @@ def _oracle_vec(og, x, u, S):
     return np.concatenate([np.asarray(m).reshape(-1), np.asarray(c).reshape(-1, order='F')])     # CasADi's column-major vec
 
 
-def _oracle_jacobian(og, x, u, S, Ny, Nu, h=1e-5):
-    """d [mean; vec(cov)] / d [x; u; vec(covar)] of the ORACLE's predict by central differences; the input covariance is
-    perturbed symmetrically (the only perturbation the value path is defined for, see check_callback_blocks), so the
-    columns of the covariance block are to be compared folded: col(p, q) + col(q, p)."""
+def _oracle_jacobian(og, x, u, S, Ny, Nu, h=1e-3):
+    """d [mean; vec(cov)] / d [x; u; vec(covar)] of the ORACLE's predict by fourth-order central differences (the exact-moment
+    covariance is a difference of O(1) terms, good to ~1e-10 absolute: with the two-point stencil at h = 1e-5 that noise alone
+    is 1e-5 in the quotient -- seen on the GPU tier at N = 200; the five-point stencil at h = 1e-3 keeps both error terms below
+    1e-6); the input covariance is perturbed symmetrically (the only perturbation the value path is defined for, see
+    check_callback_blocks), so the columns of the covariance block are to be compared folded: col(p, q) + col(q, p)."""
     Nx = Ny + Nu
     z = np.concatenate([x, u])
     J = np.zeros((Ny + Ny * Ny, Nx + Nx * Nx))
+
+    def stencil(f):
+        return (-f(2.0) + 8.0 * f(1.0) - 8.0 * f(-1.0) + f(-2.0)) / (12.0 * h)
+
     for k in range(Nx):
         e = np.zeros(Nx)
         e[k] = h
-        J[:, k] = (_oracle_vec(og, (z + e)[:Ny], (z + e)[Ny:], S) - _oracle_vec(og, (z - e)[:Ny], (z - e)[Ny:], S)) / (2 * h)
+        J[:, k] = stencil(lambda s: _oracle_vec(og, (z + s * e)[:Ny], (z + s * e)[Ny:], S))
     for qq in range(Nx):
         for pp in range(Nx):
             E = np.zeros((Nx, Nx))
             E[pp, qq] = E[qq, pp] = h
-            J[:, Nx + pp + Nx * qq] = (_oracle_vec(og, x, u, S + E) - _oracle_vec(og, x, u, S - E)) / (2 * h)
+            J[:, Nx + pp + Nx * qq] = stencil(lambda s: _oracle_vec(og, x, u, S + s * E))
     return J
 
 

@@ -104,6 +104,12 @@ def test_emu_predict_behind_tail(emu):
         emu.set_tuning('cu_count', 8)
 
 
+def test_emu_variance_persistent_schedule(emu):
+    # 16 emulated slots; Np = 320 / 384 -> 3 block rows (the last one partial at 320), 2-3 block columns, two outputs
+    pc.check_variance_persistent(emu, N=300, d=3, Ny=2, B=200)
+    pc.check_variance_persistent(emu, N=384, d=4, Ny=1, B=330)
+
+
 def test_emu_jitter_rule(emu, train_small):
     pc.check_jitter_rule(emu, train_small)
 

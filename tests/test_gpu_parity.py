@@ -98,6 +98,13 @@ def test_callback_classes_execute_under_stub_casadi(lib, version):
     pc.check_callback_classes(lib, stub_casadi, version, N=200, Ny=3, Nu=2, Nt=4)
 
 
+def test_variance_persistent_schedule(lib):
+    """vargemm_persist.hpp at the C2 size (512 slots, 2528 tiles) and on a ragged two-output shape: same bits as the
+    one-tile-per-workgroup launch, oracle bars."""
+    pc.check_variance_persistent(lib, N=4096, d=6, Ny=1, B=10000)
+    pc.check_variance_persistent(lib, N=1500, d=4, Ny=2, B=3000)
+
+
 def test_jitter_rule(lib, train_small):
     pc.check_jitter_rule(lib, train_small)
 
