@@ -656,17 +656,85 @@ static void solve_alpha(const Ctx& cx, Workspace& ws, const double* y, long sy) 
                        chunks, ws.wstride(), (long)Np);
 }
 
+// The device copy of a persistent product's tile lists (vargemm_persist.hpp), made once per shape and device and kept for
+// the life of the process (a few hundred KB each).
+struct SchedKey {
+    int device, mode, tilesM, tilesN, batch, K, slots;
+    bool operator<(const SchedKey& o) const {
+        return std::tie(device, mode, tilesM, tilesN, batch, K, slots) < std::tie(o.device, o.mode, o.tilesM, o.tilesN, o.batch, o.K, o.slots);
+    }
+};
+static std::map<SchedKey, VarSchedDev> g_sched_cache;
+static std::mutex g_sched_mutex;
+
+static int get_schedule(int device, int mode, int tilesM, int tilesN, int batch, int K, int slots, VarSchedDev* out) {
+    std::lock_guard<std::mutex> lk(g_sched_mutex);
+    const SchedKey key{device, mode, tilesM, tilesN, batch, K, slots};
+    auto it = g_sched_cache.find(key);
+    if (it != g_sched_cache.end()) { *out = it->second; return GPMPC_OK; }
+    const VarSchedule s = mode == PG_VAR ? var_schedule(tilesM, tilesN, batch, K, slots) : xtx_schedule(tilesM, batch, K, slots);
+    VarSchedDev v;
+    v.mode = mode; v.tilesM = tilesM; v.tilesN = tilesN; v.batch = batch; v.K = K; v.slots = slots;
+    HIPCHK(hipMalloc(&v.list, std::max<size_t>(1, s.list.size()) * sizeof(int)));
+    HIPCHK(hipMalloc(&v.off, s.off.size() * sizeof(int)));
+    HIPCHK(hipMemcpy(v.list, s.list.data(), s.list.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(v.off, s.off.data(), s.off.size() * sizeof(int), hipMemcpyHostToDevice));
+    if (getenv("GPMPC_VERBOSE"))
+        std::fprintf(stderr, "gpmpc: %s schedule %d x %d x %d tiles on %d slots: heaviest slot %.0f half slabs, mean %.1f (+%.2f %%), %d of %d tiles at home\n",
+                     mode == PG_VAR ? "variance" : "K^-1", tilesM, tilesN, batch, slots, s.max_load, s.mean_load,
+                     100.0 * (s.max_load / s.mean_load - 1.0), s.home, (int)s.list.size());
+    g_sched_cache[key] = v;
+    *out = v;
+    return GPMPC_OK;
+}
+
+// Lower triangle of K^-1 = L^-T L^-1 for the first n matrices of `ws` (a6, optimize.py:489-490).  X = L^-1 is copied
+// transposed into ws.K (the factorisation consumed it; only blocks on and above the diagonal are written, which no
+// factorisation reads), so that both operands of X^T X are contiguous along the contraction index; the product is one
+// persistent launch over a static schedule when the mean slot load reaches twice the longest tile, the one-tile-per-
+// workgroup DMA kernel (64-row tiles) below that.  Both sum every element over the same slabs in the same order with the
+// same LDS image, so an element's bits do not depend on n or on which of the two ran (the lock-step restart search
+// relies on that: api_train.inl).
+// zmap / zhost (device / host copy, optional): the n matrices are zhost[0 .. n) of the workspace instead of its first n.
+static int invk_lower(const Ctx& cx, Workspace& ws, int n, const int* zmap = nullptr, const int* zhost = nullptr) {
+    const int Np = ws.Np;
+    const long sM = ws.mat();
+    hipLaunchKernelGGL(transpose_lower_kernel, dim3(Np / 64, Np / 64, n), dim3(256), 0, cx.stream, (const double*)ws.Inv, ws.K, Np, zmap);
+    GemmP p = gemm_base(cx);
+    p.A = ws.K; p.lda = Np; p.sA = sM; p.a_mc = 0;
+    p.B = ws.K; p.ldb = Np; p.sB = sM; p.b_nc = 0;
+    p.kflags = KA_GE_M | KB_GE_N;
+    p.C = ws.InvK; p.ldc = Np; p.sC = sM;
+    p.M = Np; p.N = Np; p.K = Np; p.lower = 1;
+    int dev = 0;
+    HIPCHK(hipGetDevice(&dev));
+    static const int persist_env = getenv("GPMPC_VARGEMM_PERSIST") ? atoi(getenv("GPMPC_VARGEMM_PERSIST")) : 1;
+    const int persist = g_vargemm_persist >= 0 ? g_vargemm_persist : persist_env;
+    const int T = (Np + VAR_TILE - 1) / VAR_TILE, slots = 2 * g_cu_count[dev];
+    double total = 0.0;
+    for (int tm = 0; tm < T; ++tm) total += (double)(tm + 1) * (2 * ((Np - tm * VAR_TILE) / 16) + 1);
+    total *= n;
+    if (persist && gemm_dma_supported(p) && n < 256 && T < 4096 && (persist > 1 || total / slots >= 2.0 * (2 * (Np / 16) + 1))) {
+        VarSchedDev sd;
+        CHK(get_schedule(dev, PG_XTX, T, T, n, Np, slots, &sd));
+        launch_persist_gemm<PG_XTX>(p, sd, cx.stream, zmap);
+    } else if (zmap) {                                            // a few scattered matrices: one launch each
+        for (int i = 0; i < n; ++i) {
+            GemmP q = p;
+            q.A = q.B = ws.K + zhost[i] * sM;
+            q.C = ws.InvK + zhost[i] * sM;
+            launch_gemm(q, 1, cx.stream, 64);
+        }
+    } else {
+        launch_gemm(p, n, cx.stream, 64);
+    }
+    return GPMPC_OK;
+}
+
 // K^-1 = L^-T L^-1 (lower triangle by MFMA, then mirrored)
 static int compute_invK(const Ctx& cx, Workspace& ws) {
     CHK(ws_need_invK(ws));
-    const long ld = ws.Np, sM = ws.mat();
-    GemmP p = gemm_base(cx);
-    p.A = ws.Inv; p.lda = ld; p.sA = sM; p.a_mc = 1;
-    p.B = ws.Inv; p.ldb = ld; p.sB = sM; p.b_nc = 1;
-    p.kflags = KA_GE_M | KB_GE_N;
-    p.C = ws.InvK; p.ldc = ld; p.sC = sM;
-    p.M = ws.Np; p.N = ws.Np; p.K = ws.Np; p.lower = 1;
-    launch_gemm(p, ws.batch, cx.stream);
+    CHK(invk_lower(cx, ws, ws.batch));
     hipLaunchKernelGGL(symmetrize_kernel, dim3(ws.Np / 64, ws.Np / 64, ws.batch), dim3(256), 0, cx.stream, ws.InvK,
                        ws.Np);
     return GPMPC_OK;

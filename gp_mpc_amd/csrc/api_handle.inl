@@ -47,6 +47,9 @@ struct gpmpc_gp {
     Workspace tws;                       // training workspace, batch = 1 (lazy)
     Workspace bws;                       // lock-step restart search: batch = up to TRAIN_BATCH_CAP points of one output (lazy)
     double *bYc = nullptr, *bmpar = nullptr, *bgradPartial = nullptr, *bgradOut = nullptr;
+    int* bzmap = nullptr;                                // slots of a subset of the batch (gradients of retained points)
+    struct LockRet { int pos = -1; std::vector<double> theta; };
+    std::vector<LockRet> lock_ret;                       // per restart of the lock-step search: where its last value-only point's factors are
     double* gradPartial = nullptr;
     double* gradOut = nullptr;
     std::vector<double> hyper;           // host copy [Ny][nh()]: [ell.., sf, sn, mean parameters]
@@ -74,7 +77,6 @@ struct gpmpc_gp {
     double* VT = nullptr;    // L^-1 ks per test point (sensitivities: K^-1 ks = L^-T (L^-1 ks) without K^-1)
     double *sensH = nullptr, *sensV = nullptr;   // staging of gpmpc_predict_sens outputs in host-pointer mode
     double* ccpart = nullptr;                    // chunk partials of the small-batch cross-covariance kernel
-    VarSchedDev vsched;                          // tile lists of the persistent variance product (vargemm_persist.hpp)
     bool have_beta = false;
     Prof prof;
     TailState tail;
@@ -267,13 +269,12 @@ int gpmpc_destroy(gpmpc_gp* h) {
     ws_free(h->ws);
     ws_free(h->tws);
     ws_free(h->bws);
-    hipFree(h->bYc); hipFree(h->bmpar); hipFree(h->bgradPartial); hipFree(h->bgradOut);
+    hipFree(h->bYc); hipFree(h->bmpar); hipFree(h->bgradPartial); hipFree(h->bgradOut); hipFree(h->bzmap);
     hipFree(h->XT); hipFree(h->Y); hipFree(h->gradPartial); hipFree(h->gradOut);
     hipFree(h->mpar); hipFree(h->Yc); hipFree(h->tmpar); hipFree(h->tYc);
     hipFree(h->Z); hipFree(h->Sigma); hipFree(h->KsT); hipFree(h->part); hipFree(h->meanT);
     hipFree(h->mean); hipFree(h->var); hipFree(h->J); hipFree(h->cov); hipFree(h->em); hipFree(h->ems);
     hipFree(h->beta); hipFree(h->UT); hipFree(h->VT); hipFree(h->sensH); hipFree(h->sensV); hipFree(h->ccpart);
-    hipFree(h->vsched.list); hipFree(h->vsched.off);
     for (int ph = 0; ph < GPMPC_PH_COUNT; ++ph)
         for (auto& pr : h->prof.ev[ph]) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     for (auto e : h->prof.pool) hipEventDestroy(e);

@@ -97,27 +97,6 @@ static int ensure_scratch(gpmpc_gp* h, int B, bool keep_tail = false) {
 // the tail directly on the main queue, and the mean Ks^T alpha is formed on the workers' queue behind alpha, next to
 // the variance product.  Only with device pointers on the handle's own queue (the inputs are ready when the call is
 // made) and without the Jacobian (its sums are fused with alpha into the cross-covariance kernel).
-// The tile lists of the persistent variance product for this shape, made once and kept on the handle.
-static int ensure_var_schedule(gpmpc_gp* h, int tilesM, int tilesN, int batch, int K, int slots) {
-    VarSchedDev& v = h->vsched;
-    if (v.list && v.tilesM == tilesM && v.tilesN == tilesN && v.batch == batch && v.K == K && v.slots == slots) return GPMPC_OK;
-    const VarSchedule s = var_schedule(tilesM, tilesN, batch, K, slots);
-    if (v.list) {                                       // (kernels that read the old lists may still be queued)
-        HIPCHK(hipStreamSynchronize(h->stream));
-        hipFree(v.list); hipFree(v.off);
-        v.list = v.off = nullptr;
-    }
-    HIPCHK(hipMalloc(&v.list, s.list.size() * sizeof(int)));
-    HIPCHK(hipMalloc(&v.off, s.off.size() * sizeof(int)));
-    HIPCHK(hipMemcpy(v.list, s.list.data(), s.list.size() * sizeof(int), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(v.off, s.off.data(), s.off.size() * sizeof(int), hipMemcpyHostToDevice));
-    v.tilesM = tilesM; v.tilesN = tilesN; v.batch = batch; v.K = K; v.slots = slots;
-    if (getenv("GPMPC_VERBOSE"))
-        std::fprintf(stderr, "gpmpc: variance schedule %d x %d x %d tiles on %d slots: heaviest slot %.0f half slabs, mean %.1f (+%.2f %%), %d tiles at home\n",
-                     tilesM, tilesN, batch, slots, s.max_load, s.mean_load, 100.0 * (s.max_load / s.mean_load - 1.0), s.home);
-    return GPMPC_OK;
-}
-
 static int predict_chunk(gpmpc_gp* h, int B, const double* dZ, double* dMean, double* dVar, double* dJ, double* VT = nullptr,
                          bool behind_tail = false) {
     const Ctx cx = h->cx();
@@ -211,8 +190,9 @@ static int predict_chunk(gpmpc_gp* h, int B, const double* dZ, double* dMean, do
         const int slots = 2 * g_cu_count[h->device], tilesN = (Bp + VAR_TILE - 1) / VAR_TILE;
         if (persist && tile == VAR_TILE && !VT && Ny < 256 && tilesM < 4096 && tilesN < 4096 && gemm_dma_supported(p) &&
             (long)tilesM * tilesN * Ny >= (persist > 1 ? 1 : 2L * slots)) {
-            CHK(ensure_var_schedule(h, tilesM, tilesN, Ny, Np, slots));
-            launch_vargemm_persist(p, h->vsched, cx.stream);
+            VarSchedDev sd;
+            CHK(get_schedule(h->device, PG_VAR, tilesM, tilesN, Ny, Np, slots, &sd));
+            launch_persist_gemm<PG_VAR>(p, sd, cx.stream);
             ++h->n_var_persist;
         } else {
             launch_gemm(p, Ny, cx.stream, tile);

@@ -14,13 +14,7 @@ static void enqueue_nll_grad(gpmpc_gp* h, Workspace& ws, const Ctx& cx, int nmea
     const int d = h->d, Np = h->Np;
     {
         PhaseTimer t(h, GPMPC_PH_INVK);
-        GemmP p = gemm_base(cx);  // lower triangle of K^-1 = L^-T L^-1 is all the gradient pass reads
-        p.A = ws.Inv; p.lda = Np; p.sA = ws.mat(); p.a_mc = 1;
-        p.B = ws.Inv; p.ldb = Np; p.sB = ws.mat(); p.b_nc = 1;
-        p.kflags = KA_GE_M | KB_GE_N;
-        p.C = ws.InvK; p.ldc = Np; p.sC = ws.mat();
-        p.M = Np; p.N = Np; p.K = Np; p.lower = 1;
-        launch_gemm(p, 1, cx.stream);
+        (void)invk_lower(cx, ws, 1);   // the lower triangle of K^-1 = L^-T L^-1 is all the gradient pass reads
     }
     PhaseTimer t(h, GPMPC_PH_NLL);
     hipLaunchKernelGGL(nll_grad_kernel, dim3(Np / 64, Np / 64), dim3(256), 0, cx.stream, h->XT, ws.hyper, ws.InvK,
@@ -180,12 +174,20 @@ extern "C" int gpmpc_rccl_comm_count(void* comm, int* count) {
 // dimension.  A point's result does not depend on what else is in its batch (no tile-owner workers here: the execution is
 // chosen without looking at the batch size; every batched kernel treats its matrices independently), so the search of a
 // restart is the same whether it runs alone or next to 63 others -- bitwise: the restart shard stays world-size invariant.
+// Line-search trials ask for the value only (K build, factorisation with L^-1, alpha, log det); the batch leaves every
+// point's factors in its slot of the batch workspace, and the restart whose trial is accepted asks for the gradient of
+// that point in the next round: K^-1 and the gradient pass on the retained L^-1 of the accepted points only (`zmap`: a
+// subset of the slots), before the round's new points overwrite the slots.  130 of the 450 evaluations of the 64-restart
+// C4 run are rejected trials: they cost 0.64 of a value + gradient evaluation.  (When the restarts of a rank do not fit one
+// batch the slots would be overwritten in between: every trial is evaluated with its gradient then, as before.)
 constexpr int TRAIN_BATCH_CAP_MAX = 64;
 static int g_train_batch_cap = 0;            // gpmpc_set_tuning("train_batch_cap", n): 0 = automatic (memory), 1 = one point at a time
 static constexpr int BGS = DMAX + 2 + MPW;   // stride of a point's gradient in bgradOut
 
 struct NllReq {
     const double* theta = nullptr;           // [nh]
+    int id = 0;                              // the restart (its slot in the pool)
+    bool grad_of_last = false;               // no evaluation: the gradient at the point this restart evaluated last (value only)
     bool want_grad = false;
     double f = std::numeric_limits<double>::infinity();
     double* g = nullptr;                     // [nh], want_grad
@@ -204,9 +206,11 @@ static int ensure_batch_ws(gpmpc_gp* h, int want) {
     if (h->bws.K && h->bws.batch >= want) return GPMPC_OK;
     HIPCHK(hipStreamSynchronize(h->stream));
     ws_free(h->bws);
-    hipFree(h->bYc); hipFree(h->bmpar); hipFree(h->bgradPartial); hipFree(h->bgradOut);
+    hipFree(h->bYc); hipFree(h->bmpar); hipFree(h->bgradPartial); hipFree(h->bgradOut); hipFree(h->bzmap);
     h->bYc = h->bmpar = h->bgradPartial = h->bgradOut = nullptr;
+    h->bzmap = nullptr;
     CHK(ws_alloc(h->bws, want, Np, d));
+    HIPCHK(hipMalloc(&h->bzmap, (size_t)want * sizeof(int)));
     CHK(ws_need_invK(h->bws));
     HIPCHK(hipMalloc(&h->bgradPartial, (size_t)want * (Np / 64) * (Np / 64) * (DMAX + 2) * sizeof(double)));
     HIPCHK(hipMalloc(&h->bgradOut, (size_t)want * BGS * sizeof(double)));
@@ -257,16 +261,8 @@ static int nll_batch_core(gpmpc_gp* h, int a, int n, NllReq* const* req, bool wa
         if (want_grad) {
             {
                 PhaseTimer t(h, GPMPC_PH_INVK);
-                GemmP p = gemm_base(cx);      // lower triangle of K^-1 = L^-T L^-1 is all the gradient pass reads
-                p.A = ws.Inv; p.lda = Np; p.sA = ws.mat(); p.a_mc = 1;
-                p.B = ws.Inv; p.ldb = Np; p.sB = ws.mat(); p.b_nc = 1;
-                p.kflags = KA_GE_M | KB_GE_N;
-                p.C = ws.InvK; p.ldc = Np; p.sC = ws.mat();
-                p.M = Np; p.N = Np; p.K = Np; p.lower = 1;
-                // (64-row tiles: what one matrix gets at this size; the tile the launcher picks for 64 matrices -- 128 rows,
-                //  whose heaviest tile is the duration of the launch for this doubly triangular product -- was measured
-                //  slower: 2.2 against 1.8 ms per point)
-                launch_gemm(p, n, cx.stream, 64);
+                // the lower triangle of K^-1 = L^-T L^-1 is all the gradient pass reads; an element's bits do not depend on n
+                (void)invk_lower(cx, ws, n);
             }
             PhaseTimer t(h, GPMPC_PH_NLL);
             hipLaunchKernelGGL(nll_grad_kernel, dim3(Np / 64, Np / 64, n), dim3(256), 0, cx.stream, h->XT, ws.hyper, ws.InvK,
@@ -293,30 +289,87 @@ static int nll_batch_core(gpmpc_gp* h, int a, int n, NllReq* const* req, bool wa
     return GPMPC_OK;
 }
 
+// The gradients of points whose factors a value-only batch left in the batch workspace (slots pos[i]): K^-1 of those
+// matrices and the gradient pass, nothing else.  Same kernels on the same factors as a value + gradient evaluation.
+static int nll_grad_retained(gpmpc_gp* h, int a, const std::vector<NllReq*>& G, const std::vector<int>& pos) {
+    (void)a;
+    const int d = h->d, Np = h->Np, nh = h->nh(), nmean = mean_param_count(h->mean_kind, d), m = (int)G.size();
+    Workspace ws = h->bws;
+    Ctx cx = h->cx();
+    cx.no_workers = true;
+    HIPCHK(hipMemcpyAsync(h->bzmap, pos.data(), m * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    {
+        PhaseTimer t(h, GPMPC_PH_INVK);
+        CHK(invk_lower(cx, ws, m, h->bzmap, pos.data()));
+    }
+    {
+        PhaseTimer t(h, GPMPC_PH_NLL);
+        hipLaunchKernelGGL(nll_grad_kernel, dim3(Np / 64, Np / 64, m), dim3(256), 0, cx.stream, h->XT, ws.hyper, ws.InvK, ws.alpha,
+                           h->bgradPartial, h->N, Np, d, (const int*)h->bzmap);
+        hipLaunchKernelGGL(nll_grad_finish_kernel, dim3(m), dim3(256), 0, cx.stream, h->bgradPartial, ws.hyper, h->bgradOut, Np, d,
+                           BGS, (const int*)h->bzmap);
+        if (nmean)
+            hipLaunchKernelGGL(mean_grad_kernel, dim3(m), dim3(256), 0, cx.stream, h->XT, ws.alpha, h->bgradOut + d + 2, h->mean_kind,
+                               h->N, Np, d, BGS, (const int*)h->bzmap);
+    }
+    HIPCHK(hipGetLastError());
+    std::vector<double> gv((size_t)h->bws.batch * BGS);
+    HIPCHK(hipMemcpyAsync(gv.data(), h->bgradOut, gv.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (int i = 0; i < m; ++i) {
+        std::memcpy(G[i]->g, &gv[(size_t)pos[i] * BGS], nh * sizeof(double));
+        G[i]->rc = GPMPC_OK;
+        add_log_prior(h, G[i]->theta, nullptr, G[i]->g);
+    }
+    return GPMPC_OK;
+}
+
 // Evaluates every request (any number, mixed).  Device failures are returned; unusable points are marked in their request.
-static int nll_batch(gpmpc_gp* h, int a, std::vector<NllReq*>& reqs) {
-    const int d = h->d;
-    std::vector<NllReq*> group[2];
+// retain: the value-only points of this call fit one batch and their factors are to be remembered per restart (h->lock_ret)
+// for a grad_of_last request in the NEXT call.
+static int nll_batch(gpmpc_gp* h, int a, std::vector<NllReq*>& reqs, bool retain = false) {
+    const int d = h->d, nh = h->nh();
+    std::vector<NllReq*> group[2], last;
+    std::vector<int> last_pos;
     for (NllReq* r : reqs) {
+        if (r->grad_of_last) {
+            r->rc = GPMPC_EINVAL;                // unless the slot still holds this point
+            if (r->id >= 0 && r->id < (int)h->lock_ret.size()) {
+                const auto& lr = h->lock_ret[r->id];
+                if (lr.pos >= 0 && (int)lr.theta.size() == nh && std::memcmp(lr.theta.data(), r->theta, nh * sizeof(double)) == 0) {
+                    last.push_back(r);
+                    last_pos.push_back(lr.pos);
+                }
+            }
+            continue;
+        }
         bool usable = true;
         for (int k = 0; k < d + 1; ++k) usable &= (r->theta[k] == r->theta[k]) && r->theta[k] != 0.0;
-        for (int k = d + 1; k < h->nh(); ++k) usable &= r->theta[k] == r->theta[k];
+        for (int k = d + 1; k < nh; ++k) usable &= r->theta[k] == r->theta[k];
         if (!usable) { r->rc = GPMPC_EINVAL; continue; }
         if (g_fail_nll_after.load(std::memory_order_relaxed) > 0 && g_fail_nll_after.fetch_sub(1) == 1)
             return fail(GPMPC_EHIP, "injected device failure (fail_nll_after)");
         r->rc = GPMPC_ENOTPD;                    // until an evaluation succeeds
         group[r->want_grad ? 1 : 0].push_back(r);
     }
+    static const bool verbose = getenv("GPMPC_VERBOSE") != nullptr;
+    if (!last.empty()) {                         // first: the batches below overwrite the slots
+        const auto t0 = std::chrono::steady_clock::now();
+        CHK(nll_grad_retained(h, a, last, last_pos));
+        if (verbose)
+            fprintf(stderr, "gpmpc: lock-step gradients of %d retained point%s: %.3f ms\n", (int)last.size(), last.size() == 1 ? "" : "s",
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    }
     const size_t total = group[0].size() + group[1].size();
     if (total == 0) return GPMPC_OK;
+    for (auto& lr : h->lock_ret) lr.pos = -1;
     CHK(ensure_batch_ws(h, (int)std::max(group[0].size(), group[1].size())));
     const int cap = h->bws.batch;
-    for (int wg = 1; wg >= 0; --wg) {
+    for (int wg = 1; wg >= 0; --wg) {            // value-only points last: their factors stay in the slots
         std::vector<NllReq*>& G = group[wg];
         for (size_t b0 = 0; b0 < G.size(); b0 += cap) {
             const int n = (int)std::min<size_t>(cap, G.size() - b0);
             std::vector<int> failed;
-            static const bool verbose = getenv("GPMPC_VERBOSE") != nullptr;
             const auto t0 = std::chrono::steady_clock::now();
             CHK(nll_batch_core(h, a, n, &G[b0], wg == 1, 0.0, failed));
             if (verbose)
@@ -328,12 +381,19 @@ static int nll_batch(gpmpc_gp* h, int a, std::vector<NllReq*>& reqs) {
                 for (int i : failed) again.push_back(G[b0 + i]);
                 std::vector<int> failed2;
                 CHK(nll_batch_core(h, a, (int)again.size(), again.data(), wg == 1, 1e-8, failed2));
+            } else if (wg == 0 && retain && G.size() <= (size_t)cap) {
+                for (int i = 0; i < n; ++i) {
+                    NllReq* r = G[i];
+                    if (r->rc != GPMPC_OK || r->id < 0 || r->id >= (int)h->lock_ret.size()) continue;
+                    h->lock_ret[r->id].pos = i;
+                    h->lock_ret[r->id].theta.assign(r->theta, r->theta + nh);
+                }
             }
         }
     }
     // completion on the host, as gpmpc_nll does: the hyper-priors (calc_NLL has no N/2 log 2 pi term)
     for (NllReq* r : reqs)
-        if (r->rc == GPMPC_OK) add_log_prior(h, r->theta, &r->f, r->want_grad ? r->g : nullptr);
+        if (r->rc == GPMPC_OK && !r->grad_of_last) add_log_prior(h, r->theta, &r->f, r->want_grad ? r->g : nullptr);
     h->nll_last_a = -1;
     return GPMPC_OK;
 }
@@ -353,7 +413,8 @@ struct LockstepPool {
     };
     std::vector<Slot> slots;
     // worker side: evaluate `theta` (value, or value + gradient into g); false = unusable point / failure
-    bool evaluate(int id, const double* theta, int nh, double* f, double* g) {
+    // (of_last: no evaluation, the gradient of the point this restart evaluated last -- value only -- into g)
+    bool evaluate(int id, const double* theta, int nh, double* f, double* g, bool of_last = false) {
         std::unique_lock<std::mutex> lk(m);
         if (abort) return false;
         Slot& s = slots[id];
@@ -361,6 +422,8 @@ struct LockstepPool {
         s.grad.assign(nh, 0.0);
         s.req = NllReq();
         s.req.theta = s.theta.data();
+        s.req.id = id;
+        s.req.grad_of_last = of_last;
         s.req.want_grad = g != nullptr;
         s.req.g = s.grad.data();
         s.posted = true;
@@ -369,7 +432,7 @@ struct LockstepPool {
         cv_driver.notify_one();
         cv_worker.wait(lk, [&] { return s.served_epoch >= my_epoch && !s.posted; });
         if (s.req.rc != GPMPC_OK) return false;
-        *f = s.req.f;
+        if (f) *f = s.req.f;
         if (g) std::memcpy(g, s.grad.data(), nh * sizeof(double));
         return true;
     }
@@ -476,17 +539,32 @@ extern "C" int gpmpc_train_multistart(gpmpc_gp* h, int nstart, const double* sta
             LockstepPool pool;
             pool.n_threads = (int)mine.size();
             pool.slots.resize(mine.size());
+            // value-only trials with the gradient of the accepted point from its retained factors: when this rank's restarts
+            // fit one batch (GPMPC_TRAIN_RETAIN=0: every trial with its gradient, as when they do not fit)
+            static const bool retain_env = !(getenv("GPMPC_TRAIN_RETAIN") && atoi(getenv("GPMPC_TRAIN_RETAIN")) == 0);
+            bool retain = false;
+            if (retain_env) {
+                const int erc = ensure_batch_ws(h, (int)mine.size());
+                if (erc != GPMPC_OK) { local_rc = erc; local_err = g_err; }
+                retain = erc == GPMPC_OK && h->bws.batch >= (int)mine.size();
+            }
+            h->lock_ret.assign(mine.size(), gpmpc_gp::LockRet());
             std::vector<BoxResult> results(mine.size());
             std::vector<long> it_each(mine.size(), 0), ev_each(mine.size(), 0);
             std::vector<std::thread> threads;
             for (int id = 0; id < (int)mine.size(); ++id)
                 threads.emplace_back([&, id]() {
-                    BoxProblem Pt = P;                          // (value + gradient at every trial point: one kind of batch)
-                    Pt.eval = [&pool, id, nh](const double* th, double* f, double* g) -> bool {
-                        std::vector<double> gtmp(nh);
-                        return pool.evaluate(id, th, nh, f, g ? g : gtmp.data());
-                    };
-                    Pt.grad_last = nullptr;
+                    BoxProblem Pt = P;
+                    if (retain) {
+                        Pt.eval = [&pool, id, nh](const double* th, double* f, double* g) -> bool { return pool.evaluate(id, th, nh, f, g); };
+                        Pt.grad_last = [&pool, id, nh](const double* th, double* g) -> bool { return pool.evaluate(id, th, nh, nullptr, g, true); };
+                    } else {                                    // (value + gradient at every trial point: one kind of batch)
+                        Pt.eval = [&pool, id, nh](const double* th, double* f, double* g) -> bool {
+                            std::vector<double> gtmp(nh);
+                            return pool.evaluate(id, th, nh, f, g ? g : gtmp.data());
+                        };
+                        Pt.grad_last = nullptr;
+                    }
                     results[id] = run_restart(Pt, mine[id], it_each[id], ev_each[id]);
                     pool.finished();
                 });
@@ -499,7 +577,7 @@ extern "C" int gpmpc_train_multistart(gpmpc_gp* h, int nstart, const double* sta
                     for (auto& sl : pool.slots)
                         if (sl.posted) reqs.push_back(&sl.req);
                     lk.unlock();
-                    int rc = local_rc == GPMPC_OK ? nll_batch(h, a, reqs) : local_rc;
+                    int rc = local_rc == GPMPC_OK ? nll_batch(h, a, reqs, retain) : local_rc;
                     lk.lock();
                     if (rc != GPMPC_OK && local_rc == GPMPC_OK) { local_rc = rc; local_err = g_err; }
                     if (local_rc != GPMPC_OK) {

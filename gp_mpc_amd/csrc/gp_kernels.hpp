@@ -572,10 +572,12 @@ __global__ void __launch_bounds__(256) mean_resid_kernel(const double* __restric
 // const: -sum alpha; linear a_k: -sum alpha_i x_ik; polynomial a_k: -sum alpha_i x_ik^2, b_k: -sum alpha_i x_ik.
 // One workgroup, one wave per parameter in turn, fixed order.  out[count].
 __global__ void __launch_bounds__(256) mean_grad_kernel(const double* __restrict__ XT, const double* __restrict__ alpha,
-                                                        double* __restrict__ out, int kind, int N, int Np, int d, int gstride = 0) {
+                                                        double* __restrict__ out, int kind, int N, int Np, int d, int gstride = 0,
+                                                        const int* __restrict__ zmap = nullptr) {
     const int count = mean_param_count(kind, d), lane = threadIdx.x & 63;
-    alpha += (long)blockIdx.x * Np;              // grid (batch): alpha number b, out + b * gstride
-    out += (long)blockIdx.x * gstride;
+    const int b = zmap ? zmap[blockIdx.x] : (int)blockIdx.x;   // grid (batch): alpha number b, out + b * gstride (zmap: a subset)
+    alpha += (long)b * Np;
+    out += (long)b * gstride;
     for (int e = threadIdx.x >> 6; e < count; e += 4) {
         const bool is_c = e == count - 1;
         const int k = (kind == MEAN_POLY && e >= d) ? e - d : e;
@@ -764,13 +766,15 @@ __global__ void __launch_bounds__(256) nll_reduce_kernel(const double* __restric
 // (the lock-step restart search evaluates many hyper-parameter points of ONE data set at once).
 __global__ void __launch_bounds__(256) nll_grad_kernel(const double* __restrict__ XT, const double* __restrict__ hyper,
                                                        const double* __restrict__ invK, const double* __restrict__ alpha,
-                                                       double* __restrict__ partial, int N, int Np, int d) {
+                                                       double* __restrict__ partial, int N, int Np, int d,
+                                                       const int* __restrict__ zmap = nullptr) {
     const int tn = blockIdx.x, tm = blockIdx.y, tid = threadIdx.x;
     const int tiles = Np / 64;
-    hyper += (long)blockIdx.z * (d + 2);
-    invK += (long)blockIdx.z * Np * Np;
-    alpha += (long)blockIdx.z * Np;
-    double* out = partial + ((long)blockIdx.z * tiles * tiles + (long)tm * tiles + tn) * (DMAX + 2);
+    const int bz = zmap ? zmap[blockIdx.z] : (int)blockIdx.z;   // (zmap: the matrices of a subset of a batch)
+    hyper += (long)bz * (d + 2);
+    invK += (long)bz * Np * Np;
+    alpha += (long)bz * Np;
+    double* out = partial + ((long)bz * tiles * tiles + (long)tm * tiles + tn) * (DMAX + 2);
     if (tn > tm) return;
     __shared__ double Xr[DMAX][64], Xc[DMAX][64], w[DMAX], ar[64], ac[64], red[4][DMAX + 2];
     const int m0 = tm * 64, n0 = tn * 64;
@@ -824,12 +828,14 @@ __global__ void __launch_bounds__(256) nll_grad_kernel(const double* __restrict_
 // grid (batch): element b reads partial[b], hyper row b and writes grad + b * gstride
 __global__ void __launch_bounds__(256) nll_grad_finish_kernel(const double* __restrict__ partial,
                                                               const double* __restrict__ hyper,
-                                                              double* __restrict__ grad, int Np, int d, int gstride = 0) {
+                                                              double* __restrict__ grad, int Np, int d, int gstride = 0,
+                                                              const int* __restrict__ zmap = nullptr) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, tiles = Np / 64;
+    const int bx = zmap ? zmap[blockIdx.x] : (int)blockIdx.x;
     const long nt = (long)tiles * tiles;
-    partial += (long)blockIdx.x * nt * (DMAX + 2);
-    hyper += (long)blockIdx.x * (d + 2);
-    grad += (long)blockIdx.x * gstride;
+    partial += (long)bx * nt * (DMAX + 2);
+    hyper += (long)bx * (d + 2);
+    grad += (long)bx * gstride;
     for (int e = wave; e < d + 2; e += 4) {
         const int col = e < d ? e : (e == d ? DMAX : DMAX + 1);
         double s = 0.0;
@@ -864,6 +870,29 @@ __global__ void __launch_bounds__(256) symmetrize_kernel(double* __restrict__ A,
     for (int idx = tid; idx < 4096; idx += 256) {
         const int r = idx >> 6, c = idx & 63;  // writes element (n0 + r, m0 + c) = tile[c][r]
         if (tm != tn || c > r) Aa[(long)(n0 + r) * Np + m0 + c] = tile[c][r];
+    }
+}
+
+// XT = X^T for a lower-triangular X (= L^-1): the 64 x 64 blocks on and below the diagonal of X become the blocks on and
+// above the diagonal of XT (diagonal blocks whole, zeros included); nothing else of XT is written or ever read.  Makes the
+// operands of K^-1 = X^T X contiguous along the contraction index (vargemm_persist.hpp, PG_XTX).  grid (Np/64, Np/64, batch).
+__global__ void __launch_bounds__(256) transpose_lower_kernel(const double* __restrict__ X, double* __restrict__ XT, int Np,
+                                                              const int* __restrict__ zmap = nullptr) {
+    const int bj = blockIdx.x, bi = blockIdx.y;
+    if (bj > bi) return;
+    __shared__ double tile[64][65];
+    const long bz = zmap ? zmap[blockIdx.z] : (int)blockIdx.z;
+    const double* Xa = X + bz * Np * Np;
+    double* Ta = XT + bz * Np * Np;
+    const int tid = threadIdx.x;
+    for (int idx = tid; idx < 4096; idx += 256) {
+        const int r = idx >> 6, c = idx & 63;
+        tile[r][c] = Xa[(long)(bi * 64 + r) * Np + bj * 64 + c];
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 4096; idx += 256) {
+        const int r = idx >> 6, c = idx & 63;  // XT element (bj*64 + r, bi*64 + c) = X(bi*64 + c, bj*64 + r)
+        Ta[(long)(bj * 64 + r) * Np + bi * 64 + c] = tile[c][r];
     }
 }
 

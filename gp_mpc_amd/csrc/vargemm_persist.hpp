@@ -1,17 +1,23 @@
-// Predictive variance as ONE persistent launch over a static tile schedule  (a9, gp_functions.py:122-126:
-// var_j = sf2 - sum_i (L^-1 ks_j)_i^2 for every test point j; GP.covar gp_class.py:377-380).
+// Persistent products over a static tile schedule: the predictive variance and K^-1 = L^-T L^-1.
 //
-// Same arithmetic, tiles and LDS images as gemm_f64_dma_kernel<128,128,2,4,2,4> with A = L^-1 (lower triangular, K
-// contiguous), B = KsT (K contiguous) and the column-sum-of-squares epilogue -- the per-tile results are bit-identical
-// to that kernel's -- but the 128 x 128 tiles are not handed out by the hardware dispatcher:
-//   * The tile in block row tm is tm + 1 K-units long, so the 2528 tiles of C2 (32 x 79) carry 1 ... 32 units and the
-//     512 workgroup slots of the chip get ~5 tiles each.  Workgroups are dealt to the 8 XCDs round-robin whatever
+// PG_VAR   var_j = sf2 - sum_i (L^-1 ks_j)_i^2 for every test point j  (a9, gp_functions.py:122-126; GP.covar
+//          gp_class.py:377-380): A = L^-1 (lower triangular, K contiguous), B = KsT (K contiguous), column sums of squares per
+//          128-row tile.  Same arithmetic, tiles and LDS images as gemm_f64_dma_kernel<128,128,2,4,2,4> -- the per-tile results
+//          are bit-identical to that kernel's.
+// PG_XTX   lower triangle of K^-1 = X^T X, X = L^-1  (a6, optimize.py:489-490): A = B = XT, the transposed copy of L^-1 made by
+//          transpose_lower_kernel, so that both operands are K contiguous (the M/N-contiguous instantiation of the one-tile
+//          kernel reads its fragments with twice the LDS instructions and spills); tile (tm >= tn) sums over k >= 128 tm.
+//
+// The 128 x 128 tiles are not handed out by the hardware dispatcher:
+//   * The variance tile in block row tm is tm + 1 K-units long, so the 2528 tiles of C2 (32 x 79) carry 1 ... 32 units and
+//     the 512 workgroup slots of the chip get ~5 tiles each.  Workgroups are dealt to the 8 XCDs round-robin whatever
 //     their load, and 79 columns on 8 XCDs leave one XCD with nine tenths of the others' work: in-order dispatch ends
 //     4.3 % above the mean slot load (simulation of the dispatcher, heavy rows first), i.e. the last 0.1 ms of the
 //     kernel run on a draining chip.  Here 2 x CUs workgroups stay resident and walk lists made on the host
-//     (var_schedule: longest tile first to the least loaded slot of the column's home XCD, overflow to the globally
+//     (persist_schedule: longest tile first to the least loaded slot of the tile's home XCD, overflow to the globally
 //     least loaded slot, then moves / swaps off the heaviest slot): 0.7 % above the mean, 89 % of the tiles on the XCD
-//     that also holds the rest of their Ks panel.
+//     that also holds the rest of their Ks panel.  The doubly triangular K^-1 product is worse off with the dispatcher
+//     (row tm holds tm + 1 tiles of T - tm units and as many workgroups that exit at once).
 //   * The slabs of a workgroup's tiles form one stream through the two-image ring: the first slab of the next tile is
 //     requested behind the barrier of the current tile's last step, so a tile boundary costs the epilogue and nothing
 //     else (the one-tile kernel drains its ring, writes its sums, exits, and its successor starts with an empty ring).
@@ -31,9 +37,11 @@ constexpr int VAR_TILE = 128;
 constexpr int VAR_VGPRS = 56;
 __host__ __device__ inline int var_tile_word(int z, int tm, int tn) { return (z << 24) | (tm << 12) | tn; }
 
-template <int WPS>
-__global__ void __launch_bounds__(512, WPS) __attribute__((amdgpu_num_vgpr(VAR_VGPRS))) vargemm_persist_kernel(GemmP p, const int* __restrict__ list,
-                                                                     const int* __restrict__ off) {
+enum { PG_VAR = 0, PG_XTX = 1 };
+
+template <int MODE>
+__device__ __forceinline__ void persist_gemm_body(const GemmP& p, const int* __restrict__ list, const int* __restrict__ off,
+                                                  const int* __restrict__ zmap) {
     constexpr int BM = VAR_TILE, BN = VAR_TILE, BK = 16, WGM = 2, WGN = 4, NW = WGM * WGN;
     constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 16, TN = WN / 16;
     constexpr int LA = BM / 8, LB = BN / 8, LPW = (LA + LB) / NW;
@@ -56,12 +64,14 @@ __global__ void __launch_bounds__(512, WPS) __attribute__((amdgpu_num_vgpr(VAR_V
     fb[1] = fb[0] ^ 64u;
 
     // ---- request cursor: tile ri of the list, its next slab rt of rnk
-    int ri = beg, rt = 0, rnk = 0;
+    int ri = beg, rt = 0, rnk = 0, rk0 = 0;
     unsigned vo[LPW];
     dma_rsrc_t rsA, rsB;
     auto open_request = [&](int word) {
-        const int z = word >> 24, m0 = ((word >> 12) & 4095) * BM, n0 = (word & 4095) * BN;
-        rnk = (min(p.K, m0 + BM) + BK - 1) / BK;
+        const int zw = word >> 24, m0 = ((word >> 12) & 4095) * BM, n0 = (word & 4095) * BN;
+        const int z = (MODE == PG_XTX && zmap) ? zmap[zw] : zw;     // (zmap: the matrices of a subset of a batch)
+        if (MODE == PG_VAR) { rk0 = 0; rnk = (min(p.K, m0 + BM) + BK - 1) / BK; }
+        else { rk0 = m0; rnk = (p.K - m0) / BK; }                  // (K is a multiple of 16: gemm_dma_supported)
         rsA = dma_make_rsrc(p.A + (long)z * p.sA, (unsigned)((long)p.M * p.lda * 8));
         rsB = dma_make_rsrc(p.B + (long)z * p.sB, (unsigned)((long)p.N * p.ldb * 8));
 #pragma unroll
@@ -77,7 +87,7 @@ __global__ void __launch_bounds__(512, WPS) __attribute__((amdgpu_num_vgpr(VAR_V
     auto request_next = [&](int g) {                               // next slab of the stream -> image g & 1
         if (ri >= end) return;
         char* img = smem + (g & 1) * SLAB;
-        const unsigned k0 = (unsigned)(rt * BK) * 8u;
+        const unsigned k0 = (unsigned)(rk0 + rt * BK) * 8u;
 #pragma unroll
         for (int i = 0; i < LPW; ++i) {
             const int j = wave + NW * i;
@@ -91,10 +101,22 @@ __global__ void __launch_bounds__(512, WPS) __attribute__((amdgpu_num_vgpr(VAR_V
     };
 
     // ---- compute cursor
-    int ci = beg, ct = 0, cword = list[beg];
-    int cnk = (min(p.K, ((cword >> 12) & 4095) * BM + BM) + BK - 1) / BK;
-    // a wave whose 64 rows lie entirely above a slab's K range multiplies exact zeros there: it sits the slab out
-    int kskip = (((cword >> 12) & 4095) * BM + (wm + 1) * WM + BK - 1) / BK;
+    // a wave whose 64 rows lie entirely above (PG_VAR: A(m,k) = 0 for k > m) or below (PG_XTX: A(m,k) = 0 for k < m) a slab's
+    // K range multiplies exact zeros there and sits the slab out: it works on the slabs [kslo, kshi) of its tile
+    int ci = beg, ct = 0, cword = list[beg], cnk, kslo, kshi;
+    auto open_compute = [&](int word) {
+        const int m0 = ((word >> 12) & 4095) * BM;
+        if (MODE == PG_VAR) {
+            cnk = (min(p.K, m0 + BM) + BK - 1) / BK;
+            kslo = 0;
+            kshi = (m0 + (wm + 1) * WM + BK - 1) / BK;
+        } else {
+            cnk = (p.K - m0) / BK;
+            kslo = wm * WM / BK;
+            kshi = 1 << 30;
+        }
+    };
+    open_compute(cword);
 
     d4 acc[TM][TN];
 #pragma unroll
@@ -108,7 +130,7 @@ __global__ void __launch_bounds__(512, WPS) __attribute__((amdgpu_num_vgpr(VAR_V
         dma_wait<0>();                                             // slab g has landed (this wave's pieces)
         dma_barrier();                                             // ... everybody's, and image (g + 1) & 1 is free
         request_next(g + 1);
-        if (ct < kskip) {
+        if (ct >= kslo && ct < kshi) {
             const char* img = smem + (g & 1) * SLAB;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -129,58 +151,76 @@ __global__ void __launch_bounds__(512, WPS) __attribute__((amdgpu_num_vgpr(VAR_V
         }
         if (++ct < cnk) continue;
 
-        // ---- tile finished: column sums of squares over its rows < M, then the next tile of the list
-        const int z = cword >> 24, tm = (cword >> 12) & 4095, m0 = tm * BM, n0 = (cword & 4095) * BN;
+        // ---- tile finished: its epilogue, then the next tile of the list
+        const int zw = cword >> 24, tm = (cword >> 12) & 4095, m0 = tm * BM, n0 = (cword & 4095) * BN;
+        const int z = (MODE == PG_XTX && zmap) ? zmap[zw] : zw;
+        if (MODE == PG_VAR) {                                      // column sums of squares over the tile's rows < M
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            double s = 0.0;
+            for (int j = 0; j < TN; ++j) {
+                double s = 0.0;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int m = m0 + wm * WM + i * 16 + crow(lane, r, p.crow_mode);
+                        const double v = (m < p.M) ? acc[i][j][r] : 0.0;
+                        s += v * v;
+                        acc[i][j][r] = 0.0;
+                    }
+                s += __shfl_xor(s, 16);
+                s += __shfl_xor(s, 32);
+                if (lane < 16) red[wm * BN + wn * WN + j * 16 + lane] = s;
+            }
+            lds_barrier();                                         // (the slab in flight is not waited for)
+            if (tid < BN && n0 + tid < p.N) {
+                double t = 0.0;
+#pragma unroll
+                for (int w = 0; w < WGM; ++w) t += red[w * BN + tid];
+                p.part[(long)z * p.sPart + (long)tm * p.ldpart + n0 + tid] = t;
+            }
+            // (`red` is written again after >= 8 more ring barriers: no barrier needed behind its readers)
+        } else {                                                   // the lower triangle of the product
+            double* __restrict__ C = p.C + (long)z * p.sC;
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int m = m0 + wm * WM + i * 16 + crow(lane, r, p.crow_mode);
-                    const double v = (m < p.M) ? acc[i][j][r] : 0.0;
-                    s += v * v;
-                    acc[i][j][r] = 0.0;
-                }
-            s += __shfl_xor(s, 16);
-            s += __shfl_xor(s, 32);
-            if (lane < 16) red[wm * BN + wn * WN + j * 16 + lane] = s;
-        }
-        lds_barrier();                                             // (the slab in flight is not waited for)
-        if (tid < BN && n0 + tid < p.N) {
-            double t = 0.0;
+                for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int w = 0; w < WGM; ++w) t += red[w * BN + tid];
-            p.part[(long)z * p.sPart + (long)tm * p.ldpart + n0 + tid] = t;
+                    for (int r = 0; r < 4; ++r) {
+                        const int m = m0 + wm * WM + i * 16 + crow(lane, r, p.crow_mode);
+                        const int n = n0 + wn * WN + j * 16 + fr;
+                        if (m < p.M && n <= m) C[(long)m * p.ldc + n] = acc[i][j][r];
+                        acc[i][j][r] = 0.0;
+                    }
         }
         if (++ci >= end) break;
         cword = list[ci];
         ct = 0;
-        cnk = (min(p.K, ((cword >> 12) & 4095) * BM + BM) + BK - 1) / BK;
-        kskip = (((cword >> 12) & 4095) * BM + (wm + 1) * WM + BK - 1) / BK;
-        // (`red` is written again after >= 8 more ring barriers: no barrier needed behind its readers)
+        open_compute(cword);
     }
+}
+
+__global__ void __launch_bounds__(512, 4) __attribute__((amdgpu_num_vgpr(VAR_VGPRS))) vargemm_persist_kernel(GemmP p, const int* __restrict__ list,
+                                                                                                            const int* __restrict__ off) {
+    persist_gemm_body<PG_VAR>(p, list, off, nullptr);
+}
+__global__ void __launch_bounds__(512, 4) xtx_persist_kernel(GemmP p, const int* __restrict__ list, const int* __restrict__ off,
+                                                             const int* __restrict__ zmap) {
+    persist_gemm_body<PG_XTX>(p, list, off, zmap);
 }
 
 // ---- host side: the schedule ------------------------------------------------------------------------
 // Slots are the workgroups of the launch; slot s runs on XCD s % nx.  Cost of a tile in half slabs: 2 nk + 1 (the
 // epilogue).  Returns the slot lists concatenated (tile words) and their offsets [slots + 1].
+struct PersistTile { int cost, word, x; };                        // x: home XCD (the one that holds the rest of its operand panel)
 struct VarSchedule {
     std::vector<int> list, off;
     double mean_load = 0.0, max_load = 0.0;
-    int home = 0;                                                  // tiles on their column's home XCD
+    int home = 0;                                                  // tiles on their home XCD
 };
 
-inline VarSchedule var_schedule(int tilesM, int tilesN, int batch, int K, int slots, int nx = 8) {
-    struct T { int cost, word, x; };
-    std::vector<T> tiles;
-    tiles.reserve((size_t)tilesM * tilesN * batch);
-    for (int z = 0; z < batch; ++z)
-        for (int tm = 0; tm < tilesM; ++tm) {
-            const int nk = (std::min(K, (tm + 1) * VAR_TILE) + 15) / 16;
-            for (int tn = 0; tn < tilesN; ++tn) tiles.push_back(T{2 * nk + 1, var_tile_word(z, tm, tn), (tn + z) % nx});
-        }
+inline VarSchedule persist_schedule(std::vector<PersistTile>& tiles, int slots, int nx = 8) {
+    typedef PersistTile T;
     std::stable_sort(tiles.begin(), tiles.end(), [](const T& a, const T& b) { return a.cost > b.cost; });
     long total = 0;
     for (const T& t : tiles) total += t.cost;
@@ -199,9 +239,10 @@ inline VarSchedule var_schedule(int tilesM, int tilesN, int batch, int K, int sl
         load[s] += t.cost;
         lists[s].push_back(t);
     }
-    // moves / swaps off the heaviest slot while they lower it (partners: the 32 lightest slots)
+    // moves / swaps off the heaviest slot while they lower it (partners: the 32 lightest slots); good enough at 0.3 %
     for (int it = 0; it < 4 * slots; ++it) {
         const int smax = (int)(std::max_element(load.begin(), load.end()) - load.begin());
+        if ((double)load[smax] <= 1.003 * target) break;
         std::vector<int> light(slots);
         for (int s = 0; s < slots; ++s) light[s] = s;
         const int nl = std::min(slots, 32);
@@ -256,21 +297,50 @@ inline VarSchedule var_schedule(int tilesM, int tilesN, int batch, int K, int sl
     return r;
 }
 
-// the device copy of a schedule, cached on the model handle (one shape at a time)
+// variance product: tilesM x tilesN tiles per matrix, the tile in block row tm is min(K, 128 (tm + 1)) / 16 slabs long;
+// home XCD by column (the Ks panel)
+inline VarSchedule var_schedule(int tilesM, int tilesN, int batch, int K, int slots, int nx = 8) {
+    std::vector<PersistTile> tiles;
+    tiles.reserve((size_t)tilesM * tilesN * batch);
+    for (int z = 0; z < batch; ++z)
+        for (int tm = 0; tm < tilesM; ++tm) {
+            const int nk = (std::min(K, (tm + 1) * VAR_TILE) + 15) / 16;
+            for (int tn = 0; tn < tilesN; ++tn) tiles.push_back(PersistTile{2 * nk + 1, var_tile_word(z, tm, tn), (tn + z) % nx});
+        }
+    return persist_schedule(tiles, slots, nx);
+}
+
+// K^-1 = X^T X, lower triangle: tiles (tm >= tn), each (K - 128 tm) / 16 slabs long; home XCD by block row (the tm + 1 tiles
+// of a row are equally long and share their A panel)
+inline VarSchedule xtx_schedule(int tilesM, int batch, int K, int slots, int nx = 8) {
+    std::vector<PersistTile> tiles;
+    tiles.reserve((size_t)tilesM * (tilesM + 1) / 2 * batch);
+    for (int z = 0; z < batch; ++z)
+        for (int tm = 0; tm < tilesM; ++tm) {
+            const int nk = (K - tm * VAR_TILE) / 16;
+            for (int tn = 0; tn <= tm; ++tn) tiles.push_back(PersistTile{2 * nk + 1, var_tile_word(z, tm, tn), (tm + z) % nx});
+        }
+    return persist_schedule(tiles, slots, nx);
+}
+
+// the device copy of a schedule, cached on the model handle
 struct VarSchedDev {
-    int tilesM = 0, tilesN = 0, batch = 0, K = 0, slots = 0;
+    int mode = 0, tilesM = 0, tilesN = 0, batch = 0, K = 0, slots = 0;
     int* list = nullptr;
     int* off = nullptr;
 };
 
-inline void launch_vargemm_persist(const GemmP& p, const VarSchedDev& s, hipStream_t stream) {
+template <int MODE>
+inline void launch_persist_gemm(const GemmP& p, const VarSchedDev& s, hipStream_t stream, const int* zmap = nullptr) {
     constexpr int lds = 2 * (VAR_TILE + VAR_TILE) * 128 + 2 * VAR_TILE * 8 + 16;
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&vargemm_persist_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        const void* fn = MODE == PG_VAR ? reinterpret_cast<const void*>(&vargemm_persist_kernel) : reinterpret_cast<const void*>(&xtx_persist_kernel);
+        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((vargemm_persist_kernel<4>), dim3(s.slots), dim3(512), lds, stream, p, (const int*)s.list, (const int*)s.off);
+    if (MODE == PG_VAR) hipLaunchKernelGGL(vargemm_persist_kernel, dim3(s.slots), dim3(512), lds, stream, p, (const int*)s.list, (const int*)s.off);
+    else hipLaunchKernelGGL(xtx_persist_kernel, dim3(s.slots), dim3(512), lds, stream, p, (const int*)s.list, (const int*)s.off, zmap);
 }
 
 }  // namespace gpmpc

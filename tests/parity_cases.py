@@ -1730,7 +1730,9 @@ def check_train_lockstep_invariance(lib, N, d, nstart, max_iter, seed=5, mean_fu
     p = go.synthetic_problem(N, d, 1, 1, seed=seed, sn=0.05)
     X, Y = p['X'], p['Y']
     res = []
-    for cap in (0, 1, 3):
+    # (cap, vargemm_persist): the K^-1 product of the gradient runs as one persistent launch over a static schedule when the
+    # batch is large, as one tile per workgroup when it is small -- forced both ways here: same bits
+    for cap, persist in ((0, -1), (1, -1), (3, -1), (0, 2), (0, 0)):
         h = Handle(lib, X, Y)
         if mean_func != 'zero':
             h.set_mean_func(mean_func, add_to_prediction=False)
@@ -1741,11 +1743,13 @@ def check_train_lockstep_invariance(lib, N, d, nstart, max_iter, seed=5, mean_fu
         if nm:
             starts[:, d + 2:] = 0.1
         lib.set_tuning('train_batch_cap', cap)
+        lib.set_tuning('vargemm_persist', persist)
         try:
             res.append(h.train_multistart(starts[None], lb[None], ub[None], max_iter=max_iter))
         finally:
             lib.set_tuning('train_batch_cap', 0)
-        if cap == 0:
+            lib.set_tuning('vargemm_persist', -1)
+        if cap == 0 and persist == -1:
             th = res[-1]['hyper'][0]
             best = float(np.min(res[-1]['obj'][0]))
             ref = go.nll(th, X, Y[:, 0]) if mean_func == 'zero' else go.nll_mean(th, X, Y[:, 0], mean_func)
@@ -1754,9 +1758,9 @@ def check_train_lockstep_invariance(lib, N, d, nstart, max_iter, seed=5, mean_fu
             assert np.isfinite(res[-1]['obj']).sum() >= max(1, nstart // 2)
         h.close()
     for k in ('hyper', 'obj', 'theta'):
-        assert np.array_equal(res[0][k], res[1][k], equal_nan=True), k
-        assert np.array_equal(res[0][k], res[2][k], equal_nan=True), k
-    assert res[0]['evaluations'] == res[1]['evaluations'] == res[2]['evaluations']
+        for other in res[1:]:
+            assert np.array_equal(res[0][k], other[k], equal_nan=True), k
+    assert len({r['evaluations'] for r in res}) == 1
 
 
 def check_gp_class_strict(lib, N=400, Ny=3, Nu=2, seed=29):
