@@ -376,16 +376,23 @@ static int nll_batch(gpmpc_gp* h, int a, std::vector<NllReq*>& reqs, bool retain
                 fprintf(stderr, "gpmpc: lock-step batch of %d point%s (%s): %.3f ms, %d to repeat with jitter\n", n, n == 1 ? "" : "s",
                         wg ? "value + gradient" : "value", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(),
                         (int)failed.size());
+            std::vector<int> slot_of(n);          // where each point's factors are now
+            for (int i = 0; i < n; ++i) slot_of[i] = i;
             if (!failed.empty()) {                // the reference's one-shot jitter, for the points that need it
                 std::vector<NllReq*> again;
                 for (int i : failed) again.push_back(G[b0 + i]);
                 std::vector<int> failed2;
                 CHK(nll_batch_core(h, a, (int)again.size(), again.data(), wg == 1, 1e-8, failed2));
-            } else if (wg == 0 && retain && G.size() <= (size_t)cap) {
+                // (the repeat ran in the first slots: what was there is gone, the repeated points now live there)
+                const int m = (int)again.size();
+                for (int i = 0; i < m && i < n; ++i) slot_of[i] = -1;
+                for (int j = 0; j < m; ++j) slot_of[failed[j]] = j;
+            }
+            if (wg == 0 && retain && G.size() <= (size_t)cap) {
                 for (int i = 0; i < n; ++i) {
                     NllReq* r = G[i];
-                    if (r->rc != GPMPC_OK || r->id < 0 || r->id >= (int)h->lock_ret.size()) continue;
-                    h->lock_ret[r->id].pos = i;
+                    if (r->rc != GPMPC_OK || slot_of[i] < 0 || r->id < 0 || r->id >= (int)h->lock_ret.size()) continue;
+                    h->lock_ret[r->id].pos = slot_of[i];
                     h->lock_ret[r->id].theta.assign(r->theta, r->theta + nh);
                 }
             }
