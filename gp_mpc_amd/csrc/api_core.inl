@@ -39,6 +39,7 @@ static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 static std::mutex g_factor_mutex[64];
 static int g_crow_mode[64];
 static int g_cu_count[64];
+static double* g_exp_tab[64];          // per device: the table of exp_tab (gp_kernels.hpp)
 static bool g_dev_ready[64];
 
 static int mfma_selftest(int device, int* layout_out, double* tflops_out) {
@@ -121,6 +122,12 @@ static int ensure_device(int device) {
 #else
         g_cu_count[device] = getenv("GPMPC_EMU_CUS") ? atoi(getenv("GPMPC_EMU_CUS")) : 8;
 #endif
+        if (!g_exp_tab[device]) {                               // 2^(j / 2048), correctly rounded (exp_tab, gp_kernels.hpp)
+            std::vector<double> tab(EXPT_N);
+            for (int j = 0; j < EXPT_N; ++j) tab[j] = (double)exp2l((long double)j / (long double)EXPT_N);
+            HIPCHK(hipMalloc(&g_exp_tab[device], EXPT_N * sizeof(double)));
+            HIPCHK(hipMemcpy(g_exp_tab[device], tab.data(), EXPT_N * sizeof(double), hipMemcpyHostToDevice));
+        }
         int layout = -1;
         CHK(mfma_selftest(device, &layout, nullptr));
         g_crow_mode[device] = layout;

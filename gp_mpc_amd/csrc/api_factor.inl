@@ -93,64 +93,6 @@ static void trtri_node_inv(const Ctx& cx, Workspace& ws, hipStream_t stream, lon
     launch_gemm(u, ws.batch, stream);
 }
 
-// Inverse of the diagonal range [base0, base0 + n) that FOLLOWS the chain block by block (r04).  The level-batched
-// trtri_range above starts when the whole range is factored and is then 2 log2(n / 64) dependent, latency-bound launches
-// (~100 us for 1024 rows on an idle chip, 200-240 us next to the products of the other panels) -- on the critical path
-// behind the chain for the last panel, and in front of every product that needs I_i for the others.  Here every node
-// [L11 0; L21 L22] of the same tree is two launches of its own, enqueued in the order of a binary counter and gated on the
-// chain's flags: W = L21 inv11 as soon as the node's left child is inverted and block column `trig` = its last column is
-// final (pan1[trig]: the chain's tile, colready[trig]: the workers'), inv21 = -inv22 W as soon as the right child's last
-// leaf is out (leafdone[trig]); queue order supplies every other dependency.  When the last leaf of the range is out, one
-// inv21 per level remains (log2(n / 64) launches whose W has long been formed).  Every node keeps its W in a slot of its
-// own inside the level scratch (wbase, doubles into ws.W; trtri_flagged_need says how many).  One matrix (batch 1).
-struct TrtriOp { int trig, kind, s, h2; long base, wo; };      // kind 0: inv21, 1: W; s / h2 in rows
-static std::vector<TrtriOp> trtri_flagged_ops(long base0, int n, long wbase, long* need) {
-    std::vector<TrtriOp> ops;
-    long wo = wbase;
-    for (int s = 64; s < n; s *= 2)
-        for (long b = 0; b + s < n; b += 2 * (long)s) {
-            const int h2 = (int)std::min<long>(s, n - b - s);
-            ops.push_back(TrtriOp{(int)((base0 + b + s) / 64 - 1), 1, s, h2, base0 + b, wo});
-            ops.push_back(TrtriOp{(int)((base0 + b + s + h2) / 64 - 1), 0, s, h2, base0 + b, wo});
-            wo += (long)h2 * s;
-        }
-    std::stable_sort(ops.begin(), ops.end(), [](const TrtriOp& x, const TrtriOp& y) {
-        if (x.trig != y.trig) return x.trig < y.trig;
-        if (x.kind != y.kind) return x.kind < y.kind;          // the inv21 of a block first (small nodes first), then the W it enables
-        return x.s < y.s;
-    });
-    if (need) *need = wo - wbase;
-    return ops;
-}
-static long trtri_flagged_need(int n) {
-    long need = 0;
-    (void)trtri_flagged_ops(0, n, 0, &need);
-    return need;
-}
-static void trtri_range_flagged(const Ctx& cx, Workspace& ws, hipStream_t stream, long base0, int n, long wbase, int spin_limit) {
-    const int nb = ws.Np / 64, nf = chain_flag_count(nb);
-    const long ld = ws.Np;
-    for (const TrtriOp& o : trtri_flagged_ops(base0, n, wbase, nullptr)) {
-        GemmP g = gemm_base(cx);
-        if (o.kind == 1) {                                      // W = L21 inv11
-            g.A = ws.L + (o.base + o.s) * ld + o.base; g.lda = ld; g.a_mc = 0;
-            g.B = ws.Inv + o.base * ld + o.base; g.ldb = ld; g.b_nc = 1; g.kflags = KB_GE_N;
-            g.C = ws.W + o.wo; g.ldc = o.s;
-            g.M = o.h2; g.N = o.s; g.K = o.s;
-            g.wait_flag = ws.flags + chain_pan1_index(nb, o.trig);
-            if (nb - o.trig - 2 > 0) g.wait_flag2 = ws.flags + chain_colready_index(nb, o.trig);
-        } else {                                                // inv21 = -inv22 W
-            g.A = ws.Inv + (o.base + o.s) * ld + o.base + o.s; g.lda = ld; g.a_mc = 0; g.kflags = KA_LE_M;
-            g.B = ws.W + o.wo; g.ldb = o.s; g.b_nc = 1;
-            g.C = ws.Inv + (o.base + o.s) * ld + o.base; g.ldc = ld;
-            g.M = o.h2; g.N = o.s; g.K = o.h2; g.alpha = -1.0;
-            g.wait_flag = ws.flags + 1 + o.trig;                // leafdone[trig]
-        }
-        g.err = ws.flags; g.spin_limit = spin_limit; g.sFlags = nf;
-        launch_gemm(g, 1, stream);
-    }
-}
-
 // The part of the inverse that becomes computable when rows [seg0, seg1) are factored (seg0 a multiple of
 // SEGR): the levels inside the segment, then, smallest first, the second product of every higher node
 // whose right child ends at seg1 and the first product of every node whose left child ends there.
@@ -572,31 +514,9 @@ static bool factor_chain(const Ctx& cx, Workspace& ws, int spin_limit, bool flag
         P = L;                                              // (the refined S_j are a little larger than the coarse ones)
     }
     const int ev0 = L;                                      // events: 0 .. L-2 the launches, ev0 + i: I_i done
-    // Panels whose inverse follows the chain block by block (trtri_range_flagged) instead of starting when the panel is
-    // complete: GPMPC_TRTRI_INCR = bit mask of panels (default: all but the first, whose worker launch leaves no room on the
-    // chip).  Their merge launches sit on the low-priority queue behind a gate that waits until the worker launch that
-    // factors the panel is resident (its workgroups need whole CUs; a flag-polling product that got there first could keep
-    // one from being placed).  W slots: behind the part of the level scratch the other panels' trtri_range uses.
-    static const int incr_env = getenv("GPMPC_TRTRI_INCR") ? atoi(getenv("GPMPC_TRTRI_INCR")) : ~1;
-    int incr_mask = 0;
-    long incr_wo[12] = {0};
-    if (use_workers && split && P == L && cx.bulk && ws.batch == 1 && ev0 + P + 2 < cx.n_seg - 2) {
-        long top = 0;
-        for (int i = 0; i < P; ++i) top = std::max<long>(top, (long)(pcut[i + 1] - pcut[i]) * (pcut[i + 1] - pcut[i]) / 4);
-        for (int i = 0; i < P; ++i) {                       // (panel 0 next to the FIRST launch, on the CUs it leaves empty: opt-in)
-            if (!((incr_env >> i) & 1)) continue;
-            const long need = trtri_flagged_need(pcut[i + 1] - pcut[i]);
-            if (top + need > ws.hw() * ws.hw()) break;
-            incr_wo[i] = top;
-            top += need;
-            incr_mask |= 1 << i;
-        }
-    }
-    if (verbose && use_workers) fprintf(stderr, "gpmpc: panels whose inverse follows the chain block by block: mask %d of %d panels\n", incr_mask, P);
     if (use_workers) {
         for (int i = 0; i < L; ++i) {
-            // arrival counter + flag of launch i (the first launch's only when something waits for it: words 6, 7 of the eight)
-            int* ready = i ? ws.flags + chain_ready_index(nb) + 2 * (i - 1) : (incr_mask & 1) ? ws.flags + chain_ready_index(nb) + 6 : nullptr;
+            int* ready = i ? ws.flags + chain_ready_index(nb) + 2 * (i - 1) : nullptr;   // arrival counter + flag of launch i
             auto* worker = worker_courier ? chol_worker_kernel<WORKER_MAXT_COURIER, true> : chol_worker_kernel<WORKER_MAXT, false>;
             hipLaunchKernelGGL(worker, dim3(nws[i], 1, ws.batch), dim3(WORKER_THREADS), WORKER_LDS_BYTES, cx.side,
                                ws.K, ws.L, (const double*)ws.Inv, ld, sM, nb, ws.flags, (long)nf, cx.crow_mode, spin_limit,
@@ -615,18 +535,8 @@ static bool factor_chain(const Ctx& cx, Workspace& ws, int spin_limit, bool flag
             // (all I_i share ONE level scratch: the previous one must be through with it -- an explicit event, not "it
             //  finished long ago": with several handles alive HIP multiplexes their streams onto a few hardware queues and
             //  the inverse queue of this handle can sit behind another handle's work for any length of time)
-            const bool incr = (incr_mask >> i) & 1;
-            if (incr) tq = cx.bulk;
-            if (tq != cx.aux && i >= 1 && !incr) hipStreamWaitEvent(tq, cx.seg[ev0 + i - 1], 0);
-            if (incr) {
-                // next to launch i, once it is resident; the products below need the rows under the panel as well: launch i's end
-                if (i) hipStreamWaitEvent(tq, cx.seg[i - 1], 0);
-                else hipStreamWaitEvent(tq, cx.fork, 0);        // (the flags are clear from here on)
-                hipLaunchKernelGGL(flag_gate_kernel, dim3(ws.batch), dim3(64), 0, tq, ws.flags, (long)nf,
-                                   chain_ready_index(nb) + (i ? 2 * (i - 1) : 6) + 1, 1, -1, 0, spin_limit);
-                trtri_range_flagged(cx, ws, tq, ri, a, incr_wo[i], spin_limit);
-                hipStreamWaitEvent(cx.aux, cx.seg[i], 0);
-            } else if (i + 1 < L) {
+            if (tq != cx.aux && i >= 1) hipStreamWaitEvent(tq, cx.seg[ev0 + i - 1], 0);
+            if (i + 1 < L) {
                 // behind launch i + 1, once it is resident (its workgroups need whole CUs)
                 hipStreamWaitEvent(tq, cx.seg[i], 0);
                 hipLaunchKernelGGL(flag_gate_kernel, dim3(ws.batch), dim3(64), 0, tq, ws.flags, (long)nf,
@@ -636,7 +546,7 @@ static bool factor_chain(const Ctx& cx, Workspace& ws, int spin_limit, bool flag
                 hipLaunchKernelGGL(flag_gate_kernel, dim3(ws.batch), dim3(64), 0, tq, ws.flags, (long)nf,
                                    chain_pan1_index(nb, e), 1, chain_colready_index(nb, e), 1, spin_limit);
             }
-            if (!incr) trtri_range(cx, ws, tq, ri, a);                             // I_i
+            trtri_range(cx, ws, tq, ri, a);                                        // I_i
             if (i + 2 == P) hipEventRecord(cx.seg[cx.n_seg - 2], tq);             // the side queues' last use of the level scratch
             hipEventRecord(cx.seg[ev0 + i], tq);                                   // I_i done
             if (tq != cx.aux) hipStreamWaitEvent(cx.aux, cx.seg[ev0 + i], 0);
@@ -712,20 +622,9 @@ static bool factor_chain(const Ctx& cx, Workspace& ws, int spin_limit, bool flag
         // long ago (event recorded behind its last trtri_range); only the product waits for its S.  (Waiting for the
         // whole side queue first put its last product, which ends ~50 us after the chain, in front of these eight
         // latency-bound launches.)
+        hipStreamWaitEvent(cx.stream, cx.seg[cx.n_seg - 2], 0);
         const int rl = pcut[P - 1], h = Np - rl;
-        if ((incr_mask >> (P - 1)) & 1) {
-            // the last panel's inverse has followed the chain on the low-priority queue: one inv21 per level is left when the
-            // chain ends
-            hipStreamWaitEvent(cx.bulk, cx.seg[P - 2], 0);
-            hipLaunchKernelGGL(flag_gate_kernel, dim3(ws.batch), dim3(64), 0, cx.bulk, ws.flags, (long)nf,
-                               chain_ready_index(nb) + 2 * (P - 2) + 1, 1, -1, 0, spin_limit);
-            trtri_range_flagged(cx, ws, cx.bulk, rl, h, incr_wo[P - 1], spin_limit);
-            hipEventRecord(cx.seg[ev0 + P - 1], cx.bulk);
-            hipStreamWaitEvent(cx.stream, cx.seg[ev0 + P - 1], 0);
-        } else {
-            hipStreamWaitEvent(cx.stream, cx.seg[cx.n_seg - 2], 0);
-            trtri_range(cx, ws, cx.stream, rl, h);
-        }
+        trtri_range(cx, ws, cx.stream, rl, h);
         if (!s_ready_recorded) hipEventRecord(cx.seg[cx.n_seg - 1], cx.aux);
         hipStreamWaitEvent(cx.stream, cx.seg[cx.n_seg - 1], 0);
         product(cx.stream, ws.Inv + (long)rl * ld + rl, ld, KA_LE_M, ws.W + sofs[P - 1], rl, ws.Inv + (long)rl * ld, ld,

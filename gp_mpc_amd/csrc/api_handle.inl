@@ -186,10 +186,7 @@ static int create_impl(gpmpc_gp* h, const double* X, const double* Y) {
     {
         int lo = 0, hi = 0;                                    // (numerically larger = lower priority)
         HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-        // (GPMPC_BULK_PRIORITY=0: the fourth queue at the default priority -- tuning aid for what runs there next to the products
-        //  of the inverse: the panel inverses that follow the chain, the cross-covariances behind the tail)
-        static const bool bulk_low = !(getenv("GPMPC_BULK_PRIORITY") && atoi(getenv("GPMPC_BULK_PRIORITY")) == 0);
-        HIPCHK(hipStreamCreateWithPriority(&h->bulk_stream, hipStreamDefault, bulk_low ? lo : 0));
+        HIPCHK(hipStreamCreateWithPriority(&h->bulk_stream, hipStreamDefault, lo));
     }
     // the persistent kernels ask for more than the default 64 KB of dynamic LDS (per device: set for every handle)
     HIPCHK(hipFuncSetAttribute((const void*)chol_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CHAIN_LDS_BYTES));

@@ -235,10 +235,11 @@ __global__ void __launch_bounds__(256) em_operands_kernel(const double* __restri
 // adds La_i + Lb_j, takes the lean exp and accumulates (beta_ai beta_bj - [a==b] K^-1_ij) Q_ij.  For a == b
 // the summand is symmetric in (i, j): only column tiles up to the diagonal are visited, off-diagonal
 // tiles counted twice.  partial[(b*P + p)*tiles + strip].
-template <bool DIAG, int KD>
+// TAB: exp through the 2^(j / 2048) table (exp_tab, gp_kernels.hpp; etab: the table in global memory) instead of exp_lean.
+template <bool DIAG, int KD, bool TAB = false>
 __global__ void __launch_bounds__(256) em_pair_kernel(const double* __restrict__ ops, const double* __restrict__ beta,
                                                       const double* __restrict__ invK, double* __restrict__ partial,
-                                                      int N, int Np, int Ny, int crow_mode) {
+                                                      int N, int Np, int Ny, int crow_mode, const double* __restrict__ etab = nullptr) {
     constexpr int EMK = KD;                      // cross-term depth: 8 (d <= 8: two matrix instructions per tile) or 16 (four)
     constexpr int NQ = ((KD + 2) * 64 + 255) / 256;   // staged values per thread and column tile
     const int ti = blockIdx.x, p = blockIdx.y, b = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -259,6 +260,8 @@ __global__ void __launch_bounds__(256) em_pair_kernel(const double* __restrict__
     // column-tile operands (shared by the 4 waves) are staged through LDS with a one-tile prefetch:
     // rows 0..7 Wt, row 8 Lb, row 9 beta_b  -> 640 doubles per tile
     __shared__ double Cs[2][EMK + 2][64];
+    __shared__ double Et[TAB ? EXPT_N : 1];
+    if (TAB) exp_tab_fill(Et, etab, tid, 256);                   // (visible behind the barrier that follows the first stage())
     const int fr = lane & 15, fk = lane >> 4, i0 = ti * 64 + 16 * wave;
     // A fragments (constant over the sweep) and the row data of this lane's 4 accumulator rows
     double af[KD / 4];
@@ -319,7 +322,7 @@ __global__ void __launch_bounds__(256) em_pair_kernel(const double* __restrict__
             for (int r = 0; r < 4; ++r) {
                 // no per-entry masks: beta is zero in padded rows / columns, K^-1's padded rows are masked at the load
                 // above and its padded columns are exact zeros in live rows (identity padding), Q is finite everywhere
-                const double q = exp_lean((la[r] + lbj) + c[r]);
+                const double q = TAB ? exp_tab((la[r] + lbj) + c[r], Et) : exp_lean((la[r] + lbj) + c[r]);
                 double wgt = bai[r] * bj;
                 if (diag) wgt -= ik[t][r];
                 acc = fma(diag ? mult * wgt : wgt, q, acc);

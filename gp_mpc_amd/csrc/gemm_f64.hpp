@@ -103,7 +103,6 @@ struct GemmP {
     int npad;             // row-major order: padded width of the tile grid (set by the launcher)
     // hand-offs with the persistent chain kernel (chol_chain.hpp); all null/0 for ordinary launches
     const int* wait_flag; // every workgroup waits for *wait_flag >= 1 before touching its operands
-    const int* wait_flag2; // ... and for *wait_flag2 >= 1 (optional)
     int* err;             // shared error word (time-out)
     int spin_limit;
     int skip00;           // tile (0,0) belongs to the chain kernel
@@ -161,8 +160,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) gemm_f64_kernel
     if (tme >= p.tilesMe || tne >= p.tilesNe) return;
     if (p.wait_flag) {
         __shared__ int wslot;
-        if (!wg_wait2(p.wait_flag + (long)blockIdx.z * p.sFlags, 1, p.wait_flag2 ? p.wait_flag2 + (long)blockIdx.z * p.sFlags : nullptr, 1,
-                      p.err + (long)blockIdx.z * p.sFlags,
+        if (!wg_wait2(p.wait_flag + (long)blockIdx.z * p.sFlags, 1, nullptr, 0, p.err + (long)blockIdx.z * p.sFlags,
                       p.spin_limit, &wslot))
             return;
     }

@@ -56,8 +56,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN, WPS) gemm_f64_dma_kernel(GemmP
     const int tme = (int)blockIdx.x / p.npad, tne = (int)blockIdx.x % p.npad;
     if (tme >= p.tilesMe || tne >= p.tilesNe) return;
     if (p.wait_flag) {
-        if (!wg_wait2(p.wait_flag + (long)blockIdx.z * p.sFlags, 1, p.wait_flag2 ? p.wait_flag2 + (long)blockIdx.z * p.sFlags : nullptr, 1,
-                      p.err + (long)blockIdx.z * p.sFlags,
+        if (!wg_wait2(p.wait_flag + (long)blockIdx.z * p.sFlags, 1, nullptr, 0, p.err + (long)blockIdx.z * p.sFlags,
                       p.spin_limit, slot))
             return;
     }

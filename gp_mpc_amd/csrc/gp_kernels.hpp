@@ -40,6 +40,31 @@ __device__ __forceinline__ double exp_lean(double x) {
     return ldexp(p, (int)n);
 }
 
+// exp(x) with a table of 2^(j / 2048) (16 KB, copied to LDS by the workgroup: exp_tab_fill):  x = (2048 n + j) ln2 / 2048 + r,
+// |r| <= ln2 / 4096 = 1.7e-4, exp(x) = 2^n T[j] (1 + r + r^2/2 + r^3/6) (truncation r^4 / 24 = 3.4e-17).  The integer
+// 2048 n + j is read off the low word of x * 2048 / ln2 + 1.5 * 2^52 (no rint / cvt), the reduction is Cody-Waite with the
+// constants of exp_lean scaled by 2^-11 (exact), 2^n goes in through v_ldexp_f64 (underflow flushes to 0).  Eleven VALU
+// instructions and one LDS read against the eighteen of exp_lean (three of them conversion-class, issued at a fraction of the
+// fma rate); error <= 1 ulp of T[j] rounding + 0.6 ulp.  For the exact-moment pair sums (em_kernels.hpp), whose VALU time is
+// this function; the K build keeps exp_lean (its bits are what the fixtures were checked with).
+constexpr int EXPT_LOG2 = 11, EXPT_N = 1 << EXPT_LOG2;
+__device__ __forceinline__ void exp_tab_fill(double* __restrict__ T_lds, const double* __restrict__ T_glob, int tid, int nthreads) {
+    for (int i = tid; i < EXPT_N; i += nthreads) T_lds[i] = T_glob[i];
+}
+__device__ __forceinline__ double exp_tab(double x, const double* __restrict__ T_lds) {
+    const double magic = 6755399441055744.0;                    // 1.5 * 2^52
+    const double t = fma(x, 2954.6394437405970050, magic);      // 2048 / ln 2
+    const double nf = t - magic;
+    double r = fma(-nf, 6.93147180369123816490e-01 / 2048.0, x);
+    r = fma(-nf, 1.90821492927058770002e-10 / 2048.0, r);
+    const int ki = __double2loint(t);
+    const double tj = T_lds[ki & (EXPT_N - 1)];
+    double p = fma(r, 1.0 / 6.0, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(tj * p, ki >> EXPT_LOG2);
+}
+
 // t / b, correctly rounded, from the correctly rounded reciprocal y = RN(1 / b) (computed once per workgroup and
 // dimension): q0 = t y, r = t - q0 b (exact in an fma), q = q0 + r y -- Markstein's division step: three full-rate
 // instructions instead of the ~12 of the IEEE division sequence, and the SAME bits (200 M random pairs incl. mantissas
