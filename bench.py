@@ -307,7 +307,7 @@ def run_c3(rk, steps, warmup, N=8192):
                      'note': '2 N^3 / 3 flops per output (potrf + trtri), HIP events around the whole factor phase'},
         'em_pair_kernels': {'bound': 'hbm', 'achieved': em_bytes / (em_ms / max(em_n, 1) * 1e-3) * 1e-9 if em_ms > 0 else 0.0,
                             'peak': 8000.0, 'unit': 'GB/s', 'avg_launch_ms': em_ms / max(em_n, 1), 'launches': em_n,
-                            'note': 'algorithmic bytes = lower triangles of the 6 K^-1; the kernel is bound by its 1.2e9 fp64 exp per input, not HBM'},
+                            'note': 'algorithmic bytes = lower triangles of the 6 K^-1; the kernel is bound by the issue of its 1.2e9 fp64 exp per input (PMC: profiles/r04_pmc_em_tab*), not by HBM'},
         'phases_ms_per_step': {k: v[0] / steps for k, v in prof.items() if v[1] > 0},
         'rollout_ms_per_call': t_roll,
         'finite': bool(all(np.all(np.isfinite(r[0])) and np.all(np.isfinite(r[1])) for r in res.values())),
@@ -446,7 +446,7 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': 'C2: single-output SE-ARD GP, K build + Cholesky + 10k mean+var predictions per step',
                        'N': N, 'd': d, 'Ny': 1, 'B': B, 'parallelism': f'independent GP per GPU x{world}'},
-            'roofline': {'kernel': 'gemm_f64_dma_kernel<2,4,2,4> 128x128 tile (variance GEMM + column sum of squares)',
+            'roofline': {'kernel': 'vargemm_persist_kernel: 128x128 tiles over a static schedule, 512 resident workgroups (variance GEMM + column sum of squares)',
                          'bound': 'mfma', 'achieved': achieved, 'peak': FP64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': achieved / FP64_MFMA_PEAK_TFLOPS, 'traffic': traffic, 'traffic_source': traffic_source,
                          'avg_launch_ms': gemm_ms / max(gemm_n, 1), 'launches': gemm_n,
@@ -500,10 +500,12 @@ def main():
                 'c3': {'workload': c3['config']['workload'], 'ms_per_step': c3['ms_per_step'], 'steps': c3['steps'],
                        'propagation_steps_per_s': c3['value'], 'factor_ms': c3['roofline']['avg_launch_ms'],
                        'factor_tflops': c3['roofline']['achieved'], 'factor_frac': c3['roofline']['frac'],
-                       'rollout_ms_per_call': c3['rollout_ms_per_call'], 'finite': c3['finite']},
+                       'rollout_ms_per_call': c3['rollout_ms_per_call'], 'finite': c3['finite'],
+                       'phases_ms_per_step': c3['phases_ms_per_step'], 'em_pair_kernels': c3['em_pair_kernels']},
                 'c4': {'workload': c4['config']['workload'], 'restarts_per_s': c4['value'], 'ms_per_step': c4['ms_per_step'],
                        'steps': c4['steps'], 'rccl_ranks': c4['rccl_ranks'], 'exchange': c4['exchange'],
-                       'best_nll': c4['best_nll'], 'finite_restarts': c4['finite_restarts']}}
+                       'best_nll': c4['best_nll'], 'finite_restarts': c4['finite_restarts'],
+                       'evaluations_this_rank': c4.get('evaluations_this_rank')}}
     rk.close()
     if rank == 0:
         _emit(out)

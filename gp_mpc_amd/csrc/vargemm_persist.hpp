@@ -14,9 +14,10 @@
 //     their load, and 79 columns on 8 XCDs leave one XCD with nine tenths of the others' work: in-order dispatch ends
 //     4.3 % above the mean slot load (simulation of the dispatcher, heavy rows first), i.e. the last 0.1 ms of the
 //     kernel run on a draining chip.  Here 2 x CUs workgroups stay resident and walk lists made on the host
-//     (persist_schedule: longest tile first to the least loaded slot of the tile's home XCD, overflow to the globally
-//     least loaded slot, then moves / swaps off the heaviest slot): 0.7 % above the mean, 89 % of the tiles on the XCD
-//     that also holds the rest of their Ks panel.  The doubly triangular K^-1 product is worse off with the dispatcher
+//     (persist_schedule: the XCDs are levelled first by moving a few tiles -- the only ones that leave the XCD that holds the
+//     rest of their Ks panel --, then inside every XCD longest tile first to the least loaded slot and moves / swaps off the
+//     heaviest slot): within 0.5 % of the mean.  (A first version balanced across XCDs freely: 16 % of the tiles ran away
+//     from their panel and the kernel fetched 43 % more than the dispatcher's order, profiles/r04_*.)  The doubly triangular K^-1 product is worse off with the dispatcher
 //     (row tm holds tm + 1 tiles of T - tm units and as many workgroups that exit at once).
 //   * The slabs of a workgroup's tiles form one stream through the two-image ring: the first slab of the next tile is
 //     requested behind the barrier of the current tile's last step, so a tile boundary costs the epilogue and nothing
@@ -221,69 +222,85 @@ struct VarSchedule {
 
 inline VarSchedule persist_schedule(std::vector<PersistTile>& tiles, int slots, int nx = 8) {
     typedef PersistTile T;
+    if (nx > slots || slots % nx) nx = 1;
+    const int per = slots / nx;                                    // slots of an XCD: x, x + nx, ...
     std::stable_sort(tiles.begin(), tiles.end(), [](const T& a, const T& b) { return a.cost > b.cost; });
     long total = 0;
-    for (const T& t : tiles) total += t.cost;
-    const double target = (double)total / slots;
+    std::vector<long> tot(nx, 0);
+    std::vector<std::vector<T>> byx(nx);
+    for (const T& t : tiles) { total += t.cost; tot[t.x % nx] += t.cost; byx[t.x % nx].push_back(t); }
+    // 1. level the XCDs: the largest tile that fits the gap goes from the fullest to the emptiest XCD.  Only these tiles leave
+    //    the XCD that holds the rest of their operand panel (C2: 79 columns on 8 XCDs -> about twenty of 2528).
+    const double xtarget = (double)total / nx;
+    for (int it = 0; it < (int)tiles.size(); ++it) {
+        const int xo = (int)(std::max_element(tot.begin(), tot.end()) - tot.begin());
+        const int xu = (int)(std::min_element(tot.begin(), tot.end()) - tot.begin());
+        const double gap = std::min((double)tot[xo] - xtarget, xtarget - (double)tot[xu]);
+        int pick = -1;
+        for (int i = 0; i < (int)byx[xo].size(); ++i)
+            if ((double)byx[xo][i].cost <= gap) { pick = i; break; }   // (sorted: the first that fits is the largest)
+        if (pick < 0) break;
+        const T t = byx[xo][pick];
+        byx[xo].erase(byx[xo].begin() + pick);
+        auto pos = std::lower_bound(byx[xu].begin(), byx[xu].end(), t, [](const T& a, const T& b) { return a.cost > b.cost; });
+        byx[xu].insert(pos, t);
+        tot[xo] -= t.cost;
+        tot[xu] += t.cost;
+    }
+    // 2. inside every XCD: longest tile first to its least loaded slot, then moves / swaps off its heaviest slot
     std::vector<long> load(slots, 0);
     std::vector<std::vector<T>> lists(slots);
-    if (nx > slots) nx = 1;
-    for (const T& t : tiles) {
-        int s = t.x % nx;
-        for (int c = s; c < slots; c += nx)
-            if (load[c] < load[s]) s = c;
-        if (load[s] + t.cost > target) {
-            const int g = (int)(std::min_element(load.begin(), load.end()) - load.begin());
-            if (load[g] < load[s]) s = g;
+    for (int x = 0; x < nx; ++x) {
+        for (const T& t : byx[x]) {
+            int s = x;
+            for (int c = x; c < slots; c += nx)
+                if (load[c] < load[s]) s = c;
+            load[s] += t.cost;
+            lists[s].push_back(t);
         }
-        load[s] += t.cost;
-        lists[s].push_back(t);
-    }
-    // moves / swaps off the heaviest slot while they lower it (partners: the 32 lightest slots); good enough at 0.3 %
-    for (int it = 0; it < 4 * slots; ++it) {
-        const int smax = (int)(std::max_element(load.begin(), load.end()) - load.begin());
-        if ((double)load[smax] <= 1.003 * target) break;
-        std::vector<int> light(slots);
-        for (int s = 0; s < slots; ++s) light[s] = s;
-        const int nl = std::min(slots, 32);
-        std::partial_sort(light.begin(), light.begin() + nl, light.end(), [&](int a, int b) { return load[a] < load[b]; });
-        long best = 0;
-        int bi = -1, bs = -1, bj = -1;
-        for (int li = 0; li < nl; ++li) {
-            const int s2 = light[li];
-            if (s2 == smax) continue;
-            for (int i = 0; i < (int)lists[smax].size(); ++i) {
-                const long c = lists[smax][i].cost;
-                if (load[s2] + c < load[smax]) {                   // move
-                    const long gain = load[smax] - std::max(load[smax] - c, load[s2] + c);
-                    if (gain > best) { best = gain; bi = i; bs = s2; bj = -1; }
-                }
-                for (int j = 0; j < (int)lists[s2].size(); ++j) {  // swap
-                    const long dlt = c - lists[s2][j].cost;
-                    if (dlt > 0 && load[s2] + dlt < load[smax]) {
-                        const long gain = load[smax] - std::max(load[smax] - dlt, load[s2] + dlt);
-                        if (gain > best) { best = gain; bi = i; bs = s2; bj = j; }
+        const double target = (double)tot[x] / per;
+        for (int it = 0; it < 8 * per; ++it) {
+            int smax = x;
+            for (int c = x; c < slots; c += nx)
+                if (load[c] > load[smax]) smax = c;
+            if ((double)load[smax] <= 1.002 * target) break;
+            long best = 0;
+            int bi = -1, bs = -1, bj = -1;
+            for (int s2 = x; s2 < slots; s2 += nx) {
+                if (s2 == smax || load[s2] >= load[smax]) continue;
+                for (int i = 0; i < (int)lists[smax].size(); ++i) {
+                    const long c = lists[smax][i].cost;
+                    if (load[s2] + c < load[smax]) {               // move
+                        const long gain = load[smax] - std::max(load[smax] - c, load[s2] + c);
+                        if (gain > best) { best = gain; bi = i; bs = s2; bj = -1; }
+                    }
+                    for (int j = 0; j < (int)lists[s2].size(); ++j) {   // swap
+                        const long dlt = c - lists[s2][j].cost;
+                        if (dlt > 0 && load[s2] + dlt < load[smax]) {
+                            const long gain = load[smax] - std::max(load[smax] - dlt, load[s2] + dlt);
+                            if (gain > best) { best = gain; bi = i; bs = s2; bj = j; }
+                        }
                     }
                 }
             }
-        }
-        if (bi < 0) break;
-        if (bj < 0) {
-            const T t = lists[smax][bi];
-            lists[smax].erase(lists[smax].begin() + bi);
-            lists[bs].push_back(t);
-            load[smax] -= t.cost;
-            load[bs] += t.cost;
-        } else {
-            std::swap(lists[smax][bi], lists[bs][bj]);
-            const long dlt = lists[bs][bj].cost - lists[smax][bi].cost;
-            load[smax] -= dlt;
-            load[bs] += dlt;
+            if (bi < 0) break;
+            if (bj < 0) {
+                const T t = lists[smax][bi];
+                lists[smax].erase(lists[smax].begin() + bi);
+                lists[bs].push_back(t);
+                load[smax] -= t.cost;
+                load[bs] += t.cost;
+            } else {
+                std::swap(lists[smax][bi], lists[bs][bj]);
+                const long dlt = lists[bs][bj].cost - lists[smax][bi].cost;
+                load[smax] -= dlt;
+                load[bs] += dlt;
+            }
         }
     }
     VarSchedule r;
     r.off.resize(slots + 1);
-    r.mean_load = target;
+    r.mean_load = (double)total / slots;
     for (int s = 0; s < slots; ++s) {
         std::stable_sort(lists[s].begin(), lists[s].end(), [](const T& a, const T& b) { return a.cost > b.cost; });
         r.off[s] = (int)r.list.size();
