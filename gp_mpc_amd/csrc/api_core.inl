@@ -240,6 +240,8 @@ struct Workspace {
     double *w = nullptr, *alpha = nullptr, *hyper = nullptr, *jitter = nullptr, *nll = nullptr;
     int* info = nullptr;
     int* flags = nullptr;   // hand-off words of the chain kernel, [batch][chain_flag_count(Np/64)]
+    int inv_panels = 0;     // host-side: 0 = Inv holds L^-1; W > 0: only the inverses of the diagonal blocks of W block columns
+                            // (a value-only factorisation: factor_twolevel(want_inverse = false); twolevel_inverse_all completes it)
     long mat() const { return (long)Np * Np; }
     // scratch of the triangular inverse per matrix: [0, hw^2) level scratch, then one slot per high-level node
     long hw() const { return Np / 2 + 64; }
@@ -366,6 +368,8 @@ struct Ctx {
     Prof* prof = nullptr;           // the handle's profile (phase brackets inside the factorisation)
     hipStream_t bulk = nullptr;     // fourth queue (low priority): look-ahead part of the two-level trailing updates
     TailState* tail = nullptr;      // early status + row-panel events of the chained factorisation (may be null)
+    bool value_only = false;        // the caller needs L and the diagonal blocks' inverses only (a line-search trial): where the
+                                    // execution can, it leaves L^-1 unformed and says so in ws.inv_panels
     bool no_workers = false;        // never the tile-owner workers: the choice of execution must not depend on the batch size
                                     // (lock-step restart search: a point's value may not depend on what else is in its batch)
 };

@@ -167,7 +167,62 @@ static long long* g_chain_trace = nullptr;   // developer aid: GPMPC_CHAIN_TRACE
 //     I_i = L11^-1 (level-batched, own scratch)                               ->  trtri_range
 //     L21 = A21 I_i^T   (rows below, K = 64 W, triangular)                    ->  one MFMA-rate product
 //     A22 -= L21 L21^T  (K = 64 W; look-ahead split as before)
-// want_inverse = false (value-only NLL evaluations of the restart search): L and the diagonal blocks' inverses I_i only.
+// want_inverse = false (value-only NLL evaluations of the restart search): L and the diagonal blocks' inverses I_i only
+// (ws.inv_panels = W); twolevel_inverse_all forms L^-1 from them later, for the matrices that turn out to need it.
+static int twolevel_width() {   // block columns per super-panel (GPMPC_TWOLEVEL; 0 / 1 = off)
+#ifdef GPMPC_EMULATED
+    static const int w = getenv("GPMPC_TWOLEVEL") ? atoi(getenv("GPMPC_TWOLEVEL")) : 2;
+#else
+    static const int w = getenv("GPMPC_TWOLEVEL") ? atoi(getenv("GPMPC_TWOLEVEL")) : 8;
+#endif
+    return w;
+}
+
+// One step of the right-looking blocked inversion by row panels (see factor_twolevel): panel P_i = block columns [k0, k1).
+// `batch` matrices, optionally the subset zmap[0 .. batch) of the workspace.
+static void twolevel_inverse_panel(const Ctx& cx, Workspace& ws, hipStream_t st, int k0, int k1, bool have_I, bool blocked, int batch,
+                                   const int* zmap = nullptr) {
+    const int Np = ws.Np;
+    const long ld = Np, sM = ws.mat(), sW = ws.wstride();
+    const int ri = 64 * k0, a = 64 * (k1 - k0), rn = 64 * k1, Mb = Np - rn;
+    if (!have_I) trtri_range(cx, ws, st, ri, a, blocked ? ws.Wl : nullptr, blocked ? ws.wl_stride() : 0);   // I_i
+    if (ri > 0) {
+        GemmP u = gemm_base(cx);                                           // T = -I_i S_i, then back into Inv[P_i, < r_i]
+        u.A = ws.Inv + (long)ri * ld + ri; u.lda = ld; u.sA = sM; u.a_mc = 0; u.kflags = KA_LE_M;
+        u.B = ws.Inv + (long)ri * ld; u.ldb = ld; u.sB = sM; u.b_nc = 1;
+        u.C = ws.W; u.ldc = ri; u.sC = sW;
+        u.M = a; u.N = ri; u.K = a; u.alpha = -1.0; u.zmap = zmap;
+        launch_gemm(u, batch, st);
+        hipLaunchKernelGGL(copy_rect_kernel, dim3((ri / 2 + 255) / 256, a, batch), dim3(256), 0, st, (const double*)ws.W,
+                           (long)ri, sW, ws.Inv + (long)ri * ld, ld, sM, ri, zmap);   // (ri is a multiple of 64: pairs)
+    }
+    if (Mb > 0) {
+        GemmP t = gemm_base(cx);                                           // new columns of S: L[> P_i, P_i] I_i
+        t.A = ws.L + (long)rn * ld + ri; t.lda = ld; t.sA = sM; t.a_mc = 0;
+        t.B = ws.Inv + (long)ri * ld + ri; t.ldb = ld; t.sB = sM; t.b_nc = 1; t.kflags = KB_GE_N;
+        t.C = ws.Inv + (long)rn * ld + ri; t.ldc = ld; t.sC = sM;
+        t.M = Mb; t.N = a; t.K = a; t.zmap = zmap;
+        launch_gemm(t, batch, st);
+        if (ri > 0) {
+            GemmP v = gemm_base(cx);                                       // S[> P_i, < r_i] += L[> P_i, P_i] X[P_i, < r_i]
+            v.A = ws.L + (long)rn * ld + ri; v.lda = ld; v.sA = sM; v.a_mc = 0;
+            v.B = ws.Inv + (long)ri * ld; v.ldb = ld; v.sB = sM; v.b_nc = 1;
+            v.C = ws.Inv + (long)rn * ld; v.ldc = ld; v.sC = sM;
+            v.M = Mb; v.N = ri; v.K = a; v.beta = 1.0; v.zmap = zmap;
+            launch_gemm(v, batch, st);
+        }
+    }
+}
+
+// L^-1 of `batch` matrices (the subset zmap of the workspace, or its first `batch`) from L and the inverses of the diagonal
+// blocks of W block columns each, which a value-only factorisation left in Inv: every panel step of the inversion above, one
+// after the other on `st`.  Same launches on the same operands as the inversion that accompanies a full factorisation.
+static void twolevel_inverse_all(const Ctx& cx, Workspace& ws, hipStream_t st, int W, int batch, const int* zmap) {
+    const int nb = ws.Np / 64;
+    const bool blocked = ws.Wl && (long)(32 * W) * (32 * W) <= ws.wl_stride();
+    for (int k0 = 0; k0 < nb; k0 += W) twolevel_inverse_panel(cx, ws, st, k0, std::min(nb, k0 + W), true, blocked, batch, zmap);
+}
+
 static bool factor_twolevel(const Ctx& cx, Workspace& ws, int spin_limit, int W, bool want_inverse = true) {
     const int Np = ws.Np, nb = Np / 64, nf = chain_flag_count(nb);
     const long ld = Np, sM = ws.mat(), sW = ws.wstride();
@@ -187,34 +242,7 @@ static bool factor_twolevel(const Ctx& cx, Workspace& ws, int spin_limit, int W,
     // its root, a third of the fit, for the end).  Needs a 64 W x Np scratch panel in ws.W and the event pool.
     const bool panel_inv = want_inverse && cx.aux && cx.seg && cx.n_seg >= 3 && (long)64 * W * Np <= sW;
     auto inverse_panel = [&](hipStream_t st, int k0, int k1, bool have_I) {
-        const int ri = 64 * k0, a = 64 * (k1 - k0), rn = 64 * k1, Mb = Np - rn;
-        if (!have_I) trtri_range(cx, ws, st, ri, a, blocked ? ws.Wl : nullptr, blocked ? ws.wl_stride() : 0);   // I_i
-        if (ri > 0) {
-            GemmP u = gemm_base(cx);                                           // T = -I_i S_i, then back into Inv[P_i, < r_i]
-            u.A = ws.Inv + (long)ri * ld + ri; u.lda = ld; u.sA = sM; u.a_mc = 0; u.kflags = KA_LE_M;
-            u.B = ws.Inv + (long)ri * ld; u.ldb = ld; u.sB = sM; u.b_nc = 1;
-            u.C = ws.W; u.ldc = ri; u.sC = sW;
-            u.M = a; u.N = ri; u.K = a; u.alpha = -1.0;
-            launch_gemm(u, ws.batch, st);
-            hipLaunchKernelGGL(copy_rect_kernel, dim3((ri / 2 + 255) / 256, a, ws.batch), dim3(256), 0, st, (const double*)ws.W,
-                               (long)ri, sW, ws.Inv + (long)ri * ld, ld, sM, ri);   // (ri is a multiple of 64: pairs)
-        }
-        if (Mb > 0) {
-            GemmP t = gemm_base(cx);                                           // new columns of S: L[> P_i, P_i] I_i
-            t.A = ws.L + (long)rn * ld + ri; t.lda = ld; t.sA = sM; t.a_mc = 0;
-            t.B = ws.Inv + (long)ri * ld + ri; t.ldb = ld; t.sB = sM; t.b_nc = 1; t.kflags = KB_GE_N;
-            t.C = ws.Inv + (long)rn * ld + ri; t.ldc = ld; t.sC = sM;
-            t.M = Mb; t.N = a; t.K = a;
-            launch_gemm(t, ws.batch, st);
-            if (ri > 0) {
-                GemmP v = gemm_base(cx);                                       // S[> P_i, < r_i] += L[> P_i, P_i] X[P_i, < r_i]
-                v.A = ws.L + (long)rn * ld + ri; v.lda = ld; v.sA = sM; v.a_mc = 0;
-                v.B = ws.Inv + (long)ri * ld; v.ldb = ld; v.sB = sM; v.b_nc = 1;
-                v.C = ws.Inv + (long)rn * ld; v.ldc = ld; v.sC = sM;
-                v.M = Mb; v.N = ri; v.K = a; v.beta = 1.0;
-                launch_gemm(v, ws.batch, st);
-            }
-        }
+        twolevel_inverse_panel(cx, ws, st, k0, k1, have_I, blocked, ws.batch);
     };
     int ev = 0;                                                // event pool cursor
     int inv_done = 0;                                          // block columns whose inverse panel has been enqueued
@@ -347,7 +375,8 @@ static bool factor_twolevel(const Ctx& cx, Workspace& ws, int spin_limit, int W,
     }
     if (!want_inverse) {
         // value only: the last diagonal block's inverse completes the set I_0 .. I_last (forward substitution by blocks)
-        if (blocked) trtri_range(cx, ws, cx.stream, 64 * ((nb - 1) / W * W), Np - 64 * ((nb - 1) / W * W), ws.Wl, ws.wl_stride());
+        trtri_range(cx, ws, cx.stream, 64 * ((nb - 1) / W * W), Np - 64 * ((nb - 1) / W * W), ws.Wl, ws.wl_stride());
+        ws.inv_panels = W;
         return true;
     }
     if (!panel_inv) { trtri_levels(cx, ws); return true; }
@@ -385,16 +414,16 @@ static bool factor_chain(const Ctx& cx, Workspace& ws, int spin_limit, bool flag
     if (NW > ntiles + ncour) NW = ntiles + ncour;
     const bool use_workers = NW >= 1 + ncour && nb >= 3 && (ntiles + (NW - ncour) - 1) / (NW - ncour) <= worker_maxt;
     // what the workers do not take: two-level panels (GPMPC_TWOLEVEL=<block columns per super-panel>, 0/1 = off)
-#ifdef GPMPC_EMULATED
-    static const int twolevel_W = getenv("GPMPC_TWOLEVEL") ? atoi(getenv("GPMPC_TWOLEVEL")) : 2;
-#else
-    static const int twolevel_W = getenv("GPMPC_TWOLEVEL") ? atoi(getenv("GPMPC_TWOLEVEL")) : 8;
-#endif
+    static const int twolevel_W = twolevel_width();
     if (!use_workers && twolevel_W > 1 && nb >= 2 * twolevel_W && cx.aux && cx.seg) {
         static const bool verbose2 = getenv("GPMPC_VERBOSE") != nullptr;
         if (verbose2)
             fprintf(stderr, "gpmpc: factor Np=%d batch=%d: two-level panels of %d block columns\n", Np, ws.batch, twolevel_W);
-        return factor_twolevel(cx, ws, spin_limit, twolevel_W);
+        // (value only: L and the diagonal blocks' inverses suffice -- but only the blocked super-panels leave those behind)
+        const int nsp = (nb + twolevel_W - 1) / twolevel_W;
+        const bool can_skip = cx.value_only && ws.Wl && (long)(32 * twolevel_W) * (32 * twolevel_W) <= ws.wl_stride() &&
+                              cx.n_seg >= 5 * nsp + 4 && !(getenv("GPMPC_TWOLEVEL_BLOCKED") && atoi(getenv("GPMPC_TWOLEVEL_BLOCKED")) == 0);
+        return factor_twolevel(cx, ws, spin_limit, twolevel_W, !can_skip);
     }
     // Worker launches and the row-panel schedule of the inverse.  The workers run as up to three launches
     // (GPMPC_MAX_LAUNCHES), cut where the tree of the triangular inverse has its nodes on the right spine (Np = 4096:
@@ -654,6 +683,38 @@ static void solve_alpha(const Ctx& cx, Workspace& ws, const double* y, long sy) 
                        Np, ws.mat(), (long)Np, ws.wstride());
     hipLaunchKernelGGL(gemv_lowerT_finish_kernel, dim3((Np + 255) / 256, ws.batch), dim3(256), 0, cx.stream, ws.W, ws.alpha, Np,
                        chunks, ws.wstride(), (long)Np);
+}
+
+// w = L^-1 y by blocked forward substitution from L and the inverses I_i of its diagonal blocks of W block columns (which are
+// the diagonal blocks of L^-1, so this works on a complete inverse as well as on what a value-only factorisation leaves):
+//     w[P_i] = I_i (y[P_i] - L[P_i, < r_i] w[< r_i]),      two row-dot launches per panel (rowdot_kernel), `tmp` [batch][Np].
+// The lock-step restart search takes every NLL value from this w, whether or not the point's L^-1 is ever formed.
+static void fwd_subst(const Ctx& cx, Workspace& ws, int W, const double* y, long sy, double* tmp) {
+    const int Np = ws.Np, nb = Np / 64;
+    const long ld = Np, sM = ws.mat();
+    for (int k0 = 0; k0 < nb; k0 += W) {
+        const int ri = 64 * k0, a = 64 * (std::min(nb, k0 + W) - k0);
+        const double* t = y;
+        long st = sy;
+        if (ri > 0) {
+            hipLaunchKernelGGL(rowdot_kernel, dim3(a / 4, ws.batch), dim3(256), 0, cx.stream, (const double*)ws.L, ld, sM, ri, a, 0, ri, 0,
+                               (const double*)ws.w, (long)Np, y, sy, tmp, (long)Np, -1.0);
+            t = tmp;
+            st = Np;
+        }
+        hipLaunchKernelGGL(rowdot_kernel, dim3(a / 4, ws.batch), dim3(256), 0, cx.stream, (const double*)ws.Inv, ld, sM, ri, a, ri, a, 1, t, st,
+                           (const double*)nullptr, 0L, ws.w, (long)Np, 1.0);
+    }
+}
+
+// alpha = L^-T w from the explicit inverse (the second half of solve_alpha), optionally for the subset zmap of the workspace
+static void solve_alpha_from_w(const Ctx& cx, Workspace& ws, int batch, const int* zmap) {
+    const int Np = ws.Np;
+    const int chunks = (Np + GEMVT_ROWS - 1) / GEMVT_ROWS;
+    hipLaunchKernelGGL(gemv_lowerT_part_kernel, dim3((Np + 127) / 128, chunks, batch), dim3(256), 0, cx.stream, ws.Inv, ws.w, ws.W,
+                       Np, ws.mat(), (long)Np, ws.wstride(), zmap);
+    hipLaunchKernelGGL(gemv_lowerT_finish_kernel, dim3((Np + 255) / 256, batch), dim3(256), 0, cx.stream, ws.W, ws.alpha, Np,
+                       chunks, ws.wstride(), (long)Np, zmap);
 }
 
 // The device copy of a persistent product's tile lists (vargemm_persist.hpp), made once per shape and device and kept for

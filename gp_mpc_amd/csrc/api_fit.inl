@@ -4,9 +4,11 @@
 // fit
 // ------------------------------------------------------------------------------------------------
 // gram + factor on a workspace whose hyper/jitter buffers are already on the device.
-static void gram_and_factor(gpmpc_gp* h, Workspace& ws, bool no_workers = false) {
+static void gram_and_factor(gpmpc_gp* h, Workspace& ws, bool no_workers = false, bool value_only = false) {
     Ctx cx = h->cx();
     cx.no_workers = no_workers;
+    cx.value_only = value_only;
+    ws.inv_panels = 0;                                   // (the execution that skips L^-1 says so)
     {
         PhaseTimer t(h, GPMPC_PH_GRAM);
         // (the K build also clears the status words and the chain's hand-off flags: no fill kernels in between)
@@ -30,7 +32,7 @@ static void gram_and_factor(gpmpc_gp* h, Workspace& ws, bool no_workers = false)
 // repeats only the matrices that failed (info_out[b] < 0), as a batch of their own, instead of the whole batch.
 static int factor_with_jitter(gpmpc_gp* h, Workspace& ws, const double* hyper_host, int* info_out,
                               const std::function<void()>& post = std::function<void()>(), int max_attempts = 2,
-                              double jit_init = 0.0, bool no_workers = false) {
+                              double jit_init = 0.0, bool no_workers = false, bool value_only = false) {
     const int nb = ws.batch;
     std::vector<double> jit(nb, jit_init);
     std::vector<int> info(nb, 0), res(nb, 0);
@@ -60,7 +62,7 @@ static int factor_with_jitter(gpmpc_gp* h, Workspace& ws, const double* hyper_ho
         h->tail.ev_info = h->ev_info;
         h->tail.want_early = early_status && !g_chain_trace;
         h->tail.early_done = false;
-        gram_and_factor(h, ws, no_workers);
+        gram_and_factor(h, ws, no_workers, value_only);
         HIPCHK(hipGetLastError());
         const bool check_chain = h->chain_mode && h->side_stream && ws.Np >= 128;
         if (!h->tail.early_done) {
@@ -113,7 +115,7 @@ static int factor_with_jitter(gpmpc_gp* h, Workspace& ws, const double* hyper_ho
                 HIPCHK(hipStreamSynchronize(h->side_stream));
                 if (h->aux_stream) HIPCHK(hipStreamSynchronize(h->aux_stream));
                 if (h->bulk_stream) HIPCHK(hipStreamSynchronize(h->bulk_stream));
-                gram_and_factor(h, ws, no_workers);
+                gram_and_factor(h, ws, no_workers, value_only);
                 HIPCHK(hipMemcpyAsync(pin_info, ws.info, nb * sizeof(int), hipMemcpyDeviceToHost, h->stream));
                 HIPCHK(hipEventRecord(h->ev_info, h->stream));
                 if (post) post();

@@ -49,6 +49,7 @@ struct gpmpc_gp {
     double *bYc = nullptr, *bmpar = nullptr, *bgradPartial = nullptr, *bgradOut = nullptr;
     int* bzmap = nullptr;                                // slots of a subset of the batch (gradients of retained points)
     struct LockRet { int pos = -1; std::vector<double> theta; };
+    int lock_inv_panels = 0;                             // what the last value batch left in Inv (Workspace::inv_panels)
     std::vector<LockRet> lock_ret;                       // per restart of the lock-step search: where its last value-only point's factors are
     double* gradPartial = nullptr;
     double* gradOut = nullptr;

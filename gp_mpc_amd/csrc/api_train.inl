@@ -227,7 +227,10 @@ static int ensure_batch_ws(gpmpc_gp* h, int want) {
 
 // n <= h->bws.batch points of output a, all with or all without the gradient; jit: the jitter added to every K of this
 // call (0, or 1e-8 for the repeat of the points whose first factorisation failed: optimize.py:345-350 per point).
-static int nll_batch_core(gpmpc_gp* h, int a, int n, NllReq* const* req, bool want_grad, double jit, std::vector<int>& failed) {
+// value_only (a line-search trial whose factors are kept for a possible gradient request): the factorisation may leave L^-1
+// unformed -- h->lock_inv_panels says what it left -- and alpha is not formed either.
+static int nll_batch_core(gpmpc_gp* h, int a, int n, NllReq* const* req, bool want_grad, double jit, std::vector<int>& failed,
+                          bool value_only = false) {
     const int d = h->d, Np = h->Np, nh = h->nh(), nmean = mean_param_count(h->mean_kind, d);
     Workspace ws = h->bws;                       // a view: the first n matrices
     ws.batch = n;
@@ -251,8 +254,10 @@ static int nll_batch_core(gpmpc_gp* h, int a, int n, NllReq* const* req, bool wa
     std::vector<int> info(n, 0);
     const int frc = factor_with_jitter(h, ws, kpart.data(), info.data(), [&]() {
         {
+            // w = L^-1 y by blocked substitution (the same arithmetic whether or not this point's L^-1 exists), alpha only with it
             PhaseTimer t(h, GPMPC_PH_SOLVE);
-            solve_alpha(cx, ws, ytrain, sy);
+            fwd_subst(cx, ws, twolevel_width() > 1 ? twolevel_width() : 8, ytrain, sy, ws.alpha);
+            if (!ws.inv_panels) solve_alpha_from_w(cx, ws, n, nullptr);
         }
         {
             PhaseTimer t(h, GPMPC_PH_NLL);
@@ -273,7 +278,8 @@ static int nll_batch_core(gpmpc_gp* h, int a, int n, NllReq* const* req, bool wa
                 hipLaunchKernelGGL(mean_grad_kernel, dim3(n), dim3(256), 0, cx.stream, h->XT, ws.alpha, h->bgradOut + d + 2,
                                    h->mean_kind, h->N, Np, d, BGS);
         }
-    }, 1, jit, true);
+    }, 1, jit, true, value_only && !want_grad);
+    h->lock_inv_panels = ws.inv_panels;
     if (frc != GPMPC_OK && frc != GPMPC_ENOTPD) return frc;
     HIPCHK(hipGetLastError());
     std::vector<double> fv(n), gv(want_grad ? (size_t)n * BGS : 0);
@@ -298,6 +304,14 @@ static int nll_grad_retained(gpmpc_gp* h, int a, const std::vector<NllReq*>& G, 
     Ctx cx = h->cx();
     cx.no_workers = true;
     HIPCHK(hipMemcpyAsync(h->bzmap, pos.data(), m * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    if (h->lock_inv_panels > 0) {                 // the value batch stopped at L and the diagonal blocks' inverses
+        PhaseTimer t(h, GPMPC_PH_FACTOR);
+        twolevel_inverse_all(cx, ws, cx.stream, h->lock_inv_panels, m, h->bzmap);
+    }
+    {
+        PhaseTimer t(h, GPMPC_PH_SOLVE);
+        solve_alpha_from_w(cx, ws, m, h->bzmap);
+    }
     {
         PhaseTimer t(h, GPMPC_PH_INVK);
         CHK(invk_lower(cx, ws, m, h->bzmap, pos.data()));
@@ -357,7 +371,8 @@ static int nll_batch(gpmpc_gp* h, int a, std::vector<NllReq*>& reqs, bool retain
         const auto t0 = std::chrono::steady_clock::now();
         CHK(nll_grad_retained(h, a, last, last_pos));
         if (verbose)
-            fprintf(stderr, "gpmpc: lock-step gradients of %d retained point%s: %.3f ms\n", (int)last.size(), last.size() == 1 ? "" : "s",
+            fprintf(stderr, "gpmpc: lock-step gradients of %d retained point%s (%s): %.3f ms\n", (int)last.size(), last.size() == 1 ? "" : "s",
+                    h->lock_inv_panels > 0 ? "L^-1 formed now" : "L^-1 was there",
                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     }
     const size_t total = group[0].size() + group[1].size();
@@ -371,7 +386,9 @@ static int nll_batch(gpmpc_gp* h, int a, std::vector<NllReq*>& reqs, bool retain
             const int n = (int)std::min<size_t>(cap, G.size() - b0);
             std::vector<int> failed;
             const auto t0 = std::chrono::steady_clock::now();
-            CHK(nll_batch_core(h, a, n, &G[b0], wg == 1, 0.0, failed));
+            static const bool skip_inv = !(getenv("GPMPC_TRAIN_SKIP_INVERSE") && atoi(getenv("GPMPC_TRAIN_SKIP_INVERSE")) == 0);
+            const bool vonly = wg == 0 && retain && skip_inv && G.size() <= (size_t)cap;
+            CHK(nll_batch_core(h, a, n, &G[b0], wg == 1, 0.0, failed, vonly));
             if (verbose)
                 fprintf(stderr, "gpmpc: lock-step batch of %d point%s (%s): %.3f ms, %d to repeat with jitter\n", n, n == 1 ? "" : "s",
                         wg ? "value + gradient" : "value", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(),
@@ -382,7 +399,7 @@ static int nll_batch(gpmpc_gp* h, int a, std::vector<NllReq*>& reqs, bool retain
                 std::vector<NllReq*> again;
                 for (int i : failed) again.push_back(G[b0 + i]);
                 std::vector<int> failed2;
-                CHK(nll_batch_core(h, a, (int)again.size(), again.data(), wg == 1, 1e-8, failed2));
+                CHK(nll_batch_core(h, a, (int)again.size(), again.data(), wg == 1, 1e-8, failed2, vonly));
                 // (the repeat ran in the first slots: what was there is gone, the repeated points now live there)
                 const int m = (int)again.size();
                 for (int i = 0; i < m && i < n; ++i) slot_of[i] = -1;

@@ -108,6 +108,7 @@ struct GemmP {
     int skip00;           // tile (0,0) belongs to the chain kernel
     int* done_flags;      // tiles (1,0) and (1,1) publish done_flags[0] / done_flags[1] = 1
     long sFlags;          // batch stride of the three flag pointers
+    const int* zmap;      // optional: the launch's matrices are zmap[0 .. batch) of the workspace (a subset); not with flags / part / Ct
 };
 
 // the accumulators of one wave, written transposed (EPI_COLSUMSQ with Ct: the few-column products of the sensitivities)
@@ -165,8 +166,8 @@ __global__ void __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) gemm_f64_kernel
             return;
     }
 
-    const int z1 = p.zdiv > 0 ? (int)blockIdx.z % p.zdiv : (int)blockIdx.z;
-    const int z2 = p.zdiv > 0 ? (int)blockIdx.z / p.zdiv : 0;
+    const int z1 = p.zdiv > 0 ? (int)blockIdx.z % p.zdiv : (p.zmap ? p.zmap[blockIdx.z] : (int)blockIdx.z);
+    const int z2 = p.zdiv > 0 ? (p.zmap ? p.zmap[(int)blockIdx.z / p.zdiv] : (int)blockIdx.z / p.zdiv) : 0;
     const double* __restrict__ A = p.A + (long)z1 * p.sA + (long)z2 * p.sA2;
     const double* __restrict__ B = p.B + (long)z1 * p.sB + (long)z2 * p.sB2;
     const int fr = lane & 15, fk = lane >> 4;

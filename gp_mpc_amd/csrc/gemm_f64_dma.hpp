@@ -61,8 +61,8 @@ __global__ void __launch_bounds__(64 * WGM * WGN, WPS) gemm_f64_dma_kernel(GemmP
             return;
     }
 
-    const int z1 = p.zdiv > 0 ? (int)blockIdx.z % p.zdiv : (int)blockIdx.z;
-    const int z2 = p.zdiv > 0 ? (int)blockIdx.z / p.zdiv : 0;
+    const int z1 = p.zdiv > 0 ? (int)blockIdx.z % p.zdiv : (p.zmap ? p.zmap[blockIdx.z] : (int)blockIdx.z);
+    const int z2 = p.zdiv > 0 ? (p.zmap ? p.zmap[(int)blockIdx.z / p.zdiv] : (int)blockIdx.z / p.zdiv) : 0;
     const double* __restrict__ A = p.A + (long)z1 * p.sA + (long)z2 * p.sA2;
     const double* __restrict__ B = p.B + (long)z1 * p.sB + (long)z2 * p.sB2;
     const dma_rsrc_t rsA = dma_make_rsrc(A, (unsigned)((long)(AMC ? p.K : p.M) * p.lda * 8));

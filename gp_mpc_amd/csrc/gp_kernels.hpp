@@ -315,11 +315,13 @@ __global__ void __launch_bounds__(256) crosscov_finish_kernel(const double* __re
 // dst[b][r][0 .. cols) = src[b][r][0 .. cols) for a batch of row-major rectangles (cols even, 16-byte aligned rows);
 // grid (ceil(cols / 2 / 256), rows, batch)
 __global__ void __launch_bounds__(256) copy_rect_kernel(const double* __restrict__ src, long lds_, long sS,
-                                                        double* __restrict__ dst, long ldd, long sD, int cols) {
+                                                        double* __restrict__ dst, long ldd, long sD, int cols,
+                                                        const int* __restrict__ zmap = nullptr) {
     const int c = 2 * ((int)blockIdx.x * 256 + (int)threadIdx.x);
     if (c >= cols) return;
-    const double2 v = *reinterpret_cast<const double2*>(src + (long)blockIdx.z * sS + (long)blockIdx.y * lds_ + c);
-    *reinterpret_cast<double2*>(dst + (long)blockIdx.z * sD + (long)blockIdx.y * ldd + c) = v;
+    const long bz = zmap ? zmap[blockIdx.z] : (int)blockIdx.z;
+    const double2 v = *reinterpret_cast<const double2*>(src + bz * sS + (long)blockIdx.y * lds_ + c);
+    *reinterpret_cast<double2*>(dst + bz * sD + (long)blockIdx.y * ldd + c) = v;
 }
 
 // mean_a(z_j) = ks^T alpha_a from the stored cross-covariances, for a crosscov_kernel launch that ran without alpha: the
@@ -719,20 +721,21 @@ constexpr int GEMVT_ROWS = 256;
 // grid (Np/64, ceil(Np/GEMVT_ROWS), batch), 256 threads; part: [batch][chunks][Np]
 __global__ void __launch_bounds__(256) gemv_lowerT_part_kernel(const double* __restrict__ A, const double* __restrict__ x,
                                                                double* __restrict__ part, int Np, long sA, long sx,
-                                                               long sPart) {
+                                                               long sPart, const int* __restrict__ zmap = nullptr) {
     // a lane owns TWO adjacent columns (16-byte loads, 1 KB per wave and row); the strictly upper entries it may touch
     // inside the diagonal block are stored zeros.  grid (Np/128, chunks, batch).
     __shared__ double red[4][128];
     const int lane = threadIdx.x & 63, v = threadIdx.x >> 6, k0 = blockIdx.x * 128, k = k0 + 2 * lane;
     const int r0 = blockIdx.y * GEMVT_ROWS, r1 = min(Np, r0 + GEMVT_ROWS);
-    double* __restrict__ po = part + (long)blockIdx.z * sPart + (long)blockIdx.y * Np;
+    const long bz = zmap ? zmap[blockIdx.z] : (int)blockIdx.z;
+    double* __restrict__ po = part + bz * sPart + (long)blockIdx.y * Np;
     const bool live = k < Np;                           // (Np is a multiple of 64, not of 128)
     if (r1 <= k0) {                                     // entirely above the diagonal
         if (v == 0 && live) { po[k] = 0.0; po[k + 1] = 0.0; }
         return;
     }
-    const double* __restrict__ Ab = A + (long)blockIdx.z * sA;
-    const double* __restrict__ xv = x + (long)blockIdx.z * sx;
+    const double* __restrict__ Ab = A + bz * sA;
+    const double* __restrict__ xv = x + bz * sx;
     double s0 = 0.0, s1 = 0.0, t0 = 0.0, t1 = 0.0;
     int i = max(r0, k0) + v;
     const double2 zero2 = {0.0, 0.0};
@@ -757,13 +760,38 @@ __global__ void __launch_bounds__(256) gemv_lowerT_part_kernel(const double* __r
 }
 // grid (Np/256, batch), 256 threads
 __global__ void __launch_bounds__(256) gemv_lowerT_finish_kernel(const double* __restrict__ part, double* __restrict__ out,
-                                                                 int Np, int chunks, long sPart, long so) {
+                                                                 int Np, int chunks, long sPart, long so,
+                                                                 const int* __restrict__ zmap = nullptr) {
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= Np) return;
-    const double* __restrict__ p = part + (long)blockIdx.y * sPart + k;
+    const long by = zmap ? zmap[blockIdx.y] : (int)blockIdx.y;
+    const double* __restrict__ p = part + by * sPart + k;
     double t = 0.0;
     for (int c = k / GEMVT_ROWS; c < chunks; ++c) t += p[(long)c * Np];
-    out[(long)blockIdx.y * so + k] = t;
+    out[by * so + k] = t;
+}
+
+// out[b][row0 + r] = (yin ? yin[b][row0 + r] : 0) + sign * sum_{c < (tri ? r + 1 : ncols)} A[b][(row0 + r) ld + col0 + c] x[b][col0 + c]
+// for r < nrows: the two products of a step of the blocked forward substitution w = L^-1 y from L and the inverses I_i of its
+// diagonal blocks (fwd_subst below).  A wave per row, lanes along the row (16-byte loads), fixed reduction order.
+// grid (nrows / 4, batch), 256 threads; row0, col0, ncols even (they are multiples of 64).
+__global__ void __launch_bounds__(256) rowdot_kernel(const double* __restrict__ A, long ld, long sA, int row0, int nrows, int col0, int ncols,
+                                                     int tri, const double* __restrict__ x, long sx, const double* __restrict__ yin,
+                                                     long sy, double* __restrict__ out, long so, double sign) {
+    const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= nrows) return;
+    const double2* __restrict__ row = reinterpret_cast<const double2*>(A + (long)blockIdx.y * sA + (long)(row0 + r) * ld + col0);
+    const double2* __restrict__ xv = reinterpret_cast<const double2*>(x + (long)blockIdx.y * sx + col0);
+    const int kend = tri ? r + 1 : ncols;                // (a lower-triangular operand stores exact zeros beyond its diagonal)
+    const int nq = (kend + 1) >> 1;
+    double s0 = 0.0, s1 = 0.0;
+    for (int q = lane; q < nq; q += 64) {
+        const double2 a = row[q], b = xv[q];
+        s0 = fma(a.x, b.x, s0);
+        s1 = fma(a.y, b.y, s1);
+    }
+    const double s = wave_sum(s0 + s1);
+    if (lane == 0) out[(long)blockIdx.y * so + row0 + r] = (yin ? yin[(long)blockIdx.y * sy + row0 + r] : 0.0) + sign * s;
 }
 
 // a7 tail: nll[a] = 1/2 w^T w + sum_i log|L_ii| with w = L^-1 y (= 1/2 y^T alpha + 1/2 logdet K,
