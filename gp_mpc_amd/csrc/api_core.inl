@@ -343,8 +343,6 @@ struct TailState {
     bool armed = false;          // set by gpmpc_fit, consumed (or dropped) by the next call that touches the predict scratch
     bool alpha_pending = false;  // alpha of the model workspace is being formed on the workers' queue: wait for ev_alpha
     hipEvent_t ev_chain = nullptr, ev_tail = nullptr, ev_alpha = nullptr, ev_ks = nullptr, ev_mean = nullptr;
-    hipEvent_t ev_levels = nullptr;   // the last panel's level launches are through (what is left of the fit is one product)
-    bool levels_recorded = false;
     // early status (set up by factor_with_jitter per attempt)
     int* pin_info = nullptr;
     int* cerr = nullptr;

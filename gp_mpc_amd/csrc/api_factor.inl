@@ -654,10 +654,6 @@ static bool factor_chain(const Ctx& cx, Workspace& ws, int spin_limit, bool flag
         hipStreamWaitEvent(cx.stream, cx.seg[cx.n_seg - 2], 0);
         const int rl = pcut[P - 1], h = Np - rl;
         trtri_range(cx, ws, cx.stream, rl, h);
-        if (cx.tail) {                                      // (a prediction behind the tail starts its cross-covariances here)
-            hipEventRecord(TailState::get(cx.tail->ev_levels), cx.stream);
-            cx.tail->levels_recorded = true;
-        }
         if (!s_ready_recorded) hipEventRecord(cx.seg[cx.n_seg - 1], cx.aux);
         hipStreamWaitEvent(cx.stream, cx.seg[cx.n_seg - 1], 0);
         product(cx.stream, ws.Inv + (long)rl * ld + rl, ld, KA_LE_M, ws.W + sofs[P - 1], rl, ws.Inv + (long)rl * ld, ld,

@@ -60,7 +60,6 @@ static int factor_with_jitter(gpmpc_gp* h, Workspace& ws, const double* hyper_ho
         static const bool early_status = !(getenv("GPMPC_EARLY_STATUS") && atoi(getenv("GPMPC_EARLY_STATUS")) == 0);
         h->tail.pin_info = pin_info; h->tail.cerr = cerr; h->tail.nflag = nflag; h->tail.nb = nb;
         h->tail.ev_info = h->ev_info;
-        h->tail.levels_recorded = false;
         h->tail.want_early = early_status && !g_chain_trace;
         h->tail.early_done = false;
         gram_and_factor(h, ws, no_workers, value_only);

@@ -280,7 +280,7 @@ int gpmpc_destroy(gpmpc_gp* h) {
         for (auto& pr : h->prof.ev[ph]) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     for (auto e : h->prof.pool) hipEventDestroy(e);
     if (h->ev_info) hipEventDestroy(h->ev_info);
-    for (hipEvent_t e : {h->tail.ev_chain, h->tail.ev_tail, h->tail.ev_alpha, h->tail.ev_ks, h->tail.ev_mean, h->tail.ev_levels})
+    for (hipEvent_t e : {h->tail.ev_chain, h->tail.ev_tail, h->tail.ev_alpha, h->tail.ev_ks, h->tail.ev_mean})
         if (e) hipEventDestroy(e);
     if (h->pin) hipHostFree(h->pin);
     if (h->io_pin) hipHostFree(h->io_pin);

@@ -109,9 +109,6 @@ static int predict_chunk(gpmpc_gp* h, int B, const double* dZ, double* dMean, do
     if (overlapped) {
         // (GPMPC_CROSSCOV_WGS: workgroups of the throttled launch; 0 = one per block of test points, i.e. not throttled)
         static const int cc_wgs = getenv("GPMPC_CROSSCOV_WGS") ? atoi(getenv("GPMPC_CROSSCOV_WGS")) : g_cu_count[h->device];
-        // (GPMPC_CROSSCOV_AFTER_LEVELS=1: behind the last panel's latency-bound level launches, i.e. next to the final product only)
-        static const bool after_levels = getenv("GPMPC_CROSSCOV_AFTER_LEVELS") && atoi(getenv("GPMPC_CROSSCOV_AFTER_LEVELS")) != 0;
-        if (after_levels && ts.levels_recorded) hipStreamWaitEvent(cx.bulk, ts.ev_levels, 0);
         {
             ProfScope t(&h->prof, cx.bulk, GPMPC_PH_CROSSCOV);
             launch_crosscov(cx.bulk, h->d, h->XT, h->ws.hyper, nullptr, dZ, h->KsT, h->meanT, nullptr, h->N, Np, B, Bp, Ny, nullptr,
