@@ -36,12 +36,11 @@ static int g_worker_courier = -1;   // gpmpc_set_tuning("worker_courier", 0 / 1)
 // level-by-level batched inverse of the diagonal range [base, base + n) (rows), given its 64-blocks
 // (scratch / sScratch: the W = L21 inv11 products of a level go there instead of to the head of ws.W -- a caller whose
 //  other queues use ws.W at the same time, factor_twolevel)
-// (s_start: the first level, rows of a left child -- the levels below it have been done by trtri_follow_kernel)
 static void trtri_range(const Ctx& cx, Workspace& ws, hipStream_t stream, long base0, int n, double* scratch = nullptr,
-                        long sScratch = 0, int s_start = 64) {
+                        long sScratch = 0) {
     const long ld = ws.Np, sM = ws.mat(), sW = scratch ? sScratch : ws.wstride();
     double* Wl = scratch ? scratch : ws.W;
-    for (int s = s_start; s < n; s *= 2) {
+    for (int s = 64; s < n; s *= 2) {
         const int nfull = n / (2 * s);                  // nodes with a full right child
         const int rem = n - nfull * 2 * s;              // tail: a partial node exists if rem > s
         for (int part = 0; part < 2; ++part) {
@@ -385,44 +384,6 @@ static bool factor_twolevel(const Ctx& cx, Workspace& ws, int spin_limit, int W,
     return true;
 }
 
-// Task lists of trtri_follow_kernel on the device, made once per shape (a few hundred KB in all).
-struct TrfKey {
-    int device, nb, base0, n, smax, counter0;
-    long wbase;
-    bool operator<(const TrfKey& o) const {
-        return std::tie(device, nb, base0, n, smax, counter0, wbase) < std::tie(o.device, o.nb, o.base0, o.n, o.smax, o.counter0, o.wbase);
-    }
-};
-struct TrfDev { int* tasks = nullptr; int ntasks = 0; };
-static std::map<TrfKey, TrfDev> g_trf_cache;
-static std::mutex g_trf_mutex;
-static TrfDev get_follow_tasks(int nb, int base0, int n, int smax, long wbase, int counter0) {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    std::lock_guard<std::mutex> lk(g_trf_mutex);
-    const TrfKey key{dev, nb, base0, n, smax, counter0, wbase};
-    auto it = g_trf_cache.find(key);
-    if (it != g_trf_cache.end()) return it->second;
-    const TrfList l = trtri_follow_tasks(nb, base0, n, smax, wbase, counter0);
-    TrfDev d;
-    d.ntasks = l.ntasks;
-    if (l.ntasks > 0 && hipMalloc(&d.tasks, l.tasks.size() * sizeof(int)) == hipSuccess)
-        (void)hipMemcpy(d.tasks, l.tasks.data(), l.tasks.size() * sizeof(int), hipMemcpyHostToDevice);
-    else
-        d.ntasks = 0;
-    g_trf_cache[key] = d;
-    return d;
-}
-static void launch_follow(const Ctx& cx, Workspace& ws, hipStream_t st, const TrfDev& d, int wgs, int spin_limit) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)trtri_follow_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TRF_LDS_BYTES);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(trtri_follow_kernel, dim3(std::min(wgs, d.ntasks)), dim3(256), TRF_LDS_BYTES, st, (const double*)ws.L, ws.Inv, ws.W,
-                       (long)ws.Np, (const int*)d.tasks, d.ntasks, ws.flags, cx.crow_mode, spin_limit);
-}
-
 // Chained factorisation: the sequential part of every panel step runs in ONE persistent workgroup
 // (chol_chain_kernel, main queue) that keeps a CU to itself, the bulk -- panel rows >= k+2 and the
 // trailing update -- in ordinary GEMM launches on the side queue; flags in ws.flags couple the two.
@@ -520,31 +481,6 @@ static bool factor_chain(const Ctx& cx, Workspace& ws, int spin_limit, bool flag
         }
     }
     const bool split = L >= 2;
-    // The first three levels of every panel's inverse (children of up to 256 rows) follow the chain in a resident launch of
-    // their own next to the worker launch that factors the panel (trtri_follow.hpp); trtri_range then starts at 512 rows.
-    // GPMPC_TRTRI_FOLLOW = bit mask of panels (default all), GPMPC_TRTRI_FOLLOW_WGS workgroups per launch.
-    static const int follow_env = getenv("GPMPC_TRTRI_FOLLOW") ? atoi(getenv("GPMPC_TRTRI_FOLLOW")) : ~0;
-    static const int follow_wgs = getenv("GPMPC_TRTRI_FOLLOW_WGS") ? atoi(getenv("GPMPC_TRTRI_FOLLOW_WGS")) : 16;
-    constexpr int FOLLOW_SMAX = 256;
-    int follow_mask = 0;
-    TrfDev follow_tasks[12];
-    if (use_workers && split && !getenv("GPMPC_TAIL_CUTS") && cx.bulk && ws.batch == 1 && 2 * L + 2 < cx.n_seg - 2 && follow_wgs > 0) {
-        // (made HERE, before anything of this factorisation is enqueued: a first use allocates and copies, i.e. synchronises)
-        long top = 0;
-        for (int i = 0; i < L; ++i) top = std::max<long>(top, (long)(r[i + 1] - r[i]) * (r[i + 1] - r[i]) / 4);
-        int counter0 = 0;
-        for (int i = 0; i < L; ++i) {
-            if (!((follow_env >> i) & 1)) continue;
-            const int n = r[i + 1] - r[i];
-            const TrfList probe = trtri_follow_tasks(nb, r[i], n, FOLLOW_SMAX, top, counter0);   // (sizes only; the device copy is cached)
-            if (probe.ntasks == 0 || top + probe.wneed > ws.hw() * ws.hw() || counter0 + probe.counters > nb) continue;
-            follow_tasks[i] = get_follow_tasks(nb, r[i], n, FOLLOW_SMAX, top, counter0);
-            if (follow_tasks[i].ntasks == 0) continue;
-            top += probe.wneed;
-            counter0 += probe.counters;
-            follow_mask |= 1 << i;
-        }
-    }
     auto product = [&](hipStream_t st, const double* A, long lda, int kfl, const double* B, long ldb, double* C, long ldc,
                        int M, int N, int K, double alpha, double beta) {   // C = alpha A B + beta C, A K-contiguous, B N-contiguous
         GemmP g = gemm_base(cx);
@@ -607,18 +543,9 @@ static bool factor_chain(const Ctx& cx, Workspace& ws, int spin_limit, bool flag
         P = L;                                              // (the refined S_j are a little larger than the coarse ones)
     }
     const int ev0 = L;                                      // events: 0 .. L-2 the launches, ev0 + i: I_i done
-    if (verbose && use_workers) fprintf(stderr, "gpmpc: panels whose small inverse levels follow the chain: mask %d of %d panels\n", follow_mask, P);
-    if ((follow_mask & 1) && use_workers) {
-        // panel 0 next to the FIRST worker launch, on the CUs it leaves empty: once all its workgroups and the chain are resident
-        hipStreamWaitEvent(cx.bulk, cx.fork, 0);             // (the flags are clear from here on)
-        hipLaunchKernelGGL(flag_gate_kernel, dim3(1), dim3(64), 0, cx.bulk, ws.flags, (long)nf, chain_ready_index(nb) + 7, 1, 1, 1, spin_limit);
-        launch_follow(cx, ws, cx.bulk, follow_tasks[0], follow_wgs, spin_limit);
-        hipEventRecord(cx.seg[ev0 + P + 1], cx.bulk);
-    }
     if (use_workers) {
         for (int i = 0; i < L; ++i) {
-            // arrival counter + flag of launch i (the first launch's only when something waits for it: words 6, 7 of the eight)
-            int* ready = i ? ws.flags + chain_ready_index(nb) + 2 * (i - 1) : (follow_mask & 1) ? ws.flags + chain_ready_index(nb) + 6 : nullptr;
+            int* ready = i ? ws.flags + chain_ready_index(nb) + 2 * (i - 1) : nullptr;   // arrival counter + flag of launch i
             auto* worker = worker_courier ? chol_worker_kernel<WORKER_MAXT_COURIER, true> : chol_worker_kernel<WORKER_MAXT, false>;
             hipLaunchKernelGGL(worker, dim3(nws[i], 1, ws.batch), dim3(WORKER_THREADS), WORKER_LDS_BYTES, cx.side,
                                ws.K, ws.L, (const double*)ws.Inv, ld, sM, nb, ws.flags, (long)nf, cx.crow_mode, spin_limit,
@@ -637,16 +564,6 @@ static bool factor_chain(const Ctx& cx, Workspace& ws, int spin_limit, bool flag
             // (all I_i share ONE level scratch: the previous one must be through with it -- an explicit event, not "it
             //  finished long ago": with several handles alive HIP multiplexes their streams onto a few hardware queues and
             //  the inverse queue of this handle can sit behind another handle's work for any length of time)
-            const bool follow = (follow_mask >> i) & 1;
-            if (follow && i >= 1) {                              // next to launch i, once it is resident
-                hipStreamWaitEvent(cx.bulk, cx.seg[i - 1], 0);
-                hipLaunchKernelGGL(flag_gate_kernel, dim3(1), dim3(64), 0, cx.bulk, ws.flags, (long)nf,
-                                   chain_ready_index(nb) + 2 * (i - 1) + 1, 1, -1, 0, spin_limit);
-                launch_follow(cx, ws, cx.bulk, follow_tasks[i], follow_wgs, spin_limit);
-                if (tq != cx.bulk) { hipEventRecord(cx.seg[ev0 + P - 1], cx.bulk); hipStreamWaitEvent(tq, cx.seg[ev0 + P - 1], 0); }
-            } else if (follow) {
-                hipStreamWaitEvent(tq, cx.seg[ev0 + P + 1], 0);  // (panel 0's resident launch, enqueued above)
-            }
             if (tq != cx.aux && i >= 1) hipStreamWaitEvent(tq, cx.seg[ev0 + i - 1], 0);
             if (i + 1 < L) {
                 // behind launch i + 1, once it is resident (its workgroups need whole CUs)
@@ -658,7 +575,7 @@ static bool factor_chain(const Ctx& cx, Workspace& ws, int spin_limit, bool flag
                 hipLaunchKernelGGL(flag_gate_kernel, dim3(ws.batch), dim3(64), 0, tq, ws.flags, (long)nf,
                                    chain_pan1_index(nb, e), 1, chain_colready_index(nb, e), 1, spin_limit);
             }
-            trtri_range(cx, ws, tq, ri, a, nullptr, 0, follow ? 2 * FOLLOW_SMAX : 64);   // I_i
+            trtri_range(cx, ws, tq, ri, a);                                        // I_i
             if (i + 2 == P) hipEventRecord(cx.seg[cx.n_seg - 2], tq);             // the side queues' last use of the level scratch
             hipEventRecord(cx.seg[ev0 + i], tq);                                   // I_i done
             if (tq != cx.aux) hipStreamWaitEvent(cx.aux, cx.seg[ev0 + i], 0);
@@ -736,16 +653,7 @@ static bool factor_chain(const Ctx& cx, Workspace& ws, int spin_limit, bool flag
         // latency-bound launches.)
         hipStreamWaitEvent(cx.stream, cx.seg[cx.n_seg - 2], 0);
         const int rl = pcut[P - 1], h = Np - rl;
-        const bool follow_last = (follow_mask >> (P - 1)) & 1;
-        if (follow_last) {                                  // next to the last worker launch; one inv21 per small level is left at chain end
-            hipStreamWaitEvent(cx.bulk, cx.seg[P - 2], 0);
-            hipLaunchKernelGGL(flag_gate_kernel, dim3(1), dim3(64), 0, cx.bulk, ws.flags, (long)nf,
-                               chain_ready_index(nb) + 2 * (P - 2) + 1, 1, -1, 0, spin_limit);
-            launch_follow(cx, ws, cx.bulk, follow_tasks[P - 1], follow_wgs, spin_limit);
-            hipEventRecord(cx.seg[ev0 + P - 1], cx.bulk);
-            hipStreamWaitEvent(cx.stream, cx.seg[ev0 + P - 1], 0);
-        }
-        trtri_range(cx, ws, cx.stream, rl, h, nullptr, 0, follow_last ? 2 * FOLLOW_SMAX : 64);
+        trtri_range(cx, ws, cx.stream, rl, h);
         if (!s_ready_recorded) hipEventRecord(cx.seg[cx.n_seg - 1], cx.aux);
         hipStreamWaitEvent(cx.stream, cx.seg[cx.n_seg - 1], 0);
         product(cx.stream, ws.Inv + (long)rl * ld + rl, ld, KA_LE_M, ws.W + sofs[P - 1], rl, ws.Inv + (long)rl * ld, ld,

@@ -30,8 +30,7 @@ constexpr int CHAIN_TRI_PAIRS = 1056;     // 16-byte column pairs (r, 2c), 2c <=
 // [1+6nb .. 1+7nb) colready, [1+7nb .. 1+7nb+512) progress / start time of worker w (diagnostics),
 // [1+7nb+512 .. +8) arrival counter and "all resident" flag of the second, third and fourth worker launch
 // [1+7nb+512+8 .. +nb) handed[k]: how many of the three tiles of row k+2 the workers have handed to the courier
-// [1+8nb+520 .. +2nb) node counters of the panel inverses that follow the chain (trtri_follow.hpp)
-__host__ __device__ inline int chain_flag_count(int nb) { return 1 + 10 * nb + 512 + 8; }
+__host__ __device__ inline int chain_flag_count(int nb) { return 1 + 8 * nb + 512 + 8; }
 __host__ __device__ inline int chain_handed_index(int nb) { return 1 + 7 * nb + 512 + 8; }
 __host__ __device__ inline int chain_colready_index(int nb, int k) { return 1 + 6 * nb + k; }
 __host__ __device__ inline int chain_pan1_index(int nb, int k) { return 1 + nb + k; }
