@@ -37,6 +37,7 @@ SIGNATURES = {
     'gpmpc_device_count': (ctypes.c_int, [_ip]),
     'gpmpc_device_name': (ctypes.c_int, [ctypes.c_int, ctypes.c_char_p, ctypes.c_int]),
     'gpmpc_mfma_selftest': (ctypes.c_int, [ctypes.c_int, _ip, _dp]),
+    'gpmpc_schedule_stats': (ctypes.c_int, [ctypes.c_int] * 6 + [_dp]),
     'gpmpc_create': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp, _vp,
                                     ctypes.POINTER(_vp)]),
     'gpmpc_destroy': (ctypes.c_int, [_vp]),
@@ -140,6 +141,12 @@ class GpmpcLib:
         tf = ctypes.c_double(0.0)
         self.check(self.dll.gpmpc_mfma_selftest(device, ctypes.byref(layout), ctypes.byref(tf)))
         return layout.value, tf.value
+
+    def schedule_stats(self, mode, tilesM, tilesN, batch, K, slots):
+        """Static tile schedule of the persistent products (host code): dict(tiles, max_load, mean_load, home, wrong, longest)."""
+        st = (ctypes.c_double * 6)()
+        self.check(self.dll.gpmpc_schedule_stats(int(mode), int(tilesM), int(tilesN), int(batch), int(K), int(slots), st))
+        return dict(tiles=int(st[0]), max_load=st[1], mean_load=st[2], home=int(st[3]), wrong=int(st[4]), longest=int(st[5]))
 
     def runtime_info(self):
         """{'hip_runtime', 'hip_path', 'rccl', 'rccl_path'}: the HIP runtime and RCCL build this process runs the library on."""

@@ -67,6 +67,29 @@ extern "C" int gpmpc_dgemm(int device, int transa, int transb, int M, int N, int
     return GPMPC_OK;
 }
 
+extern "C" int gpmpc_schedule_stats(int mode, int tilesM, int tilesN, int batch, int K, int slots, double* stats) {
+    if (!stats || (mode != PG_VAR && mode != PG_XTX) || tilesM <= 0 || tilesN <= 0 || batch <= 0 || batch >= 256 || slots <= 0 ||
+        tilesM >= 4096 || tilesN >= 4096 || K <= 0)
+        return fail(GPMPC_EINVAL, "bad arguments");
+    const VarSchedule s = mode == PG_VAR ? var_schedule(tilesM, tilesN, batch, K, slots) : xtx_schedule(tilesM, batch, K, slots);
+    std::map<int, int> seen;
+    for (int w : s.list) ++seen[w];
+    long expected = 0, wrong = 0;
+    for (int z = 0; z < batch; ++z)
+        for (int tm = 0; tm < tilesM; ++tm)
+            for (int tn = 0; tn < (mode == PG_VAR ? tilesN : tm + 1); ++tn) {
+                ++expected;
+                auto it = seen.find(var_tile_word(z, tm, tn));
+                if (it == seen.end() || it->second != 1) ++wrong;
+            }
+    if ((long)s.list.size() != expected) wrong += std::labs((long)s.list.size() - expected);
+    int longest = 0;
+    for (int i = 0; i < slots; ++i) longest = std::max(longest, s.off[i + 1] - s.off[i]);
+    stats[0] = (double)s.list.size(); stats[1] = s.max_load; stats[2] = s.mean_load; stats[3] = s.home; stats[4] = (double)wrong;
+    stats[5] = longest;
+    return GPMPC_OK;
+}
+
 extern "C" int gpmpc_set_tuning(const char* name, int value) {
     if (!name) return fail(GPMPC_EINVAL, "NULL name");
     if (std::strcmp(name, "gemm_tile") == 0) {

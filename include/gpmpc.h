@@ -266,6 +266,14 @@ int gpmpc_cholesky(int device, int n, double* A, double* Ainv, int* info);
 int gpmpc_dgemm(int device, int transa, int transb, int M, int N, int K, double alpha,
                 const double* A, int lda, const double* B, int ldb, double beta, double* C, int ldc);
 
+/* The static tile schedule of the persistent products (host code only, no device needed): mode 0 = the predictive variance of
+ * gp_functions.py:122-126 (tilesM x tilesN tiles of 128 x 128 per matrix, the tile in block row tm is min(K, 128 (tm + 1)) / 16
+ * slabs long), mode 1 = the lower triangle of K^-1 = L^-T L^-1 (optimize.py:489-490; tiles tm >= tn, (K - 128 tm) / 16 slabs),
+ * for `batch` matrices on `slots` resident workgroups dealt round-robin to 8 XCDs.  stats[0..5] = tiles, heaviest slot load,
+ * mean slot load (half slabs), tiles on their operand panel's home XCD, tiles scheduled more or less than once (0 when
+ * correct), longest list.  What the CPU tier checks: every tile exactly once, balance, locality. */
+int gpmpc_schedule_stats(int mode, int tilesM, int tilesN, int batch, int K, int slots, double* stats);
+
 /* Diagnostic knobs for tests and tuning runs (no reference counterpart).  "gemm_tile": 0 (automatic), 32, 64 or 128
  * pins the tile of every GEMM launch of the process, so that small problems reach the large-tile kernels.
  * "cu_count": the number of compute units of device 0 the persistent-kernel factorisation plans with (at most the

@@ -43,6 +43,26 @@ def test_library_loads_and_reports_without_gpu(built):
         assert e.value.code == _lib.EHIP and 'HIP device' in str(e.value)
 
 
+def test_persistent_schedules_cover_every_tile_once_balanced_and_local(built):
+    """The static schedules of the persistent variance / K^-1 products (vargemm_persist.hpp; host code, no GPU): every tile
+    exactly once, the heaviest slot within 1 % of the mean at the benchmark shapes, and -- the XCDs are levelled first -- all
+    but a few tiles on the XCD that holds the rest of their operand panel."""
+    lib = _lib.GpmpcLib(built)
+    c2 = lib.schedule_stats(0, 32, 79, 1, 4096, 512)              # C2: N = 4096, B = 10 000
+    assert c2['wrong'] == 0 and c2['tiles'] == 32 * 79
+    assert c2['max_load'] <= 1.01 * c2['mean_load'] and c2['home'] >= c2['tiles'] - 40, c2
+    c3 = lib.schedule_stats(0, 64, 79, 6, 8192, 512)
+    assert c3['wrong'] == 0 and c3['max_load'] <= 1.005 * c3['mean_load'], c3
+    for n in (64, 53, 9, 6):                                       # K^-1 of the lock-step search's batches (Np = 4096)
+        k = lib.schedule_stats(1, 32, 32, n, 4096, 512)
+        assert k['wrong'] == 0 and k['tiles'] == 528 * n and k['max_load'] <= 1.02 * k['mean_load'], (n, k)
+        assert k['home'] >= k['tiles'] - 16 * 8, (n, k)
+    odd = lib.schedule_stats(0, 3, 2, 2, 320, 16)                  # ragged: Np = 320 (last block row partial), emulator size
+    assert odd['wrong'] == 0 and odd['tiles'] == 12
+    one = lib.schedule_stats(1, 5, 5, 1, 640, 512)                 # fewer tiles than slots
+    assert one['wrong'] == 0 and one['tiles'] == 15 and one['longest'] == 1
+
+
 def test_gfx950_code_object_present(built):
     out = subprocess.run(['/opt/rocm/lib/llvm/bin/llvm-objdump', '--offloading', built], capture_output=True, text=True)
     txt = out.stdout + out.stderr
