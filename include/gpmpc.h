@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GPMPC_ABI_VERSION 2   /* 2 (r04): + gpmpc_profile_set_mask, gpmpc_runtime_info; gpmpc_profile_enable: nonzero = all phases again */
+#define GPMPC_ABI_VERSION 2   /* 2 (r04): + gpmpc_profile_set_mask, gpmpc_runtime_info, gpmpc_schedule_stats; gpmpc_profile_enable: nonzero = all phases again */
 
 /* status codes */
 #define GPMPC_OK 0
