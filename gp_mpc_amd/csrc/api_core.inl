@@ -343,6 +343,7 @@ struct TailState {
     bool armed = false;          // set by gpmpc_fit, consumed (or dropped) by the next call that touches the predict scratch
     bool alpha_pending = false;  // alpha of the model workspace is being formed on the workers' queue: wait for ev_alpha
     hipEvent_t ev_chain = nullptr, ev_tail = nullptr, ev_alpha = nullptr, ev_ks = nullptr, ev_mean = nullptr;
+    hipEvent_t ev_w = nullptr;   // w = L^-1 y of the pending alpha is there (the fused mean of the variance product needs no more)
     // early status (set up by factor_with_jitter per attempt)
     int* pin_info = nullptr;
     int* cerr = nullptr;

@@ -674,10 +674,12 @@ static bool factor_chain(const Ctx& cx, Workspace& ws, int spin_limit, bool flag
 
 // w = L^-1 y and alpha = L^-T w as two HBM-bound matrix-vector products with the explicit inverse.
 // y: [batch] vectors with stride sy.
-static void solve_alpha(const Ctx& cx, Workspace& ws, const double* y, long sy) {
+// (ev_w: recorded behind w -- what the variance product's fused mean waits for instead of alpha)
+static void solve_alpha(const Ctx& cx, Workspace& ws, const double* y, long sy, hipEvent_t ev_w = nullptr) {
     const int Np = ws.Np;
     hipLaunchKernelGGL(gemv_rows_kernel, dim3(Np / 4, ws.batch), dim3(256), 0, cx.stream, ws.Inv, y, ws.w, Np, ws.mat(), sy,
                        (long)Np, 1);
+    if (ev_w) hipEventRecord(ev_w, cx.stream);
     const int chunks = (Np + GEMVT_ROWS - 1) / GEMVT_ROWS;         // partial sums go through the (now idle) inverse scratch
     hipLaunchKernelGGL(gemv_lowerT_part_kernel, dim3((Np + 127) / 128, chunks, ws.batch), dim3(256), 0, cx.stream, ws.Inv, ws.w, ws.W,
                        Np, ws.mat(), (long)Np, ws.wstride());

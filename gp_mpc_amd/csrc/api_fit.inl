@@ -176,7 +176,7 @@ extern "C" int gpmpc_fit(gpmpc_gp* h, const double* hyper, int want_invK, int* i
             hipStreamWaitEvent(h->side_stream, h->tail.ev_tail, 0);
             cs.stream = h->side_stream;
             ProfScope t(&h->prof, h->side_stream, GPMPC_PH_SOLVE);
-            solve_alpha(cs, h->ws, h->y_model(), h->Np);
+            solve_alpha(cs, h->ws, h->y_model(), h->Np, TailState::get(h->tail.ev_w));
             hipEventRecord(TailState::get(h->tail.ev_alpha), h->side_stream);
         } else {
             PhaseTimer t(h, GPMPC_PH_SOLVE);
@@ -206,11 +206,12 @@ extern "C" int gpmpc_fit(gpmpc_gp* h, const double* hyper, int want_invK, int* i
 //     inv22 = L22^-1;   inv21 = -inv22 (L21 inv11)
 // i.e. four GEMMs with K = R0 plus a factorisation of m rows -- O(N^2 m) instead of O(N^3).
 static void free_predict_scratch(gpmpc_gp* h) {
-    hipFree(h->Z); hipFree(h->Sigma); hipFree(h->KsT); hipFree(h->part); hipFree(h->meanT);
+    hipFree(h->Z); hipFree(h->Sigma); hipFree(h->KsT); hipFree(h->part); hipFree(h->partm); hipFree(h->meanT);
     hipFree(h->mean); hipFree(h->var); hipFree(h->J); hipFree(h->cov); hipFree(h->UT); hipFree(h->VT);
     hipFree(h->sensH); hipFree(h->sensV); hipFree(h->em); hipFree(h->ems); hipFree(h->beta); hipFree(h->gradPartial); hipFree(h->gradOut);
     hipFree(h->ccpart); hipFree(h->Yc); hipFree(h->tYc);
     h->Yc = h->tYc = nullptr;
+    h->partm = nullptr;
     h->Z = h->Sigma = h->KsT = h->part = h->meanT = h->mean = h->var = h->J = h->cov = h->UT = h->VT = nullptr;
     h->sensH = h->sensV = h->em = h->ems = h->beta = h->gradPartial = h->gradOut = h->ccpart = nullptr;
     h->Bcap = 0;

@@ -68,6 +68,7 @@ struct gpmpc_gp {
     // predict scratch
     int Bcap = 0;
     double *Z = nullptr, *Sigma = nullptr, *KsT = nullptr, *part = nullptr, *meanT = nullptr;
+    double* partm = nullptr;                     // the mean's partial sums of the persistent variance product (same shape as part)
     double *mean = nullptr, *var = nullptr, *J = nullptr, *cov = nullptr;
     double* em = nullptr;  // exact-moment / legacy scratch
     long emBytes = 0;
@@ -273,14 +274,14 @@ int gpmpc_destroy(gpmpc_gp* h) {
     hipFree(h->bYc); hipFree(h->bmpar); hipFree(h->bgradPartial); hipFree(h->bgradOut); hipFree(h->bzmap);
     hipFree(h->XT); hipFree(h->Y); hipFree(h->gradPartial); hipFree(h->gradOut);
     hipFree(h->mpar); hipFree(h->Yc); hipFree(h->tmpar); hipFree(h->tYc);
-    hipFree(h->Z); hipFree(h->Sigma); hipFree(h->KsT); hipFree(h->part); hipFree(h->meanT);
+    hipFree(h->Z); hipFree(h->Sigma); hipFree(h->KsT); hipFree(h->part); hipFree(h->partm); hipFree(h->meanT);
     hipFree(h->mean); hipFree(h->var); hipFree(h->J); hipFree(h->cov); hipFree(h->em); hipFree(h->ems);
     hipFree(h->beta); hipFree(h->UT); hipFree(h->VT); hipFree(h->sensH); hipFree(h->sensV); hipFree(h->ccpart);
     for (int ph = 0; ph < GPMPC_PH_COUNT; ++ph)
         for (auto& pr : h->prof.ev[ph]) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     for (auto e : h->prof.pool) hipEventDestroy(e);
     if (h->ev_info) hipEventDestroy(h->ev_info);
-    for (hipEvent_t e : {h->tail.ev_chain, h->tail.ev_tail, h->tail.ev_alpha, h->tail.ev_ks, h->tail.ev_mean})
+    for (hipEvent_t e : {h->tail.ev_chain, h->tail.ev_tail, h->tail.ev_alpha, h->tail.ev_ks, h->tail.ev_mean, h->tail.ev_w})
         if (e) hipEventDestroy(e);
     if (h->pin) hipHostFree(h->pin);
     if (h->io_pin) hipHostFree(h->io_pin);

@@ -66,10 +66,10 @@ static int ensure_scratch(gpmpc_gp* h, int B, bool keep_tail = false) {
     const int need = round_up(B < chunk_size(h) ? B : chunk_size(h), 64);
     if (need <= h->Bcap) return GPMPC_OK;
     HIPCHK(hipStreamSynchronize(h->stream));
-    hipFree(h->Z); hipFree(h->Sigma); hipFree(h->KsT); hipFree(h->part); hipFree(h->meanT);
+    hipFree(h->Z); hipFree(h->Sigma); hipFree(h->KsT); hipFree(h->part); hipFree(h->partm); hipFree(h->meanT);
     hipFree(h->mean); hipFree(h->var); hipFree(h->J); hipFree(h->cov); hipFree(h->UT); hipFree(h->VT);
     hipFree(h->sensH); hipFree(h->sensV); hipFree(h->ccpart);
-    h->UT = h->VT = h->sensH = h->sensV = h->ccpart = nullptr;
+    h->UT = h->VT = h->sensH = h->sensV = h->ccpart = h->partm = nullptr;
     h->Z = h->Sigma = h->KsT = h->part = h->meanT = h->mean = h->var = h->J = h->cov = nullptr;
     h->Bcap = 0;
     const size_t d = h->d, Ny = h->Ny, Np = h->Np, Bc = need;
@@ -77,6 +77,7 @@ static int ensure_scratch(gpmpc_gp* h, int B, bool keep_tail = false) {
     HIPCHK(hipMalloc(&h->Sigma, Bc * d * d * sizeof(double)));
     HIPCHK(hipMalloc(&h->KsT, Ny * Bc * Np * sizeof(double)));
     HIPCHK(hipMalloc(&h->part, Ny * (Np / 16) * Bc * sizeof(double)));
+    HIPCHK(hipMalloc(&h->partm, Ny * (Np / VAR_TILE + 1) * Bc * sizeof(double)));
     HIPCHK(hipMalloc(&h->meanT, Ny * Bc * sizeof(double)));
     HIPCHK(hipMalloc(&h->mean, Bc * Ny * sizeof(double)));
     HIPCHK(hipMalloc(&h->var, Bc * Ny * sizeof(double)));
@@ -106,6 +107,23 @@ static int predict_chunk(gpmpc_gp* h, int B, const double* dZ, double* dMean, do
     const bool overlapped = behind_tail && overlap_env && dVar && !dJ && !VT && B > 64 && cx.bulk && cx.side &&
                             h->stream == h->own_stream;
     TailState& ts = h->tail;
+    // Large batches whose variance product runs as the persistent kernel take the mean from its fused reduction
+    // (sum_i V_ij w_i, w = L^-1 y: vargemm_persist.hpp) instead of from the cross-covariance kernel or a kernel of its own:
+    // decided here, before the cross-covariances are formed (GPMPC_FUSED_MEAN=0: as before).
+    static const int persist_env0 = getenv("GPMPC_VARGEMM_PERSIST") ? atoi(getenv("GPMPC_VARGEMM_PERSIST")) : 1;
+    static const bool fused_mean_env = !(getenv("GPMPC_FUSED_MEAN") && atoi(getenv("GPMPC_FUSED_MEAN")) == 0);
+    bool fused_mean = false;
+    if (dVar && dMean && !dJ && !VT && B > 64 && fused_mean_env) {
+        const int persist0 = g_vargemm_persist >= 0 ? g_vargemm_persist : persist_env0;
+        const int tM = (Np + VAR_TILE - 1) / VAR_TILE, tN = (Bp + VAR_TILE - 1) / VAR_TILE, slots0 = 2 * g_cu_count[h->device];
+        GemmP q = gemm_base(cx);
+        q.A = h->ws.Inv; q.lda = Np; q.sA = (long)Np * Np; q.kflags = KA_LE_M;
+        q.B = h->KsT; q.ldb = Np; q.sB = (long)Bp * Np;
+        q.M = Np; q.N = Bp; q.K = Np;
+        const int tile0 = g_gemm_force_tile ? g_gemm_force_tile : gemm_pick_tile(q, Ny);
+        fused_mean = persist0 && tile0 == VAR_TILE && Ny < 256 && tM < 4096 && tN < 4096 && gemm_dma_supported(q) &&
+                     (long)tM * tN * Ny >= (persist0 > 1 ? 1 : 2L * slots0);
+    }
     if (overlapped) {
         // (GPMPC_CROSSCOV_WGS: workgroups of the throttled launch; 0 = one per block of test points, i.e. not throttled)
         static const int cc_wgs = getenv("GPMPC_CROSSCOV_WGS") ? atoi(getenv("GPMPC_CROSSCOV_WGS")) : g_cu_count[h->device];
@@ -116,7 +134,10 @@ static int predict_chunk(gpmpc_gp* h, int B, const double* dZ, double* dMean, do
         }
         hipEventRecord(TailState::get(ts.ev_ks), cx.bulk);
         hipStreamWaitEvent(cx.stream, ts.ev_ks, 0);
-        if (dMean) {                                    // behind alpha (same queue), next to the variance product
+        if (dMean && fused_mean) {
+            // the variance product needs w = L^-1 y for its fused mean: the first kernel of the pending alpha
+            if (ts.alpha_pending) hipStreamWaitEvent(cx.stream, ts.ev_w, 0);
+        } else if (dMean) {                             // behind alpha (same queue), next to the variance product
             hipStreamWaitEvent(cx.side, ts.ev_ks, 0);
             if (!ts.alpha_pending) {                    // (alpha was formed on the main queue: behind the tail then)
                 hipEventRecord(TailState::get(ts.ev_tail), cx.stream);
@@ -132,7 +153,7 @@ static int predict_chunk(gpmpc_gp* h, int B, const double* dZ, double* dMean, do
         PhaseTimer t(h, GPMPC_PH_CROSSCOV);
         // few test points (an MPC's shooting nodes): cut the training points in chunks so that the launch fills the chip
         const int nch = (Bp <= CROSSCOV_SMALL_B && Np >= CROSSCOV_CHUNK_MIN_NP) ? CROSSCOV_CHUNKS : 1;
-        launch_crosscov(cx.stream, h->d, h->XT, h->ws.hyper, h->ws.alpha, dZ, h->KsT, h->meanT, dJ, h->N, Np, B, Bp, Ny,
+        launch_crosscov(cx.stream, h->d, h->XT, h->ws.hyper, fused_mean ? nullptr : h->ws.alpha, dZ, h->KsT, h->meanT, dJ, h->N, Np, B, Bp, Ny,
                         h->ccpart, nch);
     }
     // One point: a dedicated kernel streams L^-1 once at 5.6 TB/s (C3 size).  Measured at N = 8192, Ny = 6
@@ -192,20 +213,22 @@ static int predict_chunk(gpmpc_gp* h, int B, const double* dZ, double* dMean, do
             (long)tilesM * tilesN * Ny >= (persist > 1 ? 1 : 2L * slots)) {
             VarSchedDev sd;
             CHK(get_schedule(h->device, PG_VAR, tilesM, tilesN, Ny, Np, slots, &sd));
+            if (fused_mean) { p.wvec = h->ws.w; p.sWv = Np; p.partm = h->partm; }
             launch_persist_gemm<PG_VAR>(p, sd, cx.stream);
             ++h->n_var_persist;
         } else {
+            if (fused_mean) return fail(GPMPC_EINVAL, "internal: fused mean without the persistent variance product");
             launch_gemm(p, Ny, cx.stream, tile);
         }
     }
-    if (overlapped && dMean) {
+    if (overlapped && dMean && !fused_mean) {
         hipStreamWaitEvent(cx.stream, ts.ev_mean, 0);
         ts.alpha_pending = false;                       // (the main queue is now ordered behind alpha as well)
     }
     {
         PhaseTimer t(h, GPMPC_PH_FINISH);
         hipLaunchKernelGGL(var_finish_kernel, dim3(B), dim3(256), 0, cx.stream, h->part, h->meanT,
-                           h->ws.hyper, dMean, dVar, B, Bp, Ny, h->d, tilesM);
+                           h->ws.hyper, dMean, dVar, B, Bp, Ny, h->d, tilesM, fused_mean ? (const double*)h->partm : nullptr);
         if (h->mean_kind && h->mean_add && (dMean || dJ))   // build_gp(meanFunc=...): mean += m(z), gp_functions.py:131,135
             hipLaunchKernelGGL(mean_add_kernel, dim3((unsigned)(((long)B * Ny + 255) / 256)), dim3(256), 0, cx.stream, dZ, h->mpar,
                                dMean, dJ, (double*)nullptr, h->mean_kind, B, Ny, h->d);

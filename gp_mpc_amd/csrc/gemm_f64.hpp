@@ -108,6 +108,9 @@ struct GemmP {
     int skip00;           // tile (0,0) belongs to the chain kernel
     int* done_flags;      // tiles (1,0) and (1,1) publish done_flags[0] / done_flags[1] = 1
     long sFlags;          // batch stride of the three flag pointers
+    const double* wvec;   // persistent variance product only (vargemm_persist.hpp): w = L^-1 y per matrix (stride sWv) and
+    long sWv;             // ... partm[b*sPart + tile_m*ldpart + n] = sum_{m in tile_m} (A B)[m][n] w[m]: the predictive mean ks^T alpha = (L^-1 ks)^T w
+    double* partm;
     const int* zmap;      // optional: the launch's matrices are zmap[0 .. batch) of the workspace (a subset); not with flags / part / Ct
 };
 

@@ -395,13 +395,23 @@ inline void launch_crosscov(hipStream_t st, int d, const double* XT, const doubl
 // written by the variance kernels (gp_functions.py:125-126,136: kss = sf^2, no noise), and the
 // transposition of mean to the caller's [B][Ny] layout.  One workgroup per test point, fixed-order
 // (deterministic) reduction over the row tiles.  grid (B), 256 threads.
+// partm (optional): the mean as per-row-tile partial sums of the variance product's fused reduction instead of meanT.
 __global__ void __launch_bounds__(256) var_finish_kernel(const double* __restrict__ part, const double* __restrict__ meanT,
                                                          const double* __restrict__ hyper, double* __restrict__ mean,
                                                          double* __restrict__ var, int B, int Bp, int Ny, int d,
-                                                         int tilesM) {
+                                                         int tilesM, const double* __restrict__ partm = nullptr) {
     const int b = blockIdx.x, tid = threadIdx.x;
     __shared__ double red[4];
     for (int a = 0; a < Ny; ++a) {
+        if (mean && partm) {
+            double s = 0.0;
+            for (int t = tid; t < tilesM; t += 256) s += partm[((long)a * tilesM + t) * Bp + b];
+            s = wave_sum(s);
+            if ((tid & 63) == 0) red[tid >> 6] = s;
+            __syncthreads();
+            if (tid == 0) mean[(long)b * Ny + a] = (red[0] + red[1]) + (red[2] + red[3]);
+            __syncthreads();
+        }
         if (var) {
             double s = 0.0;
             for (int t = tid; t < tilesM; t += 256) s += part[((long)a * tilesM + t) * Bp + b];
@@ -414,7 +424,7 @@ __global__ void __launch_bounds__(256) var_finish_kernel(const double* __restric
             }
             __syncthreads();
         }
-        if (mean && tid == 0) mean[(long)b * Ny + a] = meanT[(long)a * Bp + b];
+        if (mean && !partm && tid == 0) mean[(long)b * Ny + a] = meanT[(long)a * Bp + b];
     }
 }
 

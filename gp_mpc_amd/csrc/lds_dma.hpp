@@ -26,6 +26,7 @@ inline void dma_load16_relaxed(const dma_rsrc_t& r, char* lds_wave_base, unsigne
 template <int N> inline void dma_wait() {}
 inline void dma_barrier() { __syncthreads(); }
 inline void lds_barrier() { __syncthreads(); }
+inline void lds_flush() {}
 #else
 typedef int dma_rsrc_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ dma_rsrc_t dma_make_rsrc(const void* base, unsigned bytes) {
@@ -63,6 +64,12 @@ template <int N> __device__ __forceinline__ void dma_wait() {
 __device__ __forceinline__ void dma_barrier() {
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+// this wave's LDS stores are complete (lgkmcnt(0)): whoever passes a later raw barrier sees them
+__device__ __forceinline__ void lds_flush() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0xc07f);
     asm volatile("" ::: "memory");
 }
 // workgroup barrier behind LDS stores of this wave only: lgkmcnt(0), DMA loads stay in flight

@@ -1,6 +1,9 @@
 // Persistent products over a static tile schedule: the predictive variance and K^-1 = L^-T L^-1.
 //
-// PG_VAR   var_j = sf2 - sum_i (L^-1 ks_j)_i^2 for every test point j  (a9, gp_functions.py:122-126; GP.covar
+// PG_VAR   var_j = sf2 - sum_i (L^-1 ks_j)_i^2 for every test point j -- and, fused into the same epilogue, the mean
+//          ks_j^T alpha = (L^-1 ks_j)^T (L^-1 y) as partial sums sum_i V_ij w_i (GemmP::wvec / partm: no second pass over the
+//          328 MB of cross-covariances, which as a kernel of its own next to this one cost the step 70 us) --
+//          (a9, gp_functions.py:118-126; GP.covar
 //          gp_class.py:377-380): A = L^-1 (lower triangular, K contiguous), B = KsT (K contiguous), column sums of squares per
 //          128-row tile.  Same arithmetic, tiles and LDS images as gemm_f64_dma_kernel<128,128,2,4,2,4> -- the per-tile results
 //          are bit-identical to that kernel's.
@@ -32,10 +35,10 @@ namespace gpmpc {
 
 // tile word: batch index z (8 bits) | block row tm (12 bits) | block column tn (12 bits)
 constexpr int VAR_TILE = 128;
-// amdgpu_num_vgpr counts halves of the unified 512-entry file of gfx90a+ (the backend doubles the request): 56 = a budget of
-// 112 registers (109 used, no spills), so that four waves per SIMD leave 64 per lane and the alpha / mean kernels of the
-// workers' queue (<= 48 registers), which run NEXT TO the variance product, still find room on the persistent kernel's CUs
-constexpr int VAR_VGPRS = 56;
+// amdgpu_num_vgpr counts halves of the unified 512-entry file of gfx90a+ (the backend doubles the request): 58 = a budget of
+// 116 registers (what does not fit is reloaded at tile switches only), so that four waves per SIMD leave 48 per lane and the
+// alpha kernels of the workers' queue (<= 40 registers), which run NEXT TO the variance product, still find room on its CUs
+constexpr int VAR_VGPRS = 58;
 __host__ __device__ inline int var_tile_word(int z, int tm, int tn) { return (z << 24) | (tm << 12) | tn; }
 
 enum { PG_VAR = 0, PG_XTX = 1 };
@@ -49,6 +52,8 @@ __device__ __forceinline__ void persist_gemm_body(const GemmP& p, const int* __r
     constexpr int IMG_A = BM * 128, SLAB = (BM + BN) * 128;
     char* smem = (char*)GPMPC_DYN_SMEM();
     double* red = reinterpret_cast<double*>(smem + 2 * SLAB);      // [WGM][BN], not part of the ring
+    double* red2 = red + WGM * BN;                                 // ... the same for the mean's partial sums
+    double* wl = red2 + WGM * BN;                                  // [2][BM]: w of the current tile's rows (two tiles in turn)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -105,8 +110,14 @@ __device__ __forceinline__ void persist_gemm_body(const GemmP& p, const int* __r
     // a wave whose 64 rows lie entirely above (PG_VAR: A(m,k) = 0 for k > m) or below (PG_XTX: A(m,k) = 0 for k < m) a slab's
     // K range multiplies exact zeros there and sits the slab out: it works on the slabs [kslo, kshi) of its tile
     int ci = beg, ct = 0, cword = list[beg], cnk, kslo, kshi;
-    auto open_compute = [&](int word) {
+    auto open_compute = [&](int word, int par) {
         const int m0 = ((word >> 12) & 4095) * BM;
+        if (MODE == PG_VAR && p.partm) {
+            // w of the tile's rows for the fused mean: read in the epilogue, at least eight ring barriers from here; the buffer
+            // of the previous tile may still be read by a slower wave's epilogue, hence two of them
+            if (tid < BM) wl[par * BM + tid] = (m0 + tid < p.M) ? p.wvec[(long)(word >> 24) * p.sWv + m0 + tid] : 0.0;
+            lds_flush();
+        }
         if (MODE == PG_VAR) {
             cnk = (min(p.K, m0 + BM) + BK - 1) / BK;
             kslo = 0;
@@ -117,7 +128,7 @@ __device__ __forceinline__ void persist_gemm_body(const GemmP& p, const int* __r
             kshi = 1 << 30;
         }
     };
-    open_compute(cword);
+    open_compute(cword, ci & 1);
 
     d4 acc[TM][TN];
 #pragma unroll
@@ -156,21 +167,29 @@ __device__ __forceinline__ void persist_gemm_body(const GemmP& p, const int* __r
         const int zw = cword >> 24, tm = (cword >> 12) & 4095, m0 = tm * BM, n0 = (cword & 4095) * BN;
         const int z = (MODE == PG_XTX && zmap) ? zmap[zw] : zw;
         if (MODE == PG_VAR) {                                      // column sums of squares over the tile's rows < M
+            const bool with_mean = p.partm != nullptr;             // ... and the mean's partial sums sum_m V[m][n] w[m]
+            const double* wt = wl + (ci & 1) * BM + wm * WM;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                double s = 0.0;
+                double s = 0.0, s2 = 0.0;
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int m = m0 + wm * WM + i * 16 + crow(lane, r, p.crow_mode);
-                        const double v = (m < p.M) ? acc[i][j][r] : 0.0;
+                        const int ml = i * 16 + crow(lane, r, p.crow_mode);
+                        const double v = (m0 + wm * WM + ml < p.M) ? acc[i][j][r] : 0.0;
                         s += v * v;
+                        if (with_mean) s2 = fma(v, wt[ml], s2);
                         acc[i][j][r] = 0.0;
                     }
                 s += __shfl_xor(s, 16);
                 s += __shfl_xor(s, 32);
                 if (lane < 16) red[wm * BN + wn * WN + j * 16 + lane] = s;
+                if (with_mean) {
+                    s2 += __shfl_xor(s2, 16);
+                    s2 += __shfl_xor(s2, 32);
+                    if (lane < 16) red2[wm * BN + wn * WN + j * 16 + lane] = s2;
+                }
             }
             lds_barrier();                                         // (the slab in flight is not waited for)
             if (tid < BN && n0 + tid < p.N) {
@@ -178,6 +197,12 @@ __device__ __forceinline__ void persist_gemm_body(const GemmP& p, const int* __r
 #pragma unroll
                 for (int w = 0; w < WGM; ++w) t += red[w * BN + tid];
                 p.part[(long)z * p.sPart + (long)tm * p.ldpart + n0 + tid] = t;
+                if (with_mean) {
+                    double t2 = 0.0;
+#pragma unroll
+                    for (int w = 0; w < WGM; ++w) t2 += red2[w * BN + tid];
+                    p.partm[(long)z * p.sPart + (long)tm * p.ldpart + n0 + tid] = t2;
+                }
             }
             // (`red` is written again after >= 8 more ring barriers: no barrier needed behind its readers)
         } else {                                                   // the lower triangle of the product
@@ -197,7 +222,7 @@ __device__ __forceinline__ void persist_gemm_body(const GemmP& p, const int* __r
         if (++ci >= end) break;
         cword = list[ci];
         ct = 0;
-        open_compute(cword);
+        open_compute(cword, ci & 1);
     }
 }
 
@@ -349,7 +374,7 @@ struct VarSchedDev {
 
 template <int MODE>
 inline void launch_persist_gemm(const GemmP& p, const VarSchedDev& s, hipStream_t stream, const int* zmap = nullptr) {
-    constexpr int lds = 2 * (VAR_TILE + VAR_TILE) * 128 + 2 * VAR_TILE * 8 + 16;
+    constexpr int lds = 2 * (VAR_TILE + VAR_TILE) * 128 + (2 + 2 + 2) * VAR_TILE * 8 + 16;   // ring, red, red2, wl
     static bool attr_set = false;
     if (!attr_set) {
         const void* fn = MODE == PG_VAR ? reinterpret_cast<const void*>(&vargemm_persist_kernel) : reinterpret_cast<const void*>(&xtx_persist_kernel);
