@@ -389,7 +389,9 @@ inline int gemm_pick_tile(const GemmP& p, int batch) {
         return p.lower ? (b + 1) / 2 : b;
     };
     static const int t128 = getenv("GPMPC_T128") ? atoi(getenv("GPMPC_T128")) : 512;
-    static const int t64 = getenv("GPMPC_T64") ? atoi(getenv("GPMPC_T64")) : 256;   // (256 instead of 512: -14 us on the C2 inverse tail with the DMA-staged 64-row kernel)
+    // (r03: 256 instead of 512: -14 us on the C2 inverse tail with the DMA-staged 64-row kernel; r04, with the prediction running
+    //  behind the tail: 384 / 512 instead of 256: -35 / -30 us per C2 step, C3 and C4 unchanged -- tools/gpu_r04_s.sh)
+    static const int t64 = getenv("GPMPC_T64") ? atoi(getenv("GPMPC_T64")) : 384;
     if (p.N <= 32 || p.M <= 32) return 32;     // skinny products (a handful of prediction points)
     // A triangular operand makes the heaviest tile K / 128 slabs long while the average is half that: unless the
     // average work per workgroup slot (512 of them) reaches the heaviest tile, the heaviest tiles alone set the time
