@@ -1,12 +1,11 @@
 // Persistent products over a static tile schedule: the predictive variance and K^-1 = L^-T L^-1.
 //
-// PG_VAR   var_j = sf2 - sum_i (L^-1 ks_j)_i^2 for every test point j -- and, fused into the same epilogue, the mean
-//          ks_j^T alpha = (L^-1 ks_j)^T (L^-1 y) as partial sums sum_i V_ij w_i (GemmP::wvec / partm: no second pass over the
-//          328 MB of cross-covariances, which as a kernel of its own next to this one cost the step 70 us) --
-//          (a9, gp_functions.py:118-126; GP.covar
-//          gp_class.py:377-380): A = L^-1 (lower triangular, K contiguous), B = KsT (K contiguous), column sums of squares per
-//          128-row tile.  Same arithmetic, tiles and LDS images as gemm_f64_dma_kernel<128,128,2,4,2,4> -- the per-tile results
-//          are bit-identical to that kernel's.
+// PG_VAR   var_j = sf2 - sum_i (L^-1 ks_j)_i^2 for every test point j  (a9, gp_functions.py:118-126; GP.covar gp_class.py:377-380):
+//          A = L^-1 (lower triangular, K contiguous), B = KsT (K contiguous), column sums of squares per 128-row tile.  Same
+//          arithmetic, tiles and LDS images as gemm_f64_dma_kernel<128,128,2,4,2,4>: the per-tile sums are bit-identical to
+//          that kernel's.  Fused into the same epilogue (GemmP::wvec / partm): the mean ks_j^T alpha = (L^-1 ks_j)^T (L^-1 y)
+//          as partial sums sum_i V_ij w_i -- no second pass over the 328 MB of cross-covariances, which as a kernel of its
+//          own next to this one cost the C2 step 70 us.
 // PG_XTX   lower triangle of K^-1 = X^T X, X = L^-1  (a6, optimize.py:489-490): A = B = XT, the transposed copy of L^-1 made by
 //          transpose_lower_kernel, so that both operands are K contiguous (the M/N-contiguous instantiation of the one-tile
 //          kernel reads its fragments with twice the LDS instructions and spills); tile (tm >= tn) sums over k >= 128 tm.
@@ -20,12 +19,13 @@
 //     (persist_schedule: the XCDs are levelled first by moving a few tiles -- the only ones that leave the XCD that holds the
 //     rest of their Ks panel --, then inside every XCD longest tile first to the least loaded slot and moves / swaps off the
 //     heaviest slot): within 0.5 % of the mean.  (A first version balanced across XCDs freely: 16 % of the tiles ran away
-//     from their panel and the kernel fetched 43 % more than the dispatcher's order, profiles/r04_*.)  The doubly triangular K^-1 product is worse off with the dispatcher
-//     (row tm holds tm + 1 tiles of T - tm units and as many workgroups that exit at once).
+//     from their panel and the kernel fetched 43 % more than the dispatcher's order, profiles/r04_*.)  The doubly triangular
+//     K^-1 product is worse off with the dispatcher (row tm holds tm + 1 tiles of T - tm units and as many workgroups that exit at once).
 //   * The slabs of a workgroup's tiles form one stream through the two-image ring: the first slab of the next tile is
 //     requested behind the barrier of the current tile's last step, so a tile boundary costs the epilogue and nothing
 //     else (the one-tile kernel drains its ring, writes its sums, exits, and its successor starts with an empty ring).
-//     The epilogue's scratch has its own 2 KB of LDS for that reason, and its barrier waits for LDS traffic only.
+//     The epilogue's scratch has its own LDS for that reason (6 KB: two sets of partial sums, w of two tiles), and its
+//     barrier waits for LDS traffic only.
 #pragma once
 #include <algorithm>
 #include <vector>
