@@ -169,6 +169,15 @@ static long long* g_chain_trace = nullptr;   // developer aid: GPMPC_CHAIN_TRACE
 //     A22 -= L21 L21^T  (K = 64 W; look-ahead split as before)
 // want_inverse = false (value-only NLL evaluations of the restart search): L and the diagonal blocks' inverses I_i only
 // (ws.inv_panels = W); twolevel_inverse_all forms L^-1 from them later, for the matrices that turn out to need it.
+// the chain kernel's publications as write-through stores + flag, no L2 write-back (wg_sync.hpp; GPMPC_CHAIN_WT=0: release fence)
+static int chain_wt_publish() {
+    static const int v = getenv("GPMPC_CHAIN_WT") ? atoi(getenv("GPMPC_CHAIN_WT")) : 1;
+    return v;
+}
+static int worker_wt_publish() {   // the same for the tile-owner workers and the courier (GPMPC_WORKER_WT)
+    static const int v = getenv("GPMPC_WORKER_WT") ? atoi(getenv("GPMPC_WORKER_WT")) : 1;
+    return v;
+}
 static int twolevel_width() {   // block columns per super-panel (GPMPC_TWOLEVEL; 0 / 1 = off)
 #ifdef GPMPC_EMULATED
     static const int w = getenv("GPMPC_TWOLEVEL") ? atoi(getenv("GPMPC_TWOLEVEL")) : 2;
@@ -265,7 +274,7 @@ static bool factor_twolevel(const Ctx& cx, Workspace& ws, int spin_limit, int W,
         hipStreamWaitEvent(cx.stream, cx.join, 0);
         hipLaunchKernelGGL(chol_chain_kernel, dim3(1, 1, ws.batch), dim3(256), CHAIN_LDS_BYTES, cx.stream, (const double*)ws.K,
                            ws.L, ws.Inv, ld, sM, nb, ws.flags, (long)nf, ws.info, cx.crow_mode, spin_limit, g_chain_trace, 0, k0,
-                           k1);
+                           k1, 3, chain_wt_publish());
         hipLaunchKernelGGL(flag_gate_kernel, dim3(ws.batch), dim3(64), 0, cx.side, ws.flags, (long)nf, 1 + k0, 1, -1, 0,
                            spin_limit);                       // bulk workgroups only once this chain launch is resident
         for (int k = k0; k < k1; ++k) {
@@ -498,12 +507,13 @@ static bool factor_chain(const Ctx& cx, Workspace& ws, int spin_limit, bool flag
     // right behind the leaf: since the courier and the workers' look-ahead start from inv_kk, the early publication wins
     // (r03 A/B: chain 1.310 -> 1.302 ms).  GPMPC_MERGE_PUBLISH=1: the old way.
     static const bool merge_publish = getenv("GPMPC_MERGE_PUBLISH") && atoi(getenv("GPMPC_MERGE_PUBLISH")) != 0;
+    const int wt_publish = chain_wt_publish();
     static const int late_polls = getenv("GPMPC_LATE_POLLS") ? atoi(getenv("GPMPC_LATE_POLLS")) : 3;   // (tuning aid, chol_chain.hpp land())
     {   // the chain kernel ends with the last leaf, i.e. when L is complete: its duration is the Cholesky's
         ProfScope t(cx.prof, cx.stream, GPMPC_PH_CHAIN);
         hipLaunchKernelGGL(chol_chain_kernel, dim3(1, 1, ws.batch), dim3(256), CHAIN_LDS_BYTES, cx.stream, (const double*)ws.K,
                            ws.L, ws.Inv, ld, sM, nb, ws.flags, (long)nf, ws.info, cx.crow_mode, spin_limit, g_chain_trace,
-                           use_workers && merge_publish ? 1 : 0, 0, -1, late_polls);
+                           use_workers && merge_publish ? 1 : 0, 0, -1, late_polls, wt_publish);
     }
     static const bool verbose = getenv("GPMPC_VERBOSE") != nullptr;
     // (tuning aid) GPMPC_WORKER_LOOKAHEAD=0: the workers turn a panel tile into L(i,k) only at the top of step k
@@ -549,7 +559,7 @@ static bool factor_chain(const Ctx& cx, Workspace& ws, int spin_limit, bool flag
             auto* worker = worker_courier ? chol_worker_kernel<WORKER_MAXT_COURIER, true> : chol_worker_kernel<WORKER_MAXT, false>;
             hipLaunchKernelGGL(worker, dim3(nws[i], 1, ws.batch), dim3(WORKER_THREADS), WORKER_LDS_BYTES, cx.side,
                                ws.K, ws.L, (const double*)ws.Inv, ld, sM, nb, ws.flags, (long)nf, cx.crow_mode, spin_limit,
-                               r[i] / 64, i + 1 < L ? (r[i + 1] - r[i]) / 64 : nb, ready, g_chain_trace, worker_lookahead ? 1 : 0);
+                               r[i] / 64, i + 1 < L ? (r[i + 1] - r[i]) / 64 : nb, ready, g_chain_trace, worker_lookahead ? 1 : 0, worker_wt_publish());
             if (i + 1 < L) hipEventRecord(cx.seg[i], cx.side);        // launch i finished: rows P_i of L are final
         }
         const bool own_events = ev0 + P + 2 < cx.n_seg - 2;

@@ -87,7 +87,8 @@ __device__ __forceinline__ void chain_diag_tiles(double* S, const double* U, con
 __global__ void __launch_bounds__(256) chol_chain_kernel(const double* Kmat, double* L, double* Inv, long ld, long sBatch,
                                                          int nb, int* flags, long sFlags, int* info, int crow_mode,
                                                          int spin_limit, long long* trace, int merge_publish,
-                                                         int kb = 0, int ke = -1, int late_polls = 3) {
+                                                         int kb = 0, int ke = -1, int late_polls = 3, int wt = 0) {
+    // wt: publish L_kk, inv_kk and L(k+1,k) as write-through stores, no L2 write-back per publication (wg_sync.hpp)
     // [kb, ke): the block columns this launch factors (two-level execution: one launch per super-panel; the tiles of
     // block kb then carry every earlier update by stream order, no flag).  Default: the whole matrix.
     if (ke < 0) ke = nb;
@@ -136,6 +137,9 @@ __global__ void __launch_bounds__(256) chol_chain_kernel(const double* Kmat, dou
     for (int k = kb; k < ke; ++k) {
         const long o = (long)(64 * k) * ld + 64 * k;
         const long o10 = o + 64 * ld, o11 = o10 + 64;
+        const unsigned tile_bytes = (unsigned)((63 * ld + 64) * 8);
+        const wt_rsrc_t rL = wt_make_rsrc(Lb + o, tile_bytes), rI = wt_make_rsrc(Ib + o, tile_bytes),
+                        rR = wt_make_rsrc(Lb + o10, tile_bytes);
         CHAIN_STAMP(0);
         // Prefetch for the second half of the step: if the two tiles A(k+1,k), A(k+1,k+1) carry the trailing update of
         // step k-1 two thirds into the leaf (they usually do), waves 2 and 3 -- idle from there on -- issue their loads and
@@ -233,12 +237,17 @@ __global__ void __launch_bounds__(256) chol_chain_kernel(const double* Kmat, dou
             l.y = (cc + 1 <= rr) ? S[rr * LS + cc + 1] : 0.0;
             v.x = T[rr * LS + cc];
             v.y = (cc + 1 <= rr) ? T[rr * LS + cc + 1] : 0.0;
-            *reinterpret_cast<double2*>(&Lb[o + (long)rr * ld + cc]) = l;
-            *reinterpret_cast<double2*>(&Ib[o + (long)rr * ld + cc]) = v;
+            if (wt) {
+                wt_store16(rL, (unsigned)((rr * ld + cc) * 8), l);
+                wt_store16(rI, (unsigned)((rr * ld + cc) * 8), v);
+            } else {
+                *reinterpret_cast<double2*>(&Lb[o + (long)rr * ld + cc]) = l;
+                *reinterpret_cast<double2*>(&Ib[o + (long)rr * ld + cc]) = v;
+            }
         }
         // merge_publish: leafdone[k] goes out together with pan1[k] a few microseconds later, saving one L2 write-back per
         // step on this critical path (off by default since r03: the courier and the workers' look-ahead want inv_kk early)
-        if (!merge_publish || k + 1 == ke) wg_publish(&leafdone[k], 1);
+        if (!merge_publish || k + 1 == ke) { if (wt) wg_publish_wt(&leafdone[k], 1); else wg_publish(&leafdone[k], 1); }
         CHAIN_STAMP(2);
         if (k + 1 == ke) break;
         const double* Asrc = P;                       // A(k+1,k): put there by the prefetch, else fetched now
@@ -284,10 +293,12 @@ __global__ void __launch_bounds__(256) chol_chain_kernel(const double* Kmat, dou
             double2 u;
             u.x = U[rr * LS + cc];
             u.y = U[rr * LS + cc + 1];
-            *reinterpret_cast<double2*>(&Lb[o10 + (long)rr * ld + cc]) = u;
+            if (wt) wt_store16(rR, (unsigned)((rr * ld + cc) * 8), u);
+            else *reinterpret_cast<double2*>(&Lb[o10 + (long)rr * ld + cc]) = u;
         }
         CHAIN_STAMP(5);
-        if (merge_publish) wg_publish(&leafdone[k], 1, &pan1[k]);
+        if (wt) { if (merge_publish) wg_publish_wt(&leafdone[k], 1, &pan1[k]); else wg_publish_wt(&pan1[k], 1); }
+        else if (merge_publish) wg_publish(&leafdone[k], 1, &pan1[k]);
         else wg_publish(&pan1[k], 1);     // (contains the barrier that also orders the S loads above)
         CHAIN_STAMP(6);
         // A_{k+1,k+1} -= L_{k+1,k} L_{k+1,k}^T on the 10 lower 16 x 16 tiles: the four of the first 16 columns now, one

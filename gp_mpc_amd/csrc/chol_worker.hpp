@@ -54,11 +54,23 @@ __device__ __forceinline__ const double& at_byte(const double* base, unsigned by
 }
 __device__ __forceinline__ double& at_byte(double* base, unsigned byte_off) { return *(double*)((char*)base + byte_off); }
 
+// A store that another workgroup will read behind a flag: write-through (an agent-scope relaxed atomic store is a
+// global_store_dwordx2 sc1) when `wt`, so that the publication needs no L2 write-back (wg_sync.hpp), else plain.
+__device__ __forceinline__ void st_pub(double* base, unsigned byte_off, double v, int wt) {
+#ifdef GPMPC_EMULATED
+    at_byte(base, byte_off) = v;
+#else
+    if (wt) __hip_atomic_store(&at_byte(base, byte_off), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else at_byte(base, byte_off) = v;
+#endif
+}
+#define WORKER_RELEASE() do { if (!wt) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); } while (0)
+
 template <int MAXT, bool COURIER>
 __global__ void __launch_bounds__(WORKER_THREADS) chol_worker_kernel(double* Kmat, double* L, const double* Inv, long ld,
                                                                      long sBatch, int nb_all, int* flags, long sFlags,
                                                                      int crow_mode, int spin_limit, int kb, int ksteps,
-                                                                     int* ready, long long* trace, int lookahead) {
+                                                                     int* ready, long long* trace, int lookahead, int wt) {
     // optional time stamps (100 MHz wall clock) for tools/worker_trace.py: [launch][worker][step][4] from entry 4096 on
 #ifdef GPMPC_EMULATED
 #define WORKER_STAMP(i) ((void)0)
@@ -256,14 +268,14 @@ __global__ void __launch_bounds__(WORKER_THREADS) chol_worker_kernel(double* Kma
             double* dl = Lb + (long)(64 * i) * ld + 64 * k;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                at_byte(dl + r * cstep, csub) = acc[0][r];
-                at_byte(dl + r * cstep, csub + 128u) = acc[1][r];
+                st_pub(dl + r * cstep, csub, acc[0][r], wt);
+                st_pub(dl + r * cstep, csub + 128u, acc[1][r], wt);
             }
             GPMPC_DRAIN_VM();                                                                      // L(i,k) is out: the column count
             tile_to_image(acc[0], acc[1], WORKER_PAIR_BYTES);                                      // ... -> image 1, A part
             __syncthreads();
             if (tid == 0) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                WORKER_RELEASE();
                 GPMPC_DRAIN_VM();
                 flag_store(&row2done[k], 1);
                 const int before = __hip_atomic_fetch_add(&pancount[k], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -283,13 +295,13 @@ __global__ void __launch_bounds__(WORKER_THREADS) chol_worker_kernel(double* Kma
             product_ab(img1, img1 + 32768, c1[0], c1[1], true);                                    // (i,k+1) -= L(i,k) L(k+1,k)^T
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                at_byte(d1 + r * cstep, csub) = c1[0][r]; at_byte(d1 + r * cstep, csub + 128u) = c1[1][r];
-                at_byte(d2 + r * cstep, csub) = c2[0][r]; at_byte(d2 + r * cstep, csub + 128u) = c2[1][r];
+                st_pub(d1 + r * cstep, csub, c1[0][r], wt); st_pub(d1 + r * cstep, csub + 128u, c1[1][r], wt);
+                st_pub(d2 + r * cstep, csub, c2[0][r], wt); st_pub(d2 + r * cstep, csub + 128u, c2[1][r], wt);
             }
             GPMPC_DRAIN_VM();
             __syncthreads();
             if (tid == 0) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                WORKER_RELEASE();
                 GPMPC_DRAIN_VM();
                 flag_store(&tdone[2 * k], 1);
                 flag_store(&tdone[2 * k + 1], 1);
@@ -330,13 +342,13 @@ __global__ void __launch_bounds__(WORKER_THREADS) chol_worker_kernel(double* Kma
             double* dst = Lb + (long)(64 * i) * ld;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                at_byte(dst + r * cstep, csub) = acc[0][r];
-                at_byte(dst + r * cstep, csub + 128u) = acc[1][r];
+                st_pub(dst + r * cstep, csub, acc[0][r], wt);
+                st_pub(dst + r * cstep, csub + 128u, acc[1][r], wt);
             }
             GPMPC_DRAIN_VM();
             __syncthreads();
             if (tid == 0) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                WORKER_RELEASE();
                 GPMPC_DRAIN_VM();
                 if (i == 2) flag_store(&row2done[0], 1);
                 const int before = __hip_atomic_fetch_add(&pancount[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -361,13 +373,13 @@ __global__ void __launch_bounds__(WORKER_THREADS) chol_worker_kernel(double* Kma
                 double* dst = Lb + (long)(64 * i) * ld + 64 * kk;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    at_byte(dst + r * cstep, csub) = acc[0][r];
-                    at_byte(dst + r * cstep, csub + 128u) = acc[1][r];
+                    st_pub(dst + r * cstep, csub, acc[0][r], wt);
+                    st_pub(dst + r * cstep, csub + 128u, acc[1][r], wt);
                 }
                 GPMPC_DRAIN_VM();
                 __syncthreads();                           // (also: everybody is done with A and B)
                 if (tid == 0) {
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    WORKER_RELEASE();
                     GPMPC_DRAIN_VM();
                     if (i == kk + 2) flag_store(&row2done[kk], 1);
                     // count the tile; whoever completes the column raises the flag the consumers poll
@@ -394,10 +406,10 @@ __global__ void __launch_bounds__(WORKER_THREADS) chol_worker_kernel(double* Kma
                 update(0, C[n][0], C[n][1]);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    at_byte(dst + r * cstep, csub) = C[n][0][r];
-                    at_byte(dst + r * cstep, csub + 128u) = C[n][1][r];
+                    st_pub(dst + r * cstep, csub, C[n][0][r], wt);
+                    st_pub(dst + r * cstep, csub + 128u, C[n][1][r], wt);
                 }
-                wg_publish(&tdone[2 * kk + (j == kk + 2 ? 1 : 0)], 1);
+                if (wt) wg_publish_wt(&tdone[2 * kk + (j == kk + 2 ? 1 : 0)], 1); else wg_publish(&tdone[2 * kk + (j == kk + 2 ? 1 : 0)], 1);
                 if (tid == 0) ti[n] = -1;
                 __syncthreads();                           // A, B free again; ti[] visible
             }
@@ -495,7 +507,7 @@ __global__ void __launch_bounds__(WORKER_THREADS) chol_worker_kernel(double* Kma
                 }
                 if (givepend) {                        // the stores of the tiles given away have drained (dma_wait<0> above
                     if (tid == 0) {                    // is vmcnt(0)) in every wave: barrier passed -> publish the count
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                        WORKER_RELEASE();
                         GPMPC_DRAIN_VM();
                         __hip_atomic_fetch_add(&handed[k + 1], givepend, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
@@ -511,8 +523,8 @@ __global__ void __launch_bounds__(WORKER_THREADS) chol_worker_kernel(double* Kma
                     double* dst = Kb + (long)(64 * li[n]) * ld + 64 * lj[n];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        at_byte(dst + r * cstep, csub) = C[n][0][r];
-                        at_byte(dst + r * cstep, csub + 128u) = C[n][1][r];
+                        st_pub(dst + r * cstep, csub, C[n][0][r], wt);
+                        st_pub(dst + r * cstep, csub + 128u, C[n][1][r], wt);
                     }
                     if (tid == 0) ti[n] = -1;
                     ++givepend;
@@ -534,7 +546,7 @@ __global__ void __launch_bounds__(WORKER_THREADS) chol_worker_kernel(double* Kma
         __syncthreads();                               // the pair images alias A and B of the next step / of the early product
         if (givepend) {
             if (tid == 0) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                WORKER_RELEASE();
                 GPMPC_DRAIN_VM();
                 __hip_atomic_fetch_add(&handed[k + 1], givepend, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }

@@ -37,6 +37,33 @@ __device__ __forceinline__ void wg_publish(int* flag, int value, int* flag2 = nu
     }
 }
 
+// Write-through form (guide G16 recipe R1): the payload leaves as 16-byte sc1 stores, which go through the XCD's L2
+// to memory, so the publication needs no L2 write-back (buffer_wbl2, 1.7 us clean and several under load): every
+// storing wave drains, barrier, ONE lane stores the flag.  The consumer side is unchanged.
+#ifdef GPMPC_EMULATED
+struct wt_rsrc_t { char* base; };
+inline wt_rsrc_t wt_make_rsrc(void* base, unsigned) { return wt_rsrc_t{(char*)base}; }
+inline void wt_store16(const wt_rsrc_t& r, unsigned off, double2 v) { *reinterpret_cast<double2*>(r.base + off) = v; }
+#else
+typedef __amdgpu_buffer_rsrc_t wt_rsrc_t;
+__device__ __forceinline__ wt_rsrc_t wt_make_rsrc(void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ void wt_store16(wt_rsrc_t r, unsigned off, double2 v) {
+    typedef unsigned u4_t __attribute__((ext_vector_type(4)));
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4_t, v), r, (int)off, 0, /*sc1*/ 16);
+}
+#endif
+// called by ALL threads of the workgroup after their wt_store16 stores (and nothing else to publish)
+__device__ __forceinline__ void wg_publish_wt(int* flag, int value, int* flag2 = nullptr) {
+    GPMPC_DRAIN_VM();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        flag_store(flag, value);
+        if (flag2) flag_store(flag2, value);
+    }
+}
+
 // called by ALL threads: wait until *f0 >= v0 (and *f1 >= v1 if f1); false on time-out / global error.
 // `slot` is an int in LDS used to broadcast the outcome.
 __device__ __forceinline__ bool wg_wait2(const int* f0, int v0, const int* f1, int v1, int* err, int limit, int* slot,
