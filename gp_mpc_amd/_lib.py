@@ -261,7 +261,7 @@ class Handle:
     def counter(self, name):
         """'handoff_timeouts' | 'chained_factorisations' | 'single_queue_factorisations' | 'workspace_blocks_fresh' |
         'workspace_blocks_reused' | 'train_iterations' | 'train_evaluations' | 'predictions_behind_tail' |
-        'persistent_variance_products', 'w_next_to_tail' (include/gpmpc.h)."""
+        'persistent_variance_products' (include/gpmpc.h)."""
         v = ctypes.c_long(0)
         self.lib.check(self.lib.dll.gpmpc_get_counter(self.h, name.encode(), ctypes.byref(v)))
         return v.value

@@ -351,11 +351,6 @@ struct TailState {
     int nb = 0;
     hipEvent_t ev_info = nullptr;
     bool want_early = false, early_done = false;
-    // w next to the inverse's last product (factor_chain): asked for by gpmpc_fit (w_y = the residual vector), done per attempt
-    const double* w_y = nullptr;
-    long w_sy = 0;
-    bool w_done = false;
-    hipEvent_t ev_pre = nullptr;   // the last panel's own inverse is there
     static hipEvent_t get(hipEvent_t& e) {
         if (!e) hipEventCreateWithFlags(&e, hipEventDisableTiming);
         return e;

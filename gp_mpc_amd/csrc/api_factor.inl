@@ -664,35 +664,12 @@ static bool factor_chain(const Ctx& cx, Workspace& ws, int spin_limit, bool flag
         hipStreamWaitEvent(cx.stream, cx.seg[cx.n_seg - 2], 0);
         const int rl = pcut[P - 1], h = Np - rl;
         trtri_range(cx, ws, cx.stream, rl, h);
-        // w = L^-1 y next to the last product instead of behind it (gpmpc_fit, overlapped route: the variance product's fused
-        // mean waits for w, and "product -> event -> w on the workers' queue -> event -> variance product" put two queue
-        // hand-overs of 20-30 us each plus the row product's 15 us between the inverse and its consumer).  Rows < rl of L^-1
-        // are final when the inverse queue is through, the last panel's rows are -I S with S = L[P, <rl] L^-1[<rl, <rl], so
-        //     w[<rl] = L^-1[<rl, <rl] y[<rl],     w[P] = I (y[P] - L[P, <rl] w[<rl])
-        // needs the panel's own inverse I only: three row-dot launches on the workers' queue (idle since the chain ended).
-        static const bool early_w_env = !(getenv("GPMPC_EARLY_W") && atoi(getenv("GPMPC_EARLY_W")) == 0);
-        const bool early_w = early_w_env && cx.tail && cx.tail->early_done && cx.tail->w_y && s_ready_recorded;
-        if (early_w) {
-            TailState& ts = *cx.tail;
-            hipEventRecord(cx.seg[ev0 + P], cx.aux);                       // the inverse queue's last entry: L^-1[<rl, <rl] final
-            hipEventRecord(TailState::get(ts.ev_pre), cx.stream);          // I is there
-            hipStreamWaitEvent(cx.side, cx.seg[ev0 + P], 0);
-            hipStreamWaitEvent(cx.side, ts.ev_pre, 0);
-            hipLaunchKernelGGL(gemv_rows_kernel, dim3(rl / 4, ws.batch), dim3(256), 0, cx.side, ws.Inv, ts.w_y, ws.w, Np, sM, ts.w_sy,
-                               (long)Np, 1);
-            hipLaunchKernelGGL(rowdot_kernel, dim3(h / 4, ws.batch), dim3(256), 0, cx.side, (const double*)ws.L, ld, sM, rl, h, 0, rl, 0,
-                               (const double*)ws.w, (long)Np, ts.w_y, ts.w_sy, ws.alpha, (long)Np, -1.0);
-            hipLaunchKernelGGL(rowdot_kernel, dim3(h / 4, ws.batch), dim3(256), 0, cx.side, (const double*)ws.Inv, ld, sM, rl, h, rl, h, 1,
-                               (const double*)ws.alpha, (long)Np, (const double*)nullptr, 0L, ws.w, (long)Np, 1.0);
-            hipEventRecord(TailState::get(ts.ev_w), cx.side);
-            ts.w_done = true;
-        }
         if (!s_ready_recorded) hipEventRecord(cx.seg[cx.n_seg - 1], cx.aux);
         hipStreamWaitEvent(cx.stream, cx.seg[cx.n_seg - 1], 0);
         product(cx.stream, ws.Inv + (long)rl * ld + rl, ld, KA_LE_M, ws.W + sofs[P - 1], rl, ws.Inv + (long)rl * ld, ld,
                 h, rl, h, -1.0, 0.0);
         if (s_ready_recorded) {                             // ... and for whatever the inverse queue still had to do
-            if (!early_w) hipEventRecord(cx.seg[ev0 + P], cx.aux);
+            hipEventRecord(cx.seg[ev0 + P], cx.aux);
             hipStreamWaitEvent(cx.stream, cx.seg[ev0 + P], 0);
         }
         return true;
@@ -708,14 +685,11 @@ static bool factor_chain(const Ctx& cx, Workspace& ws, int spin_limit, bool flag
 // w = L^-1 y and alpha = L^-T w as two HBM-bound matrix-vector products with the explicit inverse.
 // y: [batch] vectors with stride sy.
 // (ev_w: recorded behind w -- what the variance product's fused mean waits for instead of alpha)
-// (have_w: w is there already -- or on its way on this queue --, factor_chain's early w)
-static void solve_alpha(const Ctx& cx, Workspace& ws, const double* y, long sy, hipEvent_t ev_w = nullptr, bool have_w = false) {
+static void solve_alpha(const Ctx& cx, Workspace& ws, const double* y, long sy, hipEvent_t ev_w = nullptr) {
     const int Np = ws.Np;
-    if (!have_w) {
-        hipLaunchKernelGGL(gemv_rows_kernel, dim3(Np / 4, ws.batch), dim3(256), 0, cx.stream, ws.Inv, y, ws.w, Np, ws.mat(), sy,
-                           (long)Np, 1);
-        if (ev_w) hipEventRecord(ev_w, cx.stream);
-    }
+    hipLaunchKernelGGL(gemv_rows_kernel, dim3(Np / 4, ws.batch), dim3(256), 0, cx.stream, ws.Inv, y, ws.w, Np, ws.mat(), sy,
+                       (long)Np, 1);
+    if (ev_w) hipEventRecord(ev_w, cx.stream);
     const int chunks = (Np + GEMVT_ROWS - 1) / GEMVT_ROWS;         // partial sums go through the (now idle) inverse scratch
     hipLaunchKernelGGL(gemv_lowerT_part_kernel, dim3((Np + 127) / 128, chunks, ws.batch), dim3(256), 0, cx.stream, ws.Inv, ws.w, ws.W,
                        Np, ws.mat(), (long)Np, ws.wstride());

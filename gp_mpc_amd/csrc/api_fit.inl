@@ -62,7 +62,6 @@ static int factor_with_jitter(gpmpc_gp* h, Workspace& ws, const double* hyper_ho
         h->tail.ev_info = h->ev_info;
         h->tail.want_early = early_status && !g_chain_trace;
         h->tail.early_done = false;
-        h->tail.w_done = false;
         gram_and_factor(h, ws, no_workers, value_only);
         HIPCHK(hipGetLastError());
         const bool check_chain = h->chain_mode && h->side_stream && ws.Np >= 128;
@@ -112,7 +111,6 @@ static int factor_with_jitter(gpmpc_gp* h, Workspace& ws, const double* hyper_ho
                 h->chain_mode = 0;                  // for the rest of THIS call (restored on return)
                 h->tail.want_early = false;
                 h->tail.early_done = false;
-                h->tail.w_done = false;
                 HIPCHK(hipStreamSynchronize(h->stream));
                 HIPCHK(hipStreamSynchronize(h->side_stream));
                 if (h->aux_stream) HIPCHK(hipStreamSynchronize(h->aux_stream));
@@ -167,10 +165,6 @@ extern "C" int gpmpc_fit(gpmpc_gp* h, const double* hyper, int want_invK, int* i
     CHK(upload_mean_and_residual(h, hyper, h->Ny, kpart, &h->mpar, h->Y, &h->Yc));
     alpha_ready(h);                      // (a previous fit's alpha launches on the workers' queue: ordered before this fit's)
     bool alpha_on_side = false;
-    // (the overlapped route forms w next to the inverse's last product: factor_chain)
-    h->tail.w_y = want_invK ? nullptr : h->y_model();
-    h->tail.w_sy = h->Np;
-    struct ClearW { TailState& t; ~ClearW() { t.w_y = nullptr; } } clear_w{h->tail};
     CHK(factor_with_jitter(h, h->ws, kpart.data(), info, [&]() {
         static const bool alpha_side_env = !(getenv("GPMPC_ALPHA_SIDE") && atoi(getenv("GPMPC_ALPHA_SIDE")) == 0);
         alpha_on_side = h->tail.early_done && alpha_side_env && !want_invK && h->side_stream;
@@ -182,12 +176,11 @@ extern "C" int gpmpc_fit(gpmpc_gp* h, const double* hyper, int want_invK, int* i
             hipStreamWaitEvent(h->side_stream, h->tail.ev_tail, 0);
             cs.stream = h->side_stream;
             ProfScope t(&h->prof, h->side_stream, GPMPC_PH_SOLVE);
-            solve_alpha(cs, h->ws, h->y_model(), h->Np, TailState::get(h->tail.ev_w), h->tail.w_done);
+            solve_alpha(cs, h->ws, h->y_model(), h->Np, TailState::get(h->tail.ev_w));
             hipEventRecord(TailState::get(h->tail.ev_alpha), h->side_stream);
         } else {
             PhaseTimer t(h, GPMPC_PH_SOLVE);
-            if (h->tail.w_done) hipStreamWaitEvent(h->stream, h->tail.ev_w, 0);      // (w was formed on the workers' queue)
-            solve_alpha(h->cx(), h->ws, h->y_model(), h->Np, nullptr, h->tail.w_done);
+            solve_alpha(h->cx(), h->ws, h->y_model(), h->Np);
         }
         if (want_invK) {
             PhaseTimer t(h, GPMPC_PH_INVK);
@@ -200,7 +193,6 @@ extern "C" int gpmpc_fit(gpmpc_gp* h, const double* hyper, int want_invK, int* i
     h->hyper.assign(hyper, hyper + (size_t)h->Ny * nh);
     h->fitted = true;
     // the first large prediction behind this fit may start next to the inverse's tail (predict_chunk)
-    if (h->tail.w_done) ++h->n_early_w;
     h->tail.alpha_pending = alpha_on_side;
     h->tail.armed = h->tail.early_done && !want_invK;
     return GPMPC_OK;

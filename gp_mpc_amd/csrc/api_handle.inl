@@ -28,7 +28,6 @@ struct gpmpc_gp {
     static constexpr int CHAIN_STRIKES = 3, CHAIN_REARM = 64;
     int chain_strikes = 0, chain_parked = 0;
     long n_timeouts = 0, n_chained = 0, n_single = 0;   // gpmpc_get_counter
-    long n_early_w = 0;                                  // fits whose w = L^-1 y was formed next to the inverse's last product
     long n_var_persist = 0;                              // variance products through the persistent static-schedule kernel
     long n_behind_tail = 0;                              // predictions that started next to a fit's tail (predict_behind_tail)
     long train_iters = 0, train_evals = 0;              // of the last gpmpc_train_multistart (this rank's restarts)
@@ -282,7 +281,7 @@ int gpmpc_destroy(gpmpc_gp* h) {
         for (auto& pr : h->prof.ev[ph]) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
     for (auto e : h->prof.pool) hipEventDestroy(e);
     if (h->ev_info) hipEventDestroy(h->ev_info);
-    for (hipEvent_t e : {h->tail.ev_chain, h->tail.ev_tail, h->tail.ev_alpha, h->tail.ev_ks, h->tail.ev_mean, h->tail.ev_w, h->tail.ev_pre})
+    for (hipEvent_t e : {h->tail.ev_chain, h->tail.ev_tail, h->tail.ev_alpha, h->tail.ev_ks, h->tail.ev_mean, h->tail.ev_w})
         if (e) hipEventDestroy(e);
     if (h->pin) hipHostFree(h->pin);
     if (h->io_pin) hipHostFree(h->io_pin);
@@ -377,7 +376,6 @@ int gpmpc_get_counter(gpmpc_gp* h, const char* name, long* value) {
     else if (std::strcmp(name, "single_queue_factorisations") == 0) *value = h->n_single;
     else if (std::strcmp(name, "predictions_behind_tail") == 0) *value = h->n_behind_tail;
     else if (std::strcmp(name, "persistent_variance_products") == 0) *value = h->n_var_persist;
-    else if (std::strcmp(name, "w_next_to_tail") == 0) *value = h->n_early_w;
     else if (std::strcmp(name, "train_iterations") == 0) *value = h->train_iters;
     else if (std::strcmp(name, "train_evaluations") == 0) *value = h->train_evals;
     else if (std::strcmp(name, "workspace_blocks_reused") == 0 || std::strcmp(name, "workspace_blocks_fresh") == 0) {

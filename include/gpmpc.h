@@ -109,8 +109,7 @@ int gpmpc_synchronize(gpmpc_gp* h);
  * after three consecutive time-outs the handle stays on the single-queue path for 64 fits.  Handles of one process
  * take turns for the factorisation itself.  Counters: "handoff_timeouts", "chained_factorisations",
  * "single_queue_factorisations", "predictions_behind_tail" (see gpmpc_fit), "persistent_variance_products" (variance products
- * of gpmpc_predict_mean_var that ran as one persistent launch over a static tile schedule, vargemm_persist.hpp), "w_next_to_tail"
- * (fits whose w = L^-1 y was formed next to the last product of the inverse instead of behind it); process-wide: "workspace_blocks_fresh" / "workspace_blocks_reused" (the N x N blocks
+ * of gpmpc_predict_mean_var that ran as one persistent launch over a static tile schedule, vargemm_persist.hpp); process-wide: "workspace_blocks_fresh" / "workspace_blocks_reused" (the N x N blocks
  * of a workspace, >= 64 MB, come from size classes and return to a free list: gpmpc_append at large N re-uses what the
  * previous append gave back instead of paying for fresh multi-GB allocations). */
 int gpmpc_get_counter(gpmpc_gp* h, const char* name, long* value);

@@ -292,9 +292,6 @@ def check_predict_behind_tail(lib, N, d, B, sn=0.1, seed=77, strict=True, expect
         assert np.max(np.abs(mean - mean2)) <= 1e-13 * np.abs(om).max()
     if expect_overlap is not None:
         assert (h.counter('predictions_behind_tail') == repeats) == bool(expect_overlap), h.counter('predictions_behind_tail')
-        # (the same fits form w = L^-1 y next to the inverse's last product, unless switched off: GPMPC_EARLY_W=0)
-        if os.environ.get('GPMPC_EARLY_W', '1') != '0':
-            assert (h.counter('w_next_to_tail') == repeats) == bool(expect_overlap), h.counter('w_next_to_tail')
     f = h.get_factors()
     assert relF(f['chol'][0], o['chol'][0]) <= 1e-10
     assert np.max(np.abs(f['alpha'][0] - o['alpha'][0])) <= 1e-9 * np.abs(o["alpha"][0]).max() * (0.1 / sn) ** 2
