@@ -70,12 +70,25 @@ __device__ __forceinline__ bool wg_wait2(const int* f0, int v0, const int* f1, i
                                          int errcode = 2) {
     if (threadIdx.x == 0) {
         int ok = 1, spins = 0;
+#ifdef GPMPC_POLL_SERIAL   // (r01-r04a: flag, sleep, error word -- two memory round trips per look)
         while (flag_load(f0) < v0 || (f1 && flag_load(f1) < v1)) {
             __builtin_amdgcn_s_sleep(8);
             if (flag_load(err) != 0) { ok = 0; break; }
+#else
+        for (;;) {
+            // the flag(s) and the error word of one look travel together: ONE round trip (~1 us across XCDs) per look
+            const int a = flag_load(f0), b = f1 ? flag_load(f1) : v1, e = flag_load(err);
+            if (a >= v0 && b >= v1) break;
+            if (e != 0) { ok = 0; break; }
+            __builtin_amdgcn_s_sleep(8);
+#endif
+#ifdef GPMPC_POLL_SERIAL
             if (++spins > limit) {                 // errcode tells the host who gave up, err[-..] what it last saw
-                const int a = flag_load(f0) >= v0, b = !f1 || flag_load(f1) >= v1;   // which one is missing
-                flag_store(err, errcode + 100000000 * a + 200000000 * b);
+#else
+            if (++spins > 2 * limit) {             // (a look takes half the time: the give-up TIME stays what the host chose)
+#endif
+                const int ma = flag_load(f0) >= v0, mb = !f1 || flag_load(f1) >= v1;   // which one is missing
+                flag_store(err, errcode + 100000000 * ma + 200000000 * mb);
                 ok = 0;
                 break;
             }
