@@ -418,9 +418,7 @@ static bool factor_chain(const Ctx& cx, Workspace& ws, int spin_limit, bool flag
     // tile owners only (r03 A/B on one box: factor 1.675 -> 1.630 ms at C2 with the courier)
     static const bool worker_courier_env = !(getenv("GPMPC_COURIER") && atoi(getenv("GPMPC_COURIER")) == 0);
     const bool worker_courier = g_worker_courier >= 0 ? g_worker_courier != 0 : worker_courier_env;   // (gpmpc_set_tuning("worker_courier", ..))
-    // two couriers (GPMPC_COURIER=2 / tuning 2): one per stage (chol_worker.hpp)
-    static const int courier_count_env = getenv("GPMPC_COURIER") ? atoi(getenv("GPMPC_COURIER")) : 1;
-    const int ncour = !worker_courier ? 0 : (g_worker_courier >= 0 ? g_worker_courier : courier_count_env) >= 2 ? 2 : 1;
+    const int ncour = worker_courier ? 1 : 0;
     const int worker_maxt = worker_courier ? WORKER_MAXT_COURIER : WORKER_MAXT;
     if (NW > ntiles + ncour) NW = ntiles + ncour;
     const bool use_workers = NW >= 1 + ncour && nb >= 3 && (ntiles + (NW - ncour) - 1) / (NW - ncour) <= worker_maxt;
@@ -561,7 +559,7 @@ static bool factor_chain(const Ctx& cx, Workspace& ws, int spin_limit, bool flag
             auto* worker = worker_courier ? chol_worker_kernel<WORKER_MAXT_COURIER, true> : chol_worker_kernel<WORKER_MAXT, false>;
             hipLaunchKernelGGL(worker, dim3(nws[i], 1, ws.batch), dim3(WORKER_THREADS), WORKER_LDS_BYTES, cx.side,
                                ws.K, ws.L, (const double*)ws.Inv, ld, sM, nb, ws.flags, (long)nf, cx.crow_mode, spin_limit,
-                               r[i] / 64, i + 1 < L ? (r[i + 1] - r[i]) / 64 : nb, ready, g_chain_trace, worker_lookahead ? 1 : 0, worker_wt_publish(), ncour);
+                               r[i] / 64, i + 1 < L ? (r[i + 1] - r[i]) / 64 : nb, ready, g_chain_trace, worker_lookahead ? 1 : 0, worker_wt_publish());
             if (i + 1 < L) hipEventRecord(cx.seg[i], cx.side);        // launch i finished: rows P_i of L are final
         }
         const bool own_events = ev0 + P + 2 < cx.n_seg - 2;

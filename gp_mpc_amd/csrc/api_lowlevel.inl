@@ -110,7 +110,7 @@ extern "C" int gpmpc_set_tuning(const char* name, int value) {
         return GPMPC_OK;
     }
     if (std::strcmp(name, "worker_courier") == 0) {      // which worker kernel the chained factorisation launches (chol_worker.hpp)
-        if (value < -1 || value > 2) return fail(GPMPC_EINVAL, "worker_courier must be -1 (default), 0, 1 or 2 (one courier per stage)");
+        if (value < -1 || value > 1) return fail(GPMPC_EINVAL, "worker_courier must be -1 (default), 0 or 1");
         g_worker_courier = value;
         return GPMPC_OK;
     }

@@ -70,7 +70,7 @@ template <int MAXT, bool COURIER>
 __global__ void __launch_bounds__(WORKER_THREADS) chol_worker_kernel(double* Kmat, double* L, const double* Inv, long ld,
                                                                      long sBatch, int nb_all, int* flags, long sFlags,
                                                                      int crow_mode, int spin_limit, int kb, int ksteps,
-                                                                     int* ready, long long* trace, int lookahead, int wt, int ncour) {
+                                                                     int* ready, long long* trace, int lookahead, int wt) {
     // optional time stamps (100 MHz wall clock) for tools/worker_trace.py: [launch][worker][step][4] from entry 4096 on
 #ifdef GPMPC_EMULATED
 #define WORKER_STAMP(i) ((void)0)
@@ -86,8 +86,8 @@ __global__ void __launch_bounds__(WORKER_THREADS) chol_worker_kernel(double* Kma
     // With `courier` the LAST workgroup of the launch is not a tile owner but the courier of the chain (see below); the
     // others are the NW regular workers.
     constexpr bool has_courier = COURIER;              // (the launch has >= 2 workgroups then: host)
-    const int w = blockIdx.x, NW = has_courier ? (int)gridDim.x - ncour : (int)gridDim.x;
-    const bool is_courier = has_courier && w >= NW;
+    const int w = blockIdx.x, NW = has_courier ? (int)gridDim.x - 1 : (int)gridDim.x;
+    const bool is_courier = has_courier && w == NW;
     // A launch works on the trailing matrix from block kb on, for `ksteps` panel steps: everything below is
     // written for kb = 0 and made relative by shifting the base pointers and the flag arrays by kb.
     const int nb = nb_all - kb;
@@ -241,74 +241,58 @@ __global__ void __launch_bounds__(WORKER_THREADS) chol_worker_kernel(double* Kma
     // stored to K behind their update of step k - 1; handed[k] counts them), it spins on the chain's publications and runs
     // the products as their operands appear: L(k+2,k) and the diagonal tile behind inv_kk, the other tile behind the panel row.
     if (is_courier) {
-        // role 0: the one courier, both stages.  Two couriers (ncour = 2): role 1 = stage 1 only (L(k+2,k), out ~5 us after
-        // inv_kk), role 2 = stage 2 only -- it holds the two hand-off tiles, fetches L(k+2,k) and L(k+1,k) as soon as both are
-        // out and is not busy with stage 1 when the panel row appears (one courier: row seen 4-6 us late, tiles 9-10 us after it).
-        const int role = ncour == 2 ? 1 + (w - NW) : 0;
         d4 c1[2], c2[2];
         for (int k = 0; k + 2 < nb && k < ksteps; ++k) {
             const int i = k + 2;
             if (tid == 0) flag_store(progress, 1 + 4 * k);
-            const double* s1 = Kb + (long)(64 * i) * ld + 64 * (k + 1);
-            const double* s2 = Kb + (long)(64 * i) * ld + 64 * i;
             // the three tiles with the updates of columns < k: at k = 0 they are in K (K build / previous launch).  They arrive
             // with or after inv_kk (time stamps, tools/courier_trace.py), so both are awaited together and everything is
             // requested at once -- a flag poll BEHIND the tile loads would wait for them (in-order return), 3-4 us.
-            if (role != 2) {
-                if (!wg_wait2(&leafdone[k], 1, k > 0 ? &handed[k] : nullptr, 3, err, spin_limit, slot, 6000000 + 1000 * k)) return;
-                COURIER_STAMP(0);
-                // stage 1: L(i,k) like every other tile of the panel column -- the workers' step k waits for the whole column
-                // (colready) -- and the diagonal tile
-                request_blocks(Kb + (long)(64 * i) * ld + 64 * k, Ib + (long)(64 * k) * ld + 64 * k, 0, true);   // A(i,k), inv_kk -> image 0
-            } else if (k > 0) {
-                if (!wg_wait2(&handed[k], 3, nullptr, 0, err, spin_limit, slot, 6100000 + 1000 * k)) return;
-            }
-            if (role != 1) {
+            if (!wg_wait2(&leafdone[k], 1, k > 0 ? &handed[k] : nullptr, 3, err, spin_limit, slot, 6000000 + 1000 * k)) return;
+            COURIER_STAMP(0);
+            const double* s1 = Kb + (long)(64 * i) * ld + 64 * (k + 1);
+            const double* s2 = Kb + (long)(64 * i) * ld + 64 * i;
+            // stage 1: L(i,k) like every other tile of the panel column -- the workers' step k waits for the whole column
+            // (colready) -- and the diagonal tile
+            request_blocks(Kb + (long)(64 * i) * ld + 64 * k, Ib + (long)(64 * k) * ld + 64 * k, 0, true);   // A(i,k), inv_kk -> image 0
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    c1[0][r] = at_byte(s1 + r * cstep, csub); c1[1][r] = at_byte(s1 + r * cstep, csub + 128u);
-                    c2[0][r] = at_byte(s2 + r * cstep, csub); c2[1][r] = at_byte(s2 + r * cstep, csub + 128u);
-                }
+            for (int r = 0; r < 4; ++r) {
+                c1[0][r] = at_byte(s1 + r * cstep, csub); c1[1][r] = at_byte(s1 + r * cstep, csub + 128u);
+                c2[0][r] = at_byte(s2 + r * cstep, csub); c2[1][r] = at_byte(s2 + r * cstep, csub + 128u);
             }
-            if (role != 2) {
-                COURIER_STAMP(1);
-                dma_wait<0>();
-                __syncthreads();
-                d4 acc[2] = {d4{0.0, 0.0, 0.0, 0.0}, d4{0.0, 0.0, 0.0, 0.0}};
-                product(0, acc[0], acc[1], false);                                                     // L(i,k)
-                double* dl = Lb + (long)(64 * i) * ld + 64 * k;
+            COURIER_STAMP(1);
+            dma_wait<0>();
+            __syncthreads();
+            d4 acc[2] = {d4{0.0, 0.0, 0.0, 0.0}, d4{0.0, 0.0, 0.0, 0.0}};
+            product(0, acc[0], acc[1], false);                                                     // L(i,k)
+            double* dl = Lb + (long)(64 * i) * ld + 64 * k;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    st_pub(dl + r * cstep, csub, acc[0][r], wt);
-                    st_pub(dl + r * cstep, csub + 128u, acc[1][r], wt);
-                }
-                GPMPC_DRAIN_VM();                                                                      // L(i,k) is out: the column count
-                if (role == 0) tile_to_image(acc[0], acc[1], WORKER_PAIR_BYTES);                       // ... -> image 1, A part
-                __syncthreads();
-                if (tid == 0) {
-                    WORKER_RELEASE();
-                    GPMPC_DRAIN_VM();
-                    flag_store(&row2done[k], 1);
-                    const int before = __hip_atomic_fetch_add(&pancount[k], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (before + 1 == nb - k - 2) flag_store(&colready[k], 1);
-                }
-                if (role == 1) { COURIER_STAMP(2); continue; }
+            for (int r = 0; r < 4; ++r) {
+                st_pub(dl + r * cstep, csub, acc[0][r], wt);
+                st_pub(dl + r * cstep, csub + 128u, acc[1][r], wt);
             }
-            // L(i,k) as an operand image: the own product's (role 0: image 1) / fetched below (role 2: image 0)
-            const char* imgL = (const char*)smem + (role == 0 ? WORKER_PAIR_BYTES : 0);
-            if (role == 0) product_ab(imgL, imgL, c2[0], c2[1], true);                                 // (i,i)   -= L(i,k) L(i,k)^T
+            GPMPC_DRAIN_VM();                                                                      // L(i,k) is out: the column count
+            tile_to_image(acc[0], acc[1], WORKER_PAIR_BYTES);                                      // ... -> image 1, A part
+            __syncthreads();
+            if (tid == 0) {
+                WORKER_RELEASE();
+                GPMPC_DRAIN_VM();
+                flag_store(&row2done[k], 1);
+                const int before = __hip_atomic_fetch_add(&pancount[k], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (before + 1 == nb - k - 2) flag_store(&colready[k], 1);
+            }
+            const char* img1 = (const char*)smem + WORKER_PAIR_BYTES;
+            product_ab(img1, img1, c2[0], c2[1], true);                                            // (i,i)   -= L(i,k) L(i,k)^T
             double* d1 = Kb + (long)(64 * i) * ld + 64 * (k + 1);
             double* d2 = Kb + (long)(64 * i) * ld + 64 * i;
             COURIER_STAMP(2);                       // (its stores wait until the end: a flag poll behind stores waits for them)
             // stage 2, behind the chain's panel row: the off-diagonal tile, then both go to the chain
-            if (!wg_wait2(&pan1[k], 1, role == 2 ? &row2done[k] : nullptr, 1, err, spin_limit, slot, 6600000 + 1000 * k)) return;
+            if (!wg_wait2(&pan1[k], 1, nullptr, 0, err, spin_limit, slot, 6600000 + 1000 * k)) return;
             COURIER_STAMP(3);
-            request_blocks(role == 2 ? Lb + (long)(64 * i) * ld + 64 * k : nullptr, Lb + (long)(64 * (k + 1)) * ld + 64 * k,
-                           role == 0 ? 1 : 0, role == 2);                                              // (L(i,k),) L(k+1,k) -> B part
+            request_blocks(nullptr, Lb + (long)(64 * (k + 1)) * ld + 64 * k, 1, false);            // L(k+1,k) -> image 1, B part
             dma_wait<0>();
             __syncthreads();
-            if (role == 2) product_ab(imgL, imgL, c2[0], c2[1], true);                                 // (i,i)   -= L(i,k) L(i,k)^T
-            product_ab(imgL, imgL + 32768, c1[0], c1[1], true);                                        // (i,k+1) -= L(i,k) L(k+1,k)^T
+            product_ab(img1, img1 + 32768, c1[0], c1[1], true);                                    // (i,k+1) -= L(i,k) L(k+1,k)^T
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 st_pub(d1 + r * cstep, csub, c1[0][r], wt); st_pub(d1 + r * cstep, csub + 128u, c1[1][r], wt);

@@ -81,20 +81,6 @@ def test_emu_tile_owner_workers_without_courier(emu):
         emu.set_tuning('worker_courier', -1)
 
 
-def test_emu_tile_owner_workers_with_two_couriers(emu):
-    # one courier per stage: the panel tile L(k+2,k) / the two hand-off tiles (chol_worker.hpp, roles 1 and 2); one, two and
-    # (cu_count 16) three worker launches
-    emu.set_tuning('worker_courier', 2)
-    try:
-        pc.check_synthetic(emu, N=560, d=4, Ny=1, B=30, sn=0.1, strict_rel=True)
-        pc.check_synthetic(emu, N=700, d=3, Ny=1, B=10, sn=0.1, strict_rel=True)
-        emu.set_tuning('cu_count', 16)
-        pc.check_synthetic(emu, N=950, d=3, Ny=1, B=10, sn=0.1, strict_rel=True)
-    finally:
-        emu.set_tuning('cu_count', 8)
-        emu.set_tuning('worker_courier', -1)
-
-
 def test_emu_three_worker_launches(emu):
     # Np = 960 with 14 emulated workers: blocks 0-7, 8-11 and 12-14 as three worker launches, the inverse of the
     # left half behind the second and of the third quarter behind the third (factor_chain, split3)

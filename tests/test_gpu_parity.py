@@ -172,17 +172,6 @@ def test_worker_path_without_courier(lib):
         lib.set_tuning('worker_courier', -1)
 
 
-def test_worker_path_with_two_couriers(lib):
-    # one courier per stage (roles 1 and 2 of chol_worker.hpp): 222 owners of up to ten tiles
-    lib.set_tuning('worker_courier', 2)
-    try:
-        pc.check_synthetic(lib, N=4096, d=6, Ny=1, B=100, sn=1e-2, strict_rel=False)
-        pc.check_synthetic(lib, N=4000, d=6, Ny=1, B=50, sn=1e-2, strict_rel=False)
-        pc.check_synthetic(lib, N=4100, d=6, Ny=1, B=50, sn=1e-2, strict_rel=False)
-    finally:
-        lib.set_tuning('worker_courier', -1)
-
-
 def test_small_batch_chunks(lib):
     pc.check_small_batch_chunks(lib, N=2500, d=6, Ny=3)
 
