@@ -85,7 +85,7 @@ __device__ __forceinline__ bool wg_wait2(const int* f0, int v0, const int* f1, i
 #ifdef GPMPC_POLL_SERIAL
             if (++spins > limit) {                 // errcode tells the host who gave up, err[-..] what it last saw
 #else
-            if (++spins > 2 * limit) {             // (a look takes half the time: the give-up TIME stays what the host chose)
+            if ((++spins >> 1) > limit) {          // (a look takes half the time: the give-up TIME stays what the host chose; no 2 * limit: it may be INT_MAX)
 #endif
                 const int ma = flag_load(f0) >= v0, mb = !f1 || flag_load(f1) >= v1;   // which one is missing
                 flag_store(err, errcode + 100000000 * ma + 200000000 * mb);

@@ -166,6 +166,9 @@ def check_synthetic(lib, N, d, Ny, B, sn, strict_rel):
     h = Handle(lib, X, Y)
     info = h.fit(H)
     assert np.all(info == 0)
+    # (a hand-off that gives up falls back to the single-queue path with the same results: it must not hide behind them)
+    if 'GPMPC_SPIN_LIMIT' not in os.environ:
+        assert h.counter('handoff_timeouts') == 0, h.counter('handoff_timeouts')
     f = h.get_factors()
     o = go.fit(X, Y, H, want_invK=False)
     for a in range(Ny):
