@@ -26,3 +26,8 @@ timeout 600 python tools/bench_c3.py 2>gpurun_out/c3.err | grep "C5" > gpurun_ou
 GPMPC_CHAIN_TRACE=gpurun_out/chain_trace_r04.bin timeout 120 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary > /dev/null 2>&1
 python tools/chain_trace.py gpurun_out/chain_trace_r04.bin 64 > gpurun_out/r04_chain_trace.txt 2>&1; head -13 gpurun_out/r04_chain_trace.txt | tail -5
 python tools/worker_trace.py gpurun_out/chain_trace_r04.bin 64 2>&1 | grep -v "^ *[0-9]*a .*-7[0-9][0-9][0-9][0-9][0-9][0-9]" > gpurun_out/r04_worker_trace.txt; rm -f gpurun_out/chain_trace_r04.bin
+# soak (write-through hand-offs, joint polls): 1000 consecutive steps, any hand-off time-out prints a message
+timeout 300 python bench.py --steps 1000 --warmup 3 --no-cpu-baseline --no-secondary 2>gpurun_out/soak_err.log | python -c "
+import json,sys
+d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('soak 1000 steps: value %8.0f  ms/step %.3f  factor %.3f vargemm %.3f' % (d['value'], d['ms_per_step'], d['phases_ms_per_step']['factor'], d['phases_ms_per_step']['vargemm']))" | tee gpurun_out/r04_soak.txt
+echo "time-outs: $(grep -c 'timed out' gpurun_out/soak_err.log)" | tee -a gpurun_out/r04_soak.txt
