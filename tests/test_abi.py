@@ -171,3 +171,16 @@ def test_inline_dpp_instructions_respect_the_operand_hazard():
     assert r.returncode == 0, r.stdout + r.stderr
     n = int(re.search(r'(\d+) DPP instructions checked', r.stdout).group(1))
     assert n >= 800, r.stdout             # the leaf's panel (one copy per kernel since r03) and 16 x 16 inverses are in there
+
+
+def test_every_environment_switch_is_documented():
+    """INTEGRATION.md lists every GPMPC_* variable the library reads (a maintainer of the reference side finds each A/B switch there)."""
+    csrc = os.path.join(ROOT, 'gp_mpc_amd', 'csrc')
+    names = set()
+    for fn in os.listdir(csrc):
+        if fn.endswith(('.inl', '.hpp', '.hip')):
+            names |= set(re.findall(r'getenv\("(GPMPC_[A-Z0-9_]+)"\)', open(os.path.join(csrc, fn)).read()))
+    assert len(names) > 40, len(names)
+    doc = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    missing = sorted(n for n in names if n not in doc)
+    assert not missing, missing
