@@ -170,13 +170,14 @@ static long long* g_chain_trace = nullptr;   // developer aid: GPMPC_CHAIN_TRACE
 // want_inverse = false (value-only NLL evaluations of the restart search): L and the diagonal blocks' inverses I_i only
 // (ws.inv_panels = W); twolevel_inverse_all forms L^-1 from them later, for the matrices that turn out to need it.
 // the chain kernel's publications as write-through stores + flag, no L2 write-back (wg_sync.hpp; GPMPC_CHAIN_WT=0: release fence)
+static int g_handoff_wt = -1;   // gpmpc_set_tuning("handoff_write_through", 0 / 1): both kernels; -1: GPMPC_CHAIN_WT / GPMPC_WORKER_WT or default
 static int chain_wt_publish() {
     static const int v = getenv("GPMPC_CHAIN_WT") ? atoi(getenv("GPMPC_CHAIN_WT")) : 1;
-    return v;
+    return g_handoff_wt >= 0 ? g_handoff_wt : v;
 }
 static int worker_wt_publish() {   // the same for the tile-owner workers and the courier (GPMPC_WORKER_WT)
     static const int v = getenv("GPMPC_WORKER_WT") ? atoi(getenv("GPMPC_WORKER_WT")) : 1;
-    return v;
+    return g_handoff_wt >= 0 ? g_handoff_wt : v;
 }
 static int twolevel_width() {   // block columns per super-panel (GPMPC_TWOLEVEL; 0 / 1 = off)
 #ifdef GPMPC_EMULATED

@@ -114,6 +114,11 @@ extern "C" int gpmpc_set_tuning(const char* name, int value) {
         g_worker_courier = value;
         return GPMPC_OK;
     }
+    if (std::strcmp(name, "handoff_write_through") == 0) {   // hand-offs inside the chained factorisation: write-through stores + drained flag / release fence
+        if (value < -1 || value > 1) return fail(GPMPC_EINVAL, "handoff_write_through must be -1 (default), 0 or 1");
+        g_handoff_wt = value;
+        return GPMPC_OK;
+    }
     if (std::strcmp(name, "vargemm_persist") == 0) {     // variance product: 0 one tile per workgroup, 1 persistent static schedule, 2 ... at any size
         if (value < -1 || value > 2) return fail(GPMPC_EINVAL, "vargemm_persist must be -1 (default), 0, 1 or 2");
         g_vargemm_persist = value;

@@ -282,6 +282,9 @@ int gpmpc_schedule_stats(int mode, int tilesM, int tilesN, int batch, int K, int
  * the device (fault injection: how the tests reach the failure paths of the restart shard); 0 switches it off.
  * "worker_courier": 1 / 0 = the tile-owner worker launches of the chained factorisation run with / without the courier
  * workgroup (two instantiations of one kernel; default 1, or GPMPC_COURIER), -1 back to the default.
+ * "handoff_write_through": 1 = the tiles that cross workgroups inside the chained factorisation (chain kernel, tile-owner
+ * workers, courier) leave as write-through stores followed by a drained flag (default, or GPMPC_CHAIN_WT / GPMPC_WORKER_WT),
+ * 0 = plain stores and an agent-scope release (an L2 write-back) per hand-off, -1 back to the default; same results.
  * "vargemm_persist": the large-batch variance product (gp_functions.py:122-126) as 0 = one 128 x 128 tile per workgroup in
  * the dispatcher's order, 1 = one persistent launch over a static schedule when there are at least two tiles per workgroup
  * slot (default, or GPMPC_VARGEMM_PERSIST), 2 = ... at any size (tests), -1 back to the default; same bits either way.

@@ -81,6 +81,15 @@ def test_emu_tile_owner_workers_without_courier(emu):
         emu.set_tuning('worker_courier', -1)
 
 
+def test_emu_tile_owner_workers_with_release_fence_handoffs(emu):
+    # (the emulator has one coherent memory: this runs the flag protocol of the older publication form, not its fences)
+    emu.set_tuning('handoff_write_through', 0)
+    try:
+        pc.check_synthetic(emu, N=560, d=4, Ny=1, B=30, sn=0.1, strict_rel=True)
+    finally:
+        emu.set_tuning('handoff_write_through', -1)
+
+
 def test_emu_three_worker_launches(emu):
     # Np = 960 with 14 emulated workers: blocks 0-7, 8-11 and 12-14 as three worker launches, the inverse of the
     # left half behind the second and of the third quarter behind the third (factor_chain, split3)

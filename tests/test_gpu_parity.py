@@ -172,6 +172,16 @@ def test_worker_path_without_courier(lib):
         lib.set_tuning('worker_courier', -1)
 
 
+def test_worker_path_with_release_fence_handoffs(lib):
+    # the r01-r03 form of every hand-off inside the chained factorisation (plain stores + agent-scope release) stays selectable
+    lib.set_tuning('handoff_write_through', 0)
+    try:
+        pc.check_synthetic(lib, N=4096, d=6, Ny=1, B=100, sn=1e-2, strict_rel=False)
+        pc.check_synthetic(lib, N=4100, d=6, Ny=1, B=50, sn=1e-2, strict_rel=False)
+    finally:
+        lib.set_tuning('handoff_write_through', -1)
+
+
 def test_small_batch_chunks(lib):
     pc.check_small_batch_chunks(lib, N=2500, d=6, Ny=3)
 
