@@ -317,7 +317,12 @@ __global__ void __launch_bounds__(WORKER_THREADS) chol_worker_kernel(double* Kma
     // `ahead` = 1, written as a state of this ONE loop so that every heavy block (panel product, update pipeline)
     // exists once in the kernel (two copies of the panel product pushed the kernel from 197 to 256 VGPRs + 159 spills).
     int k = 0, ahead = 0;                            // ahead: bit 0 = early panel tiles are due, bit 1 = early hand-off tiles
-    int li[MAXT], lj[MAXT];            // part 3: coordinates of the resident tiles (scalar registers)
+    // part 3: coordinates of the resident tiles as the step began, in LDS behind ti / tj (never rewritten during the step).
+    // (r01-r04a kept them in two int arrays read with a run-time slot index: the compiler put those into scratch, and every
+    // tile of the update began, in the waves that request the next operand pair, with two scratch loads and a wait in front of
+    // the DMA requests -- on the one wave per SIMD whose matrix instructions nobody else can take.)
+    int* lis = tj + MAXT;
+    int* ljs = lis + MAXT;
     unsigned live = 0, urgent = 0, hand = 0, todo = 0;   //     masks: live this step / column k + 1 / next hand-off tiles / not yet updated
     bool early = false, earlyh = false;              //         tiles of column k + 1 wait for inv_{k+1} / hand-off tiles for row k + 3
     bool give = false;                               //         this step hands the tiles of row k + 3 to the courier
@@ -414,11 +419,9 @@ __global__ void __launch_bounds__(WORKER_THREADS) chol_worker_kernel(double* Kma
                 __syncthreads();                           // A, B free again; ti[] visible
             }
         }
-        auto coords = [&](int m, int& ci, int& cj) {   // li[m], lj[m] for a run-time m (scalar selects)
-            ci = li[0]; cj = lj[0];
-#pragma unroll
-            for (int q = 1; q < MAXT; ++q)
-                if (q == m) { ci = li[q]; cj = lj[q]; }
+        auto coords = [&](int m, int& ci, int& cj) {   // coordinates of slot m for a run-time m: two broadcast LDS reads
+            ci = __builtin_amdgcn_readfirstlane(lis[m]);
+            cj = __builtin_amdgcn_readfirstlane(ljs[m]);
         };
         // order of part 3: panel tiles of the next step, then its hand-off tiles, then by slot
         auto pick = [&](unsigned t) {
@@ -458,15 +461,15 @@ __global__ void __launch_bounds__(WORKER_THREADS) chol_worker_kernel(double* Kma
         // with a courier: the three tiles of row k + 3 go to it behind this step's update (stored to K, handed[k+1]);
         // they come first, no product of step k + 1 is this worker's any more
         give = has_courier && next_here;
+        if (tid < MAXT) { lis[tid] = ti[tid]; ljs[tid] = tj[tid]; }   // (read behind the barriers of the wait below)
 #pragma unroll
         for (int n = 0; n < MAXT; ++n) {
-            li[n] = __builtin_amdgcn_readfirstlane(ti[n]);
-            lj[n] = __builtin_amdgcn_readfirstlane(tj[n]);
-            if (li[n] >= 0 && lj[n] > k) {
+            const int in = __builtin_amdgcn_readfirstlane(ti[n]), jn = __builtin_amdgcn_readfirstlane(tj[n]);
+            if (in >= 0 && jn > k) {
                 live |= 1u << n;
-                if (give && li[n] == k + 3) hand |= 1u << n;
-                else if (look && lj[n] == k + 1) urgent |= 1u << n;
-                else if (look && !has_courier && li[n] == k + 3 && lj[n] >= k + 2) hand |= 1u << n;
+                if (give && in == k + 3) hand |= 1u << n;
+                else if (look && jn == k + 1) urgent |= 1u << n;
+                else if (look && !has_courier && in == k + 3 && jn >= k + 2) hand |= 1u << n;
             }
         }
         if (live == 0) { ++k; continue; }
@@ -520,7 +523,9 @@ __global__ void __launch_bounds__(WORKER_THREADS) chol_worker_kernel(double* Kma
                 }
                 update(pp, C[n][0], C[n][1]);
                 if (give && ((hand >> n) & 1u)) {      // a tile of row k + 3: to K for the courier, retired here
-                    double* dst = Kb + (long)(64 * li[n]) * ld + 64 * lj[n];
+                    int gi, gj;
+                    coords(n, gi, gj);
+                    double* dst = Kb + (long)(64 * gi) * ld + 64 * gj;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         st_pub(dst + r * cstep, csub, C[n][0][r], wt);
