@@ -184,3 +184,27 @@ def test_every_environment_switch_is_documented():
     doc = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
     missing = sorted(n for n in names if n not in doc)
     assert not missing, missing
+
+
+def test_hot_kernels_keep_their_register_budget():
+    """Resource regressions the compiler makes silently (tools/kernel_resources.py, a cross-compile of the gfx950 code):
+    the worker kernels without scratch (r04: two coordinate arrays with a run-time index had been put there, two scratch
+    loads in front of every tile's DMA requests), no vector spills in the chain and worker kernels, the persistent variance
+    product inside the 116 registers that leave room for a fifth wave per SIMD."""
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'kernel_resources.py')], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    rows = {}
+    for line in r.stdout.splitlines()[1:]:
+        m = re.match(r'(.{58}) +(\S+) +(\S+) +(\S+) +(\S+) +(\S+) +(\S+) +(\S+)$', line)
+        if m:
+            rows[m.group(1).strip()] = [int(x) if x.isdigit() else -1 for x in m.groups()[1:]]
+    workers = [k for k in rows if 'chol_worker_kernel' in k]
+    assert len(workers) == 2, sorted(rows)[:5]
+    for k in workers:
+        vgpr, agpr, vspill, sspill, scratch, occ, lds = rows[k]
+        assert scratch == 0 and vspill == 0 and vgpr <= 256 and occ >= 2, (k, rows[k])
+    chain = rows['gpmpc::chol_chain_kernel']
+    assert chain[2] == 0 and chain[4] == 0, chain
+    var = rows['gpmpc::vargemm_persist_kernel']
+    assert var[0] <= 116 and var[5] >= 4, var
