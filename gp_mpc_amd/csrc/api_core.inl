@@ -205,6 +205,15 @@ static hipError_t block_alloc(double** out, size_t bytes) {
     return e;
 }
 
+// bytes the idle list holds on `dev` (handed out again before any fresh allocation: they count as free for sizing decisions)
+static size_t block_list_idle_bytes(int dev) {
+    std::lock_guard<std::mutex> lk(g_block_mutex);
+    size_t s = 0;
+    for (const DevBlock& b : g_free_blocks)
+        if (b.dev == dev) s += b.cls;
+    return s;
+}
+
 static void block_free(double* p) {
     if (!p) return;
     (void)hipDeviceSynchronize();      // what hipFree implies: nothing in flight may still touch a block that is handed out again

@@ -516,6 +516,11 @@ static bool factor_chain(const Ctx& cx, Workspace& ws, int spin_limit, bool flag
                            ws.L, ws.Inv, ld, sM, nb, ws.flags, (long)nf, ws.info, cx.crow_mode, spin_limit, g_chain_trace,
                            use_workers && merge_publish ? 1 : 0, 0, -1, late_polls, wt_publish);
     }
+    // Early status (below): ev_chain marks the END OF THE CHAIN KERNEL, so it is recorded here, while that kernel is the main
+    // queue's last entry (GPMPC_EV_CHAIN_LATE=1, tuning aid: behind the join with the workers' queue as r04 had it).
+    static const bool ev_chain_late = getenv("GPMPC_EV_CHAIN_LATE") && atoi(getenv("GPMPC_EV_CHAIN_LATE")) != 0;
+    const bool early_status = cx.tail && cx.tail->want_early && use_workers && split;
+    if (early_status && !ev_chain_late) hipEventRecord(TailState::get(cx.tail->ev_chain), cx.stream);
     static const bool verbose = getenv("GPMPC_VERBOSE") != nullptr;
     // (tuning aid) GPMPC_WORKER_LOOKAHEAD=0: the workers turn a panel tile into L(i,k) only at the top of step k
     static const bool worker_lookahead = !(getenv("GPMPC_WORKER_LOOKAHEAD") && atoi(getenv("GPMPC_WORKER_LOOKAHEAD")) == 0);
@@ -645,12 +650,13 @@ static bool factor_chain(const Ctx& cx, Workspace& ws, int spin_limit, bool flag
     }
     hipEventRecord(cx.join, cx.side);
     hipStreamWaitEvent(cx.stream, cx.join, 0);
-    if (cx.tail && cx.tail->want_early && use_workers && split) {
+    if (early_status) {
         // Early status: the pivot word and the hand-off words are final when the chain kernel ends (the chain cannot
         // finish unless every worker launch became resident and delivered; nothing behind it polls).  The workers'
-        // queue is idle by then: it waits for the chain kernel and copies them, the caller waits on ev_info.
+        // queue has nothing left but its last launch's drain by then: it waits for the chain kernel's event and copies
+        // them, the caller waits on ev_info.  (The main queue meanwhile waits for the join above, i.e. for the workers.)
         TailState& ts = *cx.tail;
-        hipEventRecord(TailState::get(ts.ev_chain), cx.stream);          // (the chain kernel is the main queue's last entry here)
+        if (ev_chain_late) hipEventRecord(TailState::get(ts.ev_chain), cx.stream);
         hipStreamWaitEvent(cx.side, ts.ev_chain, 0);
         hipMemcpyAsync(ts.pin_info, ws.info, ts.nb * sizeof(int), hipMemcpyDeviceToHost, cx.side);
         hipMemcpyAsync(ts.cerr, ws.flags, ts.nflag * sizeof(int), hipMemcpyDeviceToHost, cx.side);
@@ -738,14 +744,26 @@ struct SchedKey {
         return std::tie(device, mode, tilesM, tilesN, batch, K, slots) < std::tie(o.device, o.mode, o.tilesM, o.tilesN, o.batch, o.K, o.slots);
     }
 };
-static std::map<SchedKey, VarSchedDev> g_sched_cache;
+struct SchedEntry { VarSchedDev v; long stamp; };
+static std::map<SchedKey, SchedEntry> g_sched_cache;
 static std::mutex g_sched_mutex;
+static long g_sched_clock = 0;
+constexpr size_t SCHED_CACHE_MAX = 96;           // distinct (shape, subset size) schedules kept per process; the least recently used goes
 
 static int get_schedule(int device, int mode, int tilesM, int tilesN, int batch, int K, int slots, VarSchedDev* out) {
     std::lock_guard<std::mutex> lk(g_sched_mutex);
     const SchedKey key{device, mode, tilesM, tilesN, batch, K, slots};
     auto it = g_sched_cache.find(key);
-    if (it != g_sched_cache.end()) { *out = it->second; return GPMPC_OK; }
+    if (it != g_sched_cache.end()) { it->second.stamp = ++g_sched_clock; *out = it->second.v; return GPMPC_OK; }
+    if (g_sched_cache.size() >= SCHED_CACHE_MAX) {       // (a lock-step search asks for one schedule per subset size m)
+        auto old_it = g_sched_cache.begin();
+        for (auto jt = g_sched_cache.begin(); jt != g_sched_cache.end(); ++jt)
+            if (jt->second.stamp < old_it->second.stamp) old_it = jt;
+        (void)hipDeviceSynchronize();                     // a launch that still walks the evicted lists must be through
+        hipFree(old_it->second.v.list);
+        hipFree(old_it->second.v.off);
+        g_sched_cache.erase(old_it);
+    }
     const VarSchedule s = mode == PG_VAR ? var_schedule(tilesM, tilesN, batch, K, slots) : xtx_schedule(tilesM, batch, K, slots);
     VarSchedDev v;
     v.mode = mode; v.tilesM = tilesM; v.tilesN = tilesN; v.batch = batch; v.K = K; v.slots = slots;
@@ -757,7 +775,7 @@ static int get_schedule(int device, int mode, int tilesM, int tilesN, int batch,
         std::fprintf(stderr, "gpmpc: %s schedule %d x %d x %d tiles on %d slots: heaviest slot %.0f half slabs, mean %.1f (+%.2f %%), %d of %d tiles at home\n",
                      mode == PG_VAR ? "variance" : "K^-1", tilesM, tilesN, batch, slots, s.max_load, s.mean_load,
                      100.0 * (s.max_load / s.mean_load - 1.0), s.home, (int)s.list.size());
-    g_sched_cache[key] = v;
+    g_sched_cache[key] = SchedEntry{v, ++g_sched_clock};
     *out = v;
     return GPMPC_OK;
 }

@@ -52,7 +52,9 @@ static int factor_with_jitter(gpmpc_gp* h, Workspace& ws, const double* hyper_ho
     if (h->chain_parked > 0) h->chain_mode = 0;
     struct Restore { gpmpc_gp* h; int m; ~Restore() { h->chain_mode = m; } } restore{h, mode_configured};
     std::unique_lock<std::mutex> turn(g_factor_mutex[h->device], std::defer_lock);
-    if (h->chain_mode) turn.lock();               // held until the status words are back, i.e. the factorisation is done
+    if (h->chain_mode) turn.lock();               // held until the status words are back: the chain kernel and the worker launches have
+                                                  // ended (what needs the whole chip); with early status the inverse's tail -- plain
+                                                  // launches that share the device like any others -- may still be in flight
     for (int attempt = 0; attempt < max_attempts; ++attempt) {
         HIPCHK(hipMemcpyAsync(ws.jitter, jit.data(), nb * sizeof(double), hipMemcpyHostToDevice, h->stream));
         // (TailState) with the tile-owner workers the status words come back when the chain kernel ends, on the workers'
@@ -448,6 +450,10 @@ extern "C" int gpmpc_set_factors(gpmpc_gp* h, const double* hyper, const double*
         std::vector<double> tmp((size_t)h->Ny * h->Np, 0.0);
         for (int a = 0; a < h->Ny; ++a) std::memcpy(tmp.data() + (size_t)a * h->Np, alpha + (size_t)a * h->N, h->N * sizeof(double));
         HIPCHK(hipMemcpy(h->ws.alpha, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice));
+        // the persistent variance product takes its mean from w = L^-1 y (api_predict.inl, fused mean): form it from the
+        // imported factor even though the caller's alpha is kept as given
+        hipLaunchKernelGGL(gemv_rows_kernel, dim3(h->Np / 4, h->ws.batch), dim3(256), 0, h->stream, h->ws.Inv, h->y_model(), h->ws.w,
+                           h->Np, h->ws.mat(), (long)h->Np, (long)h->Np, 1);
     } else {
         solve_alpha(h->cx(), h->ws, h->y_model(), h->Np);
     }

@@ -209,7 +209,22 @@ static int ensure_batch_ws(gpmpc_gp* h, int want) {
     hipFree(h->bYc); hipFree(h->bmpar); hipFree(h->bgradPartial); hipFree(h->bgradOut); hipFree(h->bzmap);
     h->bYc = h->bmpar = h->bgradPartial = h->bgradOut = nullptr;
     h->bzmap = nullptr;
-    CHK(ws_alloc(h->bws, want, Np, d));
+    {
+        // what the device has free now (the old batch workspace is released), less 10 % and 1 GB of headroom: a smaller or
+        // busier device gets a smaller batch instead of GPMPC_ENOMEM
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 0) {
+            const double usable = 0.9 * (double)(free_b + block_list_idle_bytes(h->device)) - 1.0e9;
+            want = std::max(1, std::min(want, (int)std::max(1.0, usable / per_point)));
+        }
+    }
+    int arc = ws_alloc(h->bws, want, Np, d);
+    while (arc != GPMPC_OK && want > 1) {        // still too large (fragmentation): halve until it fits
+        ws_free(h->bws);
+        want = (want + 1) / 2;
+        arc = ws_alloc(h->bws, want, Np, d);
+    }
+    CHK(arc);
     HIPCHK(hipMalloc(&h->bzmap, (size_t)want * sizeof(int)));
     CHK(ws_need_invK(h->bws));
     HIPCHK(hipMalloc(&h->bgradPartial, (size_t)want * (Np / 64) * (Np / 64) * (DMAX + 2) * sizeof(double)));
@@ -389,6 +404,8 @@ static int nll_batch(gpmpc_gp* h, int a, std::vector<NllReq*>& reqs, bool retain
             static const bool skip_inv = !(getenv("GPMPC_TRAIN_SKIP_INVERSE") && atoi(getenv("GPMPC_TRAIN_SKIP_INVERSE")) == 0);
             const bool vonly = wg == 0 && retain && skip_inv && G.size() <= (size_t)cap;
             CHK(nll_batch_core(h, a, n, &G[b0], wg == 1, 0.0, failed, vonly));
+            const int inv_first = h->lock_inv_panels;   // what this pass left in Inv (one value for the whole batch workspace)
+            bool inv_mixed = false;
             if (verbose)
                 fprintf(stderr, "gpmpc: lock-step batch of %d point%s (%s): %.3f ms, %d to repeat with jitter\n", n, n == 1 ? "" : "s",
                         wg ? "value + gradient" : "value", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(),
@@ -400,12 +417,16 @@ static int nll_batch(gpmpc_gp* h, int a, std::vector<NllReq*>& reqs, bool retain
                 for (int i : failed) again.push_back(G[b0 + i]);
                 std::vector<int> failed2;
                 CHK(nll_batch_core(h, a, (int)again.size(), again.data(), wg == 1, 1e-8, failed2, vonly));
+                // the repeat may have taken another execution than the first pass (a hand-off time-out, a parked chain): the
+                // slots then hold two kinds of Inv and h->lock_inv_panels describes only the repeat's -- retain nothing,
+                // the restarts re-evaluate (train_native.hpp: a refused grad_of_last is a full evaluation)
+                inv_mixed = h->lock_inv_panels != inv_first;
                 // (the repeat ran in the first slots: what was there is gone, the repeated points now live there)
                 const int m = (int)again.size();
                 for (int i = 0; i < m && i < n; ++i) slot_of[i] = -1;
                 for (int j = 0; j < m; ++j) slot_of[failed[j]] = j;
             }
-            if (wg == 0 && retain && G.size() <= (size_t)cap) {
+            if (wg == 0 && retain && !inv_mixed && G.size() <= (size_t)cap) {
                 for (int i = 0; i < n; ++i) {
                     NllReq* r = G[i];
                     if (r->rc != GPMPC_OK || slot_of[i] < 0 || r->id < 0 || r->id >= (int)h->lock_ret.size()) continue;

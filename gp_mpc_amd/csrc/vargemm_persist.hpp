@@ -74,7 +74,7 @@ __device__ __forceinline__ void persist_gemm_body(const GemmP& p, const int* __r
     unsigned vo[LPW];
     dma_rsrc_t rsA, rsB;
     auto open_request = [&](int word) {
-        const int zw = word >> 24, m0 = ((word >> 12) & 4095) * BM, n0 = (word & 4095) * BN;
+        const int zw = (int)((unsigned)word >> 24), m0 = ((word >> 12) & 4095) * BM, n0 = (word & 4095) * BN;
         const int z = (MODE == PG_XTX && zmap) ? zmap[zw] : zw;     // (zmap: the matrices of a subset of a batch)
         if (MODE == PG_VAR) { rk0 = 0; rnk = (min(p.K, m0 + BM) + BK - 1) / BK; }
         else { rk0 = m0; rnk = (p.K - m0) / BK; }                  // (K is a multiple of 16: gemm_dma_supported)
@@ -115,7 +115,7 @@ __device__ __forceinline__ void persist_gemm_body(const GemmP& p, const int* __r
         if (MODE == PG_VAR && p.partm) {
             // w of the tile's rows for the fused mean: read in the epilogue, at least eight ring barriers from here; the buffer
             // of the previous tile may still be read by a slower wave's epilogue, hence two of them
-            if (tid < BM) wl[par * BM + tid] = (m0 + tid < p.M) ? p.wvec[(long)(word >> 24) * p.sWv + m0 + tid] : 0.0;
+            if (tid < BM) wl[par * BM + tid] = (m0 + tid < p.M) ? p.wvec[(long)((unsigned)word >> 24) * p.sWv + m0 + tid] : 0.0;
             lds_flush();
         }
         if (MODE == PG_VAR) {
@@ -164,7 +164,7 @@ __device__ __forceinline__ void persist_gemm_body(const GemmP& p, const int* __r
         if (++ct < cnk) continue;
 
         // ---- tile finished: its epilogue, then the next tile of the list
-        const int zw = cword >> 24, tm = (cword >> 12) & 4095, m0 = tm * BM, n0 = (cword & 4095) * BN;
+        const int zw = (int)((unsigned)cword >> 24), tm = (cword >> 12) & 4095, m0 = tm * BM, n0 = (cword & 4095) * BN;
         const int z = (MODE == PG_XTX && zmap) ? zmap[zw] : zw;
         if (MODE == PG_VAR) {                                      // column sums of squares over the tile's rows < M
             const bool with_mean = p.partm != nullptr;             // ... and the mean's partial sums sum_m V[m][n] w[m]

@@ -120,6 +120,7 @@ inline hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned, int) { r
 inline hipError_t hipStreamDestroy(hipStream_t s) { emu::drain(); delete s; return hipSuccess; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { emu::drain(); return hipSuccess; }
 inline hipError_t hipDeviceSynchronize() { emu::drain(); return hipSuccess; }
+inline hipError_t hipMemGetInfo(size_t* free_b, size_t* total_b) { *free_b = (size_t)64 << 30; *total_b = (size_t)64 << 30; return hipSuccess; }
 inline hipError_t hipGetLastError() { return hipSuccess; }
 inline hipError_t hipPeekAtLastError() { return hipSuccess; }
 inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess" : "emulated HIP error"; }

@@ -223,6 +223,36 @@ def check_variance_persistent(lib, N, d, Ny, B, sn=0.1, seed=4321):
         h.close()
 
 
+def check_set_factors_persistent_mean(lib, N=300, d=4, Ny=1, B=200, seed=77):
+    """load_model / checkpoint path (gp_class.py:58-66: hyper, chol, alpha handed over, no training) followed by a large
+    batch that takes the persistent variance product: its fused mean reads w = L^-1 y, which `gpmpc_set_factors` must form
+    from the imported factor even when the caller supplies alpha (r04 advisor finding: an all-zero mean)."""
+    p = go.synthetic_problem(N, d, Ny, B, seed=seed, sn=0.1)
+    X, Y, H, Z = p['X'], p['Y'], p['hyper'], p['Z']
+    o = go.fit(X, Y, H, want_invK=False)
+    om, ov, _ = go.mean_var_jac(Z, X, H, o['alpha'], o['chol'], False)
+    sc = mean_scale(X, Z, H, o['alpha'])
+    try:
+        lib.set_tuning('gemm_tile', 128)
+        lib.set_tuning('vargemm_persist', 2)
+        for with_alpha in (True, False):
+            h = Handle(lib, X, Y)
+            h.set_factors(H, o['chol'], o['alpha'] if with_alpha else None)
+            m, v = h.predict_mean_var(Z)
+            assert h.counter('persistent_variance_products') >= 1
+            assert np.max(np.abs(m - om) / sc) <= 1e-10, (with_alpha, np.max(np.abs(m - om)), np.abs(om).max())
+            assert np.max(np.abs(v - ov) / H[:, d] ** 2) <= 1e-10
+            # ... and after a stale w: a fit at other hyper-parameters, then the stored factors again on the same handle
+            assert np.all(h.fit(H * 1.3) == 0)
+            h.set_factors(H, o['chol'], o['alpha'] if with_alpha else None)
+            m, v = h.predict_mean_var(Z)
+            assert np.max(np.abs(m - om) / sc) <= 1e-10
+            h.close()
+    finally:
+        lib.set_tuning('gemm_tile', 0)
+        lib.set_tuning('vargemm_persist', -1)
+
+
 class DevArray:
     """A double array in device memory for the device-pointer entry points: hipMalloc / hipMemcpy through the HIP runtime
     the library is linked against (ctypes, no torch: one HIP runtime per process); under the emulator device memory is

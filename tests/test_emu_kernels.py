@@ -292,3 +292,7 @@ def test_emu_training_beats_failed_reference_search(emu, train_small3):
 
 def test_emu_training_never_worse(emu):
     pc.check_training_never_worse(emu, n_cases=4)
+
+
+def test_emu_set_factors_then_persistent_mean(emu):
+    pc.check_set_factors_persistent_mean(emu)

@@ -314,3 +314,8 @@ def test_training_beats_failed_reference_search(lib, train_small3):
 
 def test_training_never_worse(lib):
     pc.check_training_never_worse(lib, n_cases=10)
+
+
+@pytest.mark.gpu
+def test_set_factors_then_persistent_mean(lib):
+    pc.check_set_factors_persistent_mean(lib)
