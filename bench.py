@@ -38,9 +38,18 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-for p in (ROOT, os.path.join(ROOT, 'oracle')):
-    if p not in sys.path:
-        sys.path.insert(0, p)
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def _oracle():
+    """The CPU restatement under oracle/ -- imported by the cpu_baseline / parity legs ONLY (after the timed regions): the
+    product legs take their inputs from gp_mpc_amd.synthetic and never see oracle/ on sys.path before this call."""
+    op = os.path.join(ROOT, 'oracle')
+    if op not in sys.path:
+        sys.path.insert(0, op)
+    import gp_oracle
+    return gp_oracle
 
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X datasheet, dense fp64 matrix (not in the local guides)
 
@@ -50,7 +59,7 @@ def cpu_baseline(p, B):
     expanded-form K (optimize.py:303-319), np.linalg.cholesky, LU np.linalg.solve for alpha and for
     v = L^-1 ks (gp_class.py:377-380), var = sf^2 - v^T v."""
     import numpy as np
-    import gp_oracle as go
+    go = _oracle()
     X, Y, H, Z = p['X'], p['Y'], p['hyper'], p['Z']
     d = X.shape[1]
     nsub = min(1000, B)
@@ -104,8 +113,28 @@ def parity_report(gm, gv, cmean, cvar, mscale, sf2):
     return {'mean_maxabs': float(dm.max()), 'mean_rel_to_max': float(dm.max() / np.abs(cmean).max()),
             'mean_max_pointwise_rel': float((dm / np.maximum(np.abs(cmean), 1e-300)).max()),
             'mean_scaled_sum_abs_ks_alpha': float((dm / mscale).max()),
+            'mean_pointwise_floored_1e-3_max': float((dm / np.maximum(np.abs(cmean), 1e-3 * np.abs(cmean).max())).max()),
             'var_maxabs_over_sf2': float(dv.max() / sf2), 'var_max_pointwise_rel': float((dv / np.abs(cvar)).max()),
             'points': int(len(cmean))}
+
+
+def oracle_parity(p, gm, gv, nsub):
+    """GPU against the oracle the parity tests use (oracle/gp_oracle.py `fit` + `mean_var_jac`: direct-difference ks,
+    Cholesky, TRIANGULAR solves -- gp_functions.py:114-126 restated) on the first `nsub` test points of the same inputs."""
+    import numpy as np
+    go = _oracle()
+    X, Y, H, Z = p['X'], p['Y'], p['hyper'], p['Z']
+    d = X.shape[1]
+    t0 = time.perf_counter()
+    o = go.fit(X, Y, H, want_invK=False)
+    om, ov, _ = go.mean_var_jac(Z[:nsub], X, H, o['alpha'], o['chol'], False)
+    secs = time.perf_counter() - t0
+    ks = go.cov_se_ard_direct(X, Z[:nsub], H[0, :d], H[0, d] ** 2)
+    mscale = np.abs(ks).T @ np.abs(o['alpha'][0])
+    rep = parity_report(gm[:nsub], gv[:nsub], om[:, 0], ov[:, 0], mscale, float(H[0, d] ** 2))
+    rep['oracle'] = 'oracle/gp_oracle.py fit + mean_var_jac (triangular solves), the checker of tests/parity_cases.py'
+    rep['oracle_seconds'] = secs
+    return rep
 
 
 _REAL_STDOUT = None
@@ -262,10 +291,10 @@ def timed(rk, h, step, steps, warmup, profile=True, phases=None):
 def run_c3(rk, steps, warmup, N=8192):
     """BASELINE config C3: 6-output GP, N = 8192, d = 8; step = fit (with K^-1) + 30-step ME / TA / EM propagation."""
     import numpy as np
-    import gp_oracle as go
     from gp_mpc_amd._lib import Handle
+    from gp_mpc_amd.synthetic import synthetic_problem
     d, Ny, T = 8, 6, 30
-    p = go.synthetic_problem(N, d, Ny, T, seed=1234 + rk.rank, sn=1e-2)
+    p = synthetic_problem(N, d, Ny, T, seed=1234 + rk.rank, sn=1e-2)
     h = Handle(rk.lib, p['X'], p['Y'], device=rk.dev_index)
     hyper = np.ascontiguousarray(p['hyper'])
     x0, U = p['Z'][0, :Ny], p['Z'][:T, Ny:]
@@ -317,16 +346,17 @@ def run_c3(rk, steps, warmup, N=8192):
     return out
 
 
-def run_c4(rk, steps, warmup, N=4096, d=6, R=64, iters=4):
+def run_c4(rk, steps, warmup, N=4096, d=6, R=64, iters=4, verify_world1=True):
     """BASELINE config C4: log-marginal likelihood + gradient, R random restarts sharded over the ranks: restart r on
     rank r mod world inside gpmpc_train_multistart, ONE ncclAllGather of the (NLL, theta) table over an RCCL communicator
     the library creates (on a CPU test box: the ranks' tables merged over gloo by gp_mpc_amd.train)."""
+    import hashlib
     import numpy as np
-    import gp_oracle as go
     from gp_mpc_amd._lib import Handle
+    from gp_mpc_amd.synthetic import synthetic_problem
     from gp_mpc_amd.train import lhs_starts, bounds_ipopt_path, sharded_multistart
     rank, world = rk.rank, rk.world
-    p = go.synthetic_problem(N, d, 1, 1, seed=1234, sn=1e-2)             # the same problem on every rank (replicated X, y)
+    p = synthetic_problem(N, d, 1, 1, seed=1234, sn=1e-2)             # the same problem on every rank (replicated X, y)
     h = Handle(rk.lib, p['X'], p['Y'], device=rk.dev_index)
     lb, ub = bounds_ipopt_path(d)
     starts = lhs_starts(R, lb, ub, 1234)[None]
@@ -347,6 +377,25 @@ def run_c4(rk, steps, warmup, N=4096, d=6, R=64, iters=4):
     if comm is not None:
         rk.lib.rccl_comm_destroy(comm)
     r = res['r']
+
+    def table_hash(rr):
+        # the gathered (NLL, theta) table and the arg-min theta*, as bytes: equal hashes = bitwise equal tables
+        tab = np.concatenate([np.asarray(rr['obj'], dtype=np.float64)[:, :, None], np.asarray(rr['theta'], dtype=np.float64)], axis=2)
+        return (hashlib.sha256(np.ascontiguousarray(tab).tobytes()).hexdigest()[:16],
+                hashlib.sha256(np.ascontiguousarray(np.asarray(rr['hyper'], dtype=np.float64)).tobytes()).hexdigest()[:16])
+
+    th, hh = table_hash(r)
+    shard_check = {'table_sha16': th, 'theta_star_sha16': hh}
+    if world > 1 and verify_world1:
+        # the same seeds searched by ONE rank (every restart local, no exchange), on rank 0 after the timed region: the
+        # shard is correct iff the two tables are bitwise equal (tests/test_restart_shard.py gates the same on gloo)
+        if rank == 0:
+            r1 = sharded_multistart(h, starts, lb[None], ub[None], max_iter=iters, dist=None, rank=0, world=1, comm=None,
+                                    want_invK=False)
+            t1, h1 = table_hash(r1)
+            shard_check.update({'world1_table_sha16': t1, 'world1_theta_star_sha16': h1,
+                                'bitwise_equal_to_world1': bool(t1 == th and h1 == hh)})
+        rk.sync(h)
     out = {
         'metric': 'GP hyper-parameter training restarts/sec, N=%d d=%d fp64 (%d restarts x %d L-BFGS iterations, NLL + analytic gradient)' % (N, d, R, iters),
         'value': R * steps / elapsed, 'unit': 'restarts/s', 'n_gpus': world, 'steps': steps, 'warmup': warmup,
@@ -354,12 +403,18 @@ def run_c4(rk, steps, warmup, N=4096, d=6, R=64, iters=4):
         'dtype': 'f64', 'data': 'synthetic',
         'config': {'workload': 'C4: %d seeded restarts of the NLL minimisation, restart r on rank r mod world, one all-gather of (NLL, theta)' % R,
                    'N': N, 'd': d, 'restarts': R, 'iterations': iters, 'parallelism': f'restart shard x{world} over RCCL'},
-        'rccl_ranks': rccl_ranks,
+        'rccl_ranks': rccl_ranks, 'shard_check': shard_check,
         'exchange': 'ncclAllGather inside gpmpc_train_multistart' if comm is not None else 'host merge over torch.distributed (no RCCL: test build)',
         'best_nll': float(np.min(r['obj'])), 'finite_restarts': int(np.isfinite(r['obj']).sum()),
         'evaluations_this_rank': int(r['evaluations']), 'restarts_this_rank': len(range(rank, R, world)),
         'device': rk.lib.device_name(rk.dev_index)}
     h.close()
+    # self-validation of a multi-GPU record: the communicator that carried the exchange must span every rank, and the
+    # sharded search must equal the one-rank search bit for bit -- otherwise the job FAILS (rc != 0, no JSON line)
+    if rk.gpu and rccl_ranks != world:
+        raise SystemExit('bench.py: the RCCL communicator of the restart shard has %d ranks, the job has %d' % (rccl_ranks, world))
+    if shard_check.get('bitwise_equal_to_world1') is False:
+        raise SystemExit('bench.py: restart shard over %d ranks differs from the one-rank search of the same seeds: %s' % (world, shard_check))
     return out
 
 
@@ -381,8 +436,8 @@ def main():
         return _launch_ranks(args.gpus)
     import numpy as np
     import torch                     # first: one HIP runtime in the process (torch's), shared by the library
-    import gp_oracle as go
     from gp_mpc_amd._lib import Handle
+    from gp_mpc_amd.synthetic import synthetic_problem
     rk = Ranks()
     rank, local_rank, world = rk.rank, rk.dev_index, rk.world
     lib = rk.lib
@@ -397,7 +452,7 @@ def main():
         return
 
     N, d, B = args.N, args.d, args.B
-    p = go.synthetic_problem(N, d, 1, B, seed=1234 + rank, sn=1e-2)
+    p = synthetic_problem(N, d, 1, B, seed=1234 + rank, sn=1e-2)
     layout, mfma_rate = lib.mfma_selftest(local_rank)
     h = Handle(lib, p['X'], p['Y'], device=local_rank)
     dev = rk.device
@@ -466,6 +521,11 @@ def main():
                                       'note': 'N^3/3 (potrf) + N^3/3 (trtri) flops: blocked right-looking Cholesky + level-batched inverse'},
             'predict_only_per_s': B / max((prof['crosscov'][0] + prof['vargemm'][0] + prof['finish'][0]) / args.steps * 1e-3, 1e-12),
             'device': lib.device_name(local_rank), 'mfma_layout': layout,
+            # the persistent chain / worker kernels assume co-residency; a hand-off that times out falls back to the
+            # single-queue factorisation (correct, slower): on a shared GPU this count says the fast path degraded
+            'handoff_timeouts': int(h.counter('handoff_timeouts')),
+            'chained_factorisations': int(h.counter('chained_factorisations')),
+            'single_queue_factorisations': int(h.counter('single_queue_factorisations')),
         }
         if world == 1 and not args.no_cpu_baseline:
             cb, cmean, cvar, mscale = cpu_baseline(p, B)
@@ -474,14 +534,16 @@ def main():
             out['parity_vs_cpu'] = parity_report(gm, gv, cmean, cvar, mscale, float(p['hyper'][0, d] ** 2))
             out['parity_vs_cpu']['note'] = ('sn = 1e-2: cond(K) ~ 1e7, the CPU path (LU solves) is itself at cond x eps; '
                                             'pointwise-relative figures are dominated by means near zero')
-            # the well-conditioned twin (sn = 0.1) the strict 1e-10 relative bars are gated on (tests: test_c2_full_size_strict_relative_bars)
-            q = go.synthetic_problem(N, d, 1, B, seed=1234 + rank, sn=0.1)
+            out['parity_vs_oracle'] = oracle_parity(p, mean.cpu().numpy()[:, 0], var.cpu().numpy()[:, 0], len(cmean))
+            # the well-conditioned twin (sn = 0.1) the strict 1e-10 relative bars are gated on (tests: test_c2_full_size_rel_to_max_and_floored_pointwise_bars)
+            q = synthetic_problem(N, d, 1, B, seed=1234 + rank, sn=0.1)
             hq = Handle(lib, q['X'], q['Y'], device=local_rank)
             hq.fit(q['hyper'])
             qm, qv = hq.predict_mean_var(q['Z'][:len(cmean)])
             hq.close()
             _, c2m, c2v, ms2 = cpu_baseline(q, B)
             out['parity_vs_cpu_sn0.1'] = parity_report(qm[:, 0], qv[:, 0], c2m, c2v, ms2, float(q['hyper'][0, d] ** 2))
+            out['parity_vs_oracle_sn0.1'] = oracle_parity(q, qm[:, 0], qv[:, 0], len(c2m))
     h.close()
     del z, mean, var
     if world > 1:
@@ -489,7 +551,7 @@ def main():
         rs = run_c4(rk, 2, 1, N=N, d=d, R=args.restarts)
         if rank == 0:
             out['restart_shard'] = {k: rs[k] for k in ('metric', 'value', 'unit', 'scaling', 'ms_per_step', 'steps', 'warmup',
-                                                        'rccl_ranks', 'exchange', 'best_nll', 'finite_restarts',
+                                                        'rccl_ranks', 'shard_check', 'exchange', 'best_nll', 'finite_restarts',
                                                         'evaluations_this_rank', 'restarts_this_rank', 'config')}
     elif not args.no_secondary:
         # driver-witnessed secondary configurations (outside the timed C2 region): 2 steps of C3, 1 of C4
@@ -503,7 +565,7 @@ def main():
                        'rollout_ms_per_call': c3['rollout_ms_per_call'], 'finite': c3['finite'],
                        'phases_ms_per_step': c3['phases_ms_per_step'], 'em_pair_kernels': c3['em_pair_kernels']},
                 'c4': {'workload': c4['config']['workload'], 'restarts_per_s': c4['value'], 'ms_per_step': c4['ms_per_step'],
-                       'steps': c4['steps'], 'rccl_ranks': c4['rccl_ranks'], 'exchange': c4['exchange'],
+                       'steps': c4['steps'], 'rccl_ranks': c4['rccl_ranks'], 'shard_check': c4['shard_check'], 'exchange': c4['exchange'],
                        'best_nll': c4['best_nll'], 'finite_restarts': c4['finite_restarts'],
                        'evaluations_this_rank': c4.get('evaluations_this_rank')}}
     rk.close()

@@ -801,26 +801,14 @@ class OracleGP:
 
 
 # --------------------------------------------------------------------------
-# synthetic workloads -- shared by tests and bench
+# synthetic workloads: the generator lives in the product package
+# (gp_mpc_amd/synthetic.py: data only, no GP arithmetic) so that bench.py needs oracle/ only
+# for its cpu_baseline leg; re-exported here for the tests that take it from the oracle
 # --------------------------------------------------------------------------
-def synthetic_problem(N, d, Ny, B, seed=1234, sn=1e-2):
-    """Seeded generator of SURVEY 8(d): X ~ N(0,1), y_a = sin(Xw)+.5cos(Xu)
-    +1e-2 eps (standardised), hyper[a] = [2(1+.1a) 1_d, 1, sn], Z ~ N(0,1),
-    Sigma = A A^T 1e-3 + 1e-6 I."""
-    rng = np.random.default_rng(seed)
-    X = rng.standard_normal((N, d))
-    Y = np.zeros((N, Ny))
-    for a in range(Ny):
-        w = rng.standard_normal(d)
-        u = rng.standard_normal(d)
-        y = np.sin(X @ w) + 0.5 * np.cos(X @ u) + 1e-2 * rng.standard_normal(N)
-        Y[:, a] = (y - y.mean()) / y.std()
-    hyper = np.zeros((Ny, d + 2))
-    for a in range(Ny):
-        hyper[a, :d] = 2.0 * (1 + 0.1 * a)
-        hyper[a, d] = 1.0
-        hyper[a, d + 1] = sn
-    Z = rng.standard_normal((B, d))
-    A = rng.standard_normal((B, d, d))
-    Sigma = np.einsum('bij,bkj->bik', A, A) * 1e-3 + 1e-6 * np.eye(d)
-    return dict(X=X, Y=Y, hyper=hyper, Z=Z, Sigma=Sigma)
+import os as _os
+import sys as _sys
+
+_ROOT = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
+if _ROOT not in _sys.path:
+    _sys.path.insert(0, _ROOT)
+from gp_mpc_amd.synthetic import synthetic_problem  # noqa: E402,F401

@@ -169,14 +169,53 @@ def synthetic3(optimize, GP):
     print('train_small3 hyper', H, 'nll', nll)
 
 
+def legacy_pin(optimize, GP, name):
+    """Reference-made pin for a12 'old_ME' (`gp`, gp_functions.py:176-256 with alpha=None): per output
+        mean = (ks^T K^-1) y   (:229, :246),      var = kss - (ks^T K^-1) ks   (:231-232, :247),   kss = covSE(z, z) = sf^2.
+    The CasADi graph itself cannot run here (casadi absent), but its two matrix products can be composed from what the
+    reference DOES run and ship: ks from its own numpy GP.covSEard (gp_class.py:314-350) at the test points of
+    <name>_model.npz, K^-1 and Y as stored in its saved model (written by gp_class.py:693-726).  The products are formed in
+    the graph's order ((ks^T K^-1) first).  Written to a file of its own so that the other fixtures stay byte-identical."""
+    d = json.load(open(f'{REF}/examples/models/gp_{name}_example.json'))
+    X, Y = np.array(d['X']), np.array(d['Y'])
+    H = np.array(d['hyper']['hyper'])
+    invK = np.array(d['hyper']['invK'])
+    chol = np.array(d['hyper']['chol'])
+    D, Ny = X.shape[1], Y.shape[1]
+    Z = np.load(os.path.join(OUT, f'{name}_model.npz'))['Z']
+    g = ref_gp(GP, X, H, chol)
+    mean = np.zeros((Ny, len(Z)))
+    var = np.zeros((Ny, len(Z)))
+    mscale = np.zeros((Ny, len(Z)))
+    vscale = np.zeros((Ny, len(Z)))
+    for a in range(Ny):
+        sf2 = H[a, D] ** 2
+        ks = g.covSEard(X.copy(), Z.copy(), H[a, :D], sf2)          # [N, n_test], reference a1 (two-input)
+        ksT_invK = ks.T @ invK[a]                                     # gp_functions.py:221-222
+        mean[a] = ksT_invK @ Y[:, a]                                  # :229
+        var[a] = sf2 - np.sum(ksT_invK * ks.T, axis=1)                # :231-232, kss = sf2 exp(0)
+        # what one rounding of the operands moves these sums by (the comparison scale; cond(K) up to 7e10 on the car model)
+        mscale[a] = (np.abs(ks).T @ np.abs(invK[a])) @ np.abs(Y[:, a])
+        vscale[a] = np.sum((np.abs(ks).T @ np.abs(invK[a])) * np.abs(ks).T, axis=1)
+    np.savez_compressed(os.path.join(OUT, f'{name}_old_me.npz'), Z=Z, ref_old_me_mean=mean, ref_old_me_var=var,
+                        mean_scale=mscale, var_scale=vscale)
+    print(name, 'old_ME pin: mean', mean[:, :2], 'var', var[:, :2])
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     optimize, GP = import_reference()
+    if len(sys.argv) > 1 and sys.argv[1] == 'legacy':       # only the old_ME pins (the other fixtures untouched)
+        legacy_pin(optimize, GP, 'tank')
+        legacy_pin(optimize, GP, 'car')
+        return
     from_model(optimize, GP, 'tank', 24, 1)
     from_model(optimize, GP, 'car', 24, 2)
     synthetic(optimize, GP)
     synthetic2(optimize, GP)
     synthetic3(optimize, GP)
+    legacy_pin(optimize, GP, 'tank')
+    legacy_pin(optimize, GP, 'car')
 
 
 if __name__ == '__main__':

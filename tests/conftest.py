@@ -51,6 +51,12 @@ def car():
 
 
 @pytest.fixture(scope='session')
+def old_me_pins():
+    """Reference-made 'old_ME' outputs (oracle/make_golden.py legacy_pin) at the test points of the two saved models."""
+    return {name: dict(np.load(os.path.join(GOLDEN, f'{name}_old_me.npz'))) for name in ('tank', 'car')}
+
+
+@pytest.fixture(scope='session')
 def train_small():
     return dict(np.load(os.path.join(GOLDEN, 'train_small.npz')))
 

@@ -37,6 +37,10 @@ def test_gpus_2_launches_two_ranks_and_reports_the_restart_shard():
     assert rs['config']['restarts'] == 4 and rs['restarts_this_rank'] == 2      # rank 0 ran restarts 0 and 2
     assert rs['finite_restarts'] == 4                                             # ... and received 1 and 3
     assert rs['rccl_ranks'] == 0 and 'host merge' in rs['exchange']              # no RCCL on a CPU box
+    # the record validates itself: the sharded table equals the one-rank search of the same seeds bit for bit
+    sc = rs['shard_check']
+    assert sc['bitwise_equal_to_world1'] is True and sc['table_sha16'] == sc['world1_table_sha16']
+    assert sc['theta_star_sha16'] == sc['world1_theta_star_sha16']
 
 
 @pytest.mark.timeout(1200)

@@ -296,3 +296,8 @@ def test_emu_training_never_worse(emu):
 
 def test_emu_set_factors_then_persistent_mean(emu):
     pc.check_set_factors_persistent_mean(emu)
+
+
+def test_emu_old_me_reference_pin(emu, tank, car, old_me_pins):
+    pc.check_old_me_reference_pin(emu, tank, old_me_pins['tank'])
+    pc.check_old_me_reference_pin(emu, car, old_me_pins['car'])

@@ -223,6 +223,22 @@ def test_legacy_methods_agree_with_me_on_well_conditioned_data():
     assert np.allclose(np.diag(c2), var[0], rtol=1e-7, atol=1e-10)
 
 
+@pytest.mark.parametrize('name', ['tank', 'car'])
+def test_old_me_matches_reference_made_pin(name, request, old_me_pins):
+    """a12 'old_ME' pinned by reference outputs: oracle `old_me` (restating gp_functions.py:176-256) against the reference's
+    own GP.covSEard composed with its stored K^-1 and Y (oracle/make_golden.py legacy_pin), on the rounding scale of the sums."""
+    g, pin = request.getfixturevalue(name), old_me_pins[name]
+    assert np.array_equal(pin['Z'], g['Z'])
+    for b, z in enumerate(pin['Z']):
+        m, c = go.old_me(g['invK'], g['X'], g['Y'], g['hyper'], z)
+        assert np.max(np.abs(m - pin['ref_old_me_mean'][:, b]) / pin['mean_scale'][:, b]) <= 1e-14
+        assert np.max(np.abs(np.diag(c) - pin['ref_old_me_var'][:, b]) / pin['var_scale'][:, b]) <= 1e-14
+        assert np.array_equal(c, np.diag(np.diag(c)))
+    # the pin is not vacuous: the sums cancel to variances far below sf^2 (on the car model, cond(K) ~ 7e10, to values of either
+    # sign -- what the reference's formulation gives there, kept as is)
+    assert np.all(np.abs(pin['ref_old_me_var']) < 1e-3 * g['hyper'][:, g['X'].shape[1]][:, None] ** 2)
+
+
 def test_predict_standardisation_and_rollout(tank):
     g = tank
     gp = go.OracleGP(g['X'], g['Y'], g['hyper'], g['chol'], g['alpha'], g['invK'],

@@ -4,10 +4,10 @@ import json, os, sys, time
 import numpy as np
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'oracle'))
-import gp_oracle as go
+from gp_mpc_amd.synthetic import synthetic_problem
 from gp_mpc_amd._lib import Handle, get_lib
 lib = get_lib()
-p = go.synthetic_problem(4096, 6, 1, 10, seed=1234, sn=1e-2)
+p = synthetic_problem(4096, 6, 1, 10, seed=1234, sn=1e-2)
 X, Y, H = p['X'], p['Y'], p['hyper']
 for n in (1, 16, 64, 256):
     N0 = 4096 - n

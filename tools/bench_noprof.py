@@ -1,11 +1,11 @@
 import os, sys, time
 sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/oracle')
 import numpy as np, torch
-import gp_oracle as go
+from gp_mpc_amd.synthetic import synthetic_problem
 from gp_mpc_amd._lib import Handle, get_lib
 lib = get_lib()
 N, d, B = 4096, 6, 10000
-p = go.synthetic_problem(N, d, 1, B, seed=1234, sn=1e-2)
+p = synthetic_problem(N, d, 1, B, seed=1234, sn=1e-2)
 h = Handle(lib, p['X'], p['Y'])
 dev = torch.device('cuda:0')
 z = torch.tensor(p['Z'], dtype=torch.float64, device=dev)

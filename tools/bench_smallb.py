@@ -11,13 +11,13 @@ import numpy as np
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'oracle'))
-import gp_oracle as go                      # synthetic generator only
+from gp_mpc_amd.synthetic import synthetic_problem
 from gp_mpc_amd._lib import Handle, get_lib
 
 N = int(os.environ.get('C3_N', 8192))
 Ny, d = 6, 8
 lib = get_lib()
-p = go.synthetic_problem(N, d, Ny, 256, seed=1234, sn=1e-2)
+p = synthetic_problem(N, d, Ny, 256, seed=1234, sn=1e-2)
 h = Handle(lib, p['X'], p['Y'])
 h.fit(p['hyper'])
 h.profile_enable(True)

@@ -6,11 +6,11 @@ import json, os, sys, time
 import numpy as np
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'oracle'))
-import gp_oracle as go
+from gp_mpc_amd.synthetic import synthetic_problem
 from gp_mpc_amd._lib import Handle, get_lib
 from gp_mpc_amd.train import train_gp
 N, d = int(os.environ.get('C4_N', 4096)), 6
-p = go.synthetic_problem(N, d, 1, 8, seed=1234, sn=1e-2)
+p = synthetic_problem(N, d, 1, 8, seed=1234, sn=1e-2)
 h = Handle(get_lib(), p['X'], p['Y'])
 hp = p['hyper'][0].copy()
 h.nll(0, hp, want_grad=True)

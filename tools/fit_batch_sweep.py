@@ -5,13 +5,13 @@ import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..'))
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..', 'oracle'))
 import numpy as np
-import gp_oracle as go
+from gp_mpc_amd.synthetic import synthetic_problem
 from gp_mpc_amd._lib import Handle, get_lib
 
 lib = get_lib()
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 for nb in (1, 2, 4, 8, 16, 32, 64):
-    p = go.synthetic_problem(N, 6, 1, 1, seed=1, sn=1e-2)
+    p = synthetic_problem(N, 6, 1, 1, seed=1, sn=1e-2)
     Y = np.repeat(p['Y'], nb, axis=1)
     hyp = np.repeat(p['hyper'], nb, axis=0) * (1.0 + 0.01 * np.arange(nb))[:, None]
     h = Handle(lib, p['X'], Y)

@@ -4,12 +4,12 @@ import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..'))
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..', 'oracle'))
 import numpy as np
-import gp_oracle as go
+from gp_mpc_amd.synthetic import synthetic_problem
 from gp_mpc_amd._lib import Handle, get_lib
 
 lib = get_lib()
 for N, Ny in ((200, 4), (500, 4), (1000, 6), (2000, 6), (4096, 2), (4096, 6)):
-    p = go.synthetic_problem(N, 6, Ny, 1, seed=1, sn=1e-2)
+    p = synthetic_problem(N, 6, Ny, 1, seed=1, sn=1e-2)
     h = Handle(lib, p['X'], p['Y'])
     hyp = p['hyper']
     for _ in range(3):
