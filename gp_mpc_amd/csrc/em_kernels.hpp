@@ -338,6 +338,124 @@ __global__ void __launch_bounds__(256) em_pair_kernel(const double* __restrict__
     if (tid == 0) partial[((long)b * P + p) * tiles + ti] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// The same pair sums with the VALU work per entry cut from 20.8 to ~16 instructions (r05; the kernel is bound by VALU issue,
+// profiles/r04_pmc_em_tab*):
+//  * the matrix instruction's accumulator is INITIALISED with La_i + Lb_j, so the exp argument comes straight out of the
+//    matrix pipe (one add per entry instead of two), and the kernel is held to 256 registers (two waves per SIMD at least),
+//    which makes the compiler keep the accumulators in VGPRs: the AGPR form cost two v_accvgpr_read per entry;
+//  * sum_ij beta_i beta_j Q_ij = sum_i beta_i (sum_j beta_j Q_ij): one fma per entry into a per-row accumulator, beta_i at the
+//    end; for a == b a second accumulator takes K^-1_ij Q_ij, and the factor 2 of the off-diagonal tiles is applied once
+//    (everything accumulated before the diagonal tile is doubled) instead of per entry;
+//  * TAB = 2: exp through the 32-entry table that meets every LDS bank once (exp_tab32, gp_kernels.hpp), TAB = 1: the
+//    2048-entry table of r04, TAB = 0: the polynomial exp_lean.
+// Same operands, same tiles, same partial[] layout as em_pair_kernel; other summation order (<= 1e-15 of sum |terms|).
+template <bool DIAG, int KD, int TAB>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
+em_pair2_kernel(const double* __restrict__ ops, const double* __restrict__ beta, const double* __restrict__ invK,
+                double* __restrict__ partial, int N, int Np, int Ny, int crow_mode, const double* __restrict__ etab) {
+    constexpr int EMK = KD;
+    constexpr int NQ = ((KD + 2) * 64 + 255) / 256;
+    const int ti = blockIdx.x, p = blockIdx.y, b = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int P = Ny * (Ny + 1) / 2, tiles = Np / 64;
+    int a = 0;
+    while ((a + 1) * (a + 2) / 2 <= p) ++a;
+    const int bb = p - a * (a + 1) / 2;
+    if ((a == bb) != DIAG) return;
+    const double* __restrict__ o = ops + ((long)b * P + p) * (2 * EMK + 2) * Np;
+    const double* __restrict__ Wt = o + (long)EMK * Np;
+    const double* __restrict__ La = o + (long)(2 * EMK) * Np;
+    const double* __restrict__ Lb = o + (long)(2 * EMK + 1) * Np;
+    const double* __restrict__ ba = beta + (long)a * Np;
+    const double* __restrict__ bbv = beta + (long)bb * Np;
+    const double* __restrict__ iK = invK + (long)a * Np * Np;
+    __shared__ double red[4];
+    __shared__ double Cs[2][EMK + 2][64];
+    __shared__ double Et[TAB == 1 ? EXPT_N : (TAB == 2 ? EXPT32_N : 1)];
+    if (TAB == 1) exp_tab_fill(Et, etab, tid, 256);              // (visible behind the barrier that follows the first stage())
+    if (TAB == 2) exp_tab32_fill(Et, etab, tid);
+    const int fr = lane & 15, fk = lane >> 4, i0 = ti * 64 + 16 * wave;
+    double af[KD / 4];
+#pragma unroll
+    for (int s4 = 0; s4 < KD / 4; ++s4) af[s4] = o[(long)(4 * s4 + fk) * Np + i0 + fr];
+    double la[4], bai[4], racc[4];
+    int irow[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        irow[r] = i0 + crow(lane, r, crow_mode);
+        la[r] = La[irow[r]];
+        bai[r] = (irow[r] < N) ? ba[irow[r]] : 0.0;
+        racc[r] = 0.0;
+    }
+    double kacc = 0.0;
+    const int jt_end = DIAG ? ti + 1 : tiles;
+    double st[NQ];
+    auto fetch = [&](int jt) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int e = tid + 256 * q, rw = e >> 6, cl = e & 63, j = jt * 64 + cl;
+            double v = 0.0;
+            if (rw < EMK) v = Wt[(long)rw * Np + j];
+            else if (rw == EMK) v = Lb[j];
+            else if (rw == EMK + 1) v = (j < N) ? bbv[j] : 0.0;
+            st[q] = v;
+        }
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int e = tid + 256 * q, rw = e >> 6, cl = e & 63;
+            if (rw < EMK + 2) Cs[buf][rw][cl] = st[q];
+        }
+    };
+    fetch(0);
+    stage(0);
+    __syncthreads();
+    int cur = 0;
+    for (int jt = 0; jt < jt_end; ++jt) {
+        if (jt + 1 < jt_end) fetch(jt + 1);
+        double ik[4][4];
+        if (DIAG) {
+            if (jt == ti) {                     // everything so far came from tiles below the diagonal: counted twice
+#pragma unroll
+                for (int r = 0; r < 4; ++r) racc[r] *= 2.0;
+                kacc *= 2.0;
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ik[t][r] = irow[r] < N ? iK[(long)irow[r] * Np + jt * 64 + 16 * t + fr] : 0.0;
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int cl = 16 * t + fr;
+            const double lbj = Cs[cur][EMK][cl];
+            const double bj = Cs[cur][EMK + 1][cl];
+            d4 c;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) c[r] = la[r] + lbj;
+#pragma unroll
+            for (int s4 = 0; s4 < KD / 4; ++s4) c = mfma16(af[s4], Cs[cur][4 * s4 + fk][cl], c);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                // no per-entry masks: beta is zero in padded rows / columns, K^-1's padded rows are masked at the load
+                // above and its padded columns are exact zeros in live rows (identity padding), Q is finite everywhere
+                const double q = TAB == 2 ? exp_tab32(c[r], Et) : TAB == 1 ? exp_tab(c[r], Et) : exp_lean(c[r]);
+                racc[r] = fma(bj, q, racc[r]);
+                if (DIAG) kacc = fma(ik[t][r], q, kacc);
+            }
+        }
+        if (jt + 1 < jt_end) stage(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+    double acc = (bai[0] * racc[0] + bai[1] * racc[1]) + (bai[2] * racc[2] + bai[3] * racc[3]);
+    if (DIAG) acc -= kacc;
+    acc = wave_sum(acc);
+    if (lane == 0) red[wave] = acc;
+    __syncthreads();
+    if (tid == 0) partial[((long)b * P + p) * tiles + ti] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 // cov_ab = t_p * sum_tiles partial;  cov_aa += sf_a^2;  cov -= mean mean^T;  symmetric fill.
 // grid (ceil(B*P/64)), 64 threads: one thread per (input, pair).
 __global__ void __launch_bounds__(64) em_finish_kernel(const double* __restrict__ partial, const double* __restrict__ prep,

@@ -65,6 +65,34 @@ __device__ __forceinline__ double exp_tab(double x, const double* __restrict__ T
     return ldexp(tj * p, ki >> EXPT_LOG2);
 }
 
+// exp(x) with a table that occupies the 64 LDS banks exactly once: 32 doubles 2^(j / 32) = 256 bytes (every 64th entry of the
+// table above, so the same correctly rounded values).  A ds_read_b64 is served in two groups of 32 lanes and a double covers
+// two of the 64 four-byte banks: two lanes of a group either read the same entry (broadcast) or entries in different bank
+// pairs -- no conflict whatever the indices are (the 2048-entry table: 5 extra LDS cycles per wave read at C3,
+// profiles/r04_pmc_em_tab1_*).  x = (32 n + j) ln2 / 32 + r, |r| <= ln2 / 64 = 1.09e-2, degree-6 Taylor remainder
+// (truncation r^7 / 5040 <= 3.5e-18), Cody-Waite with exp_lean's constants scaled by 2^-5 (exact; n ln2_hi / 32 is exact for
+// |32 n + j| < 2^21).  Fifteen full-rate VALU instructions and one conflict-free LDS read; <= 1 ulp of T[j] + 0.6 ulp.
+constexpr int EXPT32_N = 32;
+__device__ __forceinline__ void exp_tab32_fill(double* __restrict__ T_lds, const double* __restrict__ T_glob, int tid) {
+    if (tid < EXPT32_N) T_lds[tid] = T_glob[tid * (EXPT_N / EXPT32_N)];
+}
+__device__ __forceinline__ double exp_tab32(double x, const double* __restrict__ T_lds) {
+    const double magic = 6755399441055744.0;                    // 1.5 * 2^52
+    const double t = fma(x, 46.166241308446829036, magic);      // 32 / ln 2
+    const double nf = t - magic;
+    double r = fma(-nf, 6.93147180369123816490e-01 / 32.0, x);
+    r = fma(-nf, 1.90821492927058770002e-10 / 32.0, r);
+    const int ki = __double2loint(t);
+    const double tj = T_lds[ki & (EXPT32_N - 1)];
+    double p = fma(r, 1.0 / 720.0, 1.0 / 120.0);
+    p = fma(p, r, 1.0 / 24.0);
+    p = fma(p, r, 1.0 / 6.0);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(tj * p, ki >> 5);
+}
+
 // t / b, correctly rounded, from the correctly rounded reciprocal y = RN(1 / b) (computed once per workgroup and
 // dimension): q0 = t y, r = t - q0 b (exact in an fma), q = q0 + r y -- Markstein's division step: three full-rate
 // instructions instead of the ~12 of the IEEE division sequence, and the SAME bits (200 M random pairs incl. mantissas

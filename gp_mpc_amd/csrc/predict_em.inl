@@ -52,7 +52,17 @@ static int predict_moments_chunk(gpmpc_gp* h, int method, int B, const double* d
         }
         // exp of the pair sums through the 2^(j / 2048) table (gp_kernels.hpp exp_tab; GPMPC_EM_EXP_TAB=0: the polynomial exp_lean)
         static const bool exp_tab_on = !(getenv("GPMPC_EM_EXP_TAB") && atoi(getenv("GPMPC_EM_EXP_TAB")) == 0);
+        // GPMPC_EM_PAIR (tuning aid): 0 the r04 kernel, 1 em_pair2_kernel with the 2048-entry table, 2 (default) with the
+        // conflict-free 32-entry table, 3 with the polynomial exp
+        static const int pair_form = getenv("GPMPC_EM_PAIR") ? atoi(getenv("GPMPC_EM_PAIR")) : 2;
         const double* etab = g_exp_tab[h->device];
+#define GPMPC_EM_PAIR2(KDV, TABV)                                                                                                     \
+        hipLaunchKernelGGL((em_pair2_kernel<false, KDV, TABV>), dim3(tiles, P, B), dim3(256), 0, cx.stream, ops, h->beta, h->ws.InvK, \
+                           partial, N, Np, Ny, cx.crow_mode, etab);                                                                   \
+        hipLaunchKernelGGL((em_pair2_kernel<true, KDV, TABV>), dim3(tiles, P, B), dim3(256), 0, cx.stream, ops, h->beta, h->ws.InvK,  \
+                           partial, N, Np, Ny, cx.crow_mode, etab);
+#define GPMPC_EM_PAIR2_ANY(KDV)                                                                                                       \
+        if (pair_form == 1) { GPMPC_EM_PAIR2(KDV, 1) } else if (pair_form == 3) { GPMPC_EM_PAIR2(KDV, 0) } else { GPMPC_EM_PAIR2(KDV, 2) }
 #define GPMPC_EM_PAIR(KDV, TABV)                                                                                                      \
         hipLaunchKernelGGL((em_pair_kernel<false, KDV, TABV>), dim3(tiles, P, B), dim3(256), 0, cx.stream, ops, h->beta, h->ws.InvK,  \
                            partial, N, Np, Ny, cx.crow_mode, etab);                                                                   \
@@ -61,13 +71,15 @@ static int predict_moments_chunk(gpmpc_gp* h, int method, int B, const double* d
         if (KD == 8) {
             hipLaunchKernelGGL((em_operands_kernel<8>), dim3((Np + 255) / 256, P, B), dim3(256), 0, cx.stream, h->XT, dZ, h->ws.hyper,
                                prep, ops, N, Np, d, Ny);
-            if (exp_tab_on) { GPMPC_EM_PAIR(8, true) } else { GPMPC_EM_PAIR(8, false) }
+            if (pair_form != 0) { GPMPC_EM_PAIR2_ANY(8) } else if (exp_tab_on) { GPMPC_EM_PAIR(8, true) } else { GPMPC_EM_PAIR(8, false) }
         } else {      // d = 9 .. 16: the same kernels with a 16-deep cross term (gp_exact_moment is dimension-generic)
             hipLaunchKernelGGL((em_operands_kernel<16>), dim3((Np + 255) / 256, P, B), dim3(256), 0, cx.stream, h->XT, dZ, h->ws.hyper,
                                prep, ops, N, Np, d, Ny);
-            if (exp_tab_on) { GPMPC_EM_PAIR(16, true) } else { GPMPC_EM_PAIR(16, false) }
+            if (pair_form != 0) { GPMPC_EM_PAIR2_ANY(16) } else if (exp_tab_on) { GPMPC_EM_PAIR(16, true) } else { GPMPC_EM_PAIR(16, false) }
         }
 #undef GPMPC_EM_PAIR
+#undef GPMPC_EM_PAIR2
+#undef GPMPC_EM_PAIR2_ANY
         hipLaunchKernelGGL(em_finish_kernel, dim3((unsigned)(((long)B * P + 63) / 64)), dim3(64), 0, cx.stream, partial, prep,
                            h->ws.hyper, dMean, dCov, B, Ny, d, tiles);
         HIPCHK(hipGetLastError());
