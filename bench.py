@@ -113,7 +113,7 @@ def parity_report(gm, gv, cmean, cvar, mscale, sf2):
     return {'mean_maxabs': float(dm.max()), 'mean_rel_to_max': float(dm.max() / np.abs(cmean).max()),
             'mean_max_pointwise_rel': float((dm / np.maximum(np.abs(cmean), 1e-300)).max()),
             'mean_scaled_sum_abs_ks_alpha': float((dm / mscale).max()),
-            'mean_pointwise_floored_1e-3_max': float((dm / np.maximum(np.abs(cmean), 1e-3 * np.abs(cmean).max())).max()),
+            'mean_pointwise_floored_1e-2_max': float((dm / np.maximum(np.abs(cmean), 1e-2 * np.abs(cmean).max())).max()),
             'var_maxabs_over_sf2': float(dv.max() / sf2), 'var_max_pointwise_rel': float((dv / np.abs(cvar)).max()),
             'points': int(len(cmean))}
 

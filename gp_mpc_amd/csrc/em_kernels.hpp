@@ -372,7 +372,7 @@ em_pair2_kernel(const double* __restrict__ ops, const double* __restrict__ beta,
     __shared__ double Cs[2][EMK + 2][64];
     __shared__ double Et[TAB == 1 ? EXPT_N : (TAB == 2 ? EXPT32_N : 1)];
     if (TAB == 1) exp_tab_fill(Et, etab, tid, 256);              // (visible behind the barrier that follows the first stage())
-    if (TAB == 2) exp_tab32_fill(Et, etab, tid);
+    if (TAB == 2) exp_tab32_fill(Et, tid);
     const int fr = lane & 15, fk = lane >> 4, i0 = ti * 64 + 16 * wave;
     double af[KD / 4];
 #pragma unroll

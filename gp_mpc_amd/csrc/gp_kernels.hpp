@@ -55,8 +55,10 @@ __device__ __forceinline__ double exp_tab(double x, const double* __restrict__ T
     const double magic = 6755399441055744.0;                    // 1.5 * 2^52
     const double t = fma(x, 2954.6394437405970050, magic);      // 2048 / ln 2
     const double nf = t - magic;
-    double r = fma(-nf, 6.93147180369123816490e-01 / 2048.0, x);
-    r = fma(-nf, 1.90821492927058770002e-10 / 2048.0, r);
+    // ONE reduction constant (r05: one VALU instruction of twelve less): RN(ln2) / 2048 is off by < 2^-54 relative, so
+    // r = x - nf c (exact product inside the fma, one rounding) differs from the exact remainder by x 2^-54 at most -- a
+    // relative perturbation of the ARGUMENT below its own rounding error (x is a sum of rounded terms)
+    const double r = fma(-nf, 6.93147180559945309417e-01 / 2048.0, x);
     const int ki = __double2loint(t);
     const double tj = T_lds[ki & (EXPT_N - 1)];
     double p = fma(r, 1.0 / 6.0, 0.5);
@@ -70,18 +72,29 @@ __device__ __forceinline__ double exp_tab(double x, const double* __restrict__ T
 // two of the 64 four-byte banks: two lanes of a group either read the same entry (broadcast) or entries in different bank
 // pairs -- no conflict whatever the indices are (the 2048-entry table: 5 extra LDS cycles per wave read at C3,
 // profiles/r04_pmc_em_tab1_*).  x = (32 n + j) ln2 / 32 + r, |r| <= ln2 / 64 = 1.09e-2, degree-6 Taylor remainder
-// (truncation r^7 / 5040 <= 3.5e-18), Cody-Waite with exp_lean's constants scaled by 2^-5 (exact; n ln2_hi / 32 is exact for
-// |32 n + j| < 2^21).  Fifteen full-rate VALU instructions and one conflict-free LDS read; <= 1 ulp of T[j] + 0.6 ulp.
+// (truncation r^7 / 5040 <= 3.5e-18), one reduction constant RN(ln2) / 32.  Fourteen full-rate VALU instructions and one
+// conflict-free LDS read; <= 1 ulp of T[j] + 0.6 ulp + the argument perturbation x 2^-54 of the reduction (see exp_tab).
+// Measured in the exact-moment pair sums (r05, C3): 5 % slower than the 2048-entry table -- three more VALU instructions
+// per entry cost more than that table's bank conflicts -- so the pair sums keep exp_tab; the cross-covariance kernel,
+// whose workgroups are too short-lived to copy a 16 KB table each, uses this one.
 constexpr int EXPT32_N = 32;
-__device__ __forceinline__ void exp_tab32_fill(double* __restrict__ T_lds, const double* __restrict__ T_glob, int tid) {
-    if (tid < EXPT32_N) T_lds[tid] = T_glob[tid * (EXPT_N / EXPT32_N)];
+__device__ static const double EXPT32[EXPT32_N] = {              // 2^(j / 32), correctly rounded (50-digit arithmetic)
+    0x1.0000000000000p+0, 0x1.059b0d3158574p+0, 0x1.0b5586cf9890fp+0, 0x1.11301d0125b51p+0,
+    0x1.172b83c7d517bp+0, 0x1.1d4873168b9aap+0, 0x1.2387a6e756238p+0, 0x1.29e9df51fdee1p+0,
+    0x1.306fe0a31b715p+0, 0x1.371a7373aa9cbp+0, 0x1.3dea64c123422p+0, 0x1.44e086061892dp+0,
+    0x1.4bfdad5362a27p+0, 0x1.5342b569d4f82p+0, 0x1.5ab07dd485429p+0, 0x1.6247eb03a5585p+0,
+    0x1.6a09e667f3bcdp+0, 0x1.71f75e8ec5f74p+0, 0x1.7a11473eb0187p+0, 0x1.82589994cce13p+0,
+    0x1.8ace5422aa0dbp+0, 0x1.93737b0cdc5e5p+0, 0x1.9c49182a3f090p+0, 0x1.a5503b23e255dp+0,
+    0x1.ae89f995ad3adp+0, 0x1.b7f76f2fb5e47p+0, 0x1.c199bdd85529cp+0, 0x1.cb720dcef9069p+0,
+    0x1.d5818dcfba487p+0, 0x1.dfc97337b9b5fp+0, 0x1.ea4afa2a490dap+0, 0x1.f50765b6e4540p+0};
+__device__ __forceinline__ void exp_tab32_fill(double* __restrict__ T_lds, int tid) {
+    if (tid < EXPT32_N) T_lds[tid] = EXPT32[tid];
 }
 __device__ __forceinline__ double exp_tab32(double x, const double* __restrict__ T_lds) {
     const double magic = 6755399441055744.0;                    // 1.5 * 2^52
     const double t = fma(x, 46.166241308446829036, magic);      // 32 / ln 2
     const double nf = t - magic;
-    double r = fma(-nf, 6.93147180369123816490e-01 / 32.0, x);
-    r = fma(-nf, 1.90821492927058770002e-10 / 32.0, r);
+    const double r = fma(-nf, 6.93147180559945309417e-01 / 32.0, x);     // (one constant: see exp_tab)
     const int ki = __double2loint(t);
     const double tj = T_lds[ki & (EXPT32_N - 1)];
     double p = fma(r, 1.0 / 720.0, 1.0 / 120.0);
@@ -90,6 +103,22 @@ __device__ __forceinline__ double exp_tab32(double x, const double* __restrict__
     p = fma(p, r, 0.5);
     p = fma(p, r, 1.0);
     p = fma(p, r, 1.0);
+    return ldexp(tj * p, ki >> 5);
+}
+// exp(-y) for an accumulated y (a squared distance): the sign goes into the constants, no negation instruction
+__device__ __forceinline__ double exp_tab32_neg(double y, const double* __restrict__ T_lds) {
+    const double magic = 6755399441055744.0;
+    const double t = fma(y, -46.166241308446829036, magic);
+    const double nf = t - magic;                                 // rint(-y 32 / ln 2)
+    const double s = fma(nf, 6.93147180559945309417e-01 / 32.0, y);      // s = -r (one constant: see exp_tab)
+    const int ki = __double2loint(t);
+    const double tj = T_lds[ki & (EXPT32_N - 1)];
+    double p = fma(s, 1.0 / 720.0, -1.0 / 120.0);                // Taylor in r = -s: alternating signs
+    p = fma(p, s, 1.0 / 24.0);
+    p = fma(p, s, -1.0 / 6.0);
+    p = fma(p, s, 0.5);
+    p = fma(p, s, -1.0);
+    p = fma(p, s, 1.0);
     return ldexp(tj * p, ki >> 5);
 }
 
@@ -246,19 +275,27 @@ __global__ void __launch_bounds__(256) crosscov_kernel(const double* __restrict_
     const int nch = gridDim.z, clen = ((Np + nch - 1) / nch + 255) / 256 * 256;
     const int ibeg = blockIdx.z * clen, iend = min(Np, ibeg + clen);
     constexpr int NR = JAC ? JT * (D + 1) : JT;
-    __shared__ double Zs[JT][D], w[D], red[4][NR];
+    // r05 arithmetic (the kernel is bound by VALU issue: 41 -> 2 D + 17 instructions per entry at the C2 shape): coordinates
+    // pre-scaled by s_d = 1 / (sqrt 2 ell_d) -- the training point's once per JT test points, the test points' when staged --
+    // so that  -1/2 sum_d (x_d - z_d)^2 / ell_d^2 = -sum_d (xs_d - zs_d)^2  is a subtraction and an fma per dimension; the
+    // accumulator starts at -log sf^2, so sf^2 exp(.) needs no multiplication; exp through the 32-entry table that meets
+    // every LDS bank once (exp_tab32_neg); the masks of padded training / test points only where a block has any.
+    __shared__ double Zs[JT][D], w[D], red[4][NR], Et[EXPT32_N];
     const double* hy = hyper + (long)a * (D + 2);
-    if (tid < D) w[tid] = 1.0 / (hy[tid] * hy[tid]);
-    const double sf2 = hy[D] * hy[D];
+    if (tid < D) w[tid] = 0.70710678118654752440 / fabs(hy[tid]);
+    exp_tab32_fill(Et, tid);
+    __syncthreads();
+    const double neg_log_sf2 = -log(hy[D] * hy[D]);
     // alpha == nullptr (JAC == false only): the cross-covariances alone; mean_dot_kernel forms the mean later, once alpha
     // exists (the first prediction behind a fit runs next to the fit's tail, api_predict.inl)
     const double* __restrict__ al = alpha ? alpha + (long)a * Np : nullptr;
     for (int j0 = blockIdx.x * JT; j0 < Bp; j0 += gridDim.x * JT) {
     if (tid < JT * D) {
         const int jj = tid / D, dd = tid % D;
-        Zs[jj][dd] = (j0 + jj < B) ? Z[(long)(j0 + jj) * D + dd] : 0.0;
+        Zs[jj][dd] = (j0 + jj < B) ? Z[(long)(j0 + jj) * D + dd] * w[dd] : 0.0;
     }
     __syncthreads();
+    const bool all_points = j0 + JT <= B;
     double macc[JT], jacc[JAC ? JT : 1][D];
 #pragma unroll
     for (int jj = 0; jj < JT; ++jj) macc[jj] = 0.0;
@@ -272,25 +309,26 @@ __global__ void __launch_bounds__(256) crosscov_kernel(const double* __restrict_
     for (int i = ibeg + tid; i < iend; i += 256) {
         double x[D];
 #pragma unroll
-        for (int dd = 0; dd < D; ++dd) x[dd] = XT[(long)dd * Np + i];
+        for (int dd = 0; dd < D; ++dd) x[dd] = XT[(long)dd * Np + i] * w[dd];
         const double ai = al ? al[i] : 0.0;
         const bool live = i < N;
+        const bool masked = !all_points || (i - tid + 255 >= N);     // (uniform over the workgroup)
 #pragma unroll
         for (int jj = 0; jj < JT; ++jj) {
-            double dist = 0.0, df[D];
+            double dist = neg_log_sf2, df[D];
 #pragma unroll
             for (int dd = 0; dd < D; ++dd) {
                 df[dd] = x[dd] - Zs[jj][dd];
-                dist += df[dd] * df[dd] * w[dd];
+                dist = fma(df[dd], df[dd], dist);
             }
-            // (exp_lean: the kernel is bound by its fp64 VALU work, not by the 8 N B bytes it writes)
-            const double ks = (live && j0 + jj < B) ? sf2 * exp_lean(-0.5 * dist) : 0.0;
+            double ks = exp_tab32_neg(dist, Et);
+            if (masked) ks = (live && j0 + jj < B) ? ks : 0.0;
             out[(long)jj * Np + i] = ks;
-            const double ka = ks * ai;
-            macc[jj] += ka;
+            macc[jj] = fma(ks, ai, macc[jj]);            // (the same mean bits with and without the Jacobian)
             if (JAC) {
+                const double ka = ks * ai;
 #pragma unroll
-                for (int dd = 0; dd < D; ++dd) jacc[jj][dd] += ka * df[dd];
+                for (int dd = 0; dd < D; ++dd) jacc[jj][dd] = fma(ka, df[dd], jacc[jj][dd]);
             }
         }
     }
@@ -311,14 +349,14 @@ __global__ void __launch_bounds__(256) crosscov_kernel(const double* __restrict_
         if (tid < NR) {
             const double v = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
             const int jj = tid < JT ? tid : (tid - JT) / D, e = tid < JT ? 0 : 1 + (tid - JT) % D;
-            cpart[(((long)blockIdx.z * Ny + a) * Bp + j0 + jj) * (D + 1) + e] = e ? v * w[e - 1] : v;
+            cpart[(((long)blockIdx.z * Ny + a) * Bp + j0 + jj) * (D + 1) + e] = e ? v * (2.0 * w[e - 1]) : v;   // (x - z) / ell^2 = 2 s (xs - zs)
         }
     } else {
         if (tid < JT && al) meanT[(long)a * Bp + j0 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
         if (JAC && tid >= JT && tid < NR) {
             const int e = tid - JT, jj = e / D, dd = e % D;
             if (j0 + jj < B)
-                J[((long)(j0 + jj) * Ny + a) * D + dd] = ((red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid])) * w[dd];
+                J[((long)(j0 + jj) * Ny + a) * D + dd] = ((red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid])) * (2.0 * w[dd]);
         }
     }
     __syncthreads();          // Zs / red are rewritten by the next block of test points

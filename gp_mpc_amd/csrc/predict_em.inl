@@ -52,9 +52,9 @@ static int predict_moments_chunk(gpmpc_gp* h, int method, int B, const double* d
         }
         // exp of the pair sums through the 2^(j / 2048) table (gp_kernels.hpp exp_tab; GPMPC_EM_EXP_TAB=0: the polynomial exp_lean)
         static const bool exp_tab_on = !(getenv("GPMPC_EM_EXP_TAB") && atoi(getenv("GPMPC_EM_EXP_TAB")) == 0);
-        // GPMPC_EM_PAIR (tuning aid): 0 the r04 kernel, 1 em_pair2_kernel with the 2048-entry table, 2 (default) with the
-        // conflict-free 32-entry table, 3 with the polynomial exp
-        static const int pair_form = getenv("GPMPC_EM_PAIR") ? atoi(getenv("GPMPC_EM_PAIR")) : 2;
+        // GPMPC_EM_PAIR (tuning aid): 0 the r04 kernel, 1 (default) em_pair2_kernel with the 2048-entry table, 2 with the
+        // conflict-free 32-entry table, 3 with the polynomial exp (r05, C3, same box: 45.7 / 40.8 / 43.3 / 46.3 ms per step)
+        static const int pair_form = getenv("GPMPC_EM_PAIR") ? atoi(getenv("GPMPC_EM_PAIR")) : 1;
         const double* etab = g_exp_tab[h->device];
 #define GPMPC_EM_PAIR2(KDV, TABV)                                                                                                     \
         hipLaunchKernelGGL((em_pair2_kernel<false, KDV, TABV>), dim3(tiles, P, B), dim3(256), 0, cx.stream, ops, h->beta, h->ws.InvK, \
@@ -62,7 +62,7 @@ static int predict_moments_chunk(gpmpc_gp* h, int method, int B, const double* d
         hipLaunchKernelGGL((em_pair2_kernel<true, KDV, TABV>), dim3(tiles, P, B), dim3(256), 0, cx.stream, ops, h->beta, h->ws.InvK,  \
                            partial, N, Np, Ny, cx.crow_mode, etab);
 #define GPMPC_EM_PAIR2_ANY(KDV)                                                                                                       \
-        if (pair_form == 1) { GPMPC_EM_PAIR2(KDV, 1) } else if (pair_form == 3) { GPMPC_EM_PAIR2(KDV, 0) } else { GPMPC_EM_PAIR2(KDV, 2) }
+        if (pair_form == 2) { GPMPC_EM_PAIR2(KDV, 2) } else if (pair_form == 3) { GPMPC_EM_PAIR2(KDV, 0) } else { GPMPC_EM_PAIR2(KDV, 1) }
 #define GPMPC_EM_PAIR(KDV, TABV)                                                                                                      \
         hipLaunchKernelGGL((em_pair_kernel<false, KDV, TABV>), dim3(tiles, P, B), dim3(256), 0, cx.stream, ops, h->beta, h->ws.InvK,  \
                            partial, N, Np, Ny, cx.crow_mode, etab);                                                                   \

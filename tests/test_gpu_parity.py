@@ -140,7 +140,7 @@ def test_c2_full_size_vs_oracle_and_properties(lib):
 def test_c2_full_size_rel_to_max_and_floored_pointwise_bars(lib):
     """SURVEY 8c / north_star "within 1e-10 rel": the C2 size with sn = 0.1 (well conditioned).  What is gated, by name
     (check_synthetic strict_rel, parity_cases.mean_bars): ||dL||_F / ||L||_F, the variance pointwise, |dNLL| / (|NLL| + N),
-    and for the mean BOTH max|dmean| / max|mean| and the pointwise error with a floor of 1e-3 max|mean| -- all <= 1e-10;
+    and for the mean BOTH max|dmean| / max|mean| and the pointwise error with a floor of 1e-2 max|mean| (parity_cases.check_synthetic says why) -- all <= 1e-10;
     the unfloored pointwise figure (means that cross zero) is reported by bench.py, not gated."""
     t0 = time.time()
     pc.check_synthetic(lib, N=4096, d=6, Ny=1, B=10000, sn=0.1, strict_rel=True)
