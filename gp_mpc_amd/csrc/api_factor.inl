@@ -510,11 +510,13 @@ static bool factor_chain(const Ctx& cx, Workspace& ws, int spin_limit, bool flag
     static const bool merge_publish = getenv("GPMPC_MERGE_PUBLISH") && atoi(getenv("GPMPC_MERGE_PUBLISH")) != 0;
     const int wt_publish = chain_wt_publish();
     static const int late_polls = getenv("GPMPC_LATE_POLLS") ? atoi(getenv("GPMPC_LATE_POLLS")) : 3;   // (tuning aid, chol_chain.hpp land())
+    // leafdone[k] behind the panel row's products in prefetched steps (chol_chain.hpp); GPMPC_CHAIN_DEFER_PUBLISH=0: in front, as r04
+    static const bool defer_publish = !(getenv("GPMPC_CHAIN_DEFER_PUBLISH") && atoi(getenv("GPMPC_CHAIN_DEFER_PUBLISH")) == 0);
     {   // the chain kernel ends with the last leaf, i.e. when L is complete: its duration is the Cholesky's
         ProfScope t(cx.prof, cx.stream, GPMPC_PH_CHAIN);
         hipLaunchKernelGGL(chol_chain_kernel, dim3(1, 1, ws.batch), dim3(256), CHAIN_LDS_BYTES, cx.stream, (const double*)ws.K,
                            ws.L, ws.Inv, ld, sM, nb, ws.flags, (long)nf, ws.info, cx.crow_mode, spin_limit, g_chain_trace,
-                           use_workers && merge_publish ? 1 : 0, 0, -1, late_polls, wt_publish);
+                           use_workers && merge_publish ? 1 : 0, 0, -1, late_polls, wt_publish, defer_publish ? 1 : 0);
     }
     // Early status (below): ev_chain marks the END OF THE CHAIN KERNEL, so it is recorded here, while that kernel is the main
     // queue's last entry (GPMPC_EV_CHAIN_LATE=1, tuning aid: behind the join with the workers' queue as r04 had it).

@@ -79,7 +79,7 @@ __device__ __forceinline__ void chain_diag_tiles(double* S, const double* U, con
         subtract(ti[1], tj[1], a1);
     } else if (mine == 1) {
         d4 acc = d4{0.0, 0.0, 0.0, 0.0};
-        acc = lds_mm16<true>(U, 16 * ti[0], 0, U, 16 * tj[0], 0, 64, lane, acc);
+        acc = lds_mm16k<true, 64>(U, 16 * ti[0], 0, U, 16 * tj[0], 0, lane, acc);
         subtract(ti[0], tj[0], acc);
     }
 }
@@ -87,8 +87,14 @@ __device__ __forceinline__ void chain_diag_tiles(double* S, const double* U, con
 __global__ void __launch_bounds__(256) chol_chain_kernel(const double* Kmat, double* L, double* Inv, long ld, long sBatch,
                                                          int nb, int* flags, long sFlags, int* info, int crow_mode,
                                                          int spin_limit, long long* trace, int merge_publish,
-                                                         int kb = 0, int ke = -1, int late_polls = 3, int wt = 0) {
+                                                         int kb = 0, int ke = -1, int late_polls = 3, int wt = 0,
+                                                         int defer_publish = 0) {
     // wt: publish L_kk, inv_kk and L(k+1,k) as write-through stores, no L2 write-back per publication (wg_sync.hpp)
+    // defer_publish (with wt): in a step whose next tiles were prefetched, leafdone[k] goes out behind the panel row's
+    // products instead of in front of them -- the stores of L_kk / inv_kk drain under those products and the flag rides on
+    // the barrier that follows them anyway (r05: the drain + barrier of the separate publication were 1.24 us per step on
+    // the chain's critical path; the workers see inv_kk a few hundred nanoseconds later, in steps where the chain, not
+    // they, is what the step waits for: their tiles were there two thirds into the leaf)
     // [kb, ke): the block columns this launch factors (two-level execution: one launch per super-panel; the tiles of
     // block kb then carry every earlier update by stream order, no flag).  Default: the whole matrix.
     if (ke < 0) ke = nb;
@@ -247,7 +253,8 @@ __global__ void __launch_bounds__(256) chol_chain_kernel(const double* Kmat, dou
         }
         // merge_publish: leafdone[k] goes out together with pan1[k] a few microseconds later, saving one L2 write-back per
         // step on this critical path (off by default since r03: the courier and the workers' look-ahead want inv_kk early)
-        if (!merge_publish || k + 1 == ke) { if (wt) wg_publish_wt(&leafdone[k], 1); else wg_publish(&leafdone[k], 1); }
+        const bool defer_leaf = defer_publish && wt && !merge_publish && pre && k + 1 < ke;
+        if (!defer_leaf && (!merge_publish || k + 1 == ke)) { if (wt) wg_publish_wt(&leafdone[k], 1); else wg_publish(&leafdone[k], 1); }
         CHAIN_STAMP(2);
         if (k + 1 == ke) break;
         const double* Asrc = P;                       // A(k+1,k): put there by the prefetch, else fetched now
@@ -278,15 +285,26 @@ __global__ void __launch_bounds__(256) chol_chain_kernel(const double* Kmat, dou
         CHAIN_STAMP(4);
         // L_{k+1,k} = A_{k+1,k} inv_kk^T: wave w computes the 16-row strip w (4 tiles; inv_kk is lower triangular, so
         // tile tj needs depth 16 (tj + 1) only), straight from P into U
+        // (r05: the four tiles share their A fragments and advance together -- one A read per step of 4 in K, the matrix
+        //  instructions of the four independent accumulators back to back -- instead of four serial read-wait-multiply loops;
+        //  every tile still sums its k in ascending order: same bits)
         d4 acc[4];
 #pragma unroll
-        for (int tj = 0; tj < 4; ++tj) {
-            acc[tj] = d4{0.0, 0.0, 0.0, 0.0};
-            acc[tj] = lds_mm16<true>(Asrc, 16 * wave, 0, T, 16 * tj, 0, 16 * (tj + 1), lane, acc[tj]);
+        for (int tj = 0; tj < 4; ++tj) acc[tj] = d4{0.0, 0.0, 0.0, 0.0};
+        {
+            const int fr = lane & 15, fk = lane >> 4;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const double af = Asrc[(16 * wave + fr) * LS + 4 * q + fk];
+#pragma unroll
+                for (int tj = q / 4; tj < 4; ++tj) acc[tj] = mfma16(af, T[(16 * tj + fr) * LS + 4 * q + fk], acc[tj]);
+            }
         }
 #pragma unroll
         for (int tj = 0; tj < 4; ++tj) lds_put16(U, 16 * wave, 16 * tj, acc[tj], 1.0, lane, crow_mode);
+        if (defer_leaf) GPMPC_DRAIN_VM();             // this wave's L_kk / inv_kk stores (issued before the products) have left
         __syncthreads();
+        if (defer_leaf && tid == 0) flag_store(&leafdone[k], 1);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int idx = tid + 256 * i, rr = idx >> 5, cc = (idx & 31) * 2;

@@ -31,22 +31,40 @@ __device__ __forceinline__ d4 lds_mm16(const double* Sa, int ar, int ac, const d
     return acc;
 }
 
+// One product with K known at compile time: every fragment is requested before the first matrix instruction (the loop
+// above is "two LDS reads, wait, one matrix instruction" per step of 4 in K).  Same summation order: same bits.
+template <bool BT, int K>
+__device__ __forceinline__ d4 lds_mm16k(const double* Sa, int ar, int ac, const double* Sb, int br, int bc, int lane, d4 acc) {
+    const int fr = lane & 15, fk = lane >> 4;
+    double a[K / 4], b[K / 4];
+#pragma unroll
+    for (int q = 0; q < K / 4; ++q) {
+        a[q] = Sa[(ar + fr) * LS + ac + 4 * q + fk];
+        b[q] = BT ? Sb[(br + fr) * LS + bc + 4 * q + fk] : Sb[(br + 4 * q + fk) * LS + bc + fr];
+    }
+#pragma unroll
+    for (int q = 0; q < K / 4; ++q) acc = mfma16(a[q], b[q], acc);
+    return acc;
+}
+
 // Two independent products of one wave, K known at compile time: all fragments are fetched first, then the matrix
 // instructions of the two dependency chains alternate.  lds_mm16's loop is "two LDS reads, wait, one matrix instruction that
 // depends on the previous one", ~200 cycles per step of 4 in K of which the instruction itself is 64 (in-kernel stamps, r03:
 // the chain's two K = 64 diagonal-update tiles per wave took 3.0 us, 2.2 us this way; for ONE chain, and for the K = 16
 // products of the leaf, fetching first measured slower).  Same order of the summation per product: bit-identical results.
+// (bc0 / bc1 >= 0: the two products' B operands start at different columns, bc is ignored)
 template <bool BT, int K>
 __device__ __forceinline__ void lds_mm16k_x2(const double* Sa, int ar0, int ar1, int ac, const double* Sb, int br0, int br1,
-                                             int bc, int lane, d4& acc0, d4& acc1) {
+                                             int bc, int lane, d4& acc0, d4& acc1, int bc0 = -1, int bc1 = -1) {
     const int fr = lane & 15, fk = lane >> 4;
+    if (bc0 < 0) { bc0 = bc; bc1 = bc; }
     double a0[K / 4], b0[K / 4], a1[K / 4], b1[K / 4];
 #pragma unroll
     for (int q = 0; q < K / 4; ++q) {
         a0[q] = Sa[(ar0 + fr) * LS + ac + 4 * q + fk];
-        b0[q] = BT ? Sb[(br0 + fr) * LS + bc + 4 * q + fk] : Sb[(br0 + 4 * q + fk) * LS + bc + fr];
+        b0[q] = BT ? Sb[(br0 + fr) * LS + bc0 + 4 * q + fk] : Sb[(br0 + 4 * q + fk) * LS + bc0 + fr];
         a1[q] = Sa[(ar1 + fr) * LS + ac + 4 * q + fk];
-        b1[q] = BT ? Sb[(br1 + fr) * LS + bc + 4 * q + fk] : Sb[(br1 + 4 * q + fk) * LS + bc + fr];
+        b1[q] = BT ? Sb[(br1 + fr) * LS + bc1 + 4 * q + fk] : Sb[(br1 + 4 * q + fk) * LS + bc1 + fr];
     }
 #pragma unroll
     for (int q = 0; q < K / 4; ++q) {
@@ -176,12 +194,21 @@ __device__ __forceinline__ double rsqrt_newton(double x) {
 // o = 16 x panel index at RUN time: the leaf then holds this code once, not four times (the chain kernel's 55 KB of
 // straight-line code do not stay in the 64 KB instruction cache it shares with a neighbour CU, and refetching them through
 // a busy L2 cost the leaf ~3 us per call: tools/ubench/leaf_icache_bench.hip).
+// T (r05; o >= 16 only): the INVERSE of the panel's 16 x 16 diagonal block for free.  What the panel does to a lane's row,
+// a <- a L_oo^-T (column j scaled by 1 / L_jj, then a[k] -= L_kj a[j]), is a forward substitution; lanes 0-15 hold rows
+// ABOVE the panel when o >= 16 -- zeros of S's upper triangle, dead weight in every instruction -- so they start from the
+// unit vectors e_i instead and end with e_i L_oo^-T = column i of L_oo^-1, which goes to T[o + c][o + i].  Not one extra
+// VALU instruction; the unit entries pass through S's (otherwise zero, never read) block (0, o / 16) for the loads.  The
+// last block's inverse used to take an idle wave 1.31 us AFTER the last panel (profiles/r04_chain_trace.txt).
 template <int MODE>
-__device__ __forceinline__ int panel_potrf_dpp_at(double* S, double* Drinv, int lane, const int o) {
+__device__ __forceinline__ int panel_potrf_dpp_at(double* S, double* Drinv, int lane, const int o, double* T = nullptr) {
     const int r = lane, i = lane & 15;
     double a[16], d[16];
+    const bool unit_rows = T != nullptr && o >= 16;            // (wave-uniform)
+    if (unit_rows && lane < 16) S[lane * LS + o + lane] = 1.0;
 #pragma unroll
     for (int c = 0; c < 16; ++c) { a[c] = S[r * LS + o + c]; d[c] = S[(o + i) * LS + o + c]; }
+    if (unit_rows && lane < 16) S[lane * LS + o + lane] = 0.0;  // (the same wave's LDS operations complete in order)
     double y = 0.0;
 #define GPMPC_PANEL_COL(j)                                                                              \
     {                                                                                                     \
@@ -213,6 +240,9 @@ __device__ __forceinline__ int panel_potrf_dpp_at(double* S, double* Drinv, int 
     if (r >= o) {
 #pragma unroll
         for (int c = 0; c < 16; ++c) S[r * LS + o + c] = (r - o >= 16 || c <= r - o) ? a[c] : 0.0;
+    } else if (unit_rows && lane < 16) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) T[(o + c) * LS + o + lane] = a[c];     // column `lane` of the block's inverse
     }
     int bad = -1;
     if (!(y * 0.0 == 0.0)) {                 // NaN or infinity in the last reciprocal (wave-uniform, rare)
@@ -297,27 +327,56 @@ __device__ __forceinline__ int leaf_body(double* S, double* T, double* U, double
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int bad = -1;
     hook.stamp(0);
+#if GPMPC_LEAF_DPP
     if (do_chol) {
-#if GPMPC_LEAF_DPP
+        // r05 schedule.  Wave 0 factors the four 16-column panels; panels 1-3 leave the inverse of their diagonal block in
+        // T at no cost (panel_potrf_dpp_at: unit rows in the lanes above the panel), block 0's is wave 1's job next to
+        // panel 1 as before.  The assembly of the 64 x 64 inverse
+        //     [[A, 0], [C, B]]^-1 = [[A^-1, 0], [-B^-1 (C A^-1), B^-1]]        (32-blocks from 16-blocks, 64 from 32)
+        // no longer waits for the last panel: every product whose operands are final runs on the waves that idle next to
+        // wave 0's panels (the S columns of panel t are final behind panel t's barrier):
+        //   next to panel 1 (wave 1):  inv00
+        //   next to panel 2 (wave 1):  U1 = L10 inv00,  T10 = -inv11 U1,  W[:, 0:16] = L[32:64, 0:32] [inv00; T10]      (wave 2: W[:, 16:32] = L[32:64, 16:32] inv11)
+        //   next to panel 3 (wave 1):  U2 = L32 inv22,   T[32:48, 0:32] = -inv22 W[0:16, :]
+        // and behind the last panel only  T32 = -inv33 U2  (wave 0) next to  acc = inv33 W[16:32, :]  (waves 1, 2), a barrier,
+        // T[48:64, 0:32] = -(acc + T32 W[0:16, :]): two short products on the critical path instead of the last block's
+        // substitution + four (r04: 1.31 + 0.67 + 0.91 us per leaf, profiles/r04_chain_trace.txt).  W = C A^-1 of the 64-level
+        // lives in U[32:64, 0:32], U1 in U[16:32, 0:16], U2 in U[48:64, 32:48]; U is free from the barrier behind panel 0 on
+        // (the chain kernel's hook.first() reads it next to panel 0).
 #pragma unroll 1
-#else
-#pragma unroll
-#endif
         for (int t = 0; t < 4; ++t) {
-            if (wave == 0 && (phases & 1)) {
-#if GPMPC_LEAF_DPP
-                const int b = panel_potrf_dpp_at<2>(S, Dr, lane, 16 * t);
-#else
-                const int b = t == 0 ? panel_potrf<0>(S, Dr, lane) : t == 1 ? panel_potrf<1>(S, Dr, lane)
-                            : t == 2 ? panel_potrf<2>(S, Dr, lane) : panel_potrf<3>(S, Dr, lane);
-#endif
-                if (b >= 0 && bad < 0) bad = 16 * t + b;
-            } else if (wave == 1 && t >= 1 && (phases & 4)) {
-                GPMPC_INV16(S, T, 16 * (t - 1), lane, Dr);   // inverse of the previous diagonal block
+            if (wave == 0) {
+                if (phases & 1) {
+                    const int b = panel_potrf_dpp_at<2>(S, Dr, lane, 16 * t, T);
+                    if (b >= 0 && bad < 0) bad = 16 * t + b;
+                }
+            } else if (t == 0) {
+                hook.first();                           // columns 16-63 of S may still be written here (panel 0 owns 0-15)
+            } else if (wave == 1 && (phases & 8)) {
+                d4 z = d4{0.0, 0.0, 0.0, 0.0};
+                if (t == 1) {
+                    inv16_dpp(S, T, 0, lane, Dr);
+                } else if (t == 2) {
+                    lds_put16(U, 16, 0, lds_mm16<false>(S, 16, 0, T, 0, 0, 16, lane, z), 1.0, lane, crow_mode);
+                    lds_put16(T, 16, 0, lds_mm16<false>(T, 16, 16, U, 16, 0, 16, lane, z), -1.0, lane, crow_mode);
+                    d4 w0 = z, w1 = z;
+                    lds_mm16k_x2<false, 32>(S, 32, 48, 0, T, 0, 0, 0, lane, w0, w1);      // rows 32-47 / 48-63 x [inv00; T10]
+                    lds_put16(U, 32, 0, w0, 1.0, lane, crow_mode);
+                    lds_put16(U, 48, 0, w1, 1.0, lane, crow_mode);
+                } else {
+                    lds_put16(U, 48, 32, lds_mm16<false>(S, 48, 32, T, 32, 32, 16, lane, z), 1.0, lane, crow_mode);
+                    d4 f0 = z, f1 = z;
+                    lds_mm16k_x2<false, 16>(T, 32, 32, 32, U, 32, 32, 0, lane, f0, f1, 0, 16);   // inv22 x W[0:16, 0:16 | 16:32]
+                    lds_put16(T, 32, 0, f0, -1.0, lane, crow_mode);
+                    lds_put16(T, 32, 16, f1, -1.0, lane, crow_mode);
+                }
+            } else if (wave == 2 && t == 2 && (phases & 8)) {
+                d4 w0 = d4{0.0, 0.0, 0.0, 0.0}, w1 = w0;
+                lds_mm16k_x2<false, 16>(S, 32, 48, 16, T, 16, 16, 16, lane, w0, w1);      // rows 32-47 / 48-63 of L[:, 16:32] x inv11
+                lds_put16(U, 32, 16, w0, 1.0, lane, crow_mode);
+                lds_put16(U, 48, 16, w1, 1.0, lane, crow_mode);
             } else if (wave >= 2 && t == 3) {
                 hook.land();                            // waves 2 and 3 have nothing else to do behind the last panel
-            } else if (wave >= 1 && t == 0) {
-                hook.first();                           // columns 16-63 of S may still be written here (panel 0 owns 0-15)
             }
             hook.stamp(1 + 3 * t);
             if (t == 2) hook.before();
@@ -325,6 +384,54 @@ __device__ __forceinline__ int leaf_body(double* S, double* T, double* U, double
             hook.stamp(2 + 3 * t);
             if (t == 2) hook.after();
             // rank-16 update of the remaining lower tiles: A_ij -= L_it L_jt^T, t < j <= i <= 3
+            const int o = 16 * t;
+            int cnt = 0;
+            for (int i = t + 1; i <= 3 && (phases & 2); ++i)
+                for (int j = t + 1; j <= i; ++j, ++cnt)
+                    if ((cnt & 3) == wave) {
+                        d4 pacc = d4{0.0, 0.0, 0.0, 0.0};
+                        pacc = lds_mm16<true>(S, 16 * i, o, S, 16 * j, o, 16, lane, pacc);
+                        lds_sub16(S, 16 * i, 16 * j, pacc, lane, crow_mode);
+                    }
+            if (t < 3) __syncthreads();
+            if (t < 3) hook.stamp(3 + 3 * t);
+        }
+        hook.stamp(12);
+        if (phases & 8) {
+            d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+            if (wave == 0) lds_put16(T, 48, 32, lds_mm16<false>(T, 48, 48, U, 48, 32, 16, lane, acc), -1.0, lane, crow_mode);
+            else if (wave <= 2) acc = lds_mm16<false>(T, 48, 48, U, 48, 16 * (wave - 1), 16, lane, acc);
+            __syncthreads();
+            hook.stamp(13);
+            if (wave == 1 || wave == 2) {
+                acc = lds_mm16<false>(T, 48, 32, U, 32, 16 * (wave - 1), 16, lane, acc);
+                lds_put16(T, 48, 16 * (wave - 1), acc, -1.0, lane, crow_mode);
+            }
+            __syncthreads();
+            hook.stamp(14);
+        }
+        return bad;
+    }
+#endif
+    if (do_chol) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (wave == 0 && (phases & 1)) {
+                const int b = t == 0 ? panel_potrf<0>(S, Dr, lane) : t == 1 ? panel_potrf<1>(S, Dr, lane)
+                            : t == 2 ? panel_potrf<2>(S, Dr, lane) : panel_potrf<3>(S, Dr, lane);
+                if (b >= 0 && bad < 0) bad = 16 * t + b;
+            } else if (wave == 1 && t >= 1 && (phases & 4)) {
+                GPMPC_INV16(S, T, 16 * (t - 1), lane, Dr);   // inverse of the previous diagonal block
+            } else if (wave >= 2 && t == 3) {
+                hook.land();
+            } else if (wave >= 1 && t == 0) {
+                hook.first();
+            }
+            hook.stamp(1 + 3 * t);
+            if (t == 2) hook.before();
+            __syncthreads();
+            hook.stamp(2 + 3 * t);
+            if (t == 2) hook.after();
             const int o = 16 * t;
             int cnt = 0;
             for (int i = t + 1; i <= 3 && (phases & 2); ++i)
