@@ -126,7 +126,9 @@ static int predict_chunk(gpmpc_gp* h, int B, const double* dZ, double* dMean, do
     }
     if (overlapped) {
         // (GPMPC_CROSSCOV_WGS: workgroups of the throttled launch; 0 = one per block of test points, i.e. not throttled)
-        static const int cc_wgs = getenv("GPMPC_CROSSCOV_WGS") ? atoi(getenv("GPMPC_CROSSCOV_WGS")) : g_cu_count[h->device];
+        // (r05: half a workgroup per CU -- the launch is longer, 0.31 against 0.22 ms, still ends with the tail, and takes less
+        //  from the tail's latency-bound launches: step -11 ... -25 us on two boxes, profiles/r05_sweep_cuts_throttle.txt)
+        static const int cc_wgs = getenv("GPMPC_CROSSCOV_WGS") ? atoi(getenv("GPMPC_CROSSCOV_WGS")) : std::max(1, g_cu_count[h->device] / 2);
         {
             ProfScope t(&h->prof, cx.bulk, GPMPC_PH_CROSSCOV);
             launch_crosscov(cx.bulk, h->d, h->XT, h->ws.hyper, nullptr, dZ, h->KsT, h->meanT, nullptr, h->N, Np, B, Bp, Ny, nullptr,

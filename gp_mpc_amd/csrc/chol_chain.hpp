@@ -236,19 +236,33 @@ __global__ void __launch_bounds__(256) chol_chain_kernel(const double* Kmat, dou
         if (!pre && slot[2] != 0 && slot[3] != 0) pre = true;   // both loader waves saw the tiles late and landed them
         CHAIN_STAMP(1);
         if (tid == 0 && bad >= 0) atomicCAS(&info[blockIdx.z], 0, 64 * k + bad + 1);
-        for (int e = tid; e < CHAIN_TRI_PAIRS; e += 256) {   // two columns per thread: 16-byte global stores
-            const int rc = tri[e], rr = rc >> 6, cc = rc & 63;    // cc <= rr; the second column may lie above the diagonal
-            double2 l, v;
-            l.x = S[rr * LS + cc];
-            l.y = (cc + 1 <= rr) ? S[rr * LS + cc + 1] : 0.0;
-            v.x = T[rr * LS + cc];
-            v.y = (cc + 1 <= rr) ? T[rr * LS + cc + 1] : 0.0;
-            if (wt) {
-                wt_store16(rL, (unsigned)((rr * ld + cc) * 8), l);
-                wt_store16(rI, (unsigned)((rr * ld + cc) * 8), v);
-            } else {
-                *reinterpret_cast<double2*>(&Lb[o + (long)rr * ld + cc]) = l;
-                *reinterpret_cast<double2*>(&Ib[o + (long)rr * ld + cc]) = v;
+        {   // two columns per thread and pair: 16-byte global stores.  r05: the (up to) five pairs of a thread in three
+            // passes -- table look-ups, LDS reads, stores -- instead of five dependent look-up -> read -> store rounds (the
+            // loop's 1.2 us were issue latency, not the drain: profiles/r05_chain_trace_leaf_restructured.txt)
+            constexpr int NP = (CHAIN_TRI_PAIRS + 255) / 256;
+            int rc[NP];
+#pragma unroll
+            for (int q = 0; q < NP; ++q) rc[q] = (tid + 256 * q < CHAIN_TRI_PAIRS) ? (int)tri[tid + 256 * q] : -1;
+            double2 l[NP], v[NP];
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                const int rr = (rc[q] >> 6) & 63, cc = rc[q] & 63;    // cc <= rr; the second column may lie above the diagonal
+                l[q].x = S[rr * LS + cc];
+                l[q].y = (cc + 1 <= rr) ? S[rr * LS + cc + 1] : 0.0;
+                v[q].x = T[rr * LS + cc];
+                v[q].y = (cc + 1 <= rr) ? T[rr * LS + cc + 1] : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                if (rc[q] < 0) continue;
+                const int rr = rc[q] >> 6, cc = rc[q] & 63;
+                if (wt) {
+                    wt_store16(rL, (unsigned)((rr * ld + cc) * 8), l[q]);
+                    wt_store16(rI, (unsigned)((rr * ld + cc) * 8), v[q]);
+                } else {
+                    *reinterpret_cast<double2*>(&Lb[o + (long)rr * ld + cc]) = l[q];
+                    *reinterpret_cast<double2*>(&Ib[o + (long)rr * ld + cc]) = v[q];
+                }
             }
         }
         // merge_publish: leafdone[k] goes out together with pan1[k] a few microseconds later, saving one L2 write-back per

@@ -170,7 +170,9 @@ def test_inline_dpp_instructions_respect_the_operand_hazard():
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'check_dpp_hazards.py')], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout + r.stderr
     n = int(re.search(r'(\d+) DPP instructions checked', r.stdout).group(1))
-    assert n >= 800, r.stdout             # the leaf's panel (one copy per kernel since r03) and 16 x 16 inverses are in there
+    # the leaf's panel (one copy per kernel since r03) and block 0's 16 x 16 inverse are in there (r05: 752 -- the other three
+    # blocks' inverses come out of the panels' own instructions, leaf64.hpp panel_potrf_dpp_at)
+    assert n >= 700, r.stdout
 
 
 def test_every_environment_switch_is_documented():
