@@ -378,21 +378,34 @@ __device__ __forceinline__ int leaf_body(double* S, double* T, double* U, double
             } else if (wave >= 2 && t == 3) {
                 hook.land();                            // waves 2 and 3 have nothing else to do behind the last panel
             }
+            // the part of panel t-1's rank-16 update that panel t does not need (tiles (i, j), j > t: see below), on the waves
+            // without a panel: wave 3 (and wave 2 next to panel 1, where it has nothing else)
+            if (t >= 1 && t <= 2 && wave >= 2 && (phases & 2)) {
+                const int op = 16 * (t - 1);
+                int cnt = 0;
+                for (int i = t + 1; i <= 3; ++i)
+                    for (int j = t + 1; j <= i; ++j, ++cnt)
+                        if ((t == 1 ? 2 + (cnt & 1) : 3) == wave) {
+                            d4 pacc = d4{0.0, 0.0, 0.0, 0.0};
+                            pacc = lds_mm16<true>(S, 16 * i, op, S, 16 * j, op, 16, lane, pacc);
+                            lds_sub16(S, 16 * i, 16 * j, pacc, lane, crow_mode);
+                        }
+            }
             hook.stamp(1 + 3 * t);
             if (t == 2) hook.before();
             __syncthreads();
             hook.stamp(2 + 3 * t);
             if (t == 2) hook.after();
-            // rank-16 update of the remaining lower tiles: A_ij -= L_it L_jt^T, t < j <= i <= 3
+            // rank-16 update A_ij -= L_it L_jt^T, t < j <= i <= 3, in two parts (r05): only block column t + 1 -- what the next
+            // panel factors -- here, one tile per wave, on the leaf's critical path; the tiles (i, j), j > t + 1, next to that
+            // panel (above).  Every tile still receives its updates in the order of the panels: same bits as one pass.
             const int o = 16 * t;
-            int cnt = 0;
-            for (int i = t + 1; i <= 3 && (phases & 2); ++i)
-                for (int j = t + 1; j <= i; ++j, ++cnt)
-                    if ((cnt & 3) == wave) {
-                        d4 pacc = d4{0.0, 0.0, 0.0, 0.0};
-                        pacc = lds_mm16<true>(S, 16 * i, o, S, 16 * j, o, 16, lane, pacc);
-                        lds_sub16(S, 16 * i, 16 * j, pacc, lane, crow_mode);
-                    }
+            if (t < 3 && (phases & 2) && wave <= 2 - t) {
+                const int i = t + 1 + wave, j = t + 1;
+                d4 pacc = d4{0.0, 0.0, 0.0, 0.0};
+                pacc = lds_mm16<true>(S, 16 * i, o, S, 16 * j, o, 16, lane, pacc);
+                lds_sub16(S, 16 * i, 16 * j, pacc, lane, crow_mode);
+            }
             if (t < 3) __syncthreads();
             if (t < 3) hook.stamp(3 + 3 * t);
         }

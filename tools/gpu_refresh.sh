@@ -48,8 +48,8 @@ if has pmc; then
     echo "== $C rc=$?"
     python "$R/tools/pmc_summary.py" "$O/pmc_${TAG}_$N/p_results.db" > "$O/${TAG}_pmc_$N.txt" 2>&1; grep -A4 "vargemm_persist" "$O/${TAG}_pmc_$N.txt" | head -6
   done
-  python "$R/tools/traffic_json.py" "$O/pmc_${TAG}_FETCH_SIZE/p_results.db" "$O/pmc_${TAG}_WRITE_SIZE/p_results.db" "$O/pmc_${TAG}_SQ_VALU_MFMA_BUSY_CYCLES_/p_results.db" "$TAG" > "$O/${TAG}_traffic.json" 2>"$O/${TAG}_traffic.err"; head -c 600 "$O/${TAG}_traffic.json"; echo
-  rm -rf $O/pmc_${TAG}_FETCH_SIZE $O/pmc_${TAG}_WRITE_SIZE $O/pmc_${TAG}_SQ_VALU_MFMA_BUSY_CYCLES_
+  python "$R/tools/traffic_json.py" "$O/pmc_${TAG}_FETCH_SIZE/p_results.db" "$O/pmc_${TAG}_WRITE_SIZE/p_results.db" "$O/pmc_${TAG}_SQ_VALU_MFMA_BUSY_CYCLES/p_results.db" "$TAG" > "$O/${TAG}_traffic.json" 2>"$O/${TAG}_traffic.err"; head -c 600 "$O/${TAG}_traffic.json"; echo
+  rm -rf $O/pmc_${TAG}_FETCH_SIZE $O/pmc_${TAG}_WRITE_SIZE $O/pmc_${TAG}_SQ_VALU_MFMA_BUSY_CYCLES
   cat > /tmp/emv.py <<'PY'
 import sys, os
 sys.path.insert(0, os.environ['GRAFT_REPO_ROOT'])
