@@ -319,7 +319,12 @@ def run_c3(rk, steps, warmup, N=8192):
     fac_ms = prof['factor'][0] / max(prof['factor'][1], 1)
     flops = Ny * 2.0 * N ** 3 / 3.0
     em_ms, em_n = prof['em']
-    em_bytes = Ny * 4.0 * N * (N + 1)                       # the K^-1 lower triangles the a == b pair sums read
+    # exact-moment pair sums: entries (one fp64 exp each) per input = 15 full N x N pair matrices + 6 lower triangles in 64-tiles;
+    # bound by VALU issue: 14.8 instructions per entry (PMC, profiles/r05_pmc_em_*) at one wave instruction per 4 cycles and SIMD
+    Np_, P_off, P_diag = (N + 63) // 64 * 64, Ny * (Ny - 1) // 2, Ny
+    em_entries = P_off * float(Np_) ** 2 + P_diag * (Np_ // 64) * (Np_ // 64 + 1) / 2 * 4096.0
+    EM_INSTR_PER_ENTRY, SIMDS, CLOCK = 14.8, 1024, 2.4e9
+    em_peak = SIMDS * 64 * CLOCK / (4.0 * EM_INSTR_PER_ENTRY) * 1e-9          # Gentries/s the VALU can issue
     world = rk.world
     out = {
         'metric': 'GP moment-matching propagation steps/sec, N=8192 Ny=6 d=8 fp64 (fit + 30-step ME/TA/EM per step)',
@@ -334,9 +339,11 @@ def run_c3(rk, steps, warmup, N=8192):
                      'frac': flops / (fac_ms * 1e-3) * 1e-12 / FP64_MFMA_PEAK_TFLOPS if fac_ms > 0 else 0.0,
                      'traffic': None, 'avg_launch_ms': fac_ms, 'launches': prof['factor'][1],
                      'note': '2 N^3 / 3 flops per output (potrf + trtri), HIP events around the whole factor phase'},
-        'em_pair_kernels': {'bound': 'hbm', 'achieved': em_bytes / (em_ms / max(em_n, 1) * 1e-3) * 1e-9 if em_ms > 0 else 0.0,
-                            'peak': 8000.0, 'unit': 'GB/s', 'avg_launch_ms': em_ms / max(em_n, 1), 'launches': em_n,
-                            'note': 'algorithmic bytes = lower triangles of the 6 K^-1; the kernel is bound by the issue of its 1.2e9 fp64 exp per input (PMC: profiles/r04_pmc_em_tab*), not by HBM'},
+        'em_pair_kernels': {'bound': 'valu', 'achieved': em_entries / (em_ms / max(em_n, 1) * 1e-3) * 1e-9 if em_ms > 0 else 0.0,
+                            'peak': em_peak, 'unit': 'Gentry/s', 'frac': (em_entries / (em_ms / max(em_n, 1) * 1e-3) * 1e-9 / em_peak) if em_ms > 0 else 0.0,
+                            'avg_launch_ms': em_ms / max(em_n, 1), 'launches': em_n, 'entries_per_input': em_entries,
+                            'note': 'one EM evaluation (operands, both pair-sum launches, finish) per launch figure; VALU-issue floor = 14.8 instructions per entry '
+                                    '(rocprofv3 --pmc SQ_INSTS_VALU, profiles/r05_pmc_em_*) x 4 cycles per wave instruction on 1024 SIMDs at 2.4 GHz; HBM is at < 15 % here'},
         'phases_ms_per_step': {k: v[0] / steps for k, v in prof.items() if v[1] > 0},
         'rollout_ms_per_call': t_roll,
         'finite': bool(all(np.all(np.isfinite(r[0])) and np.all(np.isfinite(r[1])) for r in res.values())),

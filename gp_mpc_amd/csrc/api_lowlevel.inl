@@ -129,6 +129,11 @@ extern "C" int gpmpc_set_tuning(const char* name, int value) {
         g_train_batch_cap = value;
         return GPMPC_OK;
     }
+    if (std::strcmp(name, "em_chunk") == 0) {            // exact-moment pair sums: column tiles per workgroup (0 = default, em_kernels.hpp)
+        if (value < 0) return fail(GPMPC_EINVAL, "em_chunk must be >= 0");
+        g_em_chunk = value;
+        return GPMPC_OK;
+    }
     if (std::strcmp(name, "fail_nll_after") == 0) {      // fault injection for the tests of the restart shard's failure paths
         if (value < 0) return fail(GPMPC_EINVAL, "fail_nll_after must be >= 0");
         static const bool testing = getenv("GPMPC_TESTING") && atoi(getenv("GPMPC_TESTING")) != 0;

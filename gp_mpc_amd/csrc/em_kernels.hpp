@@ -229,138 +229,44 @@ __global__ void __launch_bounds__(256) em_operands_kernel(const double* __restri
     o[(long)(2 * EMK + 1) * Np + i] = (2.0 * log(hb[d]) - 0.5 * lkb) + qb;
 }
 
-// Pair sums on a 64-row strip.  grid (Np/64, P, B), 256 threads = 4 waves; wave w owns rows 16w..16w+15 of
-// the strip and sweeps the columns in 64-wide tiles without any barrier: the cross terms
-// 2 (ii_i S) . ij_j of a 16 x 16 tile are two v_mfma_f64_16x16x4_f64 (depth EMK = 8, zero padded); the VALU
-// adds La_i + Lb_j, takes the lean exp and accumulates (beta_ai beta_bj - [a==b] K^-1_ij) Q_ij.  For a == b
-// the summand is symmetric in (i, j): only column tiles up to the diagonal are visited, off-diagonal
-// tiles counted twice.  partial[(b*P + p)*tiles + strip].
-// TAB: exp through the 2^(j / 2048) table (exp_tab, gp_kernels.hpp; etab: the table in global memory) instead of exp_lean.
-template <bool DIAG, int KD, bool TAB = false>
-__global__ void __launch_bounds__(256) em_pair_kernel(const double* __restrict__ ops, const double* __restrict__ beta,
-                                                      const double* __restrict__ invK, double* __restrict__ partial,
-                                                      int N, int Np, int Ny, int crow_mode, const double* __restrict__ etab = nullptr) {
-    constexpr int EMK = KD;                      // cross-term depth: 8 (d <= 8: two matrix instructions per tile) or 16 (four)
-    constexpr int NQ = ((KD + 2) * 64 + 255) / 256;   // staged values per thread and column tile
-    const int ti = blockIdx.x, p = blockIdx.y, b = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int P = Ny * (Ny + 1) / 2, tiles = Np / 64;
-    int a = 0;
-    while ((a + 1) * (a + 2) / 2 <= p) ++a;
-    const int bb = p - a * (a + 1) / 2;
-    if ((a == bb) != DIAG) return;   // launched once per kind: the a == b variant carries the K^-1 registers
-    constexpr bool diag = DIAG;
-    const double* __restrict__ o = ops + ((long)b * P + p) * (2 * EMK + 2) * Np;
-    const double* __restrict__ Wt = o + (long)EMK * Np;
-    const double* __restrict__ La = o + (long)(2 * EMK) * Np;
-    const double* __restrict__ Lb = o + (long)(2 * EMK + 1) * Np;
-    const double* __restrict__ ba = beta + (long)a * Np;
-    const double* __restrict__ bbv = beta + (long)bb * Np;
-    const double* __restrict__ iK = invK + (long)a * Np * Np;
-    __shared__ double red[4];
-    // column-tile operands (shared by the 4 waves) are staged through LDS with a one-tile prefetch:
-    // rows 0..7 Wt, row 8 Lb, row 9 beta_b  -> 640 doubles per tile
-    __shared__ double Cs[2][EMK + 2][64];
-    __shared__ double Et[TAB ? EXPT_N : 1];
-    if (TAB) exp_tab_fill(Et, etab, tid, 256);                   // (visible behind the barrier that follows the first stage())
-    const int fr = lane & 15, fk = lane >> 4, i0 = ti * 64 + 16 * wave;
-    // A fragments (constant over the sweep) and the row data of this lane's 4 accumulator rows
-    double af[KD / 4];
-#pragma unroll
-    for (int s4 = 0; s4 < KD / 4; ++s4) af[s4] = o[(long)(4 * s4 + fk) * Np + i0 + fr];
-    double la[4], bai[4];
-    int irow[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        irow[r] = i0 + crow(lane, r, crow_mode);
-        la[r] = La[irow[r]];
-        bai[r] = (irow[r] < N) ? ba[irow[r]] : 0.0;
-    }
-    double acc = 0.0;
-    const int jt_end = diag ? ti + 1 : tiles;
-    double st[NQ];
-    auto fetch = [&](int jt) {   // (KD + 2) * 64 values / 256 threads: element e = tid + 256 q -> (row e / 64, col e % 64)
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const int e = tid + 256 * q, rw = e >> 6, cl = e & 63, j = jt * 64 + cl;
-            double v = 0.0;
-            if (rw < EMK) v = Wt[(long)rw * Np + j];
-            else if (rw == EMK) v = Lb[j];
-            else if (rw == EMK + 1) v = (j < N) ? bbv[j] : 0.0;
-            st[q] = v;
-        }
-    };
-    auto stage = [&](int buf) {
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const int e = tid + 256 * q, rw = e >> 6, cl = e & 63;
-            if (rw < EMK + 2) Cs[buf][rw][cl] = st[q];
-        }
-    };
-    fetch(0);
-    stage(0);
-    __syncthreads();
-    int cur = 0;
-    for (int jt = 0; jt < jt_end; ++jt) {
-        if (jt + 1 < jt_end) fetch(jt + 1);
-        const double mult = (diag && jt < ti) ? 2.0 : 1.0;
-        double ik[4][4];
-        if (diag) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) ik[t][r] = irow[r] < N ? iK[(long)irow[r] * Np + jt * 64 + 16 * t + fr] : 0.0;
-        }
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int cl = 16 * t + fr, j = jt * 64 + cl;
-            d4 c = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int s4 = 0; s4 < KD / 4; ++s4) c = mfma16(af[s4], Cs[cur][4 * s4 + fk][cl], c);
-            const double lbj = Cs[cur][EMK][cl];
-            const double bj = Cs[cur][EMK + 1][cl];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                // no per-entry masks: beta is zero in padded rows / columns, K^-1's padded rows are masked at the load
-                // above and its padded columns are exact zeros in live rows (identity padding), Q is finite everywhere
-                const double q = TAB ? exp_tab((la[r] + lbj) + c[r], Et) : exp_lean((la[r] + lbj) + c[r]);
-                double wgt = bai[r] * bj;
-                if (diag) wgt -= ik[t][r];
-                acc = fma(diag ? mult * wgt : wgt, q, acc);
-            }
-        }
-        if (jt + 1 < jt_end) stage(cur ^ 1);
-        __syncthreads();
-        cur ^= 1;
-    }
-    acc = wave_sum(acc);
-    if (lane == 0) red[wave] = acc;
-    __syncthreads();
-    if (tid == 0) partial[((long)b * P + p) * tiles + ti] = (red[0] + red[1]) + (red[2] + red[3]);
-}
-
-// The same pair sums with the VALU work per entry cut from 20.8 to ~16 instructions (r05; the kernel is bound by VALU issue,
-// profiles/r04_pmc_em_tab*):
+// Pair sums on a 64-row strip.  256 threads = 4 waves; wave w owns rows 16w..16w+15 of the strip and sweeps column tiles
+// (64 wide) without any barrier inside a tile: the cross terms 2 (ii_i S) . ij_j of a 16 x 16 tile are two
+// v_mfma_f64_16x16x4_f64 (depth EMK = 8, zero padded; four at EMK = 16), the VALU takes the exp and accumulates
+// (beta_ai beta_bj - [a==b] K^-1_ij) Q_ij.  For a == b the summand is symmetric in (i, j): only column tiles up to the diagonal
+// are visited, off-diagonal tiles counted twice.
+// grid (tiles * nch, P, B): workgroup (strip ti, chunk c) sweeps the column tiles [c chunk, (c+1) chunk) of its strip
+// (r05: one workgroup per strip left the a == b launch at the mercy of its longest strip -- 128 tiles against a mean of 64.5 --
+// and the a != b launch with 2.5 rounds of 128-tile workgroups on the chip's 768 slots, i.e. a half-empty last round;
+// profiles/r05_kernel_trace_bench_c3.txt: 482 + 766 us per input at C3); partial[(b*P + p) * tiles * nch + blockIdx.x],
+// chunks beyond a strip's range write 0.
+// r05: the VALU work per entry cut from 20.8 (r04's em_pair_kernel) to 14.8 instructions (the kernel is bound by VALU issue,
+// profiles/r04_pmc_em_tab*, r05_pmc_em_*):
 //  * the matrix instruction's accumulator is INITIALISED with La_i + Lb_j, so the exp argument comes straight out of the
-//    matrix pipe (one add per entry instead of two), and the kernel is held to 256 registers (two waves per SIMD at least),
-//    which makes the compiler keep the accumulators in VGPRs: the AGPR form cost two v_accvgpr_read per entry;
+//    matrix pipe (one add per entry instead of two), and the kernel is held to <= 168 registers (three waves per SIMD at
+//    least), which makes the compiler keep the accumulators in VGPRs: the AGPR form cost two v_accvgpr_read per entry;
 //  * sum_ij beta_i beta_j Q_ij = sum_i beta_i (sum_j beta_j Q_ij): one fma per entry into a per-row accumulator, beta_i at the
 //    end; for a == b a second accumulator takes K^-1_ij Q_ij, and the factor 2 of the off-diagonal tiles is applied once
 //    (everything accumulated before the diagonal tile is doubled) instead of per entry;
 //  * TAB = 2: exp through the 32-entry table that meets every LDS bank once (exp_tab32, gp_kernels.hpp), TAB = 1: the
 //    2048-entry table of r04, TAB = 0: the polynomial exp_lean.
-// Same operands, same tiles, same partial[] layout as em_pair_kernel; other summation order (<= 1e-15 of sum |terms|).
 template <bool DIAG, int KD, int TAB>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3)))
 em_pair2_kernel(const double* __restrict__ ops, const double* __restrict__ beta, const double* __restrict__ invK,
-                double* __restrict__ partial, int N, int Np, int Ny, int crow_mode, const double* __restrict__ etab) {
+                double* __restrict__ partial, int N, int Np, int Ny, int crow_mode, const double* __restrict__ etab, int chunk) {
     constexpr int EMK = KD;
     constexpr int NQ = ((KD + 2) * 64 + 255) / 256;
-    const int ti = blockIdx.x, p = blockIdx.y, b = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int P = Ny * (Ny + 1) / 2, tiles = Np / 64;
+    const int P = Ny * (Ny + 1) / 2, tiles = Np / 64, nch = (tiles + chunk - 1) / chunk;
+    const int ti = blockIdx.x / nch, p = blockIdx.y, b = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int a = 0;
     while ((a + 1) * (a + 2) / 2 <= p) ++a;
     const int bb = p - a * (a + 1) / 2;
     if ((a == bb) != DIAG) return;
+    const int jt_beg = (blockIdx.x % nch) * chunk, jt_end = min(DIAG ? ti + 1 : tiles, jt_beg + chunk);
+    double* __restrict__ pout = partial + ((long)b * P + p) * tiles * nch + blockIdx.x;
+    if (jt_beg >= jt_end) {                      // (a chunk beyond the diagonal of an a == b strip)
+        if (tid == 0) *pout = 0.0;
+        return;
+    }
     const double* __restrict__ o = ops + ((long)b * P + p) * (2 * EMK + 2) * Np;
     const double* __restrict__ Wt = o + (long)EMK * Np;
     const double* __restrict__ La = o + (long)(2 * EMK) * Np;
@@ -387,7 +293,6 @@ em_pair2_kernel(const double* __restrict__ ops, const double* __restrict__ beta,
         racc[r] = 0.0;
     }
     double kacc = 0.0;
-    const int jt_end = DIAG ? ti + 1 : tiles;
     double st[NQ];
     auto fetch = [&](int jt) {
 #pragma unroll
@@ -407,11 +312,11 @@ em_pair2_kernel(const double* __restrict__ ops, const double* __restrict__ beta,
             if (rw < EMK + 2) Cs[buf][rw][cl] = st[q];
         }
     };
-    fetch(0);
+    fetch(jt_beg);
     stage(0);
     __syncthreads();
     int cur = 0;
-    for (int jt = 0; jt < jt_end; ++jt) {
+    for (int jt = jt_beg; jt < jt_end; ++jt) {
         if (jt + 1 < jt_end) fetch(jt + 1);
         double ik[4][4];
         if (DIAG) {
@@ -425,7 +330,10 @@ em_pair2_kernel(const double* __restrict__ ops, const double* __restrict__ beta,
 #pragma unroll
                 for (int r = 0; r < 4; ++r) ik[t][r] = irow[r] < N ? iK[(long)irow[r] * Np + jt * 64 + 16 * t + fr] : 0.0;
         }
-#pragma unroll
+        // one 16 x 16 tile at a time (`unroll 1`, r05): four exps in flight per lane instead of sixteen -- 80 / 126 registers instead
+        // of 156 / 190, six / four waves per SIMD instead of three / two, and the table look-ups' and the matrix results'
+        // latencies hide behind other waves (C3, same box: EM phase 38.3 -> 36.7 ms; unroll 2: 37.0; profiles/r05_em_occupancy_ab.txt)
+#pragma unroll 1
         for (int t = 0; t < 4; ++t) {
             const int cl = 16 * t + fr;
             const double lbj = Cs[cur][EMK][cl];
@@ -449,11 +357,14 @@ em_pair2_kernel(const double* __restrict__ ops, const double* __restrict__ beta,
         cur ^= 1;
     }
     double acc = (bai[0] * racc[0] + bai[1] * racc[1]) + (bai[2] * racc[2] + bai[3] * racc[3]);
-    if (DIAG) acc -= kacc;
+    if (DIAG) {
+        acc -= kacc;
+        if (jt_end <= ti) acc *= 2.0;           // a chunk entirely below the diagonal: every tile of it counts twice
+    }
     acc = wave_sum(acc);
     if (lane == 0) red[wave] = acc;
     __syncthreads();
-    if (tid == 0) partial[((long)b * P + p) * tiles + ti] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (tid == 0) *pout = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 // cov_ab = t_p * sum_tiles partial;  cov_aa += sf_a^2;  cov -= mean mean^T;  symmetric fill.
@@ -470,7 +381,7 @@ __global__ void __launch_bounds__(64) em_finish_kernel(const double* __restrict_
     const int bb = p - a * (a + 1) / 2;
     const double t = prep[((long)b * (Ny + P) + Ny + p) * stride + d * d];
     double s = 0.0;
-    for (int k = 0; k < tiles; ++k) s += partial[((long)b * P + p) * tiles + k];
+    for (int k = 0; k < tiles; ++k) s += partial[((long)b * P + p) * tiles + k];   // (tiles: partial sums per pair = strips x chunks)
     double v = t * s;
     if (a == bb) v += hyper[(long)a * (d + 2) + d] * hyper[(long)a * (d + 2) + d];
     v -= mean[(long)b * Ny + a] * mean[(long)b * Ny + bb];

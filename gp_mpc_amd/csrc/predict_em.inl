@@ -1,4 +1,5 @@
 // Moment-based methods: 'EM' (a11) and the legacy 'old_ME' / 'old_TA' (a12).  Included by gpmpc_api.hip.
+static int g_em_chunk = 0;          // gpmpc_set_tuning("em_chunk", n): column tiles per workgroup of the pair sums (0 = default)
 
 // beta_a = K_a^-1 y_a (gp_functions.py:383; the reference multiplies the explicit inverse)
 static int ensure_beta(gpmpc_gp* h) {
@@ -34,7 +35,11 @@ static int predict_moments_chunk(gpmpc_gp* h, int method, int B, const double* d
         PhaseTimer t(h, GPMPC_PH_EM);
         const int KD = em_depth(d);                           // 8 or 16 (d <= DMAX = 16 is checked at gpmpc_create)
         const int P = Ny * (Ny + 1) / 2, tiles = Np / 64;
-        const long prepN = (long)B * (Ny + P) * (d * d + 1), partN = (long)B * P * tiles;
+        // column tiles per workgroup of the pair sums (em_kernels.hpp; GPMPC_EM_CHUNK, tuning aid; >= tiles: one workgroup per strip)
+        // (also gpmpc_set_tuning("em_chunk", n): the tests sweep it at small sizes)
+        static const int em_chunk_env = getenv("GPMPC_EM_CHUNK") ? atoi(getenv("GPMPC_EM_CHUNK")) : 64;   // (C3: 64 -> 38.4 ms, 32 -> 39.4, 16 -> 42.5, whole strips 39.9: profiles/r05_em_chunk_ab.txt)
+        const int em_chunk = std::max(1, std::min(g_em_chunk > 0 ? g_em_chunk : em_chunk_env, tiles)), nslots = tiles * ((tiles + em_chunk - 1) / em_chunk);
+        const long prepN = (long)B * (Ny + P) * (d * d + 1), partN = (long)B * P * nslots;
         const long opsN = (long)B * P * (2 * KD + 2) * Np, mpartN = (long)B * Ny * EM_MEAN_CHUNKS;
         CHK(ensure_em_scratch(h, (prepN + partN + opsN + mpartN) * (long)sizeof(double)));
         double* prep = h->em;
@@ -50,38 +55,30 @@ static int predict_moments_chunk(gpmpc_gp* h, int method, int B, const double* d
             HIPCHK(hipGetLastError());
             return GPMPC_OK;
         }
-        // exp of the pair sums through the 2^(j / 2048) table (gp_kernels.hpp exp_tab; GPMPC_EM_EXP_TAB=0: the polynomial exp_lean)
-        static const bool exp_tab_on = !(getenv("GPMPC_EM_EXP_TAB") && atoi(getenv("GPMPC_EM_EXP_TAB")) == 0);
-        // GPMPC_EM_PAIR (tuning aid): 0 the r04 kernel, 1 (default) em_pair2_kernel with the 2048-entry table, 2 with the
-        // conflict-free 32-entry table, 3 with the polynomial exp (r05, C3, same box: 45.7 / 40.8 / 43.3 / 46.3 ms per step)
+        // exp of the pair sums: GPMPC_EM_PAIR (tuning aid) 1 (default) the 2^(j / 2048) table, 2 the conflict-free 32-entry table,
+        // 3 the polynomial exp_lean (r05, C3, same box: 40.8 / 43.3 / 46.3 ms per step; r04's kernel 45.7)
         static const int pair_form = getenv("GPMPC_EM_PAIR") ? atoi(getenv("GPMPC_EM_PAIR")) : 1;
         const double* etab = g_exp_tab[h->device];
 #define GPMPC_EM_PAIR2(KDV, TABV)                                                                                                     \
-        hipLaunchKernelGGL((em_pair2_kernel<false, KDV, TABV>), dim3(tiles, P, B), dim3(256), 0, cx.stream, ops, h->beta, h->ws.InvK, \
-                           partial, N, Np, Ny, cx.crow_mode, etab);                                                                   \
-        hipLaunchKernelGGL((em_pair2_kernel<true, KDV, TABV>), dim3(tiles, P, B), dim3(256), 0, cx.stream, ops, h->beta, h->ws.InvK,  \
-                           partial, N, Np, Ny, cx.crow_mode, etab);
+        hipLaunchKernelGGL((em_pair2_kernel<false, KDV, TABV>), dim3(nslots, P, B), dim3(256), 0, cx.stream, ops, h->beta, h->ws.InvK, \
+                           partial, N, Np, Ny, cx.crow_mode, etab, em_chunk);                                                         \
+        hipLaunchKernelGGL((em_pair2_kernel<true, KDV, TABV>), dim3(nslots, P, B), dim3(256), 0, cx.stream, ops, h->beta, h->ws.InvK,  \
+                           partial, N, Np, Ny, cx.crow_mode, etab, em_chunk);
 #define GPMPC_EM_PAIR2_ANY(KDV)                                                                                                       \
         if (pair_form == 2) { GPMPC_EM_PAIR2(KDV, 2) } else if (pair_form == 3) { GPMPC_EM_PAIR2(KDV, 0) } else { GPMPC_EM_PAIR2(KDV, 1) }
-#define GPMPC_EM_PAIR(KDV, TABV)                                                                                                      \
-        hipLaunchKernelGGL((em_pair_kernel<false, KDV, TABV>), dim3(tiles, P, B), dim3(256), 0, cx.stream, ops, h->beta, h->ws.InvK,  \
-                           partial, N, Np, Ny, cx.crow_mode, etab);                                                                   \
-        hipLaunchKernelGGL((em_pair_kernel<true, KDV, TABV>), dim3(tiles, P, B), dim3(256), 0, cx.stream, ops, h->beta, h->ws.InvK,   \
-                           partial, N, Np, Ny, cx.crow_mode, etab);
         if (KD == 8) {
             hipLaunchKernelGGL((em_operands_kernel<8>), dim3((Np + 255) / 256, P, B), dim3(256), 0, cx.stream, h->XT, dZ, h->ws.hyper,
                                prep, ops, N, Np, d, Ny);
-            if (pair_form != 0) { GPMPC_EM_PAIR2_ANY(8) } else if (exp_tab_on) { GPMPC_EM_PAIR(8, true) } else { GPMPC_EM_PAIR(8, false) }
+            GPMPC_EM_PAIR2_ANY(8)
         } else {      // d = 9 .. 16: the same kernels with a 16-deep cross term (gp_exact_moment is dimension-generic)
             hipLaunchKernelGGL((em_operands_kernel<16>), dim3((Np + 255) / 256, P, B), dim3(256), 0, cx.stream, h->XT, dZ, h->ws.hyper,
                                prep, ops, N, Np, d, Ny);
-            if (pair_form != 0) { GPMPC_EM_PAIR2_ANY(16) } else if (exp_tab_on) { GPMPC_EM_PAIR(16, true) } else { GPMPC_EM_PAIR(16, false) }
+            GPMPC_EM_PAIR2_ANY(16)
         }
-#undef GPMPC_EM_PAIR
 #undef GPMPC_EM_PAIR2
 #undef GPMPC_EM_PAIR2_ANY
         hipLaunchKernelGGL(em_finish_kernel, dim3((unsigned)(((long)B * P + 63) / 64)), dim3(64), 0, cx.stream, partial, prep,
-                           h->ws.hyper, dMean, dCov, B, Ny, d, tiles);
+                           h->ws.hyper, dMean, dCov, B, Ny, d, nslots);
         HIPCHK(hipGetLastError());
         return GPMPC_OK;
     }

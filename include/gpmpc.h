@@ -288,6 +288,8 @@ int gpmpc_schedule_stats(int mode, int tilesM, int tilesN, int batch, int K, int
  * "vargemm_persist": the large-batch variance product (gp_functions.py:122-126) as 0 = one 128 x 128 tile per workgroup in
  * the dispatcher's order, 1 = one persistent launch over a static schedule when there are at least two tiles per workgroup
  * slot (default, or GPMPC_VARGEMM_PERSIST), 2 = ... at any size (tests), -1 back to the default; same bits either way.
+ * "em_chunk": column tiles (64 wide) one workgroup of the exact-moment pair sums sweeps (gp_exact_moment,
+ * gp_functions.py:397-414; default 64, or GPMPC_EM_CHUNK); 0 back to the default; results agree to rounding.
  * Returns GPMPC_EINVAL for an unknown name or value. */
 int gpmpc_set_tuning(const char* name, int value);
 

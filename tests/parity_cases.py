@@ -459,6 +459,35 @@ def check_moment_methods(lib, g=None):
     h.close()
 
 
+def check_em_chunks(lib, N=300, d=3, Ny=2, seed=12):
+    """Exact-moment pair sums with every split of a strip's column sweep (em_kernels.hpp: workgroup = (strip, chunk); chunks
+    beyond the diagonal of an a == b strip write zeros, chunks below it count twice): Np = 320 = 5 column tiles, chunk sizes
+    1, 2, 3 and the whole strip against the oracle (gp_functions.py:344-418) and against each other at rounding level."""
+    p = go.synthetic_problem(N, d, Ny, 3, seed=seed, sn=0.1)
+    X, Y, H, Z, S = p['X'], p['Y'], p['hyper'], p['Z'], p['Sigma'] * 30
+    h = Handle(lib, X, Y)
+    h.fit(H, want_invK=True)
+    f = h.get_factors(invK=True)
+    sf2 = H[:, d] ** 2
+    ref = None
+    try:
+        for chunk in (1, 2, 3, 1000):
+            lib.set_tuning('em_chunk', chunk)
+            m, c = h.predict('EM', Z, S)
+            for b in range(len(Z)):
+                om, oc = go.exact_moment(f['invK'], X, Y, H, Z[b], S[b])
+                sc = _em_scale(f['invK'], X, Y, H, Z[b], S[b])
+                assert np.max(np.abs(c[b] - oc) / (sc + sf2.max())) <= 1e-9, (chunk, b)
+                assert np.array_equal(c[b], c[b].T)
+            if ref is None:
+                ref = c
+            else:
+                assert np.max(np.abs(c - ref)) <= 1e-12 * max(1.0, np.abs(ref).max()) * 1e3, chunk
+    finally:
+        lib.set_tuning('em_chunk', 0)
+        h.close()
+
+
 def check_old_me_reference_pin(lib, g, pin, tol=1e-12):
     """a12 'old_ME' (`gp`, gp_functions.py:176-256, alpha=None) against REFERENCE-MADE outputs: the reference's own numpy
     GP.covSEard composed with the K^-1 and Y of its saved model in the graph's order (oracle/make_golden.py legacy_pin).

@@ -301,3 +301,7 @@ def test_emu_set_factors_then_persistent_mean(emu):
 def test_emu_old_me_reference_pin(emu, tank, car, old_me_pins):
     pc.check_old_me_reference_pin(emu, tank, old_me_pins['tank'])
     pc.check_old_me_reference_pin(emu, car, old_me_pins['car'])
+
+
+def test_emu_em_pair_sum_chunks(emu):
+    pc.check_em_chunks(emu)

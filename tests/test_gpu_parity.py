@@ -326,3 +326,7 @@ def test_set_factors_then_persistent_mean(lib):
 def test_old_me_reference_pin(lib, tank, car, old_me_pins):
     pc.check_old_me_reference_pin(lib, tank, old_me_pins['tank'])
     pc.check_old_me_reference_pin(lib, car, old_me_pins['car'])
+
+
+def test_em_pair_sum_chunks(lib):
+    pc.check_em_chunks(lib)
