@@ -178,40 +178,37 @@ __global__ void __launch_bounds__(WORKER_THREADS) chol_worker_kernel(double* Kma
         if (swave >= 4) return;
         char* img = (char*)smem + pp * WORKER_PAIR_BYTES + 1024 * swave;
         const unsigned half = (unsigned)(32 * ld * 8);        // rows 8 (wave + 4) .. : 32 rows further down
-        if (with_a) {
-            const dma_rsrc_t ra = dma_make_rsrc(pa, (unsigned)(64 * ld * 8));
-#pragma unroll
-            for (int sl = 0; sl < 4; ++sl) {
-                dma_load16(ra, img + 8192 * sl, dvo, 128u * sl);
-                dma_load16(ra, img + 8192 * sl + 4096, dvo, 128u * sl + half);
-            }
-        }
-        if (with_b) {
-            const dma_rsrc_t rb = dma_make_rsrc(pb, (unsigned)(64 * ld * 8));
-#pragma unroll
-            for (int sl = 0; sl < 4; ++sl) {
-                dma_load16(rb, img + 32768 + 8192 * sl, dvo, 128u * sl);
-                dma_load16(rb, img + 32768 + 8192 * sl + 4096, dvo, 128u * sl + half);
-            }
-        }
+        if (with_a) dma_load_block64(dma_make_rsrc(pa, (unsigned)(64 * ld * 8)), img, dvo, half);
+        if (with_b) dma_load_block64(dma_make_rsrc(pb, (unsigned)(64 * ld * 8)), img + 32768, dvo, half);
     };
     // c0, c1 += sgn * A B^T on this wave's 16 x 32 piece, operands from the landed pair image pp
     // (imgA / imgB: block images of the A and the B operand -- any landed 32 KB image serves as either)
     auto product_ab = [&](const char* imgA, const char* imgB, d4& c0, d4& c1, bool negate) {
         const char* img = imgA;
         const long boff = (imgB - imgA) - 32768;       // fb0 / fb1 carry the B part's offset inside a pair image
-#pragma unroll 1
-        for (int sl = 0; sl < 4; ++sl)             // (fully unrolled, the 24 fragment loads are hoisted and spill)
+        // Fully unrolled (r05): the 24 fragment reads of a tile are in flight under its 32 matrix instructions (227 registers,
+        // no spill with this compiler; r03 kept the slab loop rolled because it spilled then).  Same-box A/B, C2: slab loop /
+        // two slabs / all four unrolled: chain 1.2015 / 1.1670 / 1.1435 ms, step 4.140 / 4.114 / 4.093 ms
+        // (profiles/r05_worker_update_unroll_ab.txt) -- the workers bound every quarter of the chain by then.
+        // The subtraction is the matrix instruction's own NEG modifier on A (mfma16_nega), not two v_xor per K pair.
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl)
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                double2 a = *reinterpret_cast<const double2*>(img + 8192 * sl + (h ? fa1 : fa0));
+                const double2 a = *reinterpret_cast<const double2*>(img + 8192 * sl + (h ? fa1 : fa0));
                 const double2 b0 = *reinterpret_cast<const double2*>(img + boff + 8192 * sl + (h ? fb1 : fb0));
                 const double2 b1 = *reinterpret_cast<const double2*>(img + boff + 8192 * sl + 2048 + (h ? fb1 : fb0));
-                if (negate) { a.x = -a.x; a.y = -a.y; }
-                c0 = mfma16(a.x, b0.x, c0);
-                c1 = mfma16(a.x, b1.x, c1);
-                c0 = mfma16(a.y, b0.y, c0);
-                c1 = mfma16(a.y, b1.y, c1);
+                if (negate) {
+                    c0 = mfma16_nega(a.x, b0.x, c0);
+                    c1 = mfma16_nega(a.x, b1.x, c1);
+                    c0 = mfma16_nega(a.y, b0.y, c0);
+                    c1 = mfma16_nega(a.y, b1.y, c1);
+                } else {
+                    c0 = mfma16(a.x, b0.x, c0);
+                    c1 = mfma16(a.x, b1.x, c1);
+                    c0 = mfma16(a.y, b0.y, c0);
+                    c1 = mfma16(a.y, b1.y, c1);
+                }
             }
     };
     auto product = [&](int pp, d4& c0, d4& c1, bool negate) {

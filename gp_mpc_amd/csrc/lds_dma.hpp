@@ -23,6 +23,12 @@ inline void dma_load16(const dma_rsrc_t& r, char* lds_wave_base, unsigned voff, 
 inline void dma_load16_relaxed(const dma_rsrc_t& r, char* lds_wave_base, unsigned voff, unsigned soff) {
     dma_load16(r, lds_wave_base, voff, soff);
 }
+inline void dma_load_block64(const dma_rsrc_t& r, char* lds_wave_base, unsigned voff, unsigned half) {
+    for (int sl = 0; sl < 4; ++sl) {
+        dma_load16(r, lds_wave_base + 8192 * sl, voff, 128u * sl);
+        dma_load16(r, lds_wave_base + 8192 * sl + 4096, voff, 128u * sl + half);
+    }
+}
 template <int N> inline void dma_wait() {}
 inline void dma_barrier() { __syncthreads(); }
 inline void lds_barrier() { __syncthreads(); }
@@ -45,6 +51,47 @@ __device__ __forceinline__ void dma_load16(dma_rsrc_t r, char* lds_wave_base, un
                  : "=&s"(keep)
                  : "s"(__builtin_amdgcn_readfirstlane(dst)), "v"(voff), "s"(r), "s"(soff)
                  : "memory");
+}
+// This wave's share of one 64 x 64 block as ONE instruction sequence (r05): the eight loads of dma_load16(r, base + 8192 sl
+// [+ 4096], voff, 128 sl [+ half]), sl = 0 .. 3 -- four 16-column slab images x two row halves (chol_worker.hpp).  M0 and the
+// two scalar offsets advance by s_add between the loads: 3 scalar instructions per load instead of the ~10 of eight separate
+// dma_load16 calls (generic -> LDS address conversion with its null check, M0 saved and restored around every load) -- the
+// requesting wave of a SIMD reaches its own matrix instructions ~100 scalar instructions earlier per tile.
+// (One instruction sits between every write of M0 and the load that reads it, as in dma_load16.)
+__device__ __forceinline__ void dma_load_block64(dma_rsrc_t r, char* lds_wave_base, unsigned voff, unsigned half) {
+    const unsigned dst = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)lds_wave_base;
+    unsigned keep, s0, s1;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_mov_b32 %1, 0\n\t"
+        "s_mov_b32 %2, %6\n\t"
+        "buffer_load_dwordx4 %4, %5, %1 offen lds\n\t"
+        "s_add_u32 m0, m0, 0x1000\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %4, %5, %2 offen lds\n\t"
+        "s_add_u32 m0, m0, 0x1000\n\t"
+        "s_addk_i32 %1, 0x80\n\t"
+        "buffer_load_dwordx4 %4, %5, %1 offen lds\n\t"
+        "s_add_u32 m0, m0, 0x1000\n\t"
+        "s_addk_i32 %2, 0x80\n\t"
+        "buffer_load_dwordx4 %4, %5, %2 offen lds\n\t"
+        "s_add_u32 m0, m0, 0x1000\n\t"
+        "s_addk_i32 %1, 0x80\n\t"
+        "buffer_load_dwordx4 %4, %5, %1 offen lds\n\t"
+        "s_add_u32 m0, m0, 0x1000\n\t"
+        "s_addk_i32 %2, 0x80\n\t"
+        "buffer_load_dwordx4 %4, %5, %2 offen lds\n\t"
+        "s_add_u32 m0, m0, 0x1000\n\t"
+        "s_addk_i32 %1, 0x80\n\t"
+        "buffer_load_dwordx4 %4, %5, %1 offen lds\n\t"
+        "s_add_u32 m0, m0, 0x1000\n\t"
+        "s_addk_i32 %2, 0x80\n\t"
+        "buffer_load_dwordx4 %4, %5, %2 offen lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep), "=&s"(s0), "=&s"(s1)
+        : "s"(__builtin_amdgcn_readfirstlane(dst)), "v"(voff), "s"(r), "s"(__builtin_amdgcn_readfirstlane(half))
+        : "memory", "scc");
 }
 // The same load without the compiler-level memory barrier, for loads interleaved with the matrix instructions of a
 // loop whose LDS reads must stay free to move (they touch a different LDS image; the s_barrier / counted wait that

@@ -24,6 +24,11 @@ namespace gpmpc {
 __device__ __forceinline__ d4 mfma16(double a, double b, d4 c) {
     return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
+// D = C - A B: for the f64 matrix instruction the BLGP field carries NEG modifiers (bit 0: A), so the subtraction of a
+// trailing update costs no VALU instruction (the workers negated their A fragments with two v_xor per K pair before r05)
+__device__ __forceinline__ d4 mfma16_nega(double a, double b, d4 c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 1);
+}
 
 // row inside the 16x16 result tile of accumulator register r held by `lane`
 __device__ __forceinline__ int crow(int lane, int r, int mode) {

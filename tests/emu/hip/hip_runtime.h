@@ -174,7 +174,9 @@ inline emu_d4 emu_mfma_f64(double a, double b, emu_d4 c) {
     emu_d4 d = {di[0], di[1], di[2], di[3]};
     return d;
 }
-#define __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, x, y, z) emu_mfma_f64((a), (b), (c))
+// (the last operand: for the f64 matrix instruction the BLGP field holds NEG modifiers -- bit 0 negates A, bit 1 B, bit 2 C)
+#define __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, x, y, z) \
+    emu_mfma_f64(((z) & 1) ? -(a) : (a), ((z) & 2) ? -(b) : (b), ((z) & 4) ? emu_d4{-(c)[0], -(c)[1], -(c)[2], -(c)[3]} : (c))
 
 inline double atomicAdd(double* p, double v) { double o = *p; *p = o + v; return o; }
 inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
