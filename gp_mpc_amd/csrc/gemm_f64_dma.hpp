@@ -144,8 +144,9 @@ __global__ void __launch_bounds__(64 * WGM * WGN, WPS) gemm_f64_dma_kernel(GemmP
             }
         }
         const unsigned kstepA = AMC ? (unsigned)(p.lda * 8) : 8u, kstepB = BNC ? (unsigned)(p.ldb * 8) : 8u;
+        const lds_addr_t smem_at = lds_addr_of(smem);
         auto request = [&](int t) {                               // slab t of this tile -> ring image t % STAGES
-            char* img = smem + (t % STAGES) * SLAB;
+            const lds_addr_t img = smem_at + (lds_addr_t)((t % STAGES) * SLAB);
             const unsigned k0 = (unsigned)(klo + t * BK);
 #pragma unroll
             for (int i = 0; i < LPW; ++i) {

@@ -23,6 +23,12 @@ inline void dma_load16(const dma_rsrc_t& r, char* lds_wave_base, unsigned voff, 
 inline void dma_load16_relaxed(const dma_rsrc_t& r, char* lds_wave_base, unsigned voff, unsigned soff) {
     dma_load16(r, lds_wave_base, voff, soff);
 }
+// (LDS addresses as integers: under the emulator "LDS" is host memory and the handle is the pointer itself)
+typedef unsigned long lds_addr_t;
+inline lds_addr_t lds_addr_of(void* p) { return (lds_addr_t)p; }
+inline void dma_load16(const dma_rsrc_t& r, lds_addr_t lds_wave_base, unsigned voff, unsigned soff) {
+    dma_load16(r, (char*)lds_wave_base, voff, soff);
+}
 inline void dma_load_block64(const dma_rsrc_t& r, char* lds_wave_base, unsigned voff, unsigned half) {
     for (int sl = 0; sl < 4; ++sl) {
         dma_load16(r, lds_wave_base + 8192 * sl, voff, 128u * sl);
@@ -51,6 +57,19 @@ __device__ __forceinline__ void dma_load16(dma_rsrc_t r, char* lds_wave_base, un
                  : "=&s"(keep)
                  : "s"(__builtin_amdgcn_readfirstlane(dst)), "v"(voff), "s"(r), "s"(soff)
                  : "memory");
+}
+// The same with the LDS address as an integer the caller formed ONCE (lds_addr_of): the conversion of a generic pointer to an
+// LDS address carries a null check, four scalar instructions per load when it is repeated for every load of a ring (r05).
+typedef unsigned lds_addr_t;
+__device__ __forceinline__ lds_addr_t lds_addr_of(void* p) {
+    return (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long)(__attribute__((address_space(3))) char*)p);
+}
+__device__ __forceinline__ void dma_load16(dma_rsrc_t r, lds_addr_t lds_wave_base, unsigned voff, unsigned soff) {
+    // (M0 is declared clobbered instead of being saved and restored around every load: two scalar instructions less)
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :
+                 : "s"(__builtin_amdgcn_readfirstlane((int)lds_wave_base)), "v"(voff), "s"(r), "s"(soff)
+                 : "memory", "m0");
 }
 // This wave's share of one 64 x 64 block as ONE instruction sequence (r05): the eight loads of dma_load16(r, base + 8192 sl
 // [+ 4096], voff, 128 sl [+ half]), sl = 0 .. 3 -- four 16-column slab images x two row halves (chol_worker.hpp).  M0 and the

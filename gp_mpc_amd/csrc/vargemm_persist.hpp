@@ -90,6 +90,8 @@ __device__ __forceinline__ void persist_gemm_body(const GemmP& p, const int* __r
             vo[i] = (unsigned)(grow * 8) + (piece << 4);
         }
     };
+    // (the pointer form of dma_load16 here: with the integer form and its M0 clobber this kernel measured 0.7 % slower,
+    //  profiles/r05_dma_lds_address_ab.txt -- it runs inside a 116-register budget and at 96 % matrix-pipe duty)
     auto request_next = [&](int g) {                               // next slab of the stream -> image g & 1
         if (ri >= end) return;
         char* img = smem + (g & 1) * SLAB;
