@@ -415,6 +415,10 @@ static bool factor_chain(const Ctx& cx, Workspace& ws, int spin_limit, bool flag
     // polls had timed out.  So: 7 workers per engine, nothing else in flight but the chain (one matrix only).
     const int ntiles = (nb - 1) * nb / 2 - 1;            // tiles kept in registers (chol_worker.hpp)
     int NW = ws.batch == 1 && !cx.no_workers ? cx.workers - cx.workers / 8 : 0;
+    // (tuning aid) GPMPC_NW1=<n>: workgroups of the first worker launch instead of 7 per shader engine -- beyond that a
+    // workgroup may have to wait for the chain's engine (see above): the hand-off time-out and its fallback catch that
+    static const int nw1_env = getenv("GPMPC_NW1") ? atoi(getenv("GPMPC_NW1")) : 0;
+    if (NW > 0 && nw1_env > 0) NW = std::min(nw1_env, cx.workers - 1);
     // the last workgroup of every worker launch is the chain's courier (chol_worker.hpp), no tile owner; GPMPC_COURIER=0:
     // tile owners only (r03 A/B on one box: factor 1.675 -> 1.630 ms at C2 with the courier)
     static const bool worker_courier_env = !(getenv("GPMPC_COURIER") && atoi(getenv("GPMPC_COURIER")) == 0);
