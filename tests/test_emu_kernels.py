@@ -108,7 +108,7 @@ def test_emu_predict_behind_tail(emu):
     emu.set_tuning('cu_count', 16)
     try:
         pc.check_predict_behind_tail(emu, N=760, d=3, B=150)
-        pc.check_predict_behind_tail(emu, N=700, d=3, B=70, mean_only_second=True)
+        pc.check_predict_behind_tail(emu, N=650, d=3, B=70, mean_only_second=True, repeats=1)    # (Np = 704: still two worker launches)
     finally:
         emu.set_tuning('cu_count', 8)
 
@@ -258,8 +258,9 @@ def test_callback_layout_follows_the_casadi_version():
 
 
 def test_emu_training_lockstep_batches_are_composition_independent(emu):
-    pc.check_train_lockstep_invariance(emu, N=300, d=3, nstart=5, max_iter=3)                  # two-level execution (Np = 320)
-    pc.check_train_lockstep_invariance(emu, N=100, d=2, nstart=4, max_iter=3, mean_func='linear')   # flagged-GEMM execution, trained mean
+    # (sizes trimmed in r05: the five batch / schedule configurations are the point, not the length of the search)
+    pc.check_train_lockstep_invariance(emu, N=300, d=3, nstart=4, max_iter=2)                  # two-level execution (Np = 320)
+    pc.check_train_lockstep_invariance(emu, N=100, d=2, nstart=3, max_iter=2, mean_func='linear')   # flagged-GEMM execution, trained mean
 
 
 def test_emu_training_native(emu, train_small):
