@@ -12,13 +12,19 @@ Parity status
   container by `oracle/make_golden.py`, outputs frozen in `tests/golden/`):
   a1 `calc_cov_matrix` / `GP.covSEard`, a3-a5+a7 `calc_NLL_numpy`,
   a6/a8 `train_gp_numpy`, a14 `GP.covar`, and against the two saved models
-  `examples/models/gp_{tank,car}_example.json` (chol / alpha / invK).
+  `examples/models/gp_{tank,car}_example.json` (chol / alpha / invK);
+  (r05) a12 'old_ME' (`gp`, gp_functions.py:176-256, alpha=None): its two
+  matrix products composed from the reference's own `GP.covSEard` output and
+  the K^-1 / Y of its saved models (`make_golden.py legacy`,
+  tests/golden/{tank,car}_old_me.npz).
 * "PARITY UNPINNED" (CasADi-graph functions, casadi is not installable here,
-  the reference has no tests that pin them): a9 `build_gp`, a10
-  `build_TA_cov`, a11 `gp_exact_moment`/`maha`, a12 legacy `gp` /
-  `gp_taylor_approx`.  They are restated line by line below and checked
-  through mathematical identities (tests/test_oracle.py): EM(Sigma->0)==ME,
-  Monte-Carlo moments, analytic-J == finite differences, beta == alpha.
+  the reference has no tests that pin them): a9 `build_gp` (mean Jacobian;
+  its mean and variance are pinned through `GP.covSEard` / `GP.covar`), a10
+  `build_TA_cov`, a11 `gp_exact_moment`/`maha`, a12 `gp_taylor_approx`
+  ('old_TA').  They are restated line by line below and checked through
+  mathematics on the pinned functions (tests/test_oracle.py): Gauss-Hermite
+  quadrature of the pinned predictor, complex-step derivatives,
+  EM(Sigma->0)==ME, beta == alpha.
 
 All `file:line` citations are into /root/reference/gp_mpc/.
 Conventions: hyper[a] = [ell_1..ell_d, sf, sn] with sf, sn
