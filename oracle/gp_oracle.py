@@ -17,14 +17,20 @@ Parity status
   matrix products composed from the reference's own `GP.covSEard` output and
   the K^-1 / Y of its saved models (`make_golden.py legacy`,
   tests/golden/{tank,car}_old_me.npz).
-* "PARITY UNPINNED" (CasADi-graph functions, casadi is not installable here,
-  the reference has no tests that pin them): a9 `build_gp` (mean Jacobian;
-  its mean and variance are pinned through `GP.covSEard` / `GP.covar`), a10
-  `build_TA_cov`, a11 `gp_exact_moment`/`maha`, a12 `gp_taylor_approx`
-  ('old_TA').  They are restated line by line below and checked through
-  mathematics on the pinned functions (tests/test_oracle.py): Gauss-Hermite
-  quadrature of the pinned predictor, complex-step derivatives,
-  EM(Sigma->0)==ME, beta == alpha.
+* (r06) PINNED BY REFERENCE-RUN COMPOSITIONS (`make_golden.py ta | em | refmodel`; casadi is not installable, so the
+  CasADi graphs themselves cannot run, but every number below was produced by the reference's own numpy functions):
+  a9 mean and its Jacobian J: `GP.covSEard(X, z)^T alpha` (gp_class.py:314-350) and its complex-step derivative
+  (h = 1e-30: exact to rounding) on the two saved models -> tests/golden/{tank,car}_ta.npz; oracle vs pin 2e-16 of the
+  sums' rounding scale;  a10 'TA': diag(`GP.covar`) + J Sigma J^T (the one line of build_TA_cov, gp_functions.py:167-171)
+  -> same files; oracle vs pin 7e-14 (tank) / 1.4e-10 (car, cond 7e10) of max|cov|;
+  a11 'EM' (`gp_exact_moment`): tensor Gauss-Hermite quadrature (80^2 nodes, converged to 2e-15 / 2e-12) of that same
+  reference predictor on two models the reference's `train_gp_numpy` produced -> tests/golden/{em_model2,train_small}_em.npz;
+  oracle vs pin 7e-14 absolute on em_model2 (cond 4e3); on train_small (cond 7e8) 3e-6 = cond * eps * sf^2, the closed
+  form's own K^-1 arithmetic (the quadrature is the more accurate side there);
+  f2 model file: tests/golden/ref_written_model.json was written by the reference's `GP.optimize` + `GP.save_model`.
+* STILL "PARITY UNPINNED": a12 `gp_taylor_approx` ('old_TA') only -- its graph relies on CasADi's linear indexing of an
+  MX matrix (gp_functions.py:325-331, self-documented bug) which no numpy function of the reference reproduces; restated
+  twice independently (vectorised here, scalar loops in tests/test_oracle.py) and the two agree.
 
 All `file:line` citations are into /root/reference/gp_mpc/.
 Conventions: hyper[a] = [ell_1..ell_d, sf, sn] with sf, sn

@@ -15,7 +15,7 @@ of the hot path then run unmodified:
 plus the two saved models examples/models/gp_{tank,car}_example.json, the only
 known-answer artefacts the reference ships (written by gp_class.py:693-726).
 
-Usage:  python oracle/make_golden.py
+Usage:  python oracle/make_golden.py [legacy | ta | em | refmodel]      (one group only; the other fixtures stay untouched)
 """
 import json
 import os
@@ -202,12 +202,172 @@ def legacy_pin(optimize, GP, name):
     print(name, 'old_ME pin: mean', mean[:, :2], 'var', var[:, :2])
 
 
+def _ref_mean_complex(g, X, Zc, H, alpha):
+    """mean_a(z) = covSEard(X, z)^T alpha_a through the REFERENCE's own numpy kernel (gp_class.py:314-350; its operation
+    order is complex-safe: squares, sums, one dot, one exp), alpha as the reference stored / trained it."""
+    D, Ny = X.shape[1], H.shape[0]
+    Xc = X.astype(Zc.dtype)
+    return np.stack([g.covSEard(Xc.copy(), Zc.copy(), H[a, :D], H[a, D] ** 2).T @ alpha[a] for a in range(Ny)], axis=1)
+
+
+def _ref_var(g, Zq, Ny, chunk=800):
+    """var_a(z) = diag of the reference's GP.covar (gp_class.py:353-381), evaluated in chunks of points (covar forms the
+    n x n matrix per output)."""
+    out = np.zeros((len(Zq), Ny))
+    for s in range(0, len(Zq), chunk):
+        c = g.covar(Zq[s:s + chunk].copy())[:Ny]
+        out[s:s + chunk] = np.stack([np.diag(ci) for ci in c], axis=1)
+    return out
+
+
+def ta_pin(optimize, GP, name):
+    """Reference-run pin for a9's Jacobian and a10 'TA' (`build_gp` / `build_TA_cov`, gp_functions.py:146-147,152-173; CasADi
+    graphs, not runnable here), composed from code the reference DOES run:
+        mean(z) = GP.covSEard(X, z)^T alpha                    (gp_class.py:314-350, alpha from the saved model)
+        J       = Im mean(z + i h e_p) / h,  h = 1e-30         (complex step through that same function: exact to rounding)
+        var(z)  = diag GP.covar(z)                             (gp_class.py:353-381)
+        cov     = diag(var) + J Sigma J^T                      (the one line of build_TA_cov, :167-171)
+    at the test points of <name>_model.npz with seeded SPD input covariances."""
+    d = json.load(open(f'{REF}/examples/models/gp_{name}_example.json'))
+    X = np.array(d['X'])
+    H = np.array(d['hyper']['hyper'])
+    chol = np.array(d['hyper']['chol'])
+    alpha = np.array(d['hyper']['alpha'])
+    D, Ny = X.shape[1], H.shape[0]
+    Z = np.load(os.path.join(OUT, f'{name}_model.npz'))['Z']
+    n = len(Z)
+    rng = np.random.default_rng(31 + len(name))
+    A = rng.standard_normal((n, D, D)) * X.std(0)[None, :, None]
+    Sigma = 1e-2 * A @ A.transpose(0, 2, 1) + 1e-6 * np.eye(D)
+    g = ref_gp(GP, X, H, chol)
+    mean = _ref_mean_complex(g, X, Z.astype(complex), H, alpha).real
+    J = np.zeros((n, Ny, D))
+    h = 1e-30
+    for p in range(D):
+        Zc = Z.astype(complex)
+        Zc[:, p] += 1j * h
+        J[:, :, p] = _ref_mean_complex(g, X, Zc, H, alpha).imag / h
+    var = _ref_var(g, Z, Ny)
+    cov = np.einsum('bad,bde,bce->bac', J, Sigma, J)
+    cov[:, np.arange(Ny), np.arange(Ny)] += var
+    # comparison scales: the size of the terms of the sums (cond(K) up to 7e10 on the car model makes alpha huge)
+    mscale = np.zeros((n, Ny))
+    jscale = np.zeros((n, Ny, D))
+    for a in range(Ny):
+        ks = g.covSEard(X.copy(), Z.copy(), H[a, :D], H[a, D] ** 2)
+        mscale[:, a] = np.abs(ks).T @ np.abs(alpha[a])
+        for p in range(D):
+            jscale[:, a, p] = (np.abs(ks * alpha[a][:, None]) * np.abs(X[:, p:p + 1] - Z[None, :, p])).sum(0) / H[a, p] ** 2
+    np.savez_compressed(os.path.join(OUT, f'{name}_ta.npz'), Z=Z, Sigma=Sigma, ref_mean=mean, ref_J=J, ref_var=var,
+                        ref_ta_cov=cov, mean_scale=mscale, J_scale=jscale)
+    print(name, 'TA pin: mean', mean[0], 'J', J[0, 0], 'cov diag', np.diag(cov[0]))
+
+
+def em_pin(optimize, GP):
+    """Reference-run pins for a11 'EM' (`gp_exact_moment`, gp_functions.py:344-430; a CasADi graph): what it computes in closed
+    form are the first two moments of the GP prediction under z ~ N(mu, Sigma),
+        E[mean(z)],   Cov[mean(z)] + diag(E[var(z)]),
+    here by tensor Gauss-Hermite quadrature (80 x 80 nodes, checked against 64 x 64) of the REFERENCE's own numeric
+    predictor -- GP.covSEard(X, z)^T alpha and diag GP.covar(z) -- on two models the reference's `train_gp_numpy` produced
+    (d = 2, Ny = 2, N = 40; chol, alpha, invK as the reference returned them):
+      train_small.npz  smooth data, sn ~ 1e-3: cond(K) = 2e7 / 7e8.  The closed form works on K^-1 (beta = K^-1 y, sum of
+                       K^-1_ij Q_ij against sf^2), so in fp64 it carries cond * eps * sf^2 ~ 1e-6 of rounding there; the
+                       quadrature (Cholesky-based predictor) does not.  Pin at that level only.
+      em_model2.npz    rough noisy data (made here, trained by the reference from a stated start): cond(K) ~ 4e3 -> the pin
+                       holds to the quadrature's own accuracy (<= 1e-11 observed, gated at 1e-9)."""
+    rng = np.random.default_rng(606)
+    N, D, Ny = 40, 2, 2
+    X2 = rng.uniform(-2, 2, (N, D))
+    Y2 = np.stack([np.sin(3 * X2[:, 0]) * np.cos(2 * X2[:, 1]), np.cos(2.5 * X2[:, 0] + 1.5 * X2[:, 1])], axis=1) \
+        + 0.1 * rng.standard_normal((N, Ny))
+    start = np.array([[0.6, 0.6, 0.8, 1e-2], [0.7, 0.9, 0.8, 1e-2]])
+    opt = optimize.train_gp_numpy(X2, Y2, multistart=1, optimizer_opts={'disp': False}, hyper_init=start)   # reference a8
+    np.savez_compressed(os.path.join(OUT, 'em_model2.npz'), X=X2, Y=Y2, hyper=opt['hyper'], chol=opt['chol'],
+                        alpha=opt['alpha'], invK=opt['invK'], hyper_init=start)
+    print('em_model2 hyper', opt['hyper'], 'cond', [np.linalg.cond(L @ L.T) for L in opt['chol']])
+
+    cases = {'train_small': [(np.array([0.3, -0.4]), np.array([[0.09, 0.03], [0.03, 0.16]])),
+                             (np.array([-1.1, 0.6]), np.array([[0.5, -0.2], [-0.2, 0.3]])),
+                             (np.array([1.5, 1.2]), np.array([[0.02, 0.0], [0.0, 0.4]])),
+                             (np.array([0.0, 0.0]), np.array([[1e-4, 5e-5], [5e-5, 1e-4]]))],
+             'em_model2': [(np.array([0.3, -0.4]), np.array([[0.02, 0.008], [0.008, 0.03]])),
+                           (np.array([-1.1, 0.6]), np.array([[0.04, -0.015], [-0.015, 0.025]])),
+                           (np.array([1.2, 1.0]), np.array([[0.005, 0.0], [0.0, 0.04]])),
+                           (np.array([0.0, 0.0]), np.array([[1e-4, 5e-5], [5e-5, 1e-4]]))]}
+    for model, cs in cases.items():
+        t = np.load(os.path.join(OUT, model + '.npz'))
+        X, H, chol, alpha = t['X'], t['hyper'], t['chol'], t['alpha']
+        g = ref_gp(GP, X, H, chol)
+
+        def quad(mu, Sigma, n):
+            tt, w = np.polynomial.hermite_e.hermegauss(n)
+            w = w / np.sqrt(2 * np.pi)
+            A = np.linalg.cholesky(Sigma)
+            T = np.stack([gg.ravel() for gg in np.meshgrid(tt, tt, indexing='ij')], axis=1)
+            W = np.outer(w, w).ravel()
+            Zq = mu + T @ A.T
+            m = _ref_mean_complex(g, X, Zq, H, alpha)
+            v = _ref_var(g, Zq, Ny)
+            Em, Ev = W @ m, W @ v
+            return Em, (m * W[:, None]).T @ m - np.outer(Em, Em) + np.diag(Ev)
+
+        mus, Sigmas, means, covs, conv = [], [], [], [], []
+        for mu, Sigma in cs:
+            m80, c80 = quad(mu, Sigma, 80)
+            m64, c64 = quad(mu, Sigma, 64)
+            mus.append(mu); Sigmas.append(Sigma); means.append(m80); covs.append(c80)
+            conv.append([np.abs(m80 - m64).max(), np.abs(c80 - c64).max()])
+            print(model, 'EM pin: mu', mu, 'mean', m80, 'cov', c80.ravel(), '80 vs 64 nodes', conv[-1])
+        np.savez_compressed(os.path.join(OUT, model + '_em.npz'), mu=np.array(mus), Sigma=np.array(Sigmas),
+                            ref_em_mean=np.array(means), ref_em_cov=np.array(covs), quad_convergence=np.array(conv))
+
+
+def ref_written_model(optimize, GP):
+    """A model file WRITTEN BY THE REFERENCE: its `GP.optimize` (gp_class.py:82-142: normalisation + `train_gp_numpy`) and
+    its `GP.save_model` (:693-734) run here on a small seeded data set (N = 30, Ny = 2, Nu = 1, normalize=True), the instance
+    made with object.__new__ because `GP.__init__` goes on to build CasADi graphs.  The JSON is data (tests/golden/
+    ref_written_model.json); next to it the reference's GP.covar / covSEard^T alpha at test points in the standardised
+    coordinates the model works in."""
+    rng = np.random.default_rng(4242)
+    N, Ny, Nu = 30, 2, 1
+    X = rng.uniform(-1, 1, (N, Ny + Nu)) * np.array([2.0, 0.5, 3.0]) + np.array([0.5, -1.0, 0.0])
+    Y = np.stack([np.sin(X[:, 0]) + 0.3 * X[:, 2], X[:, 1] * np.cos(0.5 * X[:, 0]) - 0.1 * X[:, 2] ** 2], axis=1)
+    Y = Y + 1e-3 * rng.standard_normal(Y.shape)
+    g = object.__new__(GP)
+    g._GP__X, g._GP__Y = X.copy(), Y.copy()
+    g._GP__Ny, g._GP__Nx, g._GP__N, g._GP__Nu = Ny, Ny + Nu, N, Nu
+    g._GP__gp_method = 'TA'
+    import io
+    import contextlib
+    with contextlib.redirect_stdout(io.StringIO()):
+        g.optimize(X=X, Y=Y, opts={'disp': False}, mean_func='zero', xlb=[-2.0, -2.0], xub=[3.0, 0.0], ulb=[-3.0], uub=[3.0],
+                   multistart=1, normalize=True, optimize_nummeric=True)
+    g.save_model(os.path.join(OUT, 'ref_written_model'))
+    Zs = rng.standard_normal((10, Ny + Nu))                                 # standardised coordinates
+    covar = g.covar(Zs.copy())[:Ny]
+    mean = _ref_mean_complex(g, g._GP__X, Zs, g._GP__hyper, g._GP__alpha)
+    np.savez_compressed(os.path.join(OUT, 'ref_written_model_outputs.npz'), Zs=Zs, ref_covar=covar, ref_mean_std=mean,
+                        X_raw=X, Y_raw=Y)
+    print('reference-written model:', os.path.getsize(os.path.join(OUT, 'ref_written_model.json')), 'bytes; hyper',
+          g._GP__hyper)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     optimize, GP = import_reference()
     if len(sys.argv) > 1 and sys.argv[1] == 'legacy':       # only the old_ME pins (the other fixtures untouched)
         legacy_pin(optimize, GP, 'tank')
         legacy_pin(optimize, GP, 'car')
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == 'ta':           # r06: reference-run pins for J / TA
+        ta_pin(optimize, GP, 'tank')
+        ta_pin(optimize, GP, 'car')
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == 'em':           # r06: reference-run pin for EM
+        em_pin(optimize, GP)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == 'refmodel':     # r06: a model file written by the reference
+        ref_written_model(optimize, GP)
         return
     from_model(optimize, GP, 'tank', 24, 1)
     from_model(optimize, GP, 'car', 24, 2)
@@ -216,6 +376,10 @@ def main():
     synthetic3(optimize, GP)
     legacy_pin(optimize, GP, 'tank')
     legacy_pin(optimize, GP, 'car')
+    ta_pin(optimize, GP, 'tank')
+    ta_pin(optimize, GP, 'car')
+    em_pin(optimize, GP)
+    ref_written_model(optimize, GP)
 
 
 if __name__ == '__main__':

@@ -69,3 +69,23 @@ def train_small2():
 @pytest.fixture(scope='session')
 def train_small3():
     return dict(np.load(os.path.join(GOLDEN, 'train_small3.npz')))
+
+
+@pytest.fixture(scope='session')
+def ta_pins():
+    """Reference-run J / TA outputs (oracle/make_golden.py ta_pin) at the test points of the two saved models."""
+    return {name: dict(np.load(os.path.join(GOLDEN, f'{name}_ta.npz'))) for name in ('tank', 'car')}
+
+
+@pytest.fixture(scope='session')
+def em_pins():
+    """Reference-run exact moments (oracle/make_golden.py em_pin): model (reference-trained) + quadrature of the reference's
+    own predictor, for the ill-conditioned train_small model and the well-conditioned em_model2."""
+    return {name: (dict(np.load(os.path.join(GOLDEN, f'{name}.npz'))), dict(np.load(os.path.join(GOLDEN, f'{name}_em.npz'))))
+            for name in ('train_small', 'em_model2')}
+
+
+@pytest.fixture(scope='session')
+def ref_written():
+    """The model file the reference's own save_model wrote (oracle/make_golden.py ref_written_model) + its outputs."""
+    return os.path.join(GOLDEN, 'ref_written_model'), dict(np.load(os.path.join(GOLDEN, 'ref_written_model_outputs.npz')))

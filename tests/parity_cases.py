@@ -508,6 +508,81 @@ def check_old_me_reference_pin(lib, g, pin, tol=1e-12):
         assert np.array_equal(cb, np.diag(np.diag(cb)))
 
 
+def check_ta_reference_pin(lib, g, pin, name):
+    """a9 mean / J and a10 'TA' against REFERENCE-RUN outputs (oracle/make_golden.py ta_pin: the reference's numpy
+    GP.covSEard^T alpha, its complex-step derivative, diag GP.covar, composed by the one line of build_TA_cov
+    gp_functions.py:167-171).  The device gets the stored factors (load_model path) and predicts through gpmpc_predict_jac.
+    Bars: rounding scale of the sums (1e-13 of sum |ks alpha| resp. sum |ks alpha (x - z)| / l^2), |dvar| <= 1e-10 sf^2,
+    and for the matrix MPC factors: |dcov| <= 1e-10 max|cov| (tank, cond 6e7) / 1e-9 (car, cond 7e10)."""
+    X, Y, H = g['X'], g['Y'], g['hyper']
+    d = X.shape[1]
+    h = Handle(lib, X, Y)
+    h.set_factors(H, g['chol'], g['alpha'], g['invK'])
+    m, c, J = h.predict_jac('TA', pin['Z'], pin['Sigma'])
+    m2, c2 = h.predict('TA', pin['Z'], pin['Sigma'])
+    mm, cm = h.predict('ME', pin['Z'])
+    h.close()
+    em = np.max(np.abs(m - pin['ref_mean']) / pin['mean_scale'])
+    eJ = np.max(np.abs(J - pin['ref_J']) / pin['J_scale'])
+    ev = np.max(np.abs(np.stack([np.diag(x) for x in cm]) - pin['ref_var'])) / (H[:, d] ** 2).max()
+    ec = np.max(np.abs(c - pin['ref_ta_cov'])) / np.abs(pin['ref_ta_cov']).max()
+    print(f'[TA pin {name}] mean {em:.2e} J {eJ:.2e} (of the sums\' rounding scale)  var/sf2 {ev:.2e}  cov/max|cov| {ec:.2e}')
+    assert em <= 1e-13 and eJ <= 1e-13 and ev <= 1e-10, (em, eJ, ev)
+    assert ec <= (1e-10 if name == 'tank' else 1e-9), ec
+    assert np.array_equal(m, m2) and np.array_equal(c, c2)
+
+
+def check_em_reference_pin(lib, model, pin, name):
+    """a11 'EM' against REFERENCE-RUN moments (oracle/make_golden.py em_pin: Gauss-Hermite quadrature of the reference's own
+    numeric predictor on a model its train_gp_numpy produced; factors handed over as the reference returned them).
+    em_model2 (cond 4e3): 1e-12 absolute; train_small (cond 7e8): the closed form's K^-1 arithmetic limits every fp64
+    evaluation of gp_functions.py:408-414 to ~cond eps sf^2 (the oracle sits 3e-6 from the quadrature there)."""
+    tm, tc = {'train_small': (1e-7, 1e-5), 'em_model2': (1e-12, 1e-12)}[name]
+    h = Handle(lib, model['X'], model['Y'])
+    h.set_factors(model['hyper'], model['chol'], model['alpha'], model['invK'])
+    m, c = h.predict('EM', pin['mu'], pin['Sigma'])
+    h.close()
+    em, ec = np.max(np.abs(m - pin['ref_em_mean'])), np.max(np.abs(c - pin['ref_em_cov']))
+    print(f'[EM pin {name}] |dmean| {em:.2e} |dcov| {ec:.2e} (absolute; max|cov| {np.abs(pin["ref_em_cov"]).max():.2e})')
+    assert em <= tm and ec <= tc, (em, ec)
+
+
+def check_reference_written_model(lib, path, out, tmp_path):
+    """f2: GP.load_model on a file the REFERENCE's save_model wrote (gp_class.py:693-743), predictions in the model's
+    standardised coordinates against the reference's GP.covar / covSEard^T alpha, and our save_model writes the same key
+    set with the same values (factors re-exported from the device: exact for what was handed over)."""
+    import json
+    from gp_mpc_amd.gp import GP
+    gp = GP.load_model(path, lib=lib)
+    d = json.load(open(path + '.json'))
+    H = np.array(d['hyper']['hyper'])
+    Ny, Nx = H.shape[0], np.array(d['X']).shape[1]
+    assert gp.get_size() == (len(d['X']), Ny, Nx - Ny)
+    cv = gp.covar(out['Zs'])
+    assert np.max(np.abs(cv[:Ny] - out['ref_covar'])) <= 1e-10 * (H[:, Nx] ** 2).max()
+    gp.set_method('ME')
+    meta = {k: np.array(v) for k, v in d['meta'].items()}
+    Zraw = out['Zs'] * meta['stdZ'] + meta['meanZ']
+    alpha = np.array(d['hyper']['alpha'])
+    for b in range(len(Zraw)):
+        m, c = gp.predict(Zraw[b, :Ny], Zraw[b, Ny:], np.zeros((Nx, Nx)))
+        ms = np.array([np.abs(go.cov_se_ard_direct(np.array(d['X']), out['Zs'][b:b + 1], H[a, :Nx], H[a, Nx] ** 2))[:, 0]
+                       @ np.abs(alpha[a]) for a in range(Ny)])
+        ref = out['ref_mean_std'][b] * meta['stdY'] + meta['meanY']             # inverse_mean, gp_class.py:636-638
+        assert np.max(np.abs(m[:, 0] - ref) / (ms * meta['stdY'])) <= 1e-12, (b, m[:, 0], ref)
+        assert np.max(np.abs(np.diag(c) - out['ref_covar'][:, b, b])) <= 1e-10 * (H[:, Nx] ** 2).max()
+    gp.save_model(str(tmp_path / 'again'))
+    d2 = json.load(open(str(tmp_path / 'again') + '.json'))
+    assert set(d2) == set(d) and set(d2['hyper']) == set(d['hyper']) and set(d2['meta']) == set(d['meta'])
+    for k in ('X', 'Y', 'xlb', 'xub', 'ulb', 'uub', 'mean_func', 'normalize'):
+        assert d2[k] == d[k], k
+    for k in d['hyper']:
+        assert d2['hyper'][k] == d['hyper'][k], k
+    for k in d['meta']:
+        assert d2['meta'][k] == d['meta'][k], k
+    gp.close()
+
+
 def check_small_batch_chunks(lib, N=600, d=5, Ny=2):
     """Few test points on a larger model: the cross-covariance kernel cuts the training points into chunks and a
     second kernel adds the partial means / Jacobians (the MPC's shooting-node pattern)."""

@@ -306,3 +306,17 @@ def test_emu_old_me_reference_pin(emu, tank, car, old_me_pins):
 
 def test_emu_em_pair_sum_chunks(emu):
     pc.check_em_chunks(emu)
+
+
+@pytest.mark.parametrize('name', ['tank', 'car'])
+def test_emu_ta_reference_run_pin(emu, name, request, ta_pins):
+    pc.check_ta_reference_pin(emu, request.getfixturevalue(name), ta_pins[name], name)
+
+
+@pytest.mark.parametrize('name', ['train_small', 'em_model2'])
+def test_emu_em_reference_run_pin(emu, name, em_pins):
+    pc.check_em_reference_pin(emu, *em_pins[name], name)
+
+
+def test_emu_reference_written_model_file(emu, ref_written, tmp_path):
+    pc.check_reference_written_model(emu, *ref_written, tmp_path)

@@ -330,3 +330,19 @@ def test_old_me_reference_pin(lib, tank, car, old_me_pins):
 
 def test_em_pair_sum_chunks(lib):
     pc.check_em_chunks(lib)
+
+
+@pytest.mark.parametrize('name', ['tank', 'car'])
+def test_ta_and_jacobian_match_reference_run_pin(lib, name, request, ta_pins):
+    """a9 J / a10 TA against reference-run outputs (tests/golden/{tank,car}_ta.npz), through gpmpc_predict_jac."""
+    pc.check_ta_reference_pin(lib, request.getfixturevalue(name), ta_pins[name], name)
+
+
+@pytest.mark.parametrize('name', ['train_small', 'em_model2'])
+def test_exact_moments_match_reference_run_quadrature(lib, name, em_pins):
+    """a11 EM against quadrature of the reference's own predictor on reference-trained models (1e-12 abs on em_model2)."""
+    pc.check_em_reference_pin(lib, *em_pins[name], name)
+
+
+def test_reference_written_model_file_loads_and_round_trips(lib, ref_written, tmp_path):
+    pc.check_reference_written_model(lib, *ref_written, tmp_path)

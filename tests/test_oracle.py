@@ -532,3 +532,67 @@ def test_exact_moment_sensitivities_by_complex_step():
             mc, cc = _exact_moment_complex(f['invK'], X, Y, H, mu.astype(complex), Sc)
             assert np.max(np.abs(mc.imag / h - dm_dS[:, k, l])) <= 1e-11 * max(1.0, np.abs(dm_dS).max()), (k, l)
             assert np.max(np.abs(cc.imag / h - dc_dS[:, :, k, l])) <= 1e-11 * max(1.0, np.abs(dc_dS).max()), (k, l)
+
+
+# ---------------------------------------------------------------------------------------------
+# r06: REFERENCE-RUN pins for the CasADi-only rows (oracle/make_golden.py ta_pin / em_pin / ref_written_model): the
+# reference's own numpy GP.covSEard / GP.covar / train_gp_numpy / save_model produced every number compared with below.
+# ---------------------------------------------------------------------------------------------
+EM_PIN_TOL = {'train_small': (1e-7, 1e-5), 'em_model2': (1e-12, 1e-12)}     # (mean, cov) absolute; see em_pin's docstring
+
+
+@pytest.mark.parametrize('name', ['tank', 'car'])
+def test_mean_jacobian_and_ta_match_reference_run_pin(name, request, ta_pins):
+    """a9 mean / J and a10 'TA' (gp_functions.py:114-147,152-173) against the reference-run composition: bars are the
+    rounding scale of the sums (1e-14 of sum|ks alpha| resp. sum|ks alpha (x - z)| / l^2) and, for the quantity MPC consumes,
+    |dcov| <= 1e-10 max|cov| on the tank model (cond 6e7); the car model (cond 7e10: alpha ~ 1e6) carries 1e-9."""
+    g = request.getfixturevalue(name)
+    t = ta_pins[name]
+    m, v, J = go.mean_var_jac(t['Z'], g['X'], g['hyper'], g['alpha'], g['chol'])
+    cov = go.ta_cov(v, J, t['Sigma'])
+    d = g['X'].shape[1]
+    assert np.max(np.abs(m - t['ref_mean']) / t['mean_scale']) <= 1e-14
+    assert np.max(np.abs(J - t['ref_J']) / t['J_scale']) <= 1e-14
+    assert np.max(np.abs(v - t['ref_var'])) <= 1e-10 * (g['hyper'][:, d] ** 2).max()
+    tol = 1e-10 if name == 'tank' else 1e-9
+    assert np.max(np.abs(cov - t['ref_ta_cov'])) <= tol * np.abs(t['ref_ta_cov']).max()
+
+
+@pytest.mark.parametrize('name', ['train_small', 'em_model2'])
+def test_exact_moment_matches_reference_run_quadrature(name, em_pins):
+    """a11 'EM' (gp_functions.py:344-430) against Gauss-Hermite quadrature OF THE REFERENCE'S OWN numeric predictor on models
+    the reference trained.  em_model2 (cond 4e3): 1e-12 absolute on mean and covariance (quadrature converged to 2e-15).
+    train_small (cond 7e8): the closed form's own K^-1 arithmetic limits it to cond * eps * sf^2 ~ 1e-6."""
+    model, pin = em_pins[name]
+    tm, tc = EM_PIN_TOL[name]
+    assert pin['quad_convergence'].max() <= 5e-12
+    for i in range(len(pin['mu'])):
+        m, c = go.exact_moment(model['invK'], model['X'], model['Y'], model['hyper'], pin['mu'][i], pin['Sigma'][i])
+        assert np.max(np.abs(m - pin['ref_em_mean'][i])) <= tm, (i, m, pin['ref_em_mean'][i])
+        assert np.max(np.abs(c - pin['ref_em_cov'][i])) <= tc, (i, c, pin['ref_em_cov'][i])
+    assert np.abs(pin['ref_em_cov'][:, 0, 1]).max() > 1e-3          # cross-covariances are exercised
+
+
+def test_reference_written_model_file(ref_written):
+    """f2: the JSON the reference's GP.save_model wrote (gp_class.py:693-734): full key set, derived entries, and the oracle
+    GP built from it reproduces the reference's GP.covar / covSEard^T alpha in the model's standardised coordinates."""
+    import json
+    path, out = ref_written
+    d = json.load(open(path + '.json'))
+    assert set(d) == {'X', 'Y', 'hyper', 'mean_func', 'normalize', 'xlb', 'xub', 'ulb', 'uub', 'meta'}
+    assert set(d['hyper']) == {'hyper', 'invK', 'alpha', 'chol', 'length_scale', 'signal_var', 'noise_var', 'mean'}
+    assert set(d['meta']) == {'meanY', 'stdY', 'meanZ', 'stdZ', 'meanX', 'stdX', 'meanU', 'stdU'}
+    X, Y, H = np.array(d['X']), np.array(d['Y']), np.array(d['hyper']['hyper'])
+    Nx = X.shape[1]
+    assert np.allclose(X, (out['X_raw'] - d['meta']['meanZ']) / d['meta']['stdZ'], rtol=1e-15, atol=1e-15)
+    assert np.array_equal(np.array(d['hyper']['signal_var']), H[:, Nx] ** 2)
+    assert np.array_equal(np.array(d['hyper']['mean']), H[:, Nx + 1:])          # off by one, includes sn (gp_class.py:142)
+    f = go.fit(X, Y, H)
+    assert relF(f['chol'], np.array(d['hyper']['chol'])) <= 1e-12
+    og = go.OracleGP(X, Y, H, np.array(d['hyper']['chol']), np.array(d['hyper']['alpha']), np.array(d['hyper']['invK']),
+                     normalize=True, meta={k: np.array(v) for k, v in d['meta'].items()}, gp_method='ME')
+    m, v, _ = go.mean_var_jac(out['Zs'], X, H, og.alpha, og.chol, want_jac=False)
+    ms = np.stack([np.abs(go.cov_se_ard_direct(X, out['Zs'], H[a, :Nx], H[a, Nx] ** 2)).T @ np.abs(og.alpha[a])
+                   for a in range(len(H))], axis=1)
+    assert np.max(np.abs(m - out['ref_mean_std']) / ms) <= 1e-14
+    assert np.max(np.abs(v - np.stack([np.diag(c) for c in out['ref_covar']], axis=1))) <= 1e-10 * (H[:, Nx] ** 2).max()
