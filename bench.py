@@ -436,6 +436,7 @@ def main():
     ap.add_argument('--B', type=int, default=10000)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-secondary', action='store_true', help='skip the C3 / C4 steps after the timed C2 region')
+    ap.add_argument('--fused', action='store_true', help='C2 step as ONE gpmpc_fit_predict_mean_var call instead of gpmpc_fit + gpmpc_predict_mean_var (same bits; within 10 us)')
     ap.add_argument('--restarts', type=int, default=64, help='restarts of the restart-shard leg (C4)')
     ap.add_argument('--config', default='C2', choices=['C2', 'C3', 'C4'])
     args = ap.parse_args()
@@ -469,9 +470,17 @@ def main():
     hyper = np.ascontiguousarray(p['hyper'])
     h.set_pointer_mode(True)
 
-    def step():
+    two_calls = not (args.fused or os.environ.get('GPMPC_BENCH_FUSED') == '1')
+
+    def step_two_calls():
         h.fit(hyper)                                                    # K build + Cholesky + L^-1 + alpha
         h.predict_mean_var_dev(B, z.data_ptr(), mean.data_ptr(), var.data_ptr())   # 10k mean+var
+
+    def step_fused():
+        # the same work through ONE call of the C ABI (r06, gpmpc_fit_predict_mean_var: same bits as the two calls)
+        h.fit_predict_mean_var_dev(hyper, B, z.data_ptr(), mean.data_ptr(), var.data_ptr())
+
+    step = step_two_calls if two_calls else step_fused
 
     # Timed region: only the dominant kernel is bracketed by events (the roofline needs its launch durations from THIS region);
     # bracketing all seven phases costs 65 us per step (tools/bench_noprof.py), so the phase split comes from a second,
@@ -481,6 +490,10 @@ def main():
     elapsed_all, prof = timed(rk, h, step, phase_steps, 0)
     prof = {k: (v[0] * args.steps / phase_steps, v[1] * args.steps / phase_steps) for k, v in prof.items()}   # as if over `steps` steps (launch counts scaled, not rounded)
     prof['vargemm'] = prof_timed['vargemm']
+    # the other form of the step (two calls / one call), a short untimed-for-the-headline loop, for the record
+    elapsed_other, _ = timed(rk, h, step_fused if two_calls else step_two_calls, 10, 2, profile=False)
+    step()                                                              # (the outputs the parity legs read: the headline form's)
+    rk.sync(h)
 
     # HBM traffic of the dominant kernel: NOT measured in this run (rocprofv3 --pmc serialises dispatches); it is read
     # from the committed PMC passes under profiles/ and labelled as such
@@ -513,6 +526,10 @@ def main():
                          'frac': achieved / FP64_MFMA_PEAK_TFLOPS, 'traffic': traffic, 'traffic_source': traffic_source,
                          'avg_launch_ms': gemm_ms / max(gemm_n, 1), 'launches': gemm_n,
                          'peak_measured_mfma_only_ubench': mfma_rate},
+            'step_api': 'gpmpc_fit + gpmpc_predict_mean_var' if two_calls else 'gpmpc_fit_predict_mean_var (one call; bitwise the two calls)',
+            'ms_per_step_other_api': {'api': 'gpmpc_fit_predict_mean_var' if two_calls else 'gpmpc_fit + gpmpc_predict_mean_var',
+                                      'ms_per_step': elapsed_other / 10 * 1e3, 'steps': 10},
+            'fused_fit_predicts': int(h.counter('fused_fit_predicts')),
             'phases_ms_per_step': {k: v[0] / args.steps for k, v in prof.items() if v[1] > 0},
             'ms_per_step_all_brackets': elapsed_all / phase_steps * 1e3,   # the second pass: every phase bracketed, as r01-r03's lines were timed
             'runtime': lib.runtime_info(),

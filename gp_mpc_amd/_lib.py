@@ -52,6 +52,7 @@ SIGNATURES = {
     'gpmpc_profile_enable': (ctypes.c_int, [_vp, ctypes.c_int]),
     'gpmpc_profile_read': (ctypes.c_int, [_vp, ctypes.c_int, _dp, ctypes.POINTER(ctypes.c_long), ctypes.c_int]),
     'gpmpc_fit': (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp]),
+    'gpmpc_fit_predict_mean_var': (ctypes.c_int, [_vp, _vp, ctypes.c_int, _vp, ctypes.c_int, _vp, _vp, _vp]),
     'gpmpc_get_factors': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp]),
     'gpmpc_set_factors': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp]),
     'gpmpc_append': (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, _vp]),
@@ -449,6 +450,29 @@ class Handle:
     # -- raw device-pointer entry points (device pointer mode)
     def predict_mean_var_dev(self, B, z_ptr, mean_ptr, var_ptr):
         self.lib.check(self.lib.dll.gpmpc_predict_mean_var(self.h, B, _ptr(z_ptr), _ptr(mean_ptr), _ptr(var_ptr)))
+
+    def fit_predict_mean_var_dev(self, hyper, B, z_ptr, mean_ptr, var_ptr, want_invK=False):
+        """gpmpc_fit + gpmpc_predict_mean_var as ONE call with device pointers (the fused route of include/gpmpc.h)."""
+        hyper = _f64(hyper).reshape(self.Ny, self.nh)
+        info = np.zeros(self.Ny, dtype=np.int32)
+        rc = self.lib.dll.gpmpc_fit_predict_mean_var(self.h, _ptr(hyper), int(bool(want_invK)), info.ctypes.data_as(ctypes.c_void_p),
+                                                     int(B), ctypes.c_void_p(z_ptr), ctypes.c_void_p(mean_ptr), ctypes.c_void_p(var_ptr))
+        self.info = info
+        self.lib.check(rc)
+        return info
+
+    def fit_predict_mean_var(self, hyper, Z, want_invK=False):
+        """The same with host arrays (pointer mode host: the library runs the two calls one after the other)."""
+        hyper = _f64(hyper).reshape(self.Ny, self.nh)
+        Z = _f64(Z).reshape(-1, self.d)
+        B = Z.shape[0]
+        info = np.zeros(self.Ny, dtype=np.int32)
+        mean, var = np.zeros((B, self.Ny)), np.zeros((B, self.Ny))
+        rc = self.lib.dll.gpmpc_fit_predict_mean_var(self.h, _ptr(hyper), int(bool(want_invK)), info.ctypes.data_as(ctypes.c_void_p),
+                                                     B, _ptr(Z), _ptr(mean), _ptr(var))
+        self.info = info
+        self.lib.check(rc)
+        return info, mean, var
 
     def predict_dev(self, method, B, z_ptr, sigma_ptr, mean_ptr, cov_ptr):
         code = METHODS[method] if isinstance(method, str) else int(method)

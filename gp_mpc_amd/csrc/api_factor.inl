@@ -574,6 +574,8 @@ static bool factor_chain(const Ctx& cx, Workspace& ws, int spin_limit, bool flag
                                r[i] / 64, i + 1 < L ? (r[i + 1] - r[i]) / 64 : nb, ready, g_chain_trace, worker_lookahead ? 1 : 0, worker_wt_publish());
             if (i + 1 < L) hipEventRecord(cx.seg[i], cx.side);        // launch i finished: rows P_i of L are final
         }
+        // fused fit + predict: the cross-covariances go into the window of the last worker launch (TailState::in_window)
+        if (cx.tail && cx.tail->in_window && split) cx.tail->in_window(cx.seg[L - 2], chain_ready_index(nb) + 2 * (L - 2) + 1);
         const bool own_events = ev0 + P + 2 < cx.n_seg - 2;
         for (int i = 0; split && i + 1 < P; ++i) {
             const int ri = pcut[i], a = pcut[i + 1] - pcut[i];
@@ -698,10 +700,16 @@ static bool factor_chain(const Ctx& cx, Workspace& ws, int spin_limit, bool flag
 // w = L^-1 y and alpha = L^-T w as two HBM-bound matrix-vector products with the explicit inverse.
 // y: [batch] vectors with stride sy.
 // (ev_w: recorded behind w -- what the variance product's fused mean waits for instead of alpha)
-static void solve_alpha(const Ctx& cx, Workspace& ws, const double* y, long sy, hipEvent_t ev_w = nullptr) {
+// (solve_w: the first half alone -- the fit's tail forms w on the main queue, right behind the last product of L^-1, and the
+//  rest of alpha on the workers' queue: a variance product with the fused mean follows w without changing queues)
+static void solve_w(const Ctx& cx, Workspace& ws, const double* y, long sy) {
     const int Np = ws.Np;
     hipLaunchKernelGGL(gemv_rows_kernel, dim3(Np / 4, ws.batch), dim3(256), 0, cx.stream, ws.Inv, y, ws.w, Np, ws.mat(), sy,
                        (long)Np, 1);
+}
+static void solve_alpha(const Ctx& cx, Workspace& ws, const double* y, long sy, hipEvent_t ev_w = nullptr) {
+    const int Np = ws.Np;
+    solve_w(cx, ws, y, sy);
     if (ev_w) hipEventRecord(ev_w, cx.stream);
     const int chunks = (Np + GEMVT_ROWS - 1) / GEMVT_ROWS;         // partial sums go through the (now idle) inverse scratch
     hipLaunchKernelGGL(gemv_lowerT_part_kernel, dim3((Np + 127) / 128, chunks, ws.batch), dim3(256), 0, cx.stream, ws.Inv, ws.w, ws.W,

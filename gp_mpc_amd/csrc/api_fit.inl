@@ -64,6 +64,7 @@ static int factor_with_jitter(gpmpc_gp* h, Workspace& ws, const double* hyper_ho
         h->tail.ev_info = h->ev_info;
         h->tail.want_early = early_status && !g_chain_trace;
         h->tail.early_done = false;
+        h->tail.ks_staged = false;
         gram_and_factor(h, ws, no_workers, value_only);
         HIPCHK(hipGetLastError());
         const bool check_chain = h->chain_mode && h->side_stream && ws.Np >= 128;
@@ -117,6 +118,8 @@ static int factor_with_jitter(gpmpc_gp* h, Workspace& ws, const double* hyper_ho
                 HIPCHK(hipStreamSynchronize(h->side_stream));
                 if (h->aux_stream) HIPCHK(hipStreamSynchronize(h->aux_stream));
                 if (h->bulk_stream) HIPCHK(hipStreamSynchronize(h->bulk_stream));
+                if (h->xc_stream) HIPCHK(hipStreamSynchronize(h->xc_stream));
+                h->tail.ks_staged = false;
                 gram_and_factor(h, ws, no_workers, value_only);
                 HIPCHK(hipMemcpyAsync(pin_info, ws.info, nb * sizeof(int), hipMemcpyDeviceToHost, h->stream));
                 HIPCHK(hipEventRecord(h->ev_info, h->stream));
@@ -148,7 +151,10 @@ static int factor_with_jitter(gpmpc_gp* h, Workspace& ws, const double* hyper_ho
     return GPMPC_OK;
 }
 
-extern "C" int gpmpc_fit(gpmpc_gp* h, const double* hyper, int want_invK, int* info) {
+// gpmpc_fit, and the fit half of gpmpc_fit_predict_mean_var (api_predict.inl): `fused` (optional) is called inside the post
+// hook, i.e. with the factors' consumers being enqueued and BEFORE the host waits for the status words; it enqueues the
+// prediction behind the tail.  (If the attempt fails -- jitter rule, hand-off time-out -- the next attempt calls it again.)
+static int fit_impl(gpmpc_gp* h, const double* hyper, int want_invK, int* info, const std::function<int()>* fused) {
     if (!h || !hyper) return fail(GPMPC_EINVAL, "NULL handle/hyper");
     HIPCHK(hipSetDevice(h->device));
     const int nh = h->nh();
@@ -171,14 +177,26 @@ extern "C" int gpmpc_fit(gpmpc_gp* h, const double* hyper, int want_invK, int* i
         static const bool alpha_side_env = !(getenv("GPMPC_ALPHA_SIDE") && atoi(getenv("GPMPC_ALPHA_SIDE")) == 0);
         alpha_on_side = h->tail.early_done && alpha_side_env && !want_invK && h->side_stream;
         if (alpha_on_side) {
-            // the fit returns at the end of the chain kernel: alpha goes to the workers' queue, behind the inverse's tail,
-            // so that what the caller enqueues next on the main queue -- a variance product -- follows the tail directly
+            // the fit returns at the end of the chain kernel.  w = L^-1 y follows the inverse's tail on the main queue (r06: it
+            // used to cross to the workers' queue first, two event hand-overs in front of a variance product that needs it for
+            // its fused mean), the rest of alpha goes to the workers' queue, so that what the caller enqueues next on the main
+            // queue -- a variance product -- follows w directly.  GPMPC_W_MAIN=0: all of alpha on the workers' queue, as r05.
+            static const bool w_main = !(getenv("GPMPC_W_MAIN") && atoi(getenv("GPMPC_W_MAIN")) == 0);
             Ctx cs = h->cx();
-            hipEventRecord(TailState::get(h->tail.ev_tail), h->stream);
-            hipStreamWaitEvent(h->side_stream, h->tail.ev_tail, 0);
             cs.stream = h->side_stream;
-            ProfScope t(&h->prof, h->side_stream, GPMPC_PH_SOLVE);
-            solve_alpha(cs, h->ws, h->y_model(), h->Np, TailState::get(h->tail.ev_w));
+            if (w_main) {
+                ProfScope t(&h->prof, h->stream, GPMPC_PH_SOLVE);
+                solve_w(h->cx(), h->ws, h->y_model(), h->Np);
+                hipEventRecord(TailState::get(h->tail.ev_w), h->stream);
+                hipStreamWaitEvent(h->side_stream, h->tail.ev_w, 0);
+                solve_alpha_from_w(cs, h->ws, h->ws.batch, nullptr);
+                t.end_on(h->side_stream);
+            } else {
+                hipEventRecord(TailState::get(h->tail.ev_tail), h->stream);
+                hipStreamWaitEvent(h->side_stream, h->tail.ev_tail, 0);
+                ProfScope t(&h->prof, h->side_stream, GPMPC_PH_SOLVE);
+                solve_alpha(cs, h->ws, h->y_model(), h->Np, TailState::get(h->tail.ev_w));
+            }
             hipEventRecord(TailState::get(h->tail.ev_alpha), h->side_stream);
         } else {
             PhaseTimer t(h, GPMPC_PH_SOLVE);
@@ -188,16 +206,30 @@ extern "C" int gpmpc_fit(gpmpc_gp* h, const double* hyper, int want_invK, int* i
             PhaseTimer t(h, GPMPC_PH_INVK);
             post_rc = compute_invK(h->cx(), h->ws);
         }
+        static const bool fused_late = getenv("GPMPC_FUSED_LATE") && atoi(getenv("GPMPC_FUSED_LATE")) != 0;   // (tuning aid: the prediction behind the host's wait)
+        if (fused && post_rc == GPMPC_OK && !fused_late) {
+            h->tail.alpha_pending = alpha_on_side;      // (what the prediction orders itself against)
+            post_rc = (*fused)();
+        }
     }));
     CHK(post_rc);
+    if (fused && getenv("GPMPC_FUSED_LATE") && atoi(getenv("GPMPC_FUSED_LATE")) != 0) {
+        h->tail.alpha_pending = alpha_on_side;
+        h->tail.fused_early = false;
+        CHK((*fused)());
+    }
     if (want_invK) h->have_invK = true;
     HIPCHK(hipGetLastError());
     h->hyper.assign(hyper, hyper + (size_t)h->Ny * nh);
     h->fitted = true;
     // the first large prediction behind this fit may start next to the inverse's tail (predict_chunk)
     h->tail.alpha_pending = alpha_on_side;
-    h->tail.armed = h->tail.early_done && !want_invK;
+    h->tail.armed = h->tail.early_done && !want_invK && !fused;
     return GPMPC_OK;
+}
+
+extern "C" int gpmpc_fit(gpmpc_gp* h, const double* hyper, int want_invK, int* info) {
+    return fit_impl(h, hyper, want_invK, info, nullptr);
 }
 
 // ---- data update: a15 (GP.update_data_all gp_class.py:474-550 = append + full recomputation with the

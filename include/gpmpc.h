@@ -108,7 +108,7 @@ int gpmpc_synchronize(gpmpc_gp* h);
  * in which case THAT factorisation is repeated on the single-queue path (same result) and the next call tries again;
  * after three consecutive time-outs the handle stays on the single-queue path for 64 fits.  Handles of one process
  * take turns for the factorisation itself.  Counters: "handoff_timeouts", "chained_factorisations",
- * "single_queue_factorisations", "predictions_behind_tail" (see gpmpc_fit), "persistent_variance_products" (variance products
+ * "single_queue_factorisations", "predictions_behind_tail" (see gpmpc_fit), "fused_fit_predicts" (gpmpc_fit_predict_mean_var calls that took the fused route), "persistent_variance_products" (variance products
  * of gpmpc_predict_mean_var that ran as one persistent launch over a static tile schedule, vargemm_persist.hpp); process-wide: "workspace_blocks_fresh" / "workspace_blocks_reused" (the N x N blocks
  * of a workspace, >= 64 MB, come from size classes and return to a free list: gpmpc_append at large N re-uses what the
  * previous append gave back instead of paying for fresh multi-GB allocations). */
@@ -132,6 +132,19 @@ int gpmpc_profile_read(gpmpc_gp* h, int phase, double* total_ms, long* launches,
  * uses that window: its cross-covariances are formed on a second queue while the last row panel of L^-1 is inverted,
  * its mean next to the variance product (counter "predictions_behind_tail"; same results as any later call). */
 int gpmpc_fit(gpmpc_gp* h, const double* hyper, int want_invK, int* info);
+/* gpmpc_fit followed by gpmpc_predict_mean_var in ONE call (r06; same arguments, same results bit for bit).  What a caller
+ * that refits and then evaluates a batch does in two calls -- GP.optimize / update_data_all followed by validate or a
+ * prediction sweep, gp_class.py:131-142,145-190,474-550 -- leaves the device idle between them (the host learns `info`,
+ * returns, calls again: ~0.12 ms at N = 4096) and can start the prediction's cross-covariances only then, although they
+ * depend on hyper and Z alone.  With device pointers, the handle's own stream, no K^-1, a zero prior mean and 64 < B <=
+ * one scratch chunk the prediction's launches are enqueued before the host waits for `info` (the cross-covariances start
+ * at the end of the factorisation's chain kernel, next to the tail of L^-1); in every other case this IS the two calls.
+ * If the factorisation has to be repeated (jitter rule, hand-off time-out) the prediction is repeated behind it.
+ * Measured at N = 4096, B = 10 000: within 10 us of the two calls -- the step behind the chain is bound by the inverse's
+ * tail, not by the host (docs/history_r06.md).
+ * Counter "fused_fit_predicts". */
+int gpmpc_fit_predict_mean_var(gpmpc_gp* h, const double* hyper, int want_invK, int* info, int B, const double* Z,
+                               double* mean, double* var);
 /* Export in the reference's save_model layout (gp_class.py:693-704): hyper[Ny x gpmpc_hyper_width()],
  * chol[Ny x N x N] (lower, zeros above), alpha[Ny x N], invK[Ny x N x N]; any pointer may be NULL. */
 int gpmpc_get_factors(gpmpc_gp* h, double* hyper, double* chol, double* alpha, double* invK);

@@ -354,6 +354,56 @@ def check_predict_behind_tail(lib, N, d, B, sn=0.1, seed=77, strict=True, expect
     h.close()
 
 
+def check_fused_fit_predict(lib, N, d, B, sn=0.1, seed=91, Ny=1, repeats=2, expect_fused=True, jitter_case=False):
+    """gpmpc_fit_predict_mean_var (r06: the prediction enqueued before the host waits for the fit's status, cross-covariances
+    inside the chain's window) against the two calls it replaces on the same handle: bitwise the same mean and variance, the
+    same factors; and against the oracle.  jitter_case: ell = 8, sn = 1e-9 -- the first attempt fails, the fused
+    prediction is repeated behind the repeated factorisation (info = 1)."""
+    p = go.synthetic_problem(N, d, Ny, B, seed=seed, sn=sn)
+    X, Y, H, Z = p['X'], p['Y'], p['hyper'], p['Z']
+    if jitter_case:                      # clearly not positive definite in fp64, clearly so with 1e-8 I (as tests/golden's probe 4)
+        H = H.copy()
+        H[:, :d] = 8.0
+        H[:, d + 1] = 1e-9
+    h = Handle(lib, X, Y)
+    h.set_pointer_mode(True)
+    z = DevArray(lib, Z)
+    m1, v1 = DevArray(lib, shape=(B, Ny)), DevArray(lib, shape=(B, Ny))
+    m2, v2 = DevArray(lib, shape=(B, Ny)), DevArray(lib, shape=(B, Ny))
+    for rep in range(repeats):
+        i2 = h.fit(H)
+        h.predict_mean_var_dev(B, z.ptr, m2.ptr, v2.ptr)
+        h.synchronize()
+        f2 = h.get_factors()
+        i1 = h.fit_predict_mean_var_dev(H, B, z.ptr, m1.ptr, v1.ptr)
+        h.synchronize()
+        f1 = h.get_factors()
+        assert np.array_equal(i1, i2) and np.all(i1 == (1 if jitter_case else 0)), (i1, i2)
+        assert np.array_equal(m1.numpy(), m2.numpy()), np.abs(m1.numpy() - m2.numpy()).max()
+        assert np.array_equal(v1.numpy(), v2.numpy()), np.abs(v1.numpy() - v2.numpy()).max()
+        assert np.array_equal(f1['chol'], f2['chol']) and np.array_equal(f1['alpha'], f2['alpha'])
+    if expect_fused is not None:
+        assert (h.counter('fused_fit_predicts') == repeats) == bool(expect_fused), h.counter('fused_fit_predicts')
+    if not jitter_case:
+        o = go.fit(X, Y, H, want_invK=False)
+        om, ov, _ = go.mean_var_jac(Z, X, H, o['alpha'], o['chol'], False)
+        mean, var = m1.numpy(), v1.numpy()
+        for a in range(Ny):
+            assert np.max(np.abs(mean[:, a] - om[:, a]) / mean_scale(X, Z, H[a:a + 1], o['alpha'][a:a + 1])) <= 1e-10
+        assert np.max(np.abs(var - ov) / H[:, d] ** 2) <= 1e-10
+    # host pointers: the same entry point runs the two calls (no device buffers to stage)
+    h.set_pointer_mode(False)
+    i3, m3, v3 = h.fit_predict_mean_var(H, Z)
+    # (host-pointer predictions take their mean from the cross-covariance kernel's ks^T alpha, the large device-pointer route
+    #  from the variance product's sum_i V_ij w_i: two summation orders of the same N-term sum)
+    assert np.array_equal(i3, i1) and np.array_equal(v3, v1.numpy())
+    for a in range(Ny):                  # ... compared at the size of that sum's terms
+        assert np.max(np.abs(m3[:, a] - m1.numpy()[:, a]) / mean_scale(X, Z, H[a:a + 1], f1['alpha'][a:a + 1])) <= 1e-13
+    for a in (z, m1, v1, m2, v2):
+        a.free()
+    h.close()
+
+
 def check_jitter_rule(lib, t):
     """One-shot 1e-8 jitter (optimize.py:345-350): info semantics and NLL on the jittered K."""
     X, Y = t['X'], t['Y']

@@ -346,3 +346,15 @@ def test_exact_moments_match_reference_run_quadrature(lib, name, em_pins):
 
 def test_reference_written_model_file_loads_and_round_trips(lib, ref_written, tmp_path):
     pc.check_reference_written_model(lib, *ref_written, tmp_path)
+
+
+def test_fused_fit_predict_same_bits_as_two_calls(lib):
+    """gpmpc_fit_predict_mean_var at the C2 size and around it: bitwise the two calls' mean / variance / factors, oracle bars;
+    the jitter retry repeats the prediction behind the repeated factorisation."""
+    pc.check_fused_fit_predict(lib, N=4096, d=6, B=10000, repeats=3)
+    pc.check_fused_fit_predict(lib, N=4096, d=6, B=1000, sn=1e-2, seed=1234)
+    pc.check_fused_fit_predict(lib, N=3000, d=5, B=900)
+    pc.check_fused_fit_predict(lib, N=2048, d=4, B=700)
+    pc.check_fused_fit_predict(lib, N=1500, d=4, B=600, Ny=2)
+    pc.check_fused_fit_predict(lib, N=1000, d=4, B=300, jitter_case=True, repeats=1)
+    pc.check_fused_fit_predict(lib, N=500, d=6, B=40, expect_fused=False)

@@ -42,7 +42,7 @@ def main():
     variants = []
     for v in a.variants:
         label, _, kv = v.partition(':')
-        env = dict(x.split('=', 1) for x in kv.split(',') if x)
+        env = {k: v.replace(';', ',') for k, v in (x.split('=', 1) for x in kv.split(',') if x)}     # (';' in a value stands for ',')
         variants.append((label, env))
     backup = LIB + '.ab_backup'
     shutil.copy(LIB, backup)
