@@ -305,8 +305,11 @@ def run_c3(rk, steps, warmup, N=8192):
 
     def step():
         h.fit(hyper, want_invK=True)
-        for m in ('ME', 'TA', 'EM'):
-            res[m] = h.rollout(m, z0, U, S0)
+        # the three methods from the same start in lock-step (r06, gpmpc_rollout_multi: one pass over L^-1 per time step for
+        # 'ME' and 'TA' together; r01-r05 called gpmpc_rollout once per method)
+        mm, cc = h.rollout_multi(['ME', 'TA', 'EM'], z0, U, S0)
+        for i, m in enumerate(('ME', 'TA', 'EM')):
+            res[m] = (mm[i], cc[i])
 
     elapsed, prof = timed(rk, h, step, steps, warmup)
     # the roll-outs alone (phase brackets inside gpmpc_rollout are per launch; time them as whole calls)
@@ -316,6 +319,12 @@ def run_c3(rk, steps, warmup, N=8192):
         t1 = time.perf_counter()
         h.rollout(m, z0, U, S0)
         t_roll[m] = (time.perf_counter() - t1) * 1e3
+    for key, ms_ in (('ME+TA lock-step', ['ME', 'TA']), ('ME+TA+EM lock-step', ['ME', 'TA', 'EM'])):
+        h.rollout_multi(ms_, z0, U, S0)
+        h.synchronize()
+        t1 = time.perf_counter()
+        h.rollout_multi(ms_, z0, U, S0)
+        t_roll[key] = (time.perf_counter() - t1) * 1e3
     fac_ms = prof['factor'][0] / max(prof['factor'][1], 1)
     flops = Ny * 2.0 * N ** 3 / 3.0
     em_ms, em_n = prof['em']
@@ -328,6 +337,7 @@ def run_c3(rk, steps, warmup, N=8192):
     world = rk.world
     out = {
         'metric': 'GP moment-matching propagation steps/sec, N=8192 Ny=6 d=8 fp64 (fit + 30-step ME/TA/EM per step)',
+        'rollout_api': 'gpmpc_rollout_multi([ME, TA, EM]) -- the three methods in lock-step',
         'value': world * 3 * T * steps / elapsed, 'unit': 'propagation steps/s', 'n_gpus': world, 'steps': steps,
         'warmup': warmup, 'ms_per_step': elapsed / steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
@@ -349,8 +359,91 @@ def run_c3(rk, steps, warmup, N=8192):
         'finite': bool(all(np.all(np.isfinite(r[0])) and np.all(np.isfinite(r[1])) for r in res.values())),
         'device': rk.lib.device_name(rk.dev_index),
     }
+    # ME / TA roll-outs stream the six lower triangles of L^-1 once per time step (var_small_kernel): HBM-bound
+    linv_bytes = Ny * 4.0 * N * (N + 1)
+    out['rollout_hbm'] = {m: {'GBps': linv_bytes * T / (t_roll[m] * 1e-3) * 1e-9, 'frac_of_8TBps': linv_bytes * T / (t_roll[m] * 1e-3) / 8e12}
+                          for m in ('ME', 'TA', 'ME+TA lock-step')}
+    out['rollout_hbm']['note'] = ('algorithmic bytes per time step = the six lower triangles of L^-1 (%.2f GB), streamed once per step whether one or '
+                                  'two trajectories ride on it; whole calls incl. the feed / cross-covariance / finish launches and the final copy' % (linv_bytes * 1e-9))
+    out['c5'] = run_c5(h, p, N, Ny, d)
     h.close()
     return out
+
+
+def run_c5(h, p, N, Ny, d, Nt=30, calls=50):
+    """BASELINE config C5, the pattern an IPOPT iteration drives through the Callback: all Nt = 30 shooting nodes in one call,
+    value + mean Jacobian + 'TA' covariance (gpmpc_predict_jac), `calls` calls, host arrays in and out (what casadi hands
+    over).  HBM-bound: the lower triangles of L^-1 are streamed once per call for all nodes."""
+    import numpy as np
+    Z, Sg = p['Z'][:Nt], p['Sigma'][:Nt]
+    h.predict_jac('TA', Z, Sg)
+    h.profile_enable(True)
+    h.profile_read(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(calls):
+        m, c, J = h.predict_jac('TA', Z, Sg)
+    dt = (time.perf_counter() - t0) / calls
+    h.profile_enable(False)
+    prof = h.profile_read(reset=True)
+    vg_ms = prof['vargemm'][0] / max(prof['vargemm'][1], 1)
+    bytes_call = Ny * 4.0 * N * (N + 1)                  # lower triangle of L^-1 per output (SURVEY 8d: + 8 N d + 8 N, negligible)
+    return {'workload': 'C5 pattern: Nt=%d nodes per call, value + J + TA covariance (gpmpc_predict_jac), %d calls, N=%d Ny=%d d=%d' % (Nt, calls, N, Ny, d),
+            'ms_per_call': dt * 1e3, 'node_evals_per_s': Nt / dt, 'finite': bool(np.all(np.isfinite(c)) and np.all(np.isfinite(J))),
+            'phases_ms_per_call': {k: v[0] / calls for k, v in prof.items() if v[1] > 0},
+            'roofline': {'kernel': 'variance product for <= 32 columns (gemm_f64_dma_kernel<64,32,...>: L^-1 streamed once)', 'bound': 'hbm',
+                         'achieved': bytes_call / (vg_ms * 1e-3) * 1e-9 if vg_ms > 0 else 0.0, 'peak': 8000.0, 'unit': 'GB/s',
+                         'frac': bytes_call / (vg_ms * 1e-3) / 8e12 if vg_ms > 0 else 0.0, 'avg_launch_ms': vg_ms,
+                         'algorithmic_bytes_per_call': bytes_call, 'whole_call_GBps': bytes_call / dt * 1e-9, 'traffic': None}}
+
+
+def run_c5_small(rk, N=200, Ny=3, Nu=2, Nt=30, calls=50):
+    """The same pattern at the size of the reference's own car model (N = 200, Ny = 3, d = 5; car_example.py:163-168,198):
+    launch- and copy-latency-bound, reported as calls/s."""
+    from gp_mpc_amd._lib import Handle
+    from gp_mpc_amd.synthetic import synthetic_problem
+    d = Ny + Nu
+    p = synthetic_problem(N, d, Ny, Nt, seed=1234, sn=1e-2)
+    h = Handle(rk.lib, p['X'], p['Y'], device=rk.dev_index)
+    h.fit(p['hyper'])
+    h.predict_jac('TA', p['Z'], p['Sigma'])
+    t0 = time.perf_counter()
+    for _ in range(calls):
+        h.predict_jac('TA', p['Z'], p['Sigma'])
+    dt = (time.perf_counter() - t0) / calls
+    h.close()
+    return {'workload': 'C5 pattern at the car model size: N=%d Ny=%d d=%d, Nt=%d nodes per call' % (N, Ny, d, Nt), 'ms_per_call': dt * 1e3,
+            'node_evals_per_s': Nt / dt, 'bound': 'launch + copy latency (three launches, one upload, one download per call)'}
+
+
+def run_b1(rk, h, N, d, calls=200):
+    """SURVEY 8(d) 'predict, B=1 streaming (MPC-node pattern)': one mean + variance prediction per call on the fitted C2 model,
+    device pointers (no copies), `calls` back-to-back calls.  HBM-bound: 4 N (N+1) + 8 N d + 8 N = 67.4 MB per prediction."""
+    torch = rk.torch
+    z1 = torch.zeros((1, d), dtype=torch.float64, device=rk.device) + 0.1
+    m1 = torch.empty((1, 1), dtype=torch.float64, device=rk.device)
+    v1 = torch.empty((1, 1), dtype=torch.float64, device=rk.device)
+    for _ in range(5):
+        h.predict_mean_var_dev(1, z1.data_ptr(), m1.data_ptr(), v1.data_ptr())
+    rk.sync(h)
+    h.profile_enable(True, ('vargemm',))
+    h.profile_read(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(calls):
+        h.predict_mean_var_dev(1, z1.data_ptr(), m1.data_ptr(), v1.data_ptr())
+    rk.sync(h)
+    dt = (time.perf_counter() - t0) / calls
+    h.profile_enable(False)
+    prof = h.profile_read(reset=True)
+    k_ms = prof['vargemm'][0] / max(prof['vargemm'][1], 1)
+    nbytes = 4.0 * N * (N + 1) + 8.0 * N * d + 8.0 * N
+    return {'workload': 'B=1 mean+var predictions on the fitted C2 model (N=%d, d=%d), %d back-to-back calls, device pointers' % (N, d, calls),
+            'predictions_per_s': 1.0 / dt, 'us_per_call': dt * 1e6, 'finite': bool(torch.isfinite(m1).all() and torch.isfinite(v1).all()),
+            'roofline': {'kernel': 'var_small_kernel<1> (streams the lower triangle of L^-1 once)', 'bound': 'hbm',
+                         'achieved': nbytes / (k_ms * 1e-3) * 1e-9 if k_ms > 0 else 0.0, 'peak': 8000.0, 'unit': 'GB/s',
+                         'frac': nbytes / (k_ms * 1e-3) / 8e12 if k_ms > 0 else 0.0, 'avg_launch_us': k_ms * 1e3,
+                         'algorithmic_bytes_per_prediction': nbytes, 'whole_call_GBps': nbytes / dt * 1e-9,
+                         'whole_call_frac': nbytes / dt / 8e12, 'traffic': None,
+                         'note': 'kernel = HIP events around the variance launch; whole call = crosscov + variance + finish launches back to back'}}
 
 
 def run_c4(rk, steps, warmup, N=4096, d=6, R=64, iters=4, verify_world1=True):
@@ -414,6 +507,12 @@ def run_c4(rk, steps, warmup, N=4096, d=6, R=64, iters=4, verify_world1=True):
         'exchange': 'ncclAllGather inside gpmpc_train_multistart' if comm is not None else 'host merge over torch.distributed (no RCCL: test build)',
         'best_nll': float(np.min(r['obj'])), 'finite_restarts': int(np.isfinite(r['obj']).sum()),
         'evaluations_this_rank': int(r['evaluations']), 'restarts_this_rank': len(range(rank, R, world)),
+        # algorithmic matrix flops of this rank's share of ONE step (library counter: N^3/3 per Cholesky, per L^-1 formed, per
+        # K^-1 lower triangle) against the fp64 MFMA peak over the step's wall time (launch gaps, host optimiser, exchange included)
+        'roofline': (lambda gf: {'kernel': 'lock-step batches: two-level Cholesky (+ L^-1, K^-1 for gradient points), NLL / gradient reductions',
+                                 'bound': 'mfma', 'achieved': gf * 1e-3 / (elapsed / steps), 'peak': FP64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                                 'frac': gf * 1e-3 / (elapsed / steps) / FP64_MFMA_PEAK_TFLOPS, 'gflop_per_step_this_rank': gf,
+                                 'traffic': None})(float(h.counter('train_gflop'))),
         'device': rk.lib.device_name(rk.dev_index)}
     h.close()
     # self-validation of a multi-GPU record: the communicator that carried the exchange must span every rank, and the
@@ -568,6 +667,7 @@ def main():
             _, c2m, c2v, ms2 = cpu_baseline(q, B)
             out['parity_vs_cpu_sn0.1'] = parity_report(qm[:, 0], qv[:, 0], c2m, c2v, ms2, float(q['hyper'][0, d] ** 2))
             out['parity_vs_oracle_sn0.1'] = oracle_parity(q, qm[:, 0], qv[:, 0], len(c2m))
+    b1 = run_b1(rk, h, N, d) if (world == 1 and not args.no_secondary) else None
     h.close()
     del z, mean, var
     if world > 1:
@@ -587,11 +687,14 @@ def main():
                        'propagation_steps_per_s': c3['value'], 'factor_ms': c3['roofline']['avg_launch_ms'],
                        'factor_tflops': c3['roofline']['achieved'], 'factor_frac': c3['roofline']['frac'],
                        'rollout_ms_per_call': c3['rollout_ms_per_call'], 'finite': c3['finite'],
-                       'phases_ms_per_step': c3['phases_ms_per_step'], 'em_pair_kernels': c3['em_pair_kernels']},
+                       'phases_ms_per_step': c3['phases_ms_per_step'], 'em_pair_kernels': c3['em_pair_kernels'],
+                       'rollout_hbm': c3['rollout_hbm']},
+                'c5': dict(c3['c5'], car_size=run_c5_small(rk)),
+                'b1': b1,
                 'c4': {'workload': c4['config']['workload'], 'restarts_per_s': c4['value'], 'ms_per_step': c4['ms_per_step'],
                        'steps': c4['steps'], 'rccl_ranks': c4['rccl_ranks'], 'shard_check': c4['shard_check'], 'exchange': c4['exchange'],
                        'best_nll': c4['best_nll'], 'finite_restarts': c4['finite_restarts'],
-                       'evaluations_this_rank': c4.get('evaluations_this_rank')}}
+                       'evaluations_this_rank': c4.get('evaluations_this_rank'), 'roofline': c4['roofline']}}
     rk.close()
     if rank == 0:
         _emit(out)

@@ -63,6 +63,7 @@ SIGNATURES = {
     'gpmpc_predict_jac': (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, _vp, _vp]),
     'gpmpc_rollout': (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'gpmpc_rollout_feedback': (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'gpmpc_rollout_multi': (ctypes.c_int, [_vp, ctypes.c_int, _vp, ctypes.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'gpmpc_predict': (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, _vp, _vp, _vp, _vp]),
     'gpmpc_covar': (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp]),
     'gpmpc_nll': (ctypes.c_int, [_vp, ctypes.c_int, _vp, _dp, _vp, _ip]),
@@ -360,6 +361,23 @@ class Handle:
         mean, cov = np.zeros((T, self.Ny)), np.zeros((T, self.Ny, self.Ny))
         self.lib.check(self.lib.dll.gpmpc_rollout(self.h, code, T, _ptr(z0), _ptr(U), _ptr(Sigma0), _ptr(sa), _ptr(sb),
                                                   _ptr(mean), _ptr(cov)))
+        return mean, cov
+
+    def rollout_multi(self, methods, z0, U, Sigma0, sa=None, sb=None):
+        """M roll-outs in lock-step (gpmpc_rollout_multi): methods[M], z0[M,d] (or [d] for all), U[M,T,Nu] (or [T,Nu] for all),
+        Sigma0[M,d,d] (or [d,d]); returns mean[M,T,Ny], cov[M,T,Ny,Ny]."""
+        codes = np.array([METHODS[m] if isinstance(m, str) else int(m) for m in methods], dtype=np.int32)
+        M, Nu = len(codes), self.d - self.Ny
+        z0 = np.ascontiguousarray(np.broadcast_to(_f64(z0).reshape(-1, self.d), (M, self.d)))
+        U = np.asarray(U, dtype=np.float64)
+        T = U.shape[-2] if Nu > 0 else int(U.shape[-1] if U.ndim == 1 else U.shape[-2])
+        U = np.ascontiguousarray(np.broadcast_to(U.reshape(-1, T, max(Nu, 1)), (M, T, max(Nu, 1)))) if Nu > 0 else np.zeros((M, T, 1))
+        Sigma0 = np.ascontiguousarray(np.broadcast_to(_f64(Sigma0).reshape(-1, self.d, self.d), (M, self.d, self.d)))
+        sa = None if sa is None else _f64(sa).reshape(self.Ny)
+        sb = None if sb is None else _f64(sb).reshape(self.Ny)
+        mean, cov = np.zeros((M, T, self.Ny)), np.zeros((M, T, self.Ny, self.Ny))
+        self.lib.check(self.lib.dll.gpmpc_rollout_multi(self.h, M, codes.ctypes.data_as(ctypes.c_void_p), T, _ptr(z0), _ptr(U),
+                                                        _ptr(Sigma0), _ptr(sa), _ptr(sb), _ptr(mean), _ptr(cov)))
         return mean, cov
 
     def rollout_feedback(self, method, T, z0, Sigma0, Kz, k0, Kc, sa=None, sb=None):

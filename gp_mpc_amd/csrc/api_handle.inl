@@ -12,6 +12,9 @@ struct gpmpc_gp {
     double* roll_dev = nullptr;         // gpmpc_rollout: device staging [inputs | trajectories | scratch] (grow-only) ...
     double* roll_pin = nullptr;         // ... and its pinned mirror
     size_t roll_cap = 0;
+    double* rollm_dev = nullptr;        // gpmpc_rollout_multi: the same for M trajectories in lock-step (grow-only)
+    double* rollm_pin = nullptr;
+    size_t rollm_cap = 0;
     struct RollGraph { std::vector<long> key; hipGraphExec_t exec = nullptr; hipGraph_t graph = nullptr; };
     std::vector<RollGraph> roll_graphs; // captured T-step loops (launch-bound at small N), keyed by everything the launches depend on
     std::vector<long> roll_warm;        // key of the last plain run: a loop is captured only after it ran once uncaptured
@@ -33,6 +36,7 @@ struct gpmpc_gp {
     long n_fused = 0;                                    // gpmpc_fit_predict_mean_var calls that took the fused route
     long n_behind_tail = 0;                              // predictions that started next to a fit's tail (predict_behind_tail)
     long train_iters = 0, train_evals = 0;              // of the last gpmpc_train_multistart (this rank's restarts)
+    double train_flop = 0.0;                            // ... and its algorithmic matrix flops: N^3/3 per Cholesky, per L^-1, per K^-1 lower triangle
     int nll_last_a = -1;                                 // the training workspace holds the factors of this output ...
     std::vector<double> nll_last_row;                    // ... at these hyper-parameters (gpmpc_nll; nll_grad_last reuses them)
 #ifdef GPMPC_EMULATED
@@ -294,6 +298,8 @@ int gpmpc_destroy(gpmpc_gp* h) {
     drop_roll_graphs(h);
     if (h->roll_pin) hipHostFree(h->roll_pin);
     hipFree(h->roll_dev);
+    if (h->rollm_pin) hipHostFree(h->rollm_pin);
+    hipFree(h->rollm_dev);
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
     if (h->ev_join) hipEventDestroy(h->ev_join);
     for (auto e : h->seg_events) hipEventDestroy(e);
@@ -382,6 +388,7 @@ int gpmpc_get_counter(gpmpc_gp* h, const char* name, long* value) {
     else if (std::strcmp(name, "single_queue_factorisations") == 0) *value = h->n_single;
     else if (std::strcmp(name, "predictions_behind_tail") == 0) *value = h->n_behind_tail;
     else if (std::strcmp(name, "fused_fit_predicts") == 0) *value = h->n_fused;
+    else if (std::strcmp(name, "train_gflop") == 0) *value = (long)(h->train_flop * 1e-9 + 0.5);
     else if (std::strcmp(name, "persistent_variance_products") == 0) *value = h->n_var_persist;
     else if (std::strcmp(name, "train_iterations") == 0) *value = h->train_iters;
     else if (std::strcmp(name, "train_evaluations") == 0) *value = h->train_evals;

@@ -76,7 +76,8 @@ static int ensure_scratch(gpmpc_gp* h, int B, bool keep_tail = false) {
     HIPCHK(hipMalloc(&h->Z, Bc * d * sizeof(double)));
     HIPCHK(hipMalloc(&h->Sigma, Bc * d * d * sizeof(double)));
     HIPCHK(hipMalloc(&h->KsT, Ny * Bc * Np * sizeof(double)));
-    HIPCHK(hipMalloc(&h->part, Ny * (Np / 16) * Bc * sizeof(double)));
+    // (per-row-tile partial sums: 16-row tiles at most for a batch, one row per wave -- Np / 4 tiles -- for <= 8 points, padded to 32)
+    HIPCHK(hipMalloc(&h->part, Ny * std::max((Np / 16) * Bc, (Np / 4) * (size_t)32) * sizeof(double)));
     HIPCHK(hipMalloc(&h->partm, Ny * (Np / VAR_TILE + 1) * Bc * sizeof(double)));
     HIPCHK(hipMalloc(&h->meanT, Ny * Bc * sizeof(double)));
     HIPCHK(hipMalloc(&h->mean, Bc * Ny * sizeof(double)));
@@ -166,12 +167,14 @@ static int predict_chunk(gpmpc_gp* h, int B, const double* dZ, double* dMean, do
     static const int varsmall_max = getenv("GPMPC_VARSMALL_MAX") ? atoi(getenv("GPMPC_VARSMALL_MAX")) : 1;
     if (dVar && !VT && B <= varsmall_max && B <= 8) {
         PhaseTimer t(h, GPMPC_PH_VARGEMM);   // stream L^-1 once (HBM-bound), no MFMA padding waste
-        tilesM = Np / 32;
+        static const int rpw_env = getenv("GPMPC_VARSMALL_RPW") ? atoi(getenv("GPMPC_VARSMALL_RPW")) : 0;   // (tuning aid: rows per wave, 1 .. 8)
+        const int rpw = (rpw_env >= 1 && rpw_env <= 8 && Np % (4 * rpw_env) == 0) ? rpw_env : var_small_rows_per_wave(Np, Ny, g_cu_count[h->device]);
+        tilesM = Np / (4 * rpw);
         const dim3 grid(tilesM, Ny);
-        if (B == 1) hipLaunchKernelGGL((var_small_kernel<1>), grid, dim3(256), 0, cx.stream, h->ws.Inv, h->KsT, h->part, Np, Bp);
-        else if (B == 2) hipLaunchKernelGGL((var_small_kernel<2>), grid, dim3(256), 0, cx.stream, h->ws.Inv, h->KsT, h->part, Np, Bp);
-        else if (B <= 4) hipLaunchKernelGGL((var_small_kernel<4>), grid, dim3(256), 0, cx.stream, h->ws.Inv, h->KsT, h->part, Np, Bp);
-        else hipLaunchKernelGGL((var_small_kernel<8>), grid, dim3(256), 0, cx.stream, h->ws.Inv, h->KsT, h->part, Np, Bp);
+        if (B == 1) hipLaunchKernelGGL((var_small_kernel<1>), grid, dim3(256), 0, cx.stream, h->ws.Inv, h->KsT, h->part, Np, Bp, rpw);
+        else if (B == 2) hipLaunchKernelGGL((var_small_kernel<2>), grid, dim3(256), 0, cx.stream, h->ws.Inv, h->KsT, h->part, Np, Bp, rpw);
+        else if (B <= 4) hipLaunchKernelGGL((var_small_kernel<4>), grid, dim3(256), 0, cx.stream, h->ws.Inv, h->KsT, h->part, Np, Bp, rpw);
+        else hipLaunchKernelGGL((var_small_kernel<8>), grid, dim3(256), 0, cx.stream, h->ws.Inv, h->KsT, h->part, Np, Bp, rpw);
     } else if (dVar && B <= 64) {
         // small batch (an MPC's Nt shooting nodes): tall-skinny tiles, a row tile x all columns per workgroup,
         // so that L^-1 is streamed once and the small Ks panel is shared through LDS.  The stream is what matters:

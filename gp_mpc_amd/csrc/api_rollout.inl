@@ -153,3 +153,111 @@ extern "C" int gpmpc_rollout_feedback(gpmpc_gp* h, int method, int T, const doub
     return rollout_impl(h, method, T, z0, nullptr, Sigma0, sa, sb, Kz, k0, Kc, mean, cov, U_out);
 }
 
+
+// a17, "batch across trajectories / methods" (gp_class.py:777-804 loops over the methods and, inside, over the
+// steps): M trajectories -- each with its own method, start, controls and initial input covariance -- advance in LOCK-STEP.
+// Per time step ONE pass over the factors serves all of them: the 'ME' / 'TA' trajectories form one prediction batch (one
+// stream of the lower triangles of L^-1, 4 N (N+1) bytes per output, whatever their number up to 32: the HBM-bound part of
+// a roll-out at C3 size), the trajectories of a moment method one batched launch set.  Trajectories are independent: a
+// trajectory's numbers do not depend on what else is in the call, with one exception spelt out in include/gpmpc.h (a lone
+// 'ME' / 'TA' trajectory takes the one-column variance kernel, two or more the batched one: two summation orders).
+extern "C" int gpmpc_rollout_multi(gpmpc_gp* h, int M, const int* methods, int T, const double* z0, const double* U,
+                                   const double* Sigma0, const double* sa, const double* sb, double* mean, double* cov) {
+    if (!h) return fail(GPMPC_EINVAL, "NULL handle");
+    if (!h->fitted) return fail(GPMPC_ENOTFIT, "model has no factors (call gpmpc_fit or gpmpc_set_factors)");
+    const int d = h->d, Ny = h->Ny, Nu = d - Ny;
+    if (M <= 0 || M > 64 || T <= 0 || !methods || !z0 || !Sigma0 || !mean || !cov || (Nu > 0 && !U))
+        return fail(GPMPC_EINVAL, "bad M (1..64), T or NULL argument");
+    if (Nu < 0) return fail(GPMPC_EINVAL, "roll-out needs d >= Ny (inputs are [state, control])");
+    for (int m = 0; m < M; ++m) {
+        if (methods[m] < GPMPC_ME || methods[m] > GPMPC_OLD_TA) return fail(GPMPC_EINVAL, "No GP method with code %d", methods[m]);
+        if (methods[m] == GPMPC_OLD_TA && h->mean_kind)
+            return fail(GPMPC_EINVAL, "'old_TA' with a non-zero mean function raises in the reference (gp_functions.py:309-311); not served");
+    }
+    HIPCHK(hipSetDevice(h->device));
+    CHK(ensure_scratch(h, M));
+    // device order: 'ME', 'TA', then the moment methods, each group contiguous (perm[k] = caller's index of device slot k)
+    std::vector<int> perm;
+    int cnt[5] = {0, 0, 0, 0, 0};
+    for (int code : {GPMPC_ME, GPMPC_TA, GPMPC_EM, GPMPC_OLD_ME, GPMPC_OLD_TA})
+        for (int m = 0; m < M; ++m)
+            if (methods[m] == code) { perm.push_back(m); ++cnt[code]; }
+    const int nME = cnt[GPMPC_ME], nTA = cnt[GPMPC_TA], nA = nME + nTA;
+    const bool moments = nA < M;
+    if (moments && !h->have_invK) {
+        CHK(compute_invK(h->cx(), h->ws));
+        h->have_invK = true;
+    }
+    const int nu1 = std::max(Nu, 1);
+    const size_t nZ = (size_t)M * d, nS = (size_t)M * d * d, nU = (size_t)T * M * nu1, nM = (size_t)T * M * Ny, nC = (size_t)T * M * Ny * Ny;
+    const size_t nIn = nZ + nS + 2 * Ny + nU;
+    const size_t total = nIn + nM + nC + (size_t)M * Ny + (size_t)M * Ny * d;
+    if (total > h->rollm_cap) {
+        HIPCHK(hipStreamSynchronize(h->stream));
+        hipFree(h->rollm_dev);
+        if (h->rollm_pin) hipHostFree(h->rollm_pin);
+        h->rollm_dev = h->rollm_pin = nullptr;
+        h->rollm_cap = 0;
+        HIPCHK(hipMalloc(&h->rollm_dev, total * sizeof(double)));
+        HIPCHK(hipHostMalloc((void**)&h->rollm_pin, total * sizeof(double), hipHostMallocDefault));
+        h->rollm_cap = total;
+    }
+    double* buf = h->rollm_dev;
+    double *dZ = buf, *dS = dZ + nZ, *dsa = dS + nS, *dsb = dsa + Ny, *dU = dsb + Ny, *dM = dU + nU, *dC = dM + nM, *dV = dC + nC,
+           *dJ = dV + (size_t)M * Ny;
+    {
+        double* pz = h->rollm_pin;
+        std::memset(pz, 0, nIn * sizeof(double));
+        for (int k = 0; k < M; ++k) {
+            const int m = perm[k];
+            std::memcpy(pz + (dZ - buf) + (size_t)k * d, z0 + (size_t)m * d, d * sizeof(double));
+            std::memcpy(pz + (dS - buf) + (size_t)k * d * d, Sigma0 + (size_t)m * d * d, (size_t)d * d * sizeof(double));
+            for (int t = 0; t < T && Nu > 0; ++t)     // time-major on the device: the controls of step t are one block
+                std::memcpy(pz + (dU - buf) + ((size_t)t * M + k) * nu1, U + ((size_t)m * T + t) * Nu, Nu * sizeof(double));
+        }
+        for (int a = 0; a < Ny; ++a) pz[(dsa - buf) + a] = sa ? sa[a] : 1.0;
+        if (sb) std::memcpy(pz + (dsb - buf), sb, Ny * sizeof(double));
+    }
+    HIPCHK(hipMemcpyAsync(buf, h->rollm_pin, nIn * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (moments) CHK(ensure_beta(h));
+    int rc = GPMPC_OK;
+    for (int t = 0; t < T && rc == GPMPC_OK; ++t) {
+        double* oM = dM + (size_t)t * M * Ny;
+        double* oC = dC + (size_t)t * M * Ny * Ny;
+        if (t > 0)
+            hipLaunchKernelGGL(rollout_feed_multi_kernel, dim3(M), dim3(64), 0, h->stream, oM - (size_t)M * Ny, oC - (size_t)M * Ny * Ny,
+                               dU + (size_t)t * M * nu1, dsa, dsb, dZ, dS, Ny, d, nu1);
+        if (nA > 0) {
+            rc = predict_chunk(h, nA, dZ, oM, dV, nTA ? dJ : nullptr);
+            if (rc != GPMPC_OK) break;
+            if (nME)
+                hipLaunchKernelGGL(cov_assemble_kernel, dim3((unsigned)(((long)nME * Ny * Ny + 255) / 256)), dim3(256), 0, h->stream, dV, dJ,
+                                   (const double*)nullptr, oC, nME, Ny, d);
+            if (nTA)
+                hipLaunchKernelGGL(cov_assemble_kernel, dim3((unsigned)(((long)nTA * Ny * Ny + 255) / 256)), dim3(256), 0, h->stream,
+                                   dV + (size_t)nME * Ny, dJ + (size_t)nME * Ny * d, dS + (size_t)nME * d * d, oC + (size_t)nME * Ny * Ny,
+                                   nTA, Ny, d);
+        }
+        int off = nA;
+        for (int code : {GPMPC_EM, GPMPC_OLD_ME, GPMPC_OLD_TA}) {
+            if (!cnt[code]) continue;
+            rc = predict_moments_chunk(h, code, cnt[code], dZ + (size_t)off * d, dS + (size_t)off * d * d, oM + (size_t)off * Ny,
+                                       oC + (size_t)off * Ny * Ny);
+            if (rc != GPMPC_OK) break;
+            off += cnt[code];
+        }
+    }
+    if (rc != GPMPC_OK) { hipStreamSynchronize(h->stream); return rc; }
+    hipError_t e = hipMemcpyAsync(h->rollm_pin + (dM - buf), dM, (nM + nC) * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e != hipSuccess) return fail(GPMPC_EHIP, "%s", hipGetErrorString(e));
+    const double* hM = h->rollm_pin + (dM - buf);
+    const double* hC = h->rollm_pin + (dC - buf);
+    for (int k = 0; k < M; ++k)
+        for (int t = 0; t < T; ++t) {
+            std::memcpy(mean + ((size_t)perm[k] * T + t) * Ny, hM + ((size_t)t * M + k) * Ny, Ny * sizeof(double));
+            std::memcpy(cov + ((size_t)perm[k] * T + t) * Ny * Ny, hC + ((size_t)t * M + k) * Ny * Ny, (size_t)Ny * Ny * sizeof(double));
+        }
+    return GPMPC_OK;
+}

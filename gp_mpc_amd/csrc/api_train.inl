@@ -295,6 +295,10 @@ static int nll_batch_core(gpmpc_gp* h, int a, int n, NllReq* const* req, bool wa
         }
     }, 1, jit, true, value_only && !want_grad);
     h->lock_inv_panels = ws.inv_panels;
+    {   // algorithmic matrix flops of this batch (counter "train_gflop"): Cholesky, L^-1 unless left unformed, K^-1 with a gradient
+        const double n3 = (double)h->N * h->N * h->N / 3.0;
+        h->train_flop += n * n3 * (1.0 + (ws.inv_panels ? 0.0 : 1.0) + (want_grad ? 1.0 : 0.0));
+    }
     if (frc != GPMPC_OK && frc != GPMPC_ENOTPD) return frc;
     HIPCHK(hipGetLastError());
     std::vector<double> fv(n), gv(want_grad ? (size_t)n * BGS : 0);
@@ -319,6 +323,7 @@ static int nll_grad_retained(gpmpc_gp* h, int a, const std::vector<NllReq*>& G, 
     Ctx cx = h->cx();
     cx.no_workers = true;
     HIPCHK(hipMemcpyAsync(h->bzmap, pos.data(), m * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    h->train_flop += m * ((double)h->N * h->N * h->N / 3.0) * (h->lock_inv_panels > 0 ? 2.0 : 1.0);   // (L^-1 now) + K^-1
     if (h->lock_inv_panels > 0) {                 // the value batch stopped at L and the diagonal blocks' inverses
         PhaseTimer t(h, GPMPC_PH_FACTOR);
         twolevel_inverse_all(cx, ws, cx.stream, h->lock_inv_panels, m, h->bzmap);
@@ -529,6 +534,7 @@ extern "C" int gpmpc_train_multistart(gpmpc_gp* h, int nstart, const double* sta
     int local_rc = GPMPC_OK;
     std::string local_err;
     long iters_total = 0, evals_total = 0;
+    h->train_flop = 0.0;
     for (int a = 0; a < Ny && local_rc == GPMPC_OK; ++a) {
         BoxProblem P;
         P.n = nh;

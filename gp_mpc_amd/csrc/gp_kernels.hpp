@@ -500,10 +500,13 @@ __global__ void __launch_bounds__(256) var_finish_kernel(const double* __restric
 // triangle of L^-1 ONCE from HBM and form v_i = sum_k invL[i][k] ks_j[k] for all NB test points at once,
 // one wave per row (16 B per lane, 1 KB per wave-instruction), rows dealt so that every workgroup gets
 // the same amount of the triangle.  HBM-read bound: 4 N (N+1) bytes per output for up to 8 predictions.
-// grid (Np/32, Ny), 256 threads: 4 waves x 8 rows; part[a][blockIdx.x][j] = sum over the block's rows of v_i^2.
+// grid (Np / (4 rpw), Ny), 256 threads: 4 waves x rpw rows; part[a][blockIdx.x][j] = sum over the block's rows of v_i^2.
+// rpw (rows per wave, 1 .. 8; var_small_rows_per_wave): 8 when that still gives every CU four workgroups (C3: 1536), fewer
+// for small models -- at N = 4096, Ny = 1 eight rows per wave are 128 workgroups, half a workgroup per CU and two waves
+// per CU with one or two loads in flight each: 1.35 TB/s (r06 bench, secondary.b1); one row per wave: 1024 workgroups.
 template <int NB>
 __global__ void __launch_bounds__(256) var_small_kernel(const double* __restrict__ Inv, const double* __restrict__ KsT,
-                                                        double* __restrict__ part, int Np, int Bp) {
+                                                        double* __restrict__ part, int Np, int Bp, int rpw) {
     const int a = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nblk = gridDim.x;
     __shared__ double red[4][NB];
@@ -512,7 +515,7 @@ __global__ void __launch_bounds__(256) var_small_kernel(const double* __restrict
     double sq[NB];
 #pragma unroll
     for (int j = 0; j < NB; ++j) sq[j] = 0.0;
-    for (int rr = 0; rr < 8; ++rr) {
+    for (int rr = 0; rr < rpw; ++rr) {
         // rows are dealt block-cyclically over the workgroups: balanced triangular work
         const int i = ((rr * 4 + wave) * nblk + (int)blockIdx.x);
         const double* __restrict__ row = Ia + (long)i * Np;
@@ -539,6 +542,13 @@ __global__ void __launch_bounds__(256) var_small_kernel(const double* __restrict
     }
     __syncthreads();
     if (tid < NB) part[((long)a * nblk + blockIdx.x) * Bp + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+}
+
+// rows per wave of var_small_kernel: the most (<= 8) that still leaves four workgroups per CU, else one
+inline int var_small_rows_per_wave(int Np, int Ny, int cus) {
+    for (int rpw = 8; rpw > 1; rpw /= 2)
+        if ((long)(Np / (4 * rpw)) * Ny >= 4L * cus && Np % (4 * rpw) == 0) return rpw;
+    return 1;
 }
 
 // a10 build_TA_cov gp_functions.py:152-173: cov[b] = diag(var[b]) + J[b] Sigma[b] J[b]^T
@@ -760,6 +770,22 @@ __global__ void __launch_bounds__(64) rollout_feed_kernel(const double* __restri
             Sigma[(Ny + p) * d + Ny + q] = v;
         }
     }
+}
+
+// The open-loop hand-over of rollout_feed_kernel for M trajectories that advance in lock-step (gpmpc_rollout_multi): workgroup m
+// turns (mean, cov) of trajectory m at step t - 1 and its control u_t into its next input (z, Sigma).  grid (M), 64 threads.
+__global__ void __launch_bounds__(64) rollout_feed_multi_kernel(const double* __restrict__ mean_prev, const double* __restrict__ cov_prev,
+                                                                const double* __restrict__ u_t, const double* __restrict__ sa,
+                                                                const double* __restrict__ sb, double* __restrict__ z,
+                                                                double* __restrict__ Sigma, int Ny, int d, int nu1) {
+    const int m = blockIdx.x, tid = threadIdx.x;
+    const double* mp = mean_prev + (long)m * Ny;
+    const double* cp = cov_prev + (long)m * Ny * Ny;
+    const double* up = u_t + (long)m * nu1;
+    double* zm = z + (long)m * d;
+    double* Sm = Sigma + (long)m * d * d;
+    for (int e = tid; e < d; e += 64) zm[e] = e < Ny ? sa[e] * mp[e] + sb[e] : up[e - Ny];
+    for (int e = tid; e < Ny * Ny; e += 64) Sm[(e / Ny) * d + e % Ny] = cp[e];
 }
 
 // Matrix-vector products with the explicit factors (a5: alpha = L^-T (L^-1 y), optimize.py:353-354,494;

@@ -522,6 +522,8 @@ class GP:
         P = np.array(scipy.linalg.solve_discrete_are(A, B, Q, R))
         return -np.array(scipy.linalg.solve(R + B.T @ P @ B, B.T @ P @ A))
 
+    ROLLOUT_MULTI_MIN_N = 2048      # from this many training points on, rollout runs its methods in lock-step on the device
+
     def rollout(self, x0, u, methods=None, feedback=False, x_ref=None, Q=None, R=None, K=None, return_controls=False):
         """The numeric loop of `predict_compare` (gp_class.py:746-804) without simulator and
         plots: for every method feed (mean_t, cov_t) back into `predict` for Nt = len(u) steps.
@@ -564,6 +566,22 @@ class GP:
             Q = np.eye(Ny) if Q is None else np.asarray(Q, dtype=np.float64)      # :765-768
             R = np.eye(Nu) if R is None else np.asarray(R, dtype=np.float64)
         keep = self.__gp_method
+        if not feedback and len(methods) > 1 and self.__N >= self.ROLLOUT_MULTI_MIN_N:
+            # every method from the same start, in lock-step: ONE pass over the factors per time step serves all of them
+            # (gpmpc_rollout_multi; small models keep the per-method calls, whose loops are replayed from captured graphs)
+            covar[:Ny, :Ny] = np.diag(initVar)
+            z0 = np.concatenate([(x0 - meanX) / stdX, Us[0]])
+            mean_s, cov = self._h.rollout_multi(list(methods), z0, Us, covar, sa, sb)
+            for i in range(len(methods)):
+                controls[i] = u
+                mean[i, 0, :] = x0
+                mean[i, 1:, :] = self.inverse_mean(mean_s[i], self.__meanY, self.__stdY) if norm else mean_s[i]
+                var[i, 1:, :] = np.einsum('tii->ti', cov[i])
+                if norm:
+                    var[i, 1:, :] = self.inverse_variance(var[i, 1:, :])
+            if np.any(var < 0):
+                var = var.clip(min=0)
+            return (mean, var, controls) if return_controls else (mean, var)
         for i, m in enumerate(methods):
             covar[:Ny, :Ny] = np.diag(initVar)                                    # gp_class.py:780 (other blocks persist)
             if feedback:

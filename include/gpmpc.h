@@ -211,6 +211,18 @@ int gpmpc_rollout(gpmpc_gp* h, int method, int T, const double* z0, const double
 int gpmpc_rollout_feedback(gpmpc_gp* h, int method, int T, const double* z0, const double* Sigma0, const double* sa,
                            const double* sb, const double* Kz, const double* k0, const double* Kc, double* mean,
                            double* cov, double* U_out);
+/* M roll-outs in lock-step (r06; SURVEY a17 "batch across trajectories / methods": gp_class.py:777-804 runs the methods one
+ * after the other and synchronises with the predictor at every step).  Trajectory m has its own method methods[m], first
+ * input z0[m] (z0[M x d]), controls U[m] (U[M x T x Nu]) and initial input covariance Sigma0[m] (Sigma0[M x d x d]); sa / sb
+ * as in gpmpc_rollout.  Outputs mean[M x T x Ny], cov[M x T x Ny x Ny].  Per time step ONE pass over the factors serves
+ * every trajectory: all 'ME' / 'TA' trajectories form one prediction batch (the lower triangles of L^-1 are streamed once
+ * for up to 32 of them -- at N = 8192, Ny = 6 that stream IS the step: 1.6 GB), the trajectories of a moment method
+ * one batched launch set.  M <= 64.  Open loop only (gpmpc_rollout_feedback for the reference's feedback law).
+ * Parity: trajectories do not influence each other; a trajectory's numbers are bitwise those of gpmpc_rollout when it
+ * is the only 'ME' / 'TA' trajectory of the call (or a moment method), and otherwise agree with it to rounding (the
+ * batched variance kernel sums the same N terms in another order than the one-column kernel: ~1e-15 sf^2 per step). */
+int gpmpc_rollout_multi(gpmpc_gp* h, int M, const int* methods, int T, const double* z0, const double* U,
+                        const double* Sigma0, const double* sa, const double* sb, double* mean, double* cov);
 /* a14 GP.covar gp_class.py:353-381: covar[Ny x n x n] = sf^2 - V^T V for n new inputs. */
 int gpmpc_covar(gpmpc_gp* h, int n, const double* Xnew, double* covar);
 
@@ -232,7 +244,7 @@ int gpmpc_nll(gpmpc_gp* h, int a, const double* hyper_row, double* nll, double* 
  * accepted step always lowers the NLL; the L-BFGS memory is dropped when the set of bound-pinned variables changes.
  * optimizer_opts written for IPOPT / SLSQP have no counterpart here: only max_iter and tol exist.  Iteration and
  * evaluation totals of the last call (this rank's restarts, both stages): gpmpc_get_counter "train_iterations" /
- * "train_evaluations".  starts[Ny x nstart x W] (W =
+ * "train_evaluations", and "train_gflop" = its algorithmic matrix work (N^3/3 per Cholesky, per L^-1 formed, per K^-1).  starts[Ny x nstart x W] (W =
  * gpmpc_hyper_width): one initial point per restart -- the reference starts every restart from the same point
  * (optimize.py:462-466, its Latin-hypercube line :218 is commented out); lb, ub[Ny x W]: the box (optimize.py:434-443 or
  * :204-229; +-HUGE_VAL for none).  For every output the restart with the smallest NLL wins (first minimum, np.argmin

@@ -1198,6 +1198,54 @@ def check_rollout_replay(lib, N=150, Ny=2, d=3, T=6, seed=31):
     h.close()
 
 
+def check_rollout_multi(lib, N=150, Ny=2, d=3, T=5, seed=33, methods=('ME', 'TA', 'EM', 'old_ME')):
+    """gpmpc_rollout_multi (SURVEY a17 'batch across trajectories / methods', gp_class.py:777-804) against gpmpc_rollout:
+    * a call with ONE trajectory is bitwise the single-trajectory call, for every method;
+    * in a mixed call the moment-method trajectories are bitwise the single calls, the 'ME' / 'TA' trajectories agree with
+      them to rounding (batched variance kernel: another summation order), scaled bars 1e-10;
+    * a trajectory's bits do not depend on its position or on what else is in the call (two compositions with >= 2 'ME' / 'TA').
+    (gpmpc_rollout itself is pinned against the oracle in check_rollout_vs_oracle.)"""
+    p = go.synthetic_problem(N, d, Ny, T + 2, seed=seed, sn=0.1)
+    X, Y, H = p['X'], p['Y'], p['hyper']
+    h = Handle(lib, X, Y)
+    h.fit(H, want_invK=True)
+    Nu = d - Ny
+    rng = np.random.default_rng(seed)
+    za, zb, zc = p['Z'][0], p['Z'][1], p['Z'][2]
+    Ua, Ub = 0.3 * rng.standard_normal((T, Nu)), 0.3 * rng.standard_normal((T, Nu))
+    S0 = np.eye(d) * 1e-6
+    S0[:Ny, :Ny] = np.diag(H[:, d + 1] ** 2)
+    S1 = S0 * 2.0
+    sf2 = (H[:, d] ** 2).max()
+    single = {m: h.rollout(m, za, Ua, S0) for m in methods}
+    for m in methods:                                               # one trajectory: the same launches
+        mm, cc = h.rollout_multi([m], za, Ua, S0)
+        assert np.array_equal(mm[0], single[m][0]) and np.array_equal(cc[0], single[m][1]), m
+    mm, cc = h.rollout_multi(list(methods), za, Ua, S0)              # every method from the same start, as GP.rollout runs them
+    for i, m in enumerate(methods):
+        if m in ('ME', 'TA'):
+            assert np.max(np.abs(mm[i] - single[m][0])) <= 1e-10 * max(1.0, np.abs(single[m][0]).max()), m
+            assert np.max(np.abs(cc[i] - single[m][1])) <= 1e-10 * sf2, m
+        else:
+            assert np.array_equal(mm[i], single[m][0]) and np.array_equal(cc[i], single[m][1]), m
+    # composition / position invariance with different starts, controls and input covariances
+    m1, c1 = h.rollout_multi(['ME', 'TA'], np.stack([za, zb]), np.stack([Ua, Ub]), np.stack([S0, S1]))
+    m2, c2 = h.rollout_multi(['TA', 'ME', 'EM', 'ME'], np.stack([zb, zc, za, za]), np.stack([Ub, Ua, Ua, Ua]), np.stack([S1, S0, S0, S0]))
+    assert np.array_equal(m1[0], m2[3]) and np.array_equal(c1[0], c2[3])          # 'ME' from za
+    assert np.array_equal(m1[1], m2[0]) and np.array_equal(c1[1], c2[0])          # 'TA' from zb
+    if 'EM' in methods:
+        assert np.array_equal(m2[2], single['EM'][0]) and np.array_equal(c2[2], single['EM'][1])
+    sb = h.rollout('TA', zb, Ub, S1)
+    assert np.max(np.abs(m1[1] - sb[0])) <= 1e-10 * max(1.0, np.abs(sb[0]).max()) and np.max(np.abs(c1[1] - sb[1])) <= 1e-10 * sf2
+    for bad in (lambda: h.rollout_multi([], za, Ua, S0), lambda: h.rollout_multi([9], za, Ua, S0)):
+        try:
+            bad()
+            assert False
+        except Exception:
+            pass
+    h.close()
+
+
 def check_rollout_vs_oracle(lib, N, Ny, d, T, seed=77, uscale=0.3):
     """T-step propagation (EM / TA / ME) on the device against the oracle (restatement of gp_class.py:777-804 over
     gp_exact_moment / build_gp / build_TA_cov) on a well-conditioned model (sn = 0.1), in two ways:

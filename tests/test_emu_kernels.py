@@ -330,3 +330,7 @@ def test_emu_fused_fit_predict(emu):
     pc.check_fused_fit_predict(emu, N=300, d=3, B=80, Ny=2)
     pc.check_fused_fit_predict(emu, N=560, d=4, B=70, jitter_case=True, repeats=1)
     pc.check_fused_fit_predict(emu, N=150, d=3, B=40, expect_fused=False)      # B <= 64: the two calls
+
+
+def test_emu_rollout_multi(emu):
+    pc.check_rollout_multi(emu)

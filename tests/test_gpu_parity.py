@@ -358,3 +358,9 @@ def test_fused_fit_predict_same_bits_as_two_calls(lib):
     pc.check_fused_fit_predict(lib, N=1500, d=4, B=600, Ny=2)
     pc.check_fused_fit_predict(lib, N=1000, d=4, B=300, jitter_case=True, repeats=1)
     pc.check_fused_fit_predict(lib, N=500, d=6, B=40, expect_fused=False)
+
+
+def test_rollout_multi_lockstep_matches_single_rollouts(lib):
+    """gpmpc_rollout_multi: one pass over the factors per time step for all trajectories / methods."""
+    pc.check_rollout_multi(lib, N=1024, Ny=3, d=5, T=8)
+    pc.check_rollout_multi(lib, N=2500, Ny=2, d=4, T=4, methods=('ME', 'TA', 'EM'))
