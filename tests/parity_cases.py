@@ -167,6 +167,78 @@ def mean_bars(mean, om, floor=1e-2):
             'mean_pointwise_raw': float((dm / np.maximum(np.abs(om), 1e-300)).max())}
 
 
+def longdouble_alpha(X, y, hyper_row, iters=4):
+    """alpha = K^-1 y to extended precision (x87 80-bit, eps 1.1e-19; TEST ONLY): the exact SE-ARD kernel in longdouble
+    (direct differences), the fp64 Cholesky of its rounding as the preconditioner, `iters` steps of iterative refinement
+    with the residual y - K alpha formed in longdouble -- every step gains ~ -log10(cond(K) eps64) digits (cond <= 1e8
+    here: >= 8).  Returns (alpha, K) as longdouble arrays."""
+    from scipy.linalg import cho_factor, cho_solve
+    ld = np.longdouble
+    d = X.shape[1]
+    Xl = X.astype(ld) / hyper_row[:d].astype(ld)
+    D = np.zeros((len(X), len(X)), dtype=ld)
+    for k in range(d):
+        diff = Xl[:, k:k + 1] - Xl[:, k][None, :]
+        D += diff * diff
+    K = ld(hyper_row[d]) ** 2 * np.exp(ld(-0.5) * D)
+    K[np.diag_indices_from(K)] += ld(hyper_row[d + 1]) ** 2
+    cf = cho_factor(K.astype(np.float64), lower=True)
+    yl = y.astype(ld)
+    alpha = cho_solve(cf, y).astype(ld)
+    for _ in range(iters):
+        r = yl - K @ alpha
+        alpha = alpha + cho_solve(cf, r.astype(np.float64)).astype(ld)
+    return alpha, K
+
+
+def longdouble_mean(X, hyper_row, alpha_ld, Z):
+    """ks(z)^T alpha in longdouble for the rows of Z."""
+    ld = np.longdouble
+    d = X.shape[1]
+    Xl, Zl = X.astype(ld) / hyper_row[:d].astype(ld), Z.astype(ld) / hyper_row[:d].astype(ld)
+    out = np.zeros(len(Z), dtype=ld)
+    for b0 in range(0, len(Z), 256):
+        Zb = Zl[b0:b0 + 256]
+        D = np.zeros((len(X), len(Zb)), dtype=ld)
+        for k in range(d):
+            diff = Xl[:, k:k + 1] - Zb[:, k][None, :]
+            D += diff * diff
+        out[b0:b0 + 256] = (ld(hyper_row[d]) ** 2 * np.exp(ld(-0.5) * D)).T @ alpha_ld
+    return out
+
+
+def check_mean_against_extended_precision(lib, N, d, B, sn, nprobe=1000, seed=1234):
+    """VERDICT r05 'mean digits': is the device's mean as close to the TRUE value as numpy's?  Truth = longdouble kernel,
+    alpha refined to longdouble accuracy (longdouble_alpha), ks^T alpha in longdouble, at the first `nprobe` test points of the
+    C2 generator.  Gate: the device's pointwise error (floor 1e-3 max|mean|, the floor r04 asked for) is at most TWICE the fp64
+    oracle's own or 1e-10, and both are printed with the raw maxima.  (x87 longdouble has 11 more mantissa bits than fp64: the
+    yardstick is ~2000 x finer than what it measures, no more.)  What separates fp64 results from the truth here is the
+    rounding of K's entries (expanded form, a1) amplified by cond(K): the same for both, which is the point."""
+    p = go.synthetic_problem(N, d, 1, B, seed=seed, sn=sn)
+    X, Y, H, Z = p['X'], p['Y'], p['hyper'], p['Z'][:nprobe]
+    al, _ = longdouble_alpha(X, Y[:, 0], H[0])
+    truth = longdouble_mean(X, H[0], al, Z).astype(np.float64)
+    o = go.fit(X, Y, H, want_invK=False)
+    om, _, _ = go.mean_var_jac(Z, X, H, o['alpha'], o['chol'], False)
+    h = Handle(lib, X, Y)
+    h.fit(H)
+    gm_big, _ = h.predict_mean_var(p['Z'])              # the 10 000-point route (mean from the variance product's fused sums)
+    gm_small, _ = h.predict_mean_var(Z[:40])            # the small-batch route (ks^T alpha)
+    h.close()
+    big = np.abs(truth).max()
+    floor = np.maximum(np.abs(truth), 1e-3 * big)
+    e_gpu = np.abs(gm_big[:nprobe, 0] - truth)
+    e_small = np.abs(gm_small[:, 0] - truth[:40])
+    e_orc = np.abs(om[:, 0] - truth)
+    print(f'[mean vs longdouble truth, N={N} sn={sn}] max|err|/max|mean|: device {e_gpu.max() / big:.2e} (small batch {e_small.max() / big:.2e}) '
+          f'oracle {e_orc.max() / big:.2e};  pointwise with floor 1e-3: device {(e_gpu / floor).max():.2e} oracle {(e_orc / floor).max():.2e}; '
+          f'device vs oracle {np.abs(gm_big[:nprobe, 0] - om[:, 0]).max() / big:.2e}')
+    # (VERDICT r05 #7: "|gpu - truth| <= 2 |oracle - truth| (or 1e-10 of the stated scale)")
+    assert (e_gpu / floor).max() <= max(2.0 * (e_orc / floor).max(), 1e-10)
+    assert e_gpu.max() <= max(2.0 * e_orc.max(), 1e-10 * big) and e_small.max() <= max(2.0 * e_orc.max(), 1e-10 * big)
+    return dict(device=float((e_gpu / floor).max()), oracle=float((e_orc / floor).max()))
+
+
 def check_synthetic(lib, N, d, Ny, B, sn, strict_rel):
     """SURVEY 8(d) generator; GPU vs oracle on identical inputs."""
     p = go.synthetic_problem(N, d, Ny, B, seed=1234, sn=sn)
@@ -1287,6 +1359,87 @@ def check_rollout_vs_oracle(lib, N, Ny, d, T, seed=77, uscale=0.3):
     gp.close()
 
 
+def exact_moment_longdouble(X, Y, H, mu, Sigma):
+    """gp_exact_moment (gp_functions.py:344-418) evaluated in longdouble (TEST ONLY: the yardstick for how far an fp64
+    evaluation -- the oracle's, the device's -- is from the formula's exact value): K^-1 column by column is too much at
+    N = 8192, so the two places it enters are formed without it -- beta = K^-1 y by longdouble_alpha, and
+    sum_ij K^-1_ij Q_ij = trace(K^-1 Q) = sum_j (K^-1 Q[:, j])_j with Q[:, j] refined the same way in blocks of columns
+    (Q_aa is N x N: the refinement runs on all its columns at once, matrix right-hand side)."""
+    from scipy.linalg import cho_factor, cho_solve
+    ld = np.longdouble
+    Ny, (N, Nx) = len(H), X.shape
+    Hl = np.log(H.astype(ld))
+    mu = np.asarray(mu, dtype=ld).reshape(1, Nx)
+    S = np.asarray(Sigma, dtype=ld)
+    v = X.astype(ld) - mu
+    eye = np.eye(Nx, dtype=ld)
+
+    def solve_ld(A, B):                                  # small (Nx x Nx) systems: Gauss-Jordan in longdouble
+        A, B = A.copy(), B.copy()
+        n = len(A)
+        for i in range(n):
+            piv = i + int(np.argmax(np.abs(A[i:, i])))
+            A[[i, piv]], B[[i, piv]] = A[[piv, i]], B[[piv, i]]
+            B[i] = B[i] / A[i, i]
+            A[i] = A[i] / A[i, i]
+            for r in range(n):
+                if r != i:
+                    B[r] = B[r] - A[r, i] * B[i]
+                    A[r] = A[r] - A[r, i] * A[i]
+        return B
+
+    def det_ld(A):
+        A = A.copy()
+        n, det = len(A), ld(1)
+        for i in range(n):
+            piv = i + int(np.argmax(np.abs(A[i:, i])))
+            if piv != i:
+                A[[i, piv]] = A[[piv, i]]
+                det = -det
+            det = det * A[i, i]
+            A[i + 1:] = A[i + 1:] - np.outer(A[i + 1:, i] / A[i, i], A[i])
+        return abs(det)
+
+    beta, Kl, cfs = [], [], []
+    for a in range(Ny):
+        al, K = longdouble_alpha(X, Y[:, a], H[a])
+        beta.append(al)
+        Kl.append(K)
+        cfs.append(cho_factor(K.astype(np.float64), lower=True))
+    mean = np.zeros(Ny, dtype=ld)
+    log_k = np.zeros((N, Ny), dtype=ld)
+    for a in range(Ny):
+        iLam = np.diag(np.exp(-2 * Hl[a, :Nx]))
+        R = S + np.diag(np.exp(2 * Hl[a, :Nx]))
+        iR = iLam @ (eye - solve_ld(eye + S @ iLam, S @ iLam))
+        T = v @ iR
+        c = np.exp(2 * Hl[a, Nx]) / np.sqrt(det_ld(R)) * np.exp(np.sum(Hl[a, :Nx]))
+        mean[a] = np.sum(c * np.exp(-np.sum(T * v, axis=1) * ld(0.5)) * beta[a])
+        v1 = v / np.exp(Hl[a, :Nx])[None, :]
+        log_k[:, a] = 2 * Hl[a, Nx] - np.sum(v1 * v1, axis=1) * ld(0.5)
+    cov = np.zeros((Ny, Ny), dtype=ld)
+    for a in range(Ny):
+        ii = v / np.exp(2 * Hl[a, :Nx])[None, :]
+        for b in range(a + 1):
+            R = S @ np.diag(np.exp(-2 * Hl[a, :Nx]) + np.exp(-2 * Hl[b, :Nx])) + eye
+            t = 1 / np.sqrt(det_ld(R))
+            ij = v / np.exp(2 * Hl[b, :Nx])[None, :]
+            Q1 = solve_ld(R, S * ld(0.5))
+            aQ, bQ = ii @ Q1, (-ij) @ Q1
+            maha = np.sum(aQ * ii, axis=1)[:, None] + np.sum(bQ * (-ij), axis=1)[None, :] - 2 * aQ @ (-ij).T
+            Q = np.exp(log_k[:, a][:, None] + log_k[:, b][None, :] + maha)
+            s = beta[a] @ Q @ beta[b]
+            if a == b:                                   # - sum_ij K^-1_ij Q_ij = - trace(K^-1 Q), columns refined in longdouble
+                Xs = cho_solve(cfs[a], Q.astype(np.float64)).astype(ld)
+                for _ in range(3):
+                    Xs = Xs + cho_solve(cfs[a], (Q - Kl[a] @ Xs).astype(np.float64)).astype(ld)
+                s = s - np.trace(Xs)
+            cov[a, b] = cov[b, a] = t * s
+        cov[a, a] += np.exp(2 * Hl[a, Nx])
+    cov = cov - np.outer(mean, mean)
+    return mean.astype(np.float64), cov.astype(np.float64)
+
+
 def check_c3_size_step(h, p, outs=(1, 4), node=3):
     """One propagation step at the full C3 size against the ORACLE's own factors: the oracle
     fits `outs` of the model's outputs from scratch (expanded-form K, LAPACK Cholesky, LU solves: optimize.py:303-356,
@@ -1320,7 +1473,44 @@ def check_c3_size_step(h, p, outs=(1, 4), node=3):
     bar = 1e-9 * (_em_scale(o['invK'], Xs, Ys, Hs, z, S).max() + sf2.max())
     assert np.max(np.abs(m[0][outs] - em.reshape(-1))) <= 1e-10 * max(1.0, ms.max()), np.max(np.abs(m[0][outs] - em.reshape(-1)))
     assert np.max(np.abs(got - ec)) <= bar, (np.max(np.abs(got - ec)), bar)
-    return dict(ms=ms, bar_em=bar)
+    # how many digits of the matrix MPC factors next (mpc_class.py:345,422) that bar pins: the cancellation scale against
+    # |cov| and the device-vs-oracle difference against |cov| (check_em_against_extended_precision supplies the yardstick:
+    # how far an fp64 evaluation of this closed form is from its exact value)
+    scale = _em_scale(o['invK'], Xs, Ys, Hs, z, S)
+    cmax = np.abs(ec).max()
+    print(f'\n[C3 EM digits, N = {len(X)}] max|cov| {cmax:.3e}  cancellation scale / |cov| {scale.max() / cmax:.2e}  device vs oracle / |cov| '
+          f'{np.abs(got - ec).max() / cmax:.2e} (gated at 1e-9 scale / |cov| = {bar / cmax:.2e})  min eig(cov): device {np.linalg.eigvalsh(got).min():.3e} oracle {np.linalg.eigvalsh(ec).min():.3e}')
+    return dict(ms=ms, bar_em=bar, em_scale_over_cov=float(scale.max() / cmax), em_dev_vs_oracle_over_cov=float(np.abs(got - ec).max() / cmax))
+
+
+def check_em_against_extended_precision(lib, N=1024, d=8, Ny=2, seed=1234, sn=1e-2, nodes=(3, 7)):
+    """VERDICT r05 'EM digits': the exact-moment covariance of the C3 generator (d = 8, sn = 1e-2) at a size where the closed form
+    can be evaluated in longdouble on the host (exact_moment_longdouble: N^3 longdouble work per output).  Gate: the device is
+    at most TWICE as far from that value as the fp64 oracle (+ 1e-13 of the cancellation scale) -- i.e. what separates either
+    from the exact value is fp64 arithmetic on K^-1 (cond(K) eps), not the kernel -- and the digits are printed."""
+    p = go.synthetic_problem(N, d, Ny, max(nodes) + 1, seed=seed, sn=sn)
+    X, Y, H = p['X'], p['Y'], p['hyper']
+    h = Handle(lib, X, Y)
+    h.fit(H, want_invK=True)
+    f = h.get_factors(invK=True)
+    o = go.fit(X, Y, H)
+    sf2 = H[:, d] ** 2
+    out = []
+    for node in nodes:
+        z, S = p['Z'][node], p['Sigma'][node]
+        m, c = h.predict('EM', z[None], S[None])
+        om, oc = go.exact_moment(o['invK'], X, Y, H, z, S)
+        tm, tc = exact_moment_longdouble(X, Y, H, z, S)
+        scale = _em_scale(o['invK'], X, Y, H, z, S).max() + sf2.max()
+        cmax = np.abs(tc).max()
+        d_dev, d_orc = np.abs(c[0] - tc).max(), np.abs(oc - tc).max()
+        print(f'[EM vs longdouble closed form, N={N} node {node}] max|cov| {cmax:.3e} scale/|cov| {scale / cmax:.2e};  |err|/|cov|: device {d_dev / cmax:.2e} '
+              f'oracle {d_orc / cmax:.2e}  device vs oracle {np.abs(c[0] - oc).max() / cmax:.2e};  mean |err|: device {np.abs(m[0] - tm).max():.2e} oracle {np.abs(om - tm).max():.2e}')
+        assert d_dev <= max(2.0 * d_orc, 1e-10 * scale), (d_dev, d_orc)
+        assert np.abs(m[0] - tm).max() <= max(2.0 * np.abs(om - tm).max(), 1e-10 * max(1.0, np.abs(tm).max()))
+        out.append((float(d_dev / cmax), float(d_orc / cmax)))
+    h.close()
+    return out
 
 
 def check_callback_pattern(h, X, H, alpha, chol, Z, S, repeats=5):

@@ -334,3 +334,8 @@ def test_emu_fused_fit_predict(emu):
 
 def test_emu_rollout_multi(emu):
     pc.check_rollout_multi(emu)
+
+
+def test_emu_mean_and_em_against_extended_precision(emu):
+    pc.check_mean_against_extended_precision(emu, N=300, d=4, B=120, sn=1e-2, nprobe=60)
+    pc.check_em_against_extended_precision(emu, N=150, d=3, Ny=2, nodes=(1,))

@@ -364,3 +364,17 @@ def test_rollout_multi_lockstep_matches_single_rollouts(lib):
     """gpmpc_rollout_multi: one pass over the factors per time step for all trajectories / methods."""
     pc.check_rollout_multi(lib, N=1024, Ny=3, d=5, T=8)
     pc.check_rollout_multi(lib, N=2500, Ny=2, d=4, T=4, methods=('ME', 'TA', 'EM'))
+
+
+@pytest.mark.parametrize('sn', [1e-2, 0.1])
+def test_c2_mean_is_as_close_to_the_extended_precision_value_as_numpy(lib, sn):
+    """the C2 mean against a longdouble evaluation (iteratively refined alpha): gated at twice the fp64 oracle's own
+    distance from it, pointwise with the floor of 1e-3 max|mean| that the device-vs-oracle bar cannot carry (two fp64 summation
+    orders differ by ~5e-13 max|mean|)."""
+    t0 = time.time()
+    r = pc.check_mean_against_extended_precision(lib, N=4096, d=6, B=10000, sn=sn)
+    print(f'[mean digits sn={sn}] device {r["device"]:.2e} oracle {r["oracle"]:.2e} ({time.time() - t0:.0f} s)')
+
+
+def test_em_covariance_is_as_close_to_the_extended_precision_value_as_numpy(lib):
+    pc.check_em_against_extended_precision(lib, N=1024, d=8, Ny=2)

@@ -596,3 +596,32 @@ def test_reference_written_model_file(ref_written):
                    for a in range(len(H))], axis=1)
     assert np.max(np.abs(m - out['ref_mean_std']) / ms) <= 1e-14
     assert np.max(np.abs(v - np.stack([np.diag(c) for c in out['ref_covar']], axis=1))) <= 1e-10 * (H[:, Nx] ** 2).max()
+
+
+@pytest.mark.parametrize('name', ['train_small', 'em_model2'])
+def test_exact_moment_closed_form_in_longdouble_matches_reference_run_quadrature(name, em_pins):
+    """The same closed form (gp_functions.py:344-418) evaluated in longdouble (tests/parity_cases.exact_moment_longdouble: K^-1 y
+    and trace(K^-1 Q) refined to extended precision) against the reference-run quadrature: on train_small (cond 7e8), where
+    every fp64 evaluation sits 3e-6 away, it agrees to 1e-8 -- the 3e-6 is fp64 arithmetic on K^-1, not the formula."""
+    import parity_cases as pc
+    model, pin = em_pins[name]
+    tm, tc = {'train_small': (1e-9, 1e-8), 'em_model2': (1e-12, 1e-12)}[name]
+    for i in range(len(pin['mu'])):
+        m, c = pc.exact_moment_longdouble(model['X'], model['Y'], model['hyper'], pin['mu'][i], pin['Sigma'][i])
+        assert np.max(np.abs(m - pin['ref_em_mean'][i])) <= tm and np.max(np.abs(c - pin['ref_em_cov'][i])) <= tc, (i, m, c)
+
+
+def test_mean_truth_helpers_on_a_small_problem():
+    """longdouble_alpha / longdouble_mean (the yardstick of the GPU tier's mean-digits test) against the fp64 oracle where fp64 is
+    accurate (cond 1e5): they agree to cond * eps, and the refinement has converged (a fifth step moves alpha by < 1 % of fp64's error)."""
+    import parity_cases as pc
+    p = go.synthetic_problem(300, 4, 1, 20, seed=5, sn=0.1)
+    a4, K = pc.longdouble_alpha(p['X'], p['Y'][:, 0], p['hyper'][0], iters=4)
+    a5, _ = pc.longdouble_alpha(p['X'], p['Y'][:, 0], p['hyper'][0], iters=5)
+    o = go.fit(p['X'], p['Y'], p['hyper'], want_invK=False)
+    e64 = np.max(np.abs(o['alpha'][0] - a4.astype(np.float64)))
+    assert e64 <= 1e-10 * np.abs(o['alpha'][0]).max()
+    assert np.max(np.abs(a4 - a5)) <= 1e-2 * e64            # the yardstick is >= 100 x finer than fp64's own error (11 more mantissa bits)
+    t = pc.longdouble_mean(p['X'], p['hyper'][0], a4, p['Z']).astype(np.float64)
+    om, _, _ = go.mean_var_jac(p['Z'], p['X'], p['hyper'], o['alpha'], o['chol'], False)
+    assert np.max(np.abs(om[:, 0] - t)) <= 1e-11 * np.abs(t).max()
