@@ -10,7 +10,6 @@ static GemmP gemm_base(const Ctx& cx) {
 }
 
 static int g_vargemm_persist = -1;  // gpmpc_set_tuning("vargemm_persist", 0 / 1 / 2): dispatcher order / static schedule / ... at any size; -1: GPMPC_VARGEMM_PERSIST or default
-static int g_trtri_strip = -1;     // gpmpc_set_tuning("trtri_strip", 0 / 1): diagonal-block inverses by doubling / by column strips; -1: GPMPC_TRTRI_STRIP or default
 static int g_worker_courier = -1;   // gpmpc_set_tuning("worker_courier", 0 / 1): tile owners only / with the courier; -1: GPMPC_COURIER or default
 
 // Fit factorisation = right-looking blocked Cholesky (NB = 64) + level-by-level batched triangular
@@ -41,12 +40,7 @@ static void trtri_range(const Ctx& cx, Workspace& ws, hipStream_t stream, long b
                         long sScratch = 0) {
     const long ld = ws.Np, sM = ws.mat(), sW = scratch ? sScratch : ws.wstride();
     double* Wl = scratch ? scratch : ws.W;
-    // r06: the levels up to TRTRI_STRIP_N rows as ONE launch of independent column strips (trtri_strip.hpp) instead of two
-    // dependent launches per level; GPMPC_TRTRI_STRIP=0 / gpmpc_set_tuning("trtri_strip", 0): doubling from the 64-blocks as r01-r05
-    static const bool strip_env = !(getenv("GPMPC_TRTRI_STRIP") && atoi(getenv("GPMPC_TRTRI_STRIP")) == 0);
-    const bool strips = (g_trtri_strip >= 0 ? g_trtri_strip != 0 : strip_env) && n > 64 && n % 64 == 0;
-    if (strips) launch_trtri_strip(stream, ws.L, ws.Inv, ld, sM, (int)base0, n, ws.batch, cx.crow_mode);
-    for (int s = strips ? TRTRI_STRIP_N : 64; s < n; s *= 2) {
+    for (int s = 64; s < n; s *= 2) {
         const int nfull = n / (2 * s);                  // nodes with a full right child
         const int rem = n - nfull * 2 * s;              // tail: a partial node exists if rem > s
         for (int part = 0; part < 2; ++part) {

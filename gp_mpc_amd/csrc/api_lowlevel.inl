@@ -114,11 +114,6 @@ extern "C" int gpmpc_set_tuning(const char* name, int value) {
         g_worker_courier = value;
         return GPMPC_OK;
     }
-    if (std::strcmp(name, "trtri_strip") == 0) {         // diagonal-block inverses: column strips (trtri_strip.hpp) / level-by-level doubling
-        if (value < -1 || value > 1) return fail(GPMPC_EINVAL, "trtri_strip must be -1 (default), 0 or 1");
-        g_trtri_strip = value;
-        return GPMPC_OK;
-    }
     if (std::strcmp(name, "handoff_write_through") == 0) {   // hand-offs inside the chained factorisation: write-through stores + drained flag / release fence
         if (value < -1 || value > 1) return fail(GPMPC_EINVAL, "handoff_write_through must be -1 (default), 0 or 1");
         g_handoff_wt = value;

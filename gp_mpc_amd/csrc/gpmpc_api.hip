@@ -28,7 +28,6 @@
 #include "gp_kernels.hpp"
 #include "leaf64.hpp"
 #include "train_native.hpp"
-#include "trtri_strip.hpp"
 #include "vargemm_persist.hpp"
 
 using namespace gpmpc;
