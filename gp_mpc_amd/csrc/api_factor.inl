@@ -773,9 +773,16 @@ static int get_schedule(int device, int mode, int tilesM, int tilesN, int batch,
         auto old_it = g_sched_cache.begin();
         for (auto jt = g_sched_cache.begin(); jt != g_sched_cache.end(); ++jt)
             if (jt->second.stamp < old_it->second.stamp) old_it = jt;
-        (void)hipDeviceSynchronize();                     // a launch that still walks the evicted lists must be through
-        hipFree(old_it->second.v.list);
-        hipFree(old_it->second.v.off);
+        {   // a launch that still walks the evicted lists must be through -- on the device the lists live on, which need not be
+            // the current one
+            int cur = 0;
+            (void)hipGetDevice(&cur);
+            if (old_it->first.device != cur) (void)hipSetDevice(old_it->first.device);
+            (void)hipDeviceSynchronize();
+            hipFree(old_it->second.v.list);
+            hipFree(old_it->second.v.off);
+            if (old_it->first.device != cur) (void)hipSetDevice(cur);
+        }
         g_sched_cache.erase(old_it);
     }
     const VarSchedule s = mode == PG_VAR ? var_schedule(tilesM, tilesN, batch, K, slots) : xtx_schedule(tilesM, batch, K, slots);

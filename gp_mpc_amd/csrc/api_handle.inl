@@ -54,6 +54,7 @@ struct gpmpc_gp {
     Workspace bws;                       // lock-step restart search: batch = up to TRAIN_BATCH_CAP points of one output (lazy)
     double *bYc = nullptr, *bmpar = nullptr, *bgradPartial = nullptr, *bgradOut = nullptr;
     int* bzmap = nullptr;                                // slots of a subset of the batch (gradients of retained points)
+    int bws_mem_cap = 0;                                 // > 0: the batch workspace was cut to this many points by the device's free memory
     struct LockRet { int pos = -1; std::vector<double> theta; };
     int lock_inv_panels = 0;                             // what the last value batch left in Inv (Workspace::inv_panels)
     std::vector<LockRet> lock_ret;                       // per restart of the lock-step search: where its last value-only point's factors are

@@ -203,12 +203,17 @@ static int ensure_batch_ws(gpmpc_gp* h, int want) {
     int cap = (int)std::min<double>(TRAIN_BATCH_CAP_MAX, std::max(1.0, 64.0e9 / per_point));
     if (g_train_batch_cap > 0) cap = std::min(cap, g_train_batch_cap);
     want = std::max(1, std::min(want, cap));
+    // (a request that was cut to what the device's memory allowed comes back with every batch of the same size: it is met by
+    //  the workspace that cut produced -- without this the early-out below compared against the uncut request and every call
+    //  released and re-allocated the whole workspace to end at the same size)
+    if (h->bws.K && h->bws_mem_cap > 0 && want > h->bws_mem_cap && h->bws.batch >= h->bws_mem_cap) return GPMPC_OK;
     if (h->bws.K && h->bws.batch >= want) return GPMPC_OK;
     HIPCHK(hipStreamSynchronize(h->stream));
     ws_free(h->bws);
     hipFree(h->bYc); hipFree(h->bmpar); hipFree(h->bgradPartial); hipFree(h->bgradOut); hipFree(h->bzmap);
     h->bYc = h->bmpar = h->bgradPartial = h->bgradOut = nullptr;
     h->bzmap = nullptr;
+    const int want_before_mem = want;
     {
         // what the device has free now (the old batch workspace is released), less 10 % and 1 GB of headroom: a smaller or
         // busier device gets a smaller batch instead of GPMPC_ENOMEM
@@ -225,6 +230,7 @@ static int ensure_batch_ws(gpmpc_gp* h, int want) {
         arc = ws_alloc(h->bws, want, Np, d);
     }
     CHK(arc);
+    h->bws_mem_cap = want < want_before_mem ? want : 0;      // > 0: this device's memory holds no more than that many points
     HIPCHK(hipMalloc(&h->bzmap, (size_t)want * sizeof(int)));
     CHK(ws_need_invK(h->bws));
     HIPCHK(hipMalloc(&h->bgradPartial, (size_t)want * (Np / 64) * (Np / 64) * (DMAX + 2) * sizeof(double)));

@@ -267,6 +267,12 @@ __global__ void __launch_bounds__(256) chol_chain_kernel(const double* Kmat, dou
         }
         // merge_publish: leafdone[k] goes out together with pan1[k] a few microseconds later, saving one L2 write-back per
         // step on this critical path (off by default since r03: the courier and the workers' look-ahead want inv_kk early)
+        // defer_leaf: leafdone[k] is then released by a bare flag_store behind the panel row's products further down.  That is
+        // equivalent to wg_publish_wt (every wave drains its write-through stores, barrier, one lane stores the flag) ONLY IF
+        // `pre` is workgroup-uniform (it is: read from LDS behind a barrier) and NO exit path lies between the stores above and
+        // that flag_store -- the one early `return` of this loop, wg_wait2's time-out, sits in the !pre branch, which never
+        // defers.  Whoever adds an exit path to the prefetched branch must publish leafdone[k] first.  (the soak
+        // test and the bench line gate on handoff_timeouts == 0 with this on.)
         const bool defer_leaf = defer_publish && wt && !merge_publish && pre && k + 1 < ke;
         if (!defer_leaf && (!merge_publish || k + 1 == ke)) { if (wt) wg_publish_wt(&leafdone[k], 1); else wg_publish(&leafdone[k], 1); }
         CHAIN_STAMP(2);

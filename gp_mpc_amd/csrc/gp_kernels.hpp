@@ -106,8 +106,13 @@ __device__ __forceinline__ double exp_tab32(double x, const double* __restrict__
     return ldexp(tj * p, ki >> 5);
 }
 // exp(-y) for an accumulated y (a squared distance): the sign goes into the constants, no negation instruction
+// (y is clamped at 800 -- exp(-800) = 0 in fp64 -- so that the integer taken from the low word of t cannot wrap: beyond
+//  y ~ 4.65e7, i.e. |x - z| / ell ~ 1e4, it did, and ldexp returned inf or garbage instead of 0; y = +inf from
+//  -log(sf^2) with sf = 0 becomes 0 as well instead of NaN.  Unreachable with trained hyper-parameters, reachable through
+//  gpmpc_set_factors; ADVICE r05.  One v_min_f64 per entry.)
 __device__ __forceinline__ double exp_tab32_neg(double y, const double* __restrict__ T_lds) {
     const double magic = 6755399441055744.0;
+    y = fmin(y, 800.0);
     const double t = fma(y, -46.166241308446829036, magic);
     const double nf = t - magic;                                 // rint(-y 32 / ln 2)
     const double s = fma(nf, 6.93147180559945309417e-01 / 32.0, y);      // s = -r (one constant: see exp_tab)

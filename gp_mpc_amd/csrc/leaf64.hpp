@@ -205,6 +205,15 @@ __device__ __forceinline__ int panel_potrf_dpp_at(double* S, double* Drinv, int 
     const int r = lane, i = lane & 15;
     double a[16], d[16];
     const bool unit_rows = T != nullptr && o >= 16;            // (wave-uniform)
+    // PRECONDITION of the free inverse: S's block (0, o / 16) -- rows 0-15, columns o .. o + 15 -- holds exact zeros (strictly
+    // upper part of the 64 x 64 tile).  Every caller stages the LOWER triangle and zeroes the rest (leaf64_kernel, the chain's
+    // initial / non-prefetched loads; the prefetched path never writes above the diagonal); a caller that staged the full
+    // symmetric tile would get a wrong inv_kk silently.  The emulated build checks it.
+#ifdef GPMPC_EMULATED
+    if (unit_rows && lane < 16)
+        for (int c = 0; c < 16; ++c)
+            if (S[lane * LS + o + c] != 0.0) { fprintf(stderr, "leaf64: S above the diagonal is not zero (row %d, column %d)\n", lane, o + c); abort(); }
+#endif
     if (unit_rows && lane < 16) S[lane * LS + o + lane] = 1.0;
 #pragma unroll
     for (int c = 0; c < 16; ++c) { a[c] = S[r * LS + o + c]; d[c] = S[(o + i) * LS + o + c]; }

@@ -1276,6 +1276,35 @@ def check_rollout_replay(lib, N=150, Ny=2, d=3, T=6, seed=31):
     h.close()
 
 
+def check_far_points(lib, N=150, d=3, Ny=2, seed=9):
+    """Test points 1e5 length scales away from every training point (the table exp of the cross-covariance
+    kernel took its integer from the low word of a magic-number sum, which wraps beyond |x - z| / ell ~ 1e4 -- ldexp then
+    returned inf or garbage instead of 0): k(X, z) = 0, so mean = 0 and var = sf^2 exactly, in the large-batch and the
+    small-batch route; and sf = 0 handed in through gpmpc_set_factors gives zeros, not NaN."""
+    p = go.synthetic_problem(N, d, Ny, 80, seed=seed, sn=0.1)
+    X, Y, H = p['X'], p['Y'], p['hyper']
+    h = Handle(lib, X, Y)
+    h.fit(H)
+    Z = p['Z'].copy()
+    Z[::2] = Z[::2] + 1e5 * H[0, :d].max() * np.array([1.0, -1.0, 1.0][:d])
+    Z[1] = 3e8
+    for Zq in (Z, Z[:3]):
+        m, v = h.predict_mean_var(Zq)
+        far = np.arange(len(Zq)) % 2 == 0
+        far[1] = True
+        assert np.all(np.isfinite(m)) and np.all(np.isfinite(v))
+        assert np.all(m[far[:len(Zq)]] == 0.0) and np.all(v[far[:len(Zq)]] == H[:, d] ** 2)
+    m, c, J = h.predict_jac('TA', Z[:4], p['Sigma'][:4])
+    assert np.all(np.isfinite(c)) and np.all(J[0] == 0.0)
+    f = h.get_factors()
+    H0 = H.copy()
+    H0[0, d] = 0.0                                                  # sf = 0 for the first output
+    h.set_factors(H0, f['chol'], f['alpha'])
+    m, v = h.predict_mean_var(p['Z'])
+    assert np.all(np.isfinite(m)) and np.all(np.isfinite(v)) and np.all(m[:, 0] == 0.0) and np.all(v[:, 0] == 0.0)
+    h.close()
+
+
 def check_rollout_multi(lib, N=150, Ny=2, d=3, T=5, seed=33, methods=('ME', 'TA', 'EM', 'old_ME')):
     """gpmpc_rollout_multi (SURVEY a17 'batch across trajectories / methods', gp_class.py:777-804) against gpmpc_rollout:
     * a call with ONE trajectory is bitwise the single-trajectory call, for every method;

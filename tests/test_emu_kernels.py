@@ -339,3 +339,7 @@ def test_emu_rollout_multi(emu):
 def test_emu_mean_and_em_against_extended_precision(emu):
     pc.check_mean_against_extended_precision(emu, N=300, d=4, B=120, sn=1e-2, nprobe=60)
     pc.check_em_against_extended_precision(emu, N=150, d=3, Ny=2, nodes=(1,))
+
+
+def test_emu_far_points_and_zero_signal_variance(emu):
+    pc.check_far_points(emu)

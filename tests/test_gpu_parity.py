@@ -378,3 +378,8 @@ def test_c2_mean_is_as_close_to_the_extended_precision_value_as_numpy(lib, sn):
 
 def test_em_covariance_is_as_close_to_the_extended_precision_value_as_numpy(lib):
     pc.check_em_against_extended_precision(lib, N=1024, d=8, Ny=2)
+
+
+def test_far_points_and_zero_signal_variance(lib):
+    pc.check_far_points(lib)
+    pc.check_far_points(lib, N=2500, d=3, Ny=1)
