@@ -383,3 +383,24 @@ def test_em_covariance_is_as_close_to_the_extended_precision_value_as_numpy(lib)
 def test_far_points_and_zero_signal_variance(lib):
     pc.check_far_points(lib)
     pc.check_far_points(lib, N=2500, d=3, Ny=1)
+
+
+def test_soak_chained_fits_without_a_handoff_timeout(lib):
+    """400 consecutive C2-size fits + predictions on an otherwise idle GPU with the default hand-off settings
+    (write-through stores, leafdone published behind the panel row's products): not one hand-off may time out, every
+    factorisation must have taken the chained path, and the factors of the last fit are the first fit's bit for bit."""
+    from gp_mpc_amd._lib import Handle
+    p = go.synthetic_problem(4096, 6, 1, 512, seed=1234, sn=1e-2)
+    h = Handle(lib, p['X'], p['Y'])
+    h.fit(p['hyper'])
+    f0 = h.get_factors()
+    m0, v0 = h.predict_mean_var(p['Z'])
+    for _ in range(400):
+        assert np.all(h.fit(p['hyper']) == 0)
+        m, v = h.predict_mean_var(p['Z'])
+    f1 = h.get_factors()
+    assert h.counter('handoff_timeouts') == 0 and h.counter('single_queue_factorisations') == 0, \
+        (h.counter('handoff_timeouts'), h.counter('single_queue_factorisations'))
+    assert np.array_equal(f0['chol'], f1['chol']) and np.array_equal(f0['alpha'], f1['alpha'])
+    assert np.array_equal(m, m0) and np.array_equal(v, v0)
+    h.close()
