@@ -325,11 +325,10 @@ def test_emu_reference_written_model_file(emu, ref_written, tmp_path):
 def test_emu_fused_fit_predict(emu):
     """gpmpc_fit_predict_mean_var: worker path with the cross-covariances in the last launch's window (Np = 704: two launches),
     a single launch (no window: at the chain's end), a two-output model (GEMM path, no early status), the jitter retry."""
-    pc.check_fused_fit_predict(emu, N=700, d=3, B=100)
-    pc.check_fused_fit_predict(emu, N=560, d=4, B=70)
-    pc.check_fused_fit_predict(emu, N=300, d=3, B=80, Ny=2)
+    pc.check_fused_fit_predict(emu, N=700, d=3, B=70, repeats=1)
+    pc.check_fused_fit_predict(emu, N=300, d=3, B=80, Ny=2, repeats=1)
     pc.check_fused_fit_predict(emu, N=560, d=4, B=70, jitter_case=True, repeats=1)
-    pc.check_fused_fit_predict(emu, N=150, d=3, B=40, expect_fused=False)      # B <= 64: the two calls
+    pc.check_fused_fit_predict(emu, N=150, d=3, B=40, expect_fused=False, repeats=1)      # B <= 64: the two calls
 
 
 def test_emu_rollout_multi(emu):
