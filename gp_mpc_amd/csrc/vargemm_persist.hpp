@@ -35,10 +35,13 @@ namespace gpmpc {
 
 // tile word: batch index z (8 bits) | block row tm (12 bits) | block column tn (12 bits)
 constexpr int VAR_TILE = 128;
-// amdgpu_num_vgpr counts halves of the unified 512-entry file of gfx90a+ (the backend doubles the request): 58 = a budget of
-// 116 registers (what does not fit is reloaded at tile switches only), so that four waves per SIMD leave 48 per lane and the
-// alpha kernels of the workers' queue (<= 40 registers), which run NEXT TO the variance product, still find room on its CUs
-constexpr int VAR_VGPRS = 58;
+// amdgpu_num_vgpr counts halves of the unified 512-entry file of gfx90a+ (the backend doubles the request): 60 = a budget of
+// 120 registers (what does not fit is reloaded at tile switches only), so that four waves per SIMD leave 32 per lane and the
+// alpha kernels of the workers' queue, which run NEXT TO the variance product, still find room on its CUs.  r02-r05 asked for
+// 58 = 116: registers are allocated in granules of 8, so that occupied 120 as well and only cost spills (8 VGPRs, 36 B of
+// scratch); 61 / 62 occupy 128 and lock the alpha kernels out until the product ends (profiles/r06_var_vgprs_ab.txt:
+// 58 / 59 / 60 / 61 / 62 -> step 4.054 / 4.102 / 4.037 / 4.041 / 4.056 ms, alpha 0.09 / 0.08 / 0.08 / 0.91 / 1.19 ms).
+constexpr int VAR_VGPRS = 60;
 __host__ __device__ inline int var_tile_word(int z, int tm, int tn) { return (z << 24) | (tm << 12) | tn; }
 
 enum { PG_VAR = 0, PG_XTX = 1 };

@@ -192,7 +192,7 @@ def test_hot_kernels_keep_their_register_budget():
     """Resource regressions the compiler makes silently (tools/kernel_resources.py, a cross-compile of the gfx950 code):
     the worker kernels without scratch (r04: two coordinate arrays with a run-time index had been put there, two scratch
     loads in front of every tile's DMA requests), no vector spills in the chain and worker kernels, the persistent variance
-    product inside the 116 registers that leave room for a fifth wave per SIMD."""
+    product inside the 120 registers (one allocation granule of 8: r06) that leave room for a fifth wave per SIMD."""
     import sys
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'kernel_resources.py')], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -209,4 +209,4 @@ def test_hot_kernels_keep_their_register_budget():
     chain = rows['gpmpc::chol_chain_kernel']
     assert chain[2] == 0 and chain[4] == 0, chain
     var = rows['gpmpc::vargemm_persist_kernel']
-    assert var[0] <= 116 and var[5] >= 4, var
+    assert var[0] <= 120 and var[5] >= 4, var
