@@ -11,8 +11,10 @@ itself (one process per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, rank
 torch.distributed.run the ranks it finds in the environment are used.  For N > 1 the line also carries `restart_shard`:
 the ONE part of the path that shards (BASELINE config C4) -- 64 seeded restarts of the NLL minimisation, restart r on
 rank r mod N, ONE ncclAllGather of the (NLL, theta) table inside gpmpc_train_multistart -- as restarts/s (strong
-scaling) with `rccl_ranks` = ncclCommCount of the communicator that carried it.  For N = 1 the line carries `secondary`:
-two steps of C3 and one of C4 after the timed C2 region.
+scaling) with `rccl_ranks` = ncclCommCount of the communicator that carried it.  For N = 1 the line carries `secondary`
+(after the timed C2 region): two steps of C3 (the three methods in lock-step, gpmpc_rollout_multi; `rollout_hbm`), one of C4 (with a
+flop-counted `roofline`), `c5` (Nt = 30 shooting nodes per call: value + Jacobian + TA covariance, 50 calls, at C3 size and at the
+reference's car-model size) and `b1` (B = 1 streaming predictions on the fitted C2 model), each with its HBM roofline.
 
 --config C3 (secondary, same JSON shape; the default and the headline stay C2): BASELINE.json configs[2] --
 6-output GP, N=8192, d=8: one STEP = fit of all outputs with K^-1 + a 30-step uncertainty propagation with each

@@ -2315,6 +2315,44 @@ def check_gp_class_strict(lib, N=400, Ny=3, Nu=2, seed=29):
     gp.close()
 
 
+def check_gp_rollout_lockstep(lib, N=200, Ny=2, Nu=1, T=5, seed=37, normalize=True):
+    """`GP.rollout` through gpmpc_rollout_multi (what it does from GP.ROLLOUT_MULTI_MIN_N training points on) against its
+    per-method route (gp_class.py:777-804: one method after the other): the moment methods bitwise, 'ME' / 'TA' to rounding,
+    un-standardisation and clipping included."""
+    from gp_mpc_amd.gp import GP
+    d = Ny + Nu
+    p = go.synthetic_problem(N, d, Ny, 4, seed=seed, sn=0.1)
+    rng = np.random.default_rng(seed)
+    Xraw = p['X'] * np.array([2.0, 0.5, 3.0][:d]) + np.array([0.5, -1.0, 0.2][:d])
+    Yraw = p['Y'] * np.array([1.5, 0.7][:Ny]) + np.array([0.3, -0.2][:Ny])
+    f = go.fit(p['X'], p['Y'], p['hyper'])
+    hyper = dict(hyper=p['hyper'], chol=f['chol'], alpha=f['alpha'], invK=f['invK'])
+    kw = dict(normalize=False, lib=lib)
+    Xin, Yin = p['X'], p['Y']
+    if normalize:
+        meta = dict(meanY=Yraw.mean(0), stdY=Yraw.std(0), meanZ=Xraw.mean(0), stdZ=Xraw.std(0), meanX=Xraw[:, :Ny].mean(0),
+                    stdX=Xraw[:, :Ny].std(0), meanU=Xraw[:, Ny:].mean(0), stdU=Xraw[:, Ny:].std(0))
+        kw = dict(normalize=True, lib=lib, meta=meta, xlb=[-9.0] * Ny, xub=[9.0] * Ny, ulb=[-9.0] * Nu, uub=[9.0] * Nu)
+    gp = GP(Xin, Yin, hyper=hyper, gp_method='TA', **kw)
+    x0 = (Xraw if normalize else p['X'])[3, :Ny]
+    U = 0.2 * rng.standard_normal((T, Nu)) + (Xraw[:, Ny:].mean(0) if normalize else 0.0)
+    methods = ['EM', 'TA', 'ME', 'old_ME']
+    keep = GP.ROLLOUT_MULTI_MIN_N
+    try:
+        GP.ROLLOUT_MULTI_MIN_N = 10 ** 9
+        m1, v1 = gp.rollout(x0, U, methods=methods)
+        GP.ROLLOUT_MULTI_MIN_N = 0
+        m2, v2 = gp.rollout(x0, U, methods=methods)
+    finally:
+        GP.ROLLOUT_MULTI_MIN_N = keep
+    for i, m in enumerate(methods):
+        if m in ('EM', 'old_ME'):
+            assert np.array_equal(m1[i], m2[i]) and np.array_equal(v1[i], v2[i]), m
+        else:
+            assert np.allclose(m1[i], m2[i], rtol=1e-10, atol=1e-12) and np.allclose(v1[i], v2[i], rtol=1e-8, atol=1e-12 * np.abs(v1[i]).max()), m
+    gp.close()
+
+
 def check_wide_inputs(lib, N=130, Ny=2, B=9, seed=77):
     """Input dimensions 9 .. 16: every path is instantiated up to d = 16 -- fit, mean / var / Jacobian, TA covariance,
     second-order outputs, the legacy methods, NLL + gradient, and the exact moments (gp_exact_moment,

@@ -342,3 +342,8 @@ def test_emu_mean_and_em_against_extended_precision(emu):
 
 def test_emu_far_points_and_zero_signal_variance(emu):
     pc.check_far_points(emu)
+
+
+def test_emu_gp_rollout_lockstep_route(emu):
+    pc.check_gp_rollout_lockstep(emu)
+    pc.check_gp_rollout_lockstep(emu, normalize=False, N=150)

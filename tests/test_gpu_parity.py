@@ -404,3 +404,7 @@ def test_soak_chained_fits_without_a_handoff_timeout(lib):
     assert np.array_equal(f0['chol'], f1['chol']) and np.array_equal(f0['alpha'], f1['alpha'])
     assert np.array_equal(m, m0) and np.array_equal(v, v0)
     h.close()
+
+
+def test_gp_rollout_lockstep_route(lib):
+    pc.check_gp_rollout_lockstep(lib, N=800, T=8)
