@@ -220,6 +220,13 @@ extern "C" int gpmpc_rollout_multi(gpmpc_gp* h, int M, const int* methods, int T
     }
     HIPCHK(hipMemcpyAsync(buf, h->rollm_pin, nIn * sizeof(double), hipMemcpyHostToDevice, h->stream));
     if (moments) CHK(ensure_beta(h));
+    // The moment-method trajectories of a time step do not depend on its 'ME' / 'TA' batch (separate scratch): they go to the
+    // workers' queue and run NEXT TO it -- the exact moments are VALU-bound, the batch streams L^-1 (HBM-bound) -- and the two
+    // queues meet again in front of the next hand-over (GPMPC_ROLLOUT_OVERLAP=0: one after the other on the main queue).
+    static const bool overlap_env = !(getenv("GPMPC_ROLLOUT_OVERLAP") && atoi(getenv("GPMPC_ROLLOUT_OVERLAP")) == 0);
+    const bool overlap = overlap_env && moments && nA > 0 && h->side_stream && h->stream == h->own_stream;
+    hipStream_t main_q = h->stream;
+    if (overlap) alpha_ready(h);                 // (the workers' queue may still carry a fit's alpha: ordered in front of our use of it)
     int rc = GPMPC_OK;
     for (int t = 0; t < T && rc == GPMPC_OK; ++t) {
         double* oM = dM + (size_t)t * M * Ny;
@@ -227,6 +234,10 @@ extern "C" int gpmpc_rollout_multi(gpmpc_gp* h, int M, const int* methods, int T
         if (t > 0)
             hipLaunchKernelGGL(rollout_feed_multi_kernel, dim3(M), dim3(64), 0, h->stream, oM - (size_t)M * Ny, oC - (size_t)M * Ny * Ny,
                                dU + (size_t)t * M * nu1, dsa, dsb, dZ, dS, Ny, d, nu1);
+        if (overlap) {                           // (t = 0: the inputs' upload is on the main queue)
+            hipEventRecord(h->ev_fork, main_q);
+            hipStreamWaitEvent(h->side_stream, h->ev_fork, 0);
+        }
         if (nA > 0) {
             rc = predict_chunk(h, nA, dZ, oM, dV, nTA ? dJ : nullptr);
             if (rc != GPMPC_OK) break;
@@ -239,6 +250,7 @@ extern "C" int gpmpc_rollout_multi(gpmpc_gp* h, int M, const int* methods, int T
                                    nTA, Ny, d);
         }
         int off = nA;
+        if (overlap) h->stream = h->side_stream;               // (predict_moments_chunk enqueues on the handle's current queue)
         for (int code : {GPMPC_EM, GPMPC_OLD_ME, GPMPC_OLD_TA}) {
             if (!cnt[code]) continue;
             rc = predict_moments_chunk(h, code, cnt[code], dZ + (size_t)off * d, dS + (size_t)off * d * d, oM + (size_t)off * Ny,
@@ -246,8 +258,13 @@ extern "C" int gpmpc_rollout_multi(gpmpc_gp* h, int M, const int* methods, int T
             if (rc != GPMPC_OK) break;
             off += cnt[code];
         }
+        if (overlap) {
+            h->stream = main_q;
+            hipEventRecord(h->ev_join, h->side_stream);
+            hipStreamWaitEvent(main_q, h->ev_join, 0);
+        }
     }
-    if (rc != GPMPC_OK) { hipStreamSynchronize(h->stream); return rc; }
+    if (rc != GPMPC_OK) { hipStreamSynchronize(h->stream); if (overlap) hipStreamSynchronize(h->side_stream); return rc; }
     hipError_t e = hipMemcpyAsync(h->rollm_pin + (dM - buf), dM, (nM + nC) * sizeof(double), hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (e == hipSuccess) e = hipGetLastError();
