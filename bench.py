@@ -307,14 +307,16 @@ def run_c3(rk, steps, warmup, N=8192):
 
     def step():
         h.fit(hyper, want_invK=True)
-        # the three methods from the same start in lock-step (r06, gpmpc_rollout_multi: one pass over L^-1 per time step for
-        # 'ME' and 'TA' together; r01-r05 called gpmpc_rollout once per method)
+        # the three methods from the same start (r06, gpmpc_rollout_multi: one pass over L^-1 per time step for 'ME' and 'TA'
+        # together on the main queue, the exact moments' whole horizon next to them on a second queue; r01-r05 called
+        # gpmpc_rollout once per method.  Letting the roll-out call form K^-1 next to the 'ME' / 'TA' steps instead of inside
+        # the fit measured slower: 111.7 against 108.0 ms, profiles/r06_rollout_overlap_ab.txt)
         mm, cc = h.rollout_multi(['ME', 'TA', 'EM'], z0, U, S0)
         for i, m in enumerate(('ME', 'TA', 'EM')):
             res[m] = (mm[i], cc[i])
 
     elapsed, prof = timed(rk, h, step, steps, warmup)
-    # the roll-outs alone (phase brackets inside gpmpc_rollout are per launch; time them as whole calls)
+    # the roll-outs alone (phase brackets inside gpmpc_rollout are per launch; time them as whole calls; K^-1 is there by now)
     t_roll = {}
     for m in ('ME', 'TA', 'EM'):
         h.synchronize()
@@ -339,7 +341,7 @@ def run_c3(rk, steps, warmup, N=8192):
     world = rk.world
     out = {
         'metric': 'GP moment-matching propagation steps/sec, N=8192 Ny=6 d=8 fp64 (fit + 30-step ME/TA/EM per step)',
-        'rollout_api': 'gpmpc_rollout_multi([ME, TA, EM]) -- the three methods in lock-step',
+        'rollout_api': 'gpmpc_rollout_multi([ME, TA, EM]): ME + TA as one batch per time step on the main queue, EM (and K^-1 before it) next to them on a second queue',
         'value': world * 3 * T * steps / elapsed, 'unit': 'propagation steps/s', 'n_gpus': world, 'steps': steps,
         'warmup': warmup, 'ms_per_step': elapsed / steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',

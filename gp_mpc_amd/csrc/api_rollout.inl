@@ -184,10 +184,6 @@ extern "C" int gpmpc_rollout_multi(gpmpc_gp* h, int M, const int* methods, int T
             if (methods[m] == code) { perm.push_back(m); ++cnt[code]; }
     const int nME = cnt[GPMPC_ME], nTA = cnt[GPMPC_TA], nA = nME + nTA;
     const bool moments = nA < M;
-    if (moments && !h->have_invK) {
-        CHK(compute_invK(h->cx(), h->ws));
-        h->have_invK = true;
-    }
     const int nu1 = std::max(Nu, 1);
     const size_t nZ = (size_t)M * d, nS = (size_t)M * d * d, nU = (size_t)T * M * nu1, nM = (size_t)T * M * Ny, nC = (size_t)T * M * Ny * Ny;
     const size_t nIn = nZ + nS + 2 * Ny + nU;
@@ -219,52 +215,82 @@ extern "C" int gpmpc_rollout_multi(gpmpc_gp* h, int M, const int* methods, int T
         if (sb) std::memcpy(pz + (dsb - buf), sb, Ny * sizeof(double));
     }
     HIPCHK(hipMemcpyAsync(buf, h->rollm_pin, nIn * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    if (moments) CHK(ensure_beta(h));
-    // The moment-method trajectories of a time step do not depend on its 'ME' / 'TA' batch (separate scratch): they go to the
-    // workers' queue and run NEXT TO it -- the exact moments are VALU-bound, the batch streams L^-1 (HBM-bound) -- and the two
-    // queues meet again in front of the next hand-over (GPMPC_ROLLOUT_OVERLAP=0: one after the other on the main queue).
+    // Trajectories are independent, so the two groups need not even meet per time step: with both kinds in the call the moment
+    // methods' whole horizon goes to the workers' queue -- K^-1 first if the model does not have it yet (a fit without it: the
+    // 'ME' / 'TA' group then runs NEXT TO that product, MFMA-bound against HBM-bound), then their T steps -- while the 'ME' / 'TA'
+    // group's T steps run on the main queue; the queues meet once, in front of the copy back.  (The exact moments are
+    // VALU-bound, the batch streams L^-1.)  GPMPC_ROLLOUT_OVERLAP=0: one group after the other, step by step, on the main queue.
     static const bool overlap_env = !(getenv("GPMPC_ROLLOUT_OVERLAP") && atoi(getenv("GPMPC_ROLLOUT_OVERLAP")) == 0);
-    const bool overlap = overlap_env && moments && nA > 0 && h->side_stream && h->stream == h->own_stream;
+    // (only 'EM' has scratch of its own; the legacy methods form their cross-covariances in the buffers the 'ME' / 'TA' batch uses)
+    const bool overlap = overlap_env && moments && nA > 0 && !cnt[GPMPC_OLD_ME] && !cnt[GPMPC_OLD_TA] && h->side_stream &&
+                         h->stream == h->own_stream;
     hipStream_t main_q = h->stream;
-    if (overlap) alpha_ready(h);                 // (the workers' queue may still carry a fit's alpha: ordered in front of our use of it)
     int rc = GPMPC_OK;
-    for (int t = 0; t < T && rc == GPMPC_OK; ++t) {
+    auto moments_prologue = [&]() -> int {       // K^-1 and beta, on the handle's current queue
+        if (!h->have_invK) {
+            PhaseTimer t(h, GPMPC_PH_INVK);
+            CHK(compute_invK(h->cx(), h->ws));
+            h->have_invK = true;
+        }
+        return ensure_beta(h);
+    };
+    auto feed = [&](int t, int off, int cntg) {  // (mean, cov)_{t-1} and u_t of trajectories [off, off + cntg) -> their next inputs
+        const double* pM = dM + (size_t)(t - 1) * M * Ny;
+        const double* pC = dC + (size_t)(t - 1) * M * Ny * Ny;
+        hipLaunchKernelGGL(rollout_feed_multi_kernel, dim3(cntg), dim3(64), 0, h->stream, pM + (size_t)off * Ny, pC + (size_t)off * Ny * Ny,
+                           dU + ((size_t)t * M + off) * nu1, dsa, dsb, dZ + (size_t)off * d, dS + (size_t)off * d * d, Ny, d, nu1);
+    };
+    auto step_a = [&](int t) -> int {            // the 'ME' / 'TA' batch of time step t
         double* oM = dM + (size_t)t * M * Ny;
         double* oC = dC + (size_t)t * M * Ny * Ny;
-        if (t > 0)
-            hipLaunchKernelGGL(rollout_feed_multi_kernel, dim3(M), dim3(64), 0, h->stream, oM - (size_t)M * Ny, oC - (size_t)M * Ny * Ny,
-                               dU + (size_t)t * M * nu1, dsa, dsb, dZ, dS, Ny, d, nu1);
-        if (overlap) {                           // (t = 0: the inputs' upload is on the main queue)
-            hipEventRecord(h->ev_fork, main_q);
-            hipStreamWaitEvent(h->side_stream, h->ev_fork, 0);
-        }
-        if (nA > 0) {
-            rc = predict_chunk(h, nA, dZ, oM, dV, nTA ? dJ : nullptr);
-            if (rc != GPMPC_OK) break;
-            if (nME)
-                hipLaunchKernelGGL(cov_assemble_kernel, dim3((unsigned)(((long)nME * Ny * Ny + 255) / 256)), dim3(256), 0, h->stream, dV, dJ,
-                                   (const double*)nullptr, oC, nME, Ny, d);
-            if (nTA)
-                hipLaunchKernelGGL(cov_assemble_kernel, dim3((unsigned)(((long)nTA * Ny * Ny + 255) / 256)), dim3(256), 0, h->stream,
-                                   dV + (size_t)nME * Ny, dJ + (size_t)nME * Ny * d, dS + (size_t)nME * d * d, oC + (size_t)nME * Ny * Ny,
-                                   nTA, Ny, d);
-        }
+        CHK(predict_chunk(h, nA, dZ, oM, dV, nTA ? dJ : nullptr));
+        if (nME)
+            hipLaunchKernelGGL(cov_assemble_kernel, dim3((unsigned)(((long)nME * Ny * Ny + 255) / 256)), dim3(256), 0, h->stream, dV, dJ,
+                               (const double*)nullptr, oC, nME, Ny, d);
+        if (nTA)
+            hipLaunchKernelGGL(cov_assemble_kernel, dim3((unsigned)(((long)nTA * Ny * Ny + 255) / 256)), dim3(256), 0, h->stream,
+                               dV + (size_t)nME * Ny, dJ + (size_t)nME * Ny * d, dS + (size_t)nME * d * d, oC + (size_t)nME * Ny * Ny,
+                               nTA, Ny, d);
+        return GPMPC_OK;
+    };
+    auto step_m = [&](int t) -> int {            // the moment-method trajectories of time step t
+        double* oM = dM + (size_t)t * M * Ny;
+        double* oC = dC + (size_t)t * M * Ny * Ny;
         int off = nA;
-        if (overlap) h->stream = h->side_stream;               // (predict_moments_chunk enqueues on the handle's current queue)
         for (int code : {GPMPC_EM, GPMPC_OLD_ME, GPMPC_OLD_TA}) {
             if (!cnt[code]) continue;
-            rc = predict_moments_chunk(h, code, cnt[code], dZ + (size_t)off * d, dS + (size_t)off * d * d, oM + (size_t)off * Ny,
-                                       oC + (size_t)off * Ny * Ny);
-            if (rc != GPMPC_OK) break;
+            CHK(predict_moments_chunk(h, code, cnt[code], dZ + (size_t)off * d, dS + (size_t)off * d * d, oM + (size_t)off * Ny,
+                                      oC + (size_t)off * Ny * Ny));
             off += cnt[code];
         }
-        if (overlap) {
-            h->stream = main_q;
-            hipEventRecord(h->ev_join, h->side_stream);
-            hipStreamWaitEvent(main_q, h->ev_join, 0);
+        return GPMPC_OK;
+    };
+    if (overlap) {
+        alpha_ready(h);                          // (the workers' queue may still carry a fit's alpha: the main queue is ordered behind it)
+        hipEventRecord(h->ev_fork, main_q);      // the inputs' upload, and whatever produced the factors
+        hipStreamWaitEvent(h->side_stream, h->ev_fork, 0);
+        h->stream = h->side_stream;              // (everything below enqueues on the handle's current queue)
+        rc = moments_prologue();
+        for (int t = 0; t < T && rc == GPMPC_OK; ++t) {
+            if (t > 0) feed(t, nA, M - nA);
+            rc = step_m(t);
+        }
+        hipEventRecord(h->ev_join, h->side_stream);
+        h->stream = main_q;
+        for (int t = 0; t < T && rc == GPMPC_OK; ++t) {
+            if (t > 0) feed(t, 0, nA);
+            rc = step_a(t);
+        }
+        hipStreamWaitEvent(main_q, h->ev_join, 0);
+    } else {
+        if (moments) rc = moments_prologue();
+        for (int t = 0; t < T && rc == GPMPC_OK; ++t) {
+            if (t > 0) feed(t, 0, M);
+            if (nA > 0) rc = step_a(t);
+            if (rc == GPMPC_OK && moments) rc = step_m(t);
         }
     }
-    if (rc != GPMPC_OK) { hipStreamSynchronize(h->stream); if (overlap) hipStreamSynchronize(h->side_stream); return rc; }
+    if (rc != GPMPC_OK) { hipStreamSynchronize(h->stream); if (h->side_stream) hipStreamSynchronize(h->side_stream); return rc; }
     hipError_t e = hipMemcpyAsync(h->rollm_pin + (dM - buf), dM, (nM + nC) * sizeof(double), hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (e == hipSuccess) e = hipGetLastError();

@@ -1344,6 +1344,12 @@ def check_rollout_multi(lib, N=150, Ny=2, d=3, T=5, seed=33, methods=('ME', 'TA'
         assert np.array_equal(m2[2], single['EM'][0]) and np.array_equal(c2[2], single['EM'][1])
     sb = h.rollout('TA', zb, Ub, S1)
     assert np.max(np.abs(m1[1] - sb[0])) <= 1e-10 * max(1.0, np.abs(sb[0]).max()) and np.max(np.abs(c1[1] - sb[1])) <= 1e-10 * sf2
+    # a model fitted WITHOUT K^-1: the call forms it on the moment methods' queue, next to the 'ME' / 'TA' group's steps
+    if 'EM' in methods:
+        h.fit(H)
+        m3, c3 = h.rollout_multi(['ME', 'EM', 'TA'], np.stack([za, za, zb]), np.stack([Ua, Ua, Ub]), np.stack([S0, S0, S1]))
+        assert np.array_equal(m3[1], single['EM'][0]) and np.array_equal(c3[1], single['EM'][1])
+        assert np.array_equal(m3[0], m1[0]) and np.array_equal(c3[0], c1[0]) and np.array_equal(m3[2], m1[1]) and np.array_equal(c3[2], c1[1])
     for bad in (lambda: h.rollout_multi([], za, Ua, S0), lambda: h.rollout_multi([9], za, Ua, S0)):
         try:
             bad()
