@@ -59,11 +59,23 @@ static int predict_moments_chunk(gpmpc_gp* h, int method, int B, const double* d
         // 3 the polynomial exp_lean (r05, C3, same box: 40.8 / 43.3 / 46.3 ms per step; r04's kernel 45.7)
         static const int pair_form = getenv("GPMPC_EM_PAIR") ? atoi(getenv("GPMPC_EM_PAIR")) : 1;
         const double* etab = g_exp_tab[h->device];
+        // The two pair-sum launches are independent (a != b pairs / a == b pairs, disjoint partial sums): at sizes beyond the
+        // captured-graph range the a == b launch -- the one that streams K^-1 -- goes to the inverse queue NEXT TO the other
+        // (GPMPC_EM_PAIR_OVERLAP=0: one after the other, as r01-r05)
+        static const bool pair_overlap_env = !(getenv("GPMPC_EM_PAIR_OVERLAP") && atoi(getenv("GPMPC_EM_PAIR_OVERLAP")) == 0);
+        const bool pair_overlap = pair_overlap_env && h->aux_stream && Np > 2048 && Ny > 1;
+        hipStream_t diag_q = pair_overlap ? h->aux_stream : cx.stream;
 #define GPMPC_EM_PAIR2(KDV, TABV)                                                                                                     \
+        if (pair_overlap) {                                                                                                           \
+            hipEventRecord(TailState::get(h->tail.ev_ks), cx.stream);                                                                 \
+            hipStreamWaitEvent(diag_q, h->tail.ev_ks, 0);                                                                             \
+        }                                                                                                                             \
+        hipLaunchKernelGGL((em_pair2_kernel<true, KDV, TABV>), dim3(nslots, P, B), dim3(256), 0, diag_q, ops, h->beta, h->ws.InvK,     \
+                           partial, N, Np, Ny, cx.crow_mode, etab, em_chunk);                                                         \
+        if (pair_overlap) hipEventRecord(TailState::get(h->tail.ev_mean), diag_q);                                                    \
         hipLaunchKernelGGL((em_pair2_kernel<false, KDV, TABV>), dim3(nslots, P, B), dim3(256), 0, cx.stream, ops, h->beta, h->ws.InvK, \
                            partial, N, Np, Ny, cx.crow_mode, etab, em_chunk);                                                         \
-        hipLaunchKernelGGL((em_pair2_kernel<true, KDV, TABV>), dim3(nslots, P, B), dim3(256), 0, cx.stream, ops, h->beta, h->ws.InvK,  \
-                           partial, N, Np, Ny, cx.crow_mode, etab, em_chunk);
+        if (pair_overlap) hipStreamWaitEvent(cx.stream, h->tail.ev_mean, 0);
 #define GPMPC_EM_PAIR2_ANY(KDV)                                                                                                       \
         if (pair_form == 2) { GPMPC_EM_PAIR2(KDV, 2) } else if (pair_form == 3) { GPMPC_EM_PAIR2(KDV, 0) } else { GPMPC_EM_PAIR2(KDV, 1) }
         if (KD == 8) {
