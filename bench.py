@@ -341,7 +341,7 @@ def run_c3(rk, steps, warmup, N=8192):
     world = rk.world
     out = {
         'metric': 'GP moment-matching propagation steps/sec, N=8192 Ny=6 d=8 fp64 (fit + 30-step ME/TA/EM per step)',
-        'rollout_api': 'gpmpc_rollout_multi([ME, TA, EM]): ME + TA as one batch per time step on the main queue, EM (and K^-1 before it) next to them on a second queue',
+        'rollout_api': 'gpmpc_rollout_multi([ME, TA, EM]): ME + TA as one batch per time step on the main queue, the EM horizon next to them on a second queue',
         'value': world * 3 * T * steps / elapsed, 'unit': 'propagation steps/s', 'n_gpus': world, 'steps': steps,
         'warmup': warmup, 'ms_per_step': elapsed / steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
