@@ -192,7 +192,14 @@ static int create_impl(gpmpc_gp* h, const double* X, const double* Y) {
     HIPCHK(hipStreamCreate(&h->side_stream));
     HIPCHK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
-    HIPCHK(hipStreamCreate(&h->aux_stream));
+    {
+        // (tuning aid) GPMPC_AUX_PRIORITY=low|high: priority of the inverse queue (default: normal)
+        const char* ap = getenv("GPMPC_AUX_PRIORITY");
+        int lo = 0, hi = 0;
+        HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        if (ap && (ap[0] == 'l' || ap[0] == 'h')) HIPCHK(hipStreamCreateWithPriority(&h->aux_stream, hipStreamDefault, ap[0] == 'l' ? lo : hi));
+        else HIPCHK(hipStreamCreate(&h->aux_stream));
+    }
     {
         int lo = 0, hi = 0;                                    // (numerically larger = lower priority)
         HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
