@@ -360,14 +360,7 @@ struct TailState {
     int nb = 0;
     hipEvent_t ev_info = nullptr;
     bool want_early = false, early_done = false;
-    // fused fit + predict (gpmpc_fit_predict_mean_var, api_fit.inl): the test points are known BEFORE the factorisation starts,
-    // so their cross-covariances -- which depend on the hyper-parameters only -- are formed inside the chain's window, on the
-    // CUs the last worker launch leaves free.  factor_chain calls `in_window(launch_done, gate_flag)` once its worker launches
-    // are enqueued: `launch_done` = the event behind the last-but-one launch, `gate_flag` = index of the hand-off word that
-    // says the LAST launch is resident (its workgroups need whole CUs: nothing may flood the chip before that).
-    std::function<void(hipEvent_t, int)> in_window;
-    bool fused_early = false;    // a fused prediction is being enqueued in front of the host's wait for the status words
-    bool ks_staged = false;      // set by the hook: the cross-covariances of the fused prediction are in flight, ev_ks follows them
+    bool fused_early = false;    // gpmpc_fit_predict_mean_var: a prediction is being enqueued in front of the host's wait for the status words
     static hipEvent_t get(hipEvent_t& e) {
         if (!e) hipEventCreateWithFlags(&e, hipEventDisableTiming);
         return e;

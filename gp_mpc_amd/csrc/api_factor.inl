@@ -574,8 +574,6 @@ static bool factor_chain(const Ctx& cx, Workspace& ws, int spin_limit, bool flag
                                r[i] / 64, i + 1 < L ? (r[i + 1] - r[i]) / 64 : nb, ready, g_chain_trace, worker_lookahead ? 1 : 0, worker_wt_publish());
             if (i + 1 < L) hipEventRecord(cx.seg[i], cx.side);        // launch i finished: rows P_i of L are final
         }
-        // fused fit + predict: the cross-covariances go into the window of the last worker launch (TailState::in_window)
-        if (cx.tail && cx.tail->in_window && split) cx.tail->in_window(cx.seg[L - 2], chain_ready_index(nb) + 2 * (L - 2) + 1);
         const bool own_events = ev0 + P + 2 < cx.n_seg - 2;
         for (int i = 0; split && i + 1 < P; ++i) {
             const int ri = pcut[i], a = pcut[i + 1] - pcut[i];

@@ -64,7 +64,6 @@ static int factor_with_jitter(gpmpc_gp* h, Workspace& ws, const double* hyper_ho
         h->tail.ev_info = h->ev_info;
         h->tail.want_early = early_status && !g_chain_trace;
         h->tail.early_done = false;
-        h->tail.ks_staged = false;
         gram_and_factor(h, ws, no_workers, value_only);
         HIPCHK(hipGetLastError());
         const bool check_chain = h->chain_mode && h->side_stream && ws.Np >= 128;
@@ -118,8 +117,6 @@ static int factor_with_jitter(gpmpc_gp* h, Workspace& ws, const double* hyper_ho
                 HIPCHK(hipStreamSynchronize(h->side_stream));
                 if (h->aux_stream) HIPCHK(hipStreamSynchronize(h->aux_stream));
                 if (h->bulk_stream) HIPCHK(hipStreamSynchronize(h->bulk_stream));
-                if (h->xc_stream) HIPCHK(hipStreamSynchronize(h->xc_stream));
-                h->tail.ks_staged = false;
                 gram_and_factor(h, ws, no_workers, value_only);
                 HIPCHK(hipMemcpyAsync(pin_info, ws.info, nb * sizeof(int), hipMemcpyDeviceToHost, h->stream));
                 HIPCHK(hipEventRecord(h->ev_info, h->stream));
@@ -206,18 +203,12 @@ static int fit_impl(gpmpc_gp* h, const double* hyper, int want_invK, int* info, 
             PhaseTimer t(h, GPMPC_PH_INVK);
             post_rc = compute_invK(h->cx(), h->ws);
         }
-        static const bool fused_late = getenv("GPMPC_FUSED_LATE") && atoi(getenv("GPMPC_FUSED_LATE")) != 0;   // (tuning aid: the prediction behind the host's wait)
-        if (fused && post_rc == GPMPC_OK && !fused_late) {
+        if (fused && post_rc == GPMPC_OK) {
             h->tail.alpha_pending = alpha_on_side;      // (what the prediction orders itself against)
             post_rc = (*fused)();
         }
     }));
     CHK(post_rc);
-    if (fused && getenv("GPMPC_FUSED_LATE") && atoi(getenv("GPMPC_FUSED_LATE")) != 0) {
-        h->tail.alpha_pending = alpha_on_side;
-        h->tail.fused_early = false;
-        CHK((*fused)());
-    }
     if (want_invK) h->have_invK = true;
     HIPCHK(hipGetLastError());
     h->hyper.assign(hyper, hyper + (size_t)h->Ny * nh);

@@ -22,7 +22,6 @@ struct gpmpc_gp {
     double* io_pin = nullptr;           // ... and its pinned host mirror: ONE copy each way instead of one per array
     size_t pin_ints = 0;
     hipStream_t aux_stream = nullptr, bulk_stream = nullptr;
-    hipStream_t xc_stream = nullptr;    // low priority: cross-covariances of a fused fit + predict, inside the chain's window
     std::vector<hipEvent_t> seg_events;
     int chain_mode = 1;      // 0: single queue; 1-3: chained factorisation (gpmpc_create)
     // A hand-off time-out of the persistent kernels (GPU shared with work that keeps CUs from the workgroups that have
@@ -111,7 +110,6 @@ static int prof_collect(gpmpc_gp* h) {
     HIPCHK(hipStreamSynchronize(h->stream));
     if (h->side_stream) HIPCHK(hipStreamSynchronize(h->side_stream));   // (brackets of alpha / the cross-covariances next to a fit's tail)
     if (h->bulk_stream) HIPCHK(hipStreamSynchronize(h->bulk_stream));
-    if (h->xc_stream) HIPCHK(hipStreamSynchronize(h->xc_stream));
     for (int ph = 0; ph < GPMPC_PH_COUNT; ++ph) {
         for (auto& pr : h->prof.ev[ph]) {
             float ms = 0.f;
@@ -204,7 +202,6 @@ static int create_impl(gpmpc_gp* h, const double* X, const double* Y) {
         int lo = 0, hi = 0;                                    // (numerically larger = lower priority)
         HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
         HIPCHK(hipStreamCreateWithPriority(&h->bulk_stream, hipStreamDefault, lo));
-        HIPCHK(hipStreamCreateWithPriority(&h->xc_stream, hipStreamDefault, lo));
     }
     // the persistent kernels ask for more than the default 64 KB of dynamic LDS (per device: set for every handle)
     HIPCHK(hipFuncSetAttribute((const void*)chol_chain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CHAIN_LDS_BYTES));
@@ -284,7 +281,6 @@ int gpmpc_destroy(gpmpc_gp* h) {
     if (h->stream) hipStreamSynchronize(h->stream);
     if (h->side_stream) hipStreamSynchronize(h->side_stream);
     if (h->bulk_stream) hipStreamSynchronize(h->bulk_stream);
-    if (h->xc_stream) hipStreamSynchronize(h->xc_stream);
     ws_free(h->ws);
     ws_free(h->tws);
     ws_free(h->bws);
@@ -313,7 +309,6 @@ int gpmpc_destroy(gpmpc_gp* h) {
     for (auto e : h->seg_events) hipEventDestroy(e);
     if (h->aux_stream) hipStreamDestroy(h->aux_stream);
     if (h->bulk_stream) hipStreamDestroy(h->bulk_stream);
-    if (h->xc_stream) hipStreamDestroy(h->xc_stream);
     if (h->side_stream) hipStreamDestroy(h->side_stream);
     if (h->own_stream) hipStreamDestroy(h->own_stream);
     delete h;

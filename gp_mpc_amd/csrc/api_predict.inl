@@ -130,14 +130,14 @@ static int predict_chunk(gpmpc_gp* h, int B, const double* dZ, double* dMean, do
         // (r05: half a workgroup per CU -- the launch is longer, 0.31 against 0.22 ms, still ends with the tail, and takes less
         //  from the tail's latency-bound launches: step -11 ... -25 us on two boxes, profiles/r05_sweep_cuts_throttle.txt)
         static const int cc_wgs = getenv("GPMPC_CROSSCOV_WGS") ? atoi(getenv("GPMPC_CROSSCOV_WGS")) : std::max(1, g_cu_count[h->device] / 2);
-        if (!ts.ks_staged) {     // (fused fit + predict: they were formed inside the chain's window, ev_ks is recorded behind them)
-            if (ts.fused_early && ts.ev_chain) hipStreamWaitEvent(cx.bulk, ts.ev_chain, 0);   // (enqueued before the chain has ended)
+        {
+            // (gpmpc_fit_predict_mean_var enqueues this before the chain has ended: the launch waits for the chain's end)
+            if (ts.fused_early && ts.ev_chain) hipStreamWaitEvent(cx.bulk, ts.ev_chain, 0);
             ProfScope t(&h->prof, cx.bulk, GPMPC_PH_CROSSCOV);
             launch_crosscov(cx.bulk, h->d, h->XT, h->ws.hyper, nullptr, dZ, h->KsT, h->meanT, nullptr, h->N, Np, B, Bp, Ny, nullptr,
                             1, cc_wgs);
-            hipEventRecord(TailState::get(ts.ev_ks), cx.bulk);
         }
-        ts.ks_staged = false;
+        hipEventRecord(TailState::get(ts.ev_ks), cx.bulk);
         hipStreamWaitEvent(cx.stream, ts.ev_ks, 0);
         if (dMean && fused_mean) {
             // the variance product needs w = L^-1 y for its fused mean: the first kernel of the pending alpha
@@ -336,9 +336,12 @@ extern "C" int gpmpc_predict_mean_var(gpmpc_gp* h, int B, const double* Z, doubl
 
 // Fused fit + predict: the same results as gpmpc_fit followed by gpmpc_predict_mean_var, bit for bit, with the prediction's
 // launches enqueued BEFORE the host waits for the factorisation's status words: the host's round trip between the two calls
-// (status words, return, next call: ~60-120 us at C2) is off the device's path.  The cross-covariances -- which depend on
-// the hyper-parameters and the points only -- can also be formed inside the window of the last worker launch of the chained
-// factorisation (api_factor.inl, TailState::in_window; GPMPC_FUSED_WINDOW=1): measured slower, see below.
+// (status words, return, next call: ~60-120 us at C2) is off the device's path; the cross-covariances start at the end of the
+// chain kernel (event), next to the inverse's tail, throttled, exactly as the two calls form them.  Measured at C2: -10 ... -30 us
+// per step (what bounds the step behind the chain is the inverse's tail, 0.33 ms, not the host).  Forming the
+// cross-covariances -- which depend on the hyper-parameters and the points only -- INSIDE the chain's window instead was built and
+// measured in r06 (commit 81ae31b; docs/history_r06.md): 0.5 ms slower (a sixth concurrently active stream slows every
+// dispatch-bound kernel 3-4 x; on the existing queues the launch delays the second panel's inverse), removed again.
 // Fast path: device pointers, the handle's own queue, 64 < B <= one scratch chunk, no K^-1; anything else is the two calls.
 extern "C" int gpmpc_fit_predict_mean_var(gpmpc_gp* h, const double* hyper, int want_invK, int* info, int B, const double* Z,
                                           double* mean, double* var) {
@@ -347,7 +350,7 @@ extern "C" int gpmpc_fit_predict_mean_var(gpmpc_gp* h, const double* hyper, int 
     if (!mean && !var) return fail(GPMPC_EINVAL, "both outputs NULL");
     static const bool fused_env = !(getenv("GPMPC_FUSED_FIT_PREDICT") && atoi(getenv("GPMPC_FUSED_FIT_PREDICT")) == 0);
     const bool fast = fused_env && h->ptr_mode == GPMPC_PTR_DEVICE && !want_invK && var && B > 64 && B <= chunk_size(h) &&
-                      h->stream == h->own_stream && h->xc_stream && h->side_stream && h->bulk_stream && !h->mean_kind;
+                      h->stream == h->own_stream && h->side_stream && h->bulk_stream && !h->mean_kind;
     if (!fast) {
         CHK(gpmpc_fit(h, hyper, want_invK, info));
         return gpmpc_predict_mean_var(h, B, Z, mean, var);
@@ -355,64 +358,14 @@ extern "C" int gpmpc_fit_predict_mean_var(gpmpc_gp* h, const double* hyper, int 
     HIPCHK(hipSetDevice(h->device));
     alpha_ready(h);
     CHK(ensure_scratch(h, B, true));
-    const int Bp = round_up(B, 32);
-    // GPMPC_FUSED_WINDOW: where the cross-covariances go.  2 (default) = at the chain's end on the low-priority queue, throttled,
-    // exactly as the two calls form them; 1 = inside the window of the last worker launch on a queue of their own; 0 = at the
-    // chain's end on that queue, unthrottled.  Measured at C2 (profiles/r06_fused_*): 1 and 0 LOSE 0.5-0.7 ms per step -- the
-    // handle's sixth concurrently active HIP stream makes every dispatch-bound kernel of the step 3-4 x slower (K build 46 ->
-    // 130 us, finish 18 -> 80 us), and inside the window the launch competes with the inverse's row-panel products, which
-    // are on the critical path to the tail's end; on the existing low-priority queue it delays the second panel's inverse
-    // (+80 us).  With 2 the fused call equals the two calls (-10 us): what bounds the step behind the chain is the inverse's
-    // tail (eight latency-bound level launches + one product, 0.33 ms), not the host's round trip.
-    static const int window_env = getenv("GPMPC_FUSED_WINDOW") ? atoi(getenv("GPMPC_FUSED_WINDOW")) : 2;
-    // (GPMPC_FUSED_CC_WGS: workgroups of that launch; 0 = one per block of eight test points)
-    static const int cc_wgs = getenv("GPMPC_FUSED_CC_WGS") ? atoi(getenv("GPMPC_FUSED_CC_WGS")) : 0;
-#ifdef GPMPC_EMULATED
-    const int fence = 0;
-#else
-    // never on the chain's CU, never next to a tile-owner worker (GPMPC_FUSED_FENCE=<bytes>, tuning aid)
-    static const int fence = getenv("GPMPC_FUSED_FENCE") ? atoi(getenv("GPMPC_FUSED_FENCE")) : 40 * 1024;
-#endif
-    static const bool use_xc = !(getenv("GPMPC_FUSED_XC") && atoi(getenv("GPMPC_FUSED_XC")) == 0);      // (tuning aids)
-    static const bool use_gate = !(getenv("GPMPC_FUSED_GATE") && atoi(getenv("GPMPC_FUSED_GATE")) == 0);
     TailState& ts = h->tail;
-    if (window_env == 1)
-        ts.in_window = [&](hipEvent_t launch_done, int gate_flag) {
-            hipStream_t xc = use_xc ? h->xc_stream : h->bulk_stream;
-            hipStreamWaitEvent(xc, launch_done, 0);
-            if (use_gate)
-                hipLaunchKernelGGL(flag_gate_kernel, dim3(h->ws.batch), dim3(64), 0, xc, h->ws.flags,
-                                   (long)chain_flag_count(h->ws.Np / 64), gate_flag, 1, -1, 0, h->spin_limit);
-            {
-                ProfScope t(&h->prof, xc, GPMPC_PH_CROSSCOV);
-                launch_crosscov(xc, h->d, h->XT, h->ws.hyper, nullptr, Z, h->KsT, h->meanT, nullptr, h->N, h->Np, B, Bp, h->Ny,
-                                nullptr, 1, cc_wgs, fence);
-            }
-            hipEventRecord(TailState::get(ts.ev_ks), xc);
-            ts.ks_staged = true;
-        };
-    int rc_pred = GPMPC_OK;
     const std::function<int()> fused = [&]() {
-        if (!ts.ks_staged && ts.early_done && window_env != 2) {
-            // (no window: single launch of workers, or GPMPC_FUSED_WINDOW=0) at the chain's end, next to the tail, unthrottled
-            hipStream_t xc = h->xc_stream;
-            hipStreamWaitEvent(xc, ts.ev_chain, 0);
-            {
-                ProfScope t(&h->prof, xc, GPMPC_PH_CROSSCOV);
-                launch_crosscov(xc, h->d, h->XT, h->ws.hyper, nullptr, Z, h->KsT, h->meanT, nullptr, h->N, h->Np, B, Bp, h->Ny,
-                                nullptr, 1, cc_wgs, 0);
-            }
-            hipEventRecord(TailState::get(ts.ev_ks), xc);
-            ts.ks_staged = true;
-        }
-        rc_pred = predict_chunk(h, B, Z, mean, var, nullptr, nullptr, ts.early_done || ts.ks_staged);
-        return rc_pred;
+        // (behind_tail only if this attempt returned its status early: the fallback executions run the plain route)
+        return predict_chunk(h, B, Z, mean, var, nullptr, nullptr, ts.early_done);
     };
     ts.fused_early = true;
     const int rc = fit_impl(h, hyper, 0, info, &fused);
     ts.fused_early = false;
-    ts.in_window = nullptr;
-    ts.ks_staged = false;
     ++h->n_fused;
     return rc;
 }

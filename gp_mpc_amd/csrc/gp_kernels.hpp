@@ -434,14 +434,14 @@ constexpr int CROSSCOV_CHUNK_MIN_NP = 2048;
 template <int D>
 inline void launch_crosscov_d(hipStream_t st, const double* XT, const double* hyper, const double* alpha,
                               const double* Z, double* KsT, double* meanT, double* J, int N, int Np, int B, int Bp,
-                              int Ny, double* cpart, int nch, int max_wgs, int lds_fence) {
+                              int Ny, double* cpart, int nch, int max_wgs) {
     if (!cpart) nch = 1;
     auto gx = [&](int blocks) { return max_wgs > 0 && max_wgs < blocks ? max_wgs : blocks; };   // (throttled: see the kernel)
     if (J)
         hipLaunchKernelGGL((crosscov_kernel<D, 4, true>), dim3(gx(Bp / 4), Ny, nch), dim3(256), 0, st, XT, hyper, alpha, Z, KsT,
                            meanT, J, N, Np, B, Bp, Ny, cpart);
     else
-        hipLaunchKernelGGL((crosscov_kernel<D, CROSSCOV_JT, false>), dim3(gx(Bp / CROSSCOV_JT), Ny, nch), dim3(256), lds_fence, st, XT,
+        hipLaunchKernelGGL((crosscov_kernel<D, CROSSCOV_JT, false>), dim3(gx(Bp / CROSSCOV_JT), Ny, nch), dim3(256), 0, st, XT,
                            hyper, alpha, Z, KsT, meanT, J, N, Np, B, Bp, Ny, cpart);
     if (nch > 1) {
         const long items = (long)Ny * Bp * (D + 1);
@@ -452,10 +452,8 @@ inline void launch_crosscov_d(hipStream_t st, const double* XT, const double* hy
 
 inline void launch_crosscov(hipStream_t st, int d, const double* XT, const double* hyper, const double* alpha,
                             const double* Z, double* KsT, double* meanT, double* J, int N, int Np, int B, int Bp,
-                            int Ny, double* cpart = nullptr, int nch = 1, int max_wgs = 0, int lds_fence = 0) {
-    // lds_fence: bytes of dynamic LDS the kernel asks for WITHOUT using them (J == nullptr only): a launch that runs next to the
-    // chained factorisation must not land on the chain's CU (150 of 160 KB taken) or next to a tile-owner worker (128 KB)
-#define GPMPC_CC(DD) case DD: launch_crosscov_d<DD>(st, XT, hyper, alpha, Z, KsT, meanT, J, N, Np, B, Bp, Ny, cpart, nch, max_wgs, lds_fence); break;
+                            int Ny, double* cpart = nullptr, int nch = 1, int max_wgs = 0) {
+#define GPMPC_CC(DD) case DD: launch_crosscov_d<DD>(st, XT, hyper, alpha, Z, KsT, meanT, J, N, Np, B, Bp, Ny, cpart, nch, max_wgs); break;
     switch (d) {
         GPMPC_CC(1) GPMPC_CC(2) GPMPC_CC(3) GPMPC_CC(4) GPMPC_CC(5) GPMPC_CC(6) GPMPC_CC(7) GPMPC_CC(8)
         GPMPC_CC(9) GPMPC_CC(10) GPMPC_CC(11) GPMPC_CC(12) GPMPC_CC(13) GPMPC_CC(14) GPMPC_CC(15) GPMPC_CC(16)
