@@ -4,7 +4,8 @@
 Workload (config.workload "C2"): BASELINE.json configs[1] -- single-output SE-ARD GP, N=4096, d=6,
 fp64: one STEP = K build + Cholesky (+ L^-1, alpha) at fixed hyper-parameters + 10 000 mean+variance
 predictions, everything through the C ABI of libgpmpc_hip.so with X, Y, Z and the outputs resident
-in HBM (device pointer mode).  `value` = predictions/s over whole steps (fit included), summed over
+in HBM (device pointer mode); since r06 as ONE call, gpmpc_fit_predict_mean_var (bitwise gpmpc_fit +
+gpmpc_predict_mean_var, which --two-calls times instead; the line carries the other form's ms_per_step too).  `value` = predictions/s over whole steps (fit included), summed over
 ranks.  With --gpus N every rank runs its own model / test batch on its own GPU (independent GP
 objects shard trivially, no data-path collective): weak scaling.  `python bench.py --gpus N` launches its N ranks
 itself (one process per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, rank 0 prints the line); under
@@ -539,7 +540,7 @@ def main():
     ap.add_argument('--B', type=int, default=10000)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-secondary', action='store_true', help='skip the C3 / C4 steps after the timed C2 region')
-    ap.add_argument('--fused', action='store_true', help='C2 step as ONE gpmpc_fit_predict_mean_var call instead of gpmpc_fit + gpmpc_predict_mean_var (same bits; within 10 us)')
+    ap.add_argument('--two-calls', action='store_true', help='C2 step as gpmpc_fit + gpmpc_predict_mean_var (r01-r05) instead of ONE gpmpc_fit_predict_mean_var call (same bits; the one call is 0.5-1 % faster: the host round trip between the calls is off the device path)')
     ap.add_argument('--restarts', type=int, default=64, help='restarts of the restart-shard leg (C4)')
     ap.add_argument('--config', default='C2', choices=['C2', 'C3', 'C4'])
     args = ap.parse_args()
@@ -573,7 +574,7 @@ def main():
     hyper = np.ascontiguousarray(p['hyper'])
     h.set_pointer_mode(True)
 
-    two_calls = not (args.fused or os.environ.get('GPMPC_BENCH_FUSED') == '1')
+    two_calls = args.two_calls or os.environ.get('GPMPC_BENCH_TWO_CALLS') == '1'
 
     def step_two_calls():
         h.fit(hyper)                                                    # K build + Cholesky + L^-1 + alpha
