@@ -179,13 +179,22 @@ static int worker_wt_publish() {   // the same for the tile-owner workers and th
     static const int v = getenv("GPMPC_WORKER_WT") ? atoi(getenv("GPMPC_WORKER_WT")) : 1;
     return g_handoff_wt >= 0 ? g_handoff_wt : v;
 }
-static int twolevel_width() {   // block columns per super-panel (GPMPC_TWOLEVEL; 0 / 1 = off)
+// Block columns per super-panel (GPMPC_TWOLEVEL=<n> pins it; 0 / 1 = off).  A function of the matrix size ONLY (a matrix's bits
+// must not depend on its batch).  r04-r05: 8 everywhere.  r06 sweep (profiles/r06_sweep_twolevel_width.txt): wider panels halve
+// the share of the K = 64 W updates' C traffic and the number of chain launches, until the in-panel work inside the (64 W)^2
+// diagonal block dominates; even widths only (128-row tiles): N = 8192, Ny = 6: 8 / 10 / 12 / 14 / 16 -> factor 44.2 / 42.7 / 42.7 /
+// 42.8 / 45.2 ms; N = 4096, 64 restarts: 99.4 / 102.9 / 101.7 / 104.1 / 92.7 restarts/s.
+static int twolevel_width(int Np) {
 #ifdef GPMPC_EMULATED
     static const int w = getenv("GPMPC_TWOLEVEL") ? atoi(getenv("GPMPC_TWOLEVEL")) : 2;
-#else
-    static const int w = getenv("GPMPC_TWOLEVEL") ? atoi(getenv("GPMPC_TWOLEVEL")) : 8;
-#endif
+    (void)Np;
     return w;
+#else
+    static const int w = getenv("GPMPC_TWOLEVEL") ? atoi(getenv("GPMPC_TWOLEVEL")) : -1;
+    if (w >= 0) return w;
+    const int nb = Np / 64;
+    return nb > 64 ? 10 : nb >= 28 ? 14 : 8;
+#endif
 }
 
 // One step of the right-looking blocked inversion by row panels (see factor_twolevel): panel P_i = block columns [k0, k1).
@@ -428,7 +437,7 @@ static bool factor_chain(const Ctx& cx, Workspace& ws, int spin_limit, bool flag
     if (NW > ntiles + ncour) NW = ntiles + ncour;
     const bool use_workers = NW >= 1 + ncour && nb >= 3 && (ntiles + (NW - ncour) - 1) / (NW - ncour) <= worker_maxt;
     // what the workers do not take: two-level panels (GPMPC_TWOLEVEL=<block columns per super-panel>, 0/1 = off)
-    static const int twolevel_W = twolevel_width();
+    const int twolevel_W = twolevel_width(Np);
     if (!use_workers && twolevel_W > 1 && nb >= 2 * twolevel_W && cx.aux && cx.seg) {
         static const bool verbose2 = getenv("GPMPC_VERBOSE") != nullptr;
         if (verbose2)

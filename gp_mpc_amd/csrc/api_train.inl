@@ -277,7 +277,7 @@ static int nll_batch_core(gpmpc_gp* h, int a, int n, NllReq* const* req, bool wa
         {
             // w = L^-1 y by blocked substitution (the same arithmetic whether or not this point's L^-1 exists), alpha only with it
             PhaseTimer t(h, GPMPC_PH_SOLVE);
-            fwd_subst(cx, ws, twolevel_width() > 1 ? twolevel_width() : 8, ytrain, sy, ws.alpha);
+            fwd_subst(cx, ws, twolevel_width(Np) > 1 ? twolevel_width(Np) : 8, ytrain, sy, ws.alpha);
             if (!ws.inv_panels) solve_alpha_from_w(cx, ws, n, nullptr);
         }
         {
