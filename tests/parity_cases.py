@@ -1527,8 +1527,8 @@ def check_c3_size_step(h, p, outs=(1, 4), node=3):
 def check_em_against_extended_precision(lib, N=1024, d=8, Ny=2, seed=1234, sn=1e-2, nodes=(3, 7)):
     """VERDICT r05 'EM digits': the exact-moment covariance of the C3 generator (d = 8, sn = 1e-2) at a size where the closed form
     can be evaluated in longdouble on the host (exact_moment_longdouble: N^3 longdouble work per output).  Gate: the device is
-    at most TWICE as far from that value as the fp64 oracle (+ 1e-13 of the cancellation scale) -- i.e. what separates either
-    from the exact value is fp64 arithmetic on K^-1 (cond(K) eps), not the kernel -- and the digits are printed."""
+    within an order of magnitude of the fp64 oracle's own distance from that value, or has eight digits of the covariance --
+    what separates either from the exact value is fp64 arithmetic on K^-1 (cond(K) eps) -- and the digits are printed."""
     p = go.synthetic_problem(N, d, Ny, max(nodes) + 1, seed=seed, sn=sn)
     X, Y, H = p['X'], p['Y'], p['hyper']
     h = Handle(lib, X, Y)
@@ -1547,7 +1547,11 @@ def check_em_against_extended_precision(lib, N=1024, d=8, Ny=2, seed=1234, sn=1e
         d_dev, d_orc = np.abs(c[0] - tc).max(), np.abs(oc - tc).max()
         print(f'[EM vs longdouble closed form, N={N} node {node}] max|cov| {cmax:.3e} scale/|cov| {scale / cmax:.2e};  |err|/|cov|: device {d_dev / cmax:.2e} '
               f'oracle {d_orc / cmax:.2e}  device vs oracle {np.abs(c[0] - oc).max() / cmax:.2e};  mean |err|: device {np.abs(m[0] - tm).max():.2e} oracle {np.abs(om - tm).max():.2e}')
-        assert d_dev <= max(2.0 * d_orc, 1e-10 * scale), (d_dev, d_orc)
+        # gate: within an order of magnitude of the fp64 oracle's own distance from the exact value, or eight digits of the
+        # covariance (MI355X, N = 1024, sn = 1e-2: device 1.9e-9, oracle 3.4e-10 of max|cov| at a cancellation scale of 8e8 |cov|;
+        # "1e-10 of the cancellation scale", the bar of the device-vs-oracle checks, would allow 8e-2 here and says nothing
+        # about the matrix MPC factors next)
+        assert d_dev <= max(10.0 * d_orc, 1e-8 * cmax), (d_dev, d_orc, cmax)
         assert np.abs(m[0] - tm).max() <= max(2.0 * np.abs(om - tm).max(), 1e-10 * max(1.0, np.abs(tm).max()))
         out.append((float(d_dev / cmax), float(d_orc / cmax)))
     h.close()
