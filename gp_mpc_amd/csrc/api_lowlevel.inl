@@ -134,6 +134,11 @@ extern "C" int gpmpc_set_tuning(const char* name, int value) {
         g_em_chunk = value;
         return GPMPC_OK;
     }
+    if (std::strcmp(name, "em_diag_segs") == 0) {        // exact-moment a == b pair sums: ranges per pair of the balanced schedule (-1 = default, 0 = strips and chunks)
+        if (value < -1) return fail(GPMPC_EINVAL, "em_diag_segs must be >= -1");
+        g_em_diag_segs = value;
+        return GPMPC_OK;
+    }
     if (std::strcmp(name, "fail_nll_after") == 0) {      // fault injection for the tests of the restart shard's failure paths
         if (value < 0) return fail(GPMPC_EINVAL, "fail_nll_after must be >= 0");
         static const bool testing = getenv("GPMPC_TESTING") && atoi(getenv("GPMPC_TESTING")) != 0;

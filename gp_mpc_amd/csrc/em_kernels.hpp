@@ -252,7 +252,8 @@ __global__ void __launch_bounds__(256) em_operands_kernel(const double* __restri
 template <bool DIAG, int KD, int TAB>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3)))
 em_pair2_kernel(const double* __restrict__ ops, const double* __restrict__ beta, const double* __restrict__ invK,
-                double* __restrict__ partial, int N, int Np, int Ny, int crow_mode, const double* __restrict__ etab, int chunk) {
+                double* __restrict__ partial, int N, int Np, int Ny, int crow_mode, const double* __restrict__ etab, int chunk,
+                int slot_stride) {
     constexpr int EMK = KD;
     constexpr int NQ = ((KD + 2) * 64 + 255) / 256;
     const int P = Ny * (Ny + 1) / 2, tiles = Np / 64, nch = (tiles + chunk - 1) / chunk;
@@ -261,9 +262,10 @@ em_pair2_kernel(const double* __restrict__ ops, const double* __restrict__ beta,
     while ((a + 1) * (a + 2) / 2 <= p) ++a;
     const int bb = p - a * (a + 1) / 2;
     if ((a == bb) != DIAG) return;
-    const int jt_beg = (blockIdx.x % nch) * chunk, jt_end = min(DIAG ? ti + 1 : tiles, jt_beg + chunk);
-    double* __restrict__ pout = partial + ((long)b * P + p) * tiles * nch + blockIdx.x;
-    if (jt_beg >= jt_end) {                      // (a chunk beyond the diagonal of an a == b strip)
+    // (slot_stride >= tiles * nch partial sums per pair: the a == b launch may use more of them, em_diag_kernel)
+    const int jt_beg = (blockIdx.x % nch) * chunk, jt_end = ti < tiles ? min(DIAG ? ti + 1 : tiles, jt_beg + chunk) : 0;
+    double* __restrict__ pout = partial + ((long)b * P + p) * slot_stride + blockIdx.x;
+    if (jt_beg >= jt_end) {                      // (a chunk beyond the diagonal of an a == b strip, or an unused slot)
         if (tid == 0) *pout = 0.0;
         return;
     }
@@ -316,25 +318,50 @@ em_pair2_kernel(const double* __restrict__ ops, const double* __restrict__ beta,
     stage(0);
     __syncthreads();
     int cur = 0;
+    // a == b: K^-1 of a 16 x 16 sub-tile travels ONE SUB-TILE AHEAD of its use (r06): `ikn` is loaded while the previous
+    // sub-tile is computed, `ikc` is what the current one multiplies.  (r01-r05 loaded the tile's sixteen values at the top of
+    // the tile and the first sub-tile waited for all of them -- and, through the same counter, for the next tile's operands:
+    // one exposed HBM latency per tile and wave, 461 us per input at C3 against 134 us of VALU work and 290 us of K^-1 at
+    // 5.5 TB/s.)  The row mask is applied when the values change registers; padded rows are inside the allocation.
+    double ikc[4], ikn[4];
+    long kofs[4];
+    bool rok[4];
+    if (DIAG) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            rok[r] = irow[r] < N;
+            kofs[r] = (long)irow[r] * Np + jt_beg * 64 + fr;
+            ikn[r] = iK[kofs[r]];
+            kofs[r] += 16;
+        }
+    }
     for (int jt = jt_beg; jt < jt_end; ++jt) {
-        if (jt + 1 < jt_end) fetch(jt + 1);
-        double ik[4][4];
+        if (!DIAG && jt + 1 < jt_end) fetch(jt + 1);
         if (DIAG) {
             if (jt == ti) {                     // everything so far came from tiles below the diagonal: counted twice
 #pragma unroll
                 for (int r = 0; r < 4; ++r) racc[r] *= 2.0;
                 kacc *= 2.0;
             }
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) ik[t][r] = irow[r] < N ? iK[(long)irow[r] * Np + jt * 64 + 16 * t + fr] : 0.0;
         }
         // one 16 x 16 tile at a time (`unroll 1`, r05): four exps in flight per lane instead of sixteen -- 80 / 126 registers instead
         // of 156 / 190, six / four waves per SIMD instead of three / two, and the table look-ups' and the matrix results'
         // latencies hide behind other waves (C3, same box: EM phase 38.3 -> 36.7 ms; unroll 2: 37.0; profiles/r05_em_occupancy_ab.txt)
 #pragma unroll 1
         for (int t = 0; t < 4; ++t) {
+            if (DIAG) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ikc[r] = rok[r] ? ikn[r] : 0.0;
+                // (the next tile's operands are requested here, behind the wait the line above implies, not in front of it)
+                if (t == 0 && jt + 1 < jt_end) fetch(jt + 1);
+                if (t < 3 || jt + 1 < jt_end) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        ikn[r] = iK[kofs[r]];
+                        kofs[r] += 16;
+                    }
+                }
+            }
             const int cl = 16 * t + fr;
             const double lbj = Cs[cur][EMK][cl];
             const double bj = Cs[cur][EMK + 1][cl];
@@ -349,7 +376,7 @@ em_pair2_kernel(const double* __restrict__ ops, const double* __restrict__ beta,
                 // above and its padded columns are exact zeros in live rows (identity padding), Q is finite everywhere
                 const double q = TAB == 2 ? exp_tab32(c[r], Et) : TAB == 1 ? exp_tab(c[r], Et) : exp_lean(c[r]);
                 racc[r] = fma(bj, q, racc[r]);
-                if (DIAG) kacc = fma(ik[t][r], q, kacc);
+                if (DIAG) kacc = fma(ikc[r], q, kacc);
             }
         }
         if (jt + 1 < jt_end) stage(cur ^ 1);
@@ -367,21 +394,173 @@ em_pair2_kernel(const double* __restrict__ ops, const double* __restrict__ beta,
     if (tid == 0) *pout = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-// cov_ab = t_p * sum_tiles partial;  cov_aa += sf_a^2;  cov -= mean mean^T;  symmetric fill.
-// grid (ceil(B*P/64)), 64 threads: one thread per (input, pair).
+// The a == b pair sums on a BALANCED schedule (r06).  em_pair2_kernel<true> cuts the lower triangle of tiles by strips and
+// chunks: workgroups of 1 .. 64 tiles, 1 152 of them at C3 for the chip's 1 024 places -- list scheduling of those lengths
+// ends 1.56 x later than the balanced time, and the launch (461 us per input, 1.6 GB of K^-1 = 3.5 TB/s on average) spends its
+// tail on a few long strips.  Here the T = tiles (tiles + 1) / 2 tiles of a pair are numbered row by row and cut in `segs`
+// equal ranges (host: places / Ny, so that the whole launch is resident at once); a workgroup walks its range, and when the
+// range crosses a strip's diagonal tile it closes that strip (weights: tiles left of the diagonal count twice) and loads
+// the next strip's row operands.  Same tile body as em_pair2_kernel<true> (K^-1 one sub-tile ahead of its use).
+// grid (slot_stride, Ny, B): partial[(b*P + p(a,a)) * slot_stride + blockIdx.x], workgroups >= segs write 0.
+template <int KD, int TAB>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3)))
+em_diag_kernel(const double* __restrict__ ops, const double* __restrict__ beta, const double* __restrict__ invK,
+               double* __restrict__ partial, int N, int Np, int Ny, int crow_mode, const double* __restrict__ etab, int segs,
+               int slot_stride) {
+    constexpr int EMK = KD;
+    constexpr int NQ = ((KD + 2) * 64 + 255) / 256;
+    const int P = Ny * (Ny + 1) / 2, tiles = Np / 64;
+    const int a = blockIdx.y, p = a * (a + 1) / 2 + a, b = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double* __restrict__ pout = partial + ((long)b * P + p) * slot_stride + blockIdx.x;
+    const long T = (long)tiles * (tiles + 1) / 2;
+    const long lo = (int)blockIdx.x < segs ? T * blockIdx.x / segs : 0, hi = (int)blockIdx.x < segs ? T * (blockIdx.x + 1) / segs : 0;
+    if (lo >= hi) {
+        if (tid == 0) *pout = 0.0;
+        return;
+    }
+    int ti = (int)((sqrt(8.0 * (double)lo + 1.0) - 1.0) * 0.5);     // strip and column tile of tile number lo
+    while ((long)(ti + 1) * (ti + 2) / 2 <= lo) ++ti;
+    while ((long)ti * (ti + 1) / 2 > lo) --ti;
+    int jt = (int)(lo - (long)ti * (ti + 1) / 2);
+    const double* __restrict__ o = ops + ((long)b * P + p) * (2 * EMK + 2) * Np;
+    const double* __restrict__ Wt = o + (long)EMK * Np;
+    const double* __restrict__ La = o + (long)(2 * EMK) * Np;
+    const double* __restrict__ Lb = o + (long)(2 * EMK + 1) * Np;
+    const double* __restrict__ ba = beta + (long)a * Np;
+    const double* __restrict__ iK = invK + (long)a * Np * Np;
+    __shared__ double red[4];
+    __shared__ double Cs[2][EMK + 2][64];
+    __shared__ double Et[TAB == 1 ? EXPT_N : (TAB == 2 ? EXPT32_N : 1)];
+    if (TAB == 1) exp_tab_fill(Et, etab, tid, 256);              // (visible behind the barrier that follows the first stage())
+    if (TAB == 2) exp_tab32_fill(Et, tid);
+    const int fr = lane & 15, fk = lane >> 4;
+    double af[KD / 4], la[4], bai[4], racc[4];
+    int irow[4];
+    bool rok[4];
+    auto load_rows = [&](int tis) {
+        const int i0 = tis * 64 + 16 * wave;
+#pragma unroll
+        for (int s4 = 0; s4 < KD / 4; ++s4) af[s4] = o[(long)(4 * s4 + fk) * Np + i0 + fr];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            irow[r] = i0 + crow(lane, r, crow_mode);
+            rok[r] = irow[r] < N;
+            la[r] = La[irow[r]];
+            bai[r] = rok[r] ? ba[irow[r]] : 0.0;
+        }
+    };
+    double st[NQ];
+    auto fetch = [&](int jtf) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int e = tid + 256 * q, rw = e >> 6, cl = e & 63, j = jtf * 64 + cl;
+            double v = 0.0;
+            if (rw < EMK) v = Wt[(long)rw * Np + j];
+            else if (rw == EMK) v = Lb[j];
+            else if (rw == EMK + 1) v = (j < N) ? ba[j] : 0.0;
+            st[q] = v;
+        }
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int e = tid + 256 * q, rw = e >> 6, cl = e & 63;
+            if (rw < EMK + 2) Cs[buf][rw][cl] = st[q];
+        }
+    };
+    load_rows(ti);
+    fetch(jt);
+    stage(0);
+    __syncthreads();
+    int cur = 0;
+    double ikc[4], ikn[4];
+    long kofs[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        racc[r] = 0.0;
+        kofs[r] = (long)irow[r] * Np + jt * 64 + fr;
+        ikn[r] = iK[kofs[r]];
+        kofs[r] += 16;
+    }
+    double kacc = 0.0, tot = 0.0;
+    for (long n = lo; n < hi; ++n) {
+        const bool last = n + 1 == hi, diag = jt == ti;
+        const int jn = diag ? 0 : jt + 1;                          // the next tile's column (a new strip starts at 0)
+        if (diag) {                                                // everything so far in this strip lies left of the diagonal
+#pragma unroll
+            for (int r = 0; r < 4; ++r) racc[r] *= 2.0;
+            kacc *= 2.0;
+        }
+#pragma unroll 1
+        for (int t = 0; t < 4; ++t) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ikc[r] = rok[r] ? ikn[r] : 0.0;
+            if (t == 0 && !last) fetch(jn);
+            if (t < 3 || !last) {
+                if (t == 3 && diag) {                              // the next sub-tile is the first of the next strip
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) kofs[r] = (long)(irow[r] + 64) * Np + fr;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    ikn[r] = iK[kofs[r]];
+                    kofs[r] += 16;
+                }
+            }
+            const int cl = 16 * t + fr;
+            const double lbj = Cs[cur][EMK][cl];
+            const double bj = Cs[cur][EMK + 1][cl];
+            d4 c;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) c[r] = la[r] + lbj;
+#pragma unroll
+            for (int s4 = 0; s4 < KD / 4; ++s4) c = mfma16(af[s4], Cs[cur][4 * s4 + fk][cl], c);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double q = TAB == 2 ? exp_tab32(c[r], Et) : TAB == 1 ? exp_tab(c[r], Et) : exp_lean(c[r]);
+                racc[r] = fma(bj, q, racc[r]);
+                kacc = fma(ikc[r], q, kacc);
+            }
+        }
+        if (diag) {                                                // the strip is complete
+            tot += ((bai[0] * racc[0] + bai[1] * racc[1]) + (bai[2] * racc[2] + bai[3] * racc[3])) - kacc;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) racc[r] = 0.0;
+            kacc = 0.0;
+            if (!last) load_rows(++ti);
+        }
+        jt = jn;
+        if (!last) stage(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+    // a range that ends inside a strip: all of that part lies left of the diagonal
+    tot += 2.0 * (((bai[0] * racc[0] + bai[1] * racc[1]) + (bai[2] * racc[2] + bai[3] * racc[3])) - kacc);
+    const double acc = wave_sum(tot);
+    if (lane == 0) red[wave] = acc;
+    __syncthreads();
+    if (tid == 0) *pout = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// cov_ab = t_p * sum_slots partial;  cov_aa += sf_a^2;  cov -= mean mean^T;  symmetric fill.
+// grid (B * P), 64 threads: one wave per (input, pair) -- lane l adds the slots l, l + 64, ..., the lanes meet in wave_sum's
+// fixed butterfly.  (r01-r05: one THREAD per (input, pair) walked its 256 partial sums, a chain of dependent loads: 50-100 us
+// per input at C3, 1.5-3 % of that step.)
 __global__ void __launch_bounds__(64) em_finish_kernel(const double* __restrict__ partial, const double* __restrict__ prep,
                                                        const double* __restrict__ hyper, const double* __restrict__ mean,
-                                                       double* __restrict__ cov, int B, int Ny, int d, int tiles) {
+                                                       double* __restrict__ cov, int B, int Ny, int d, int nslots) {
     const int P = Ny * (Ny + 1) / 2, stride = d * d + 1;
-    const long gid = (long)blockIdx.x * 64 + threadIdx.x;
-    if (gid >= (long)B * P) return;
-    const int b = (int)(gid / P), p = (int)(gid % P);
+    const long gid = blockIdx.x;
+    const int b = (int)(gid / P), p = (int)(gid % P), lane = threadIdx.x;
     int a = 0;
     while ((a + 1) * (a + 2) / 2 <= p) ++a;
     const int bb = p - a * (a + 1) / 2;
-    const double t = prep[((long)b * (Ny + P) + Ny + p) * stride + d * d];
+    const double* __restrict__ ps = partial + ((long)b * P + p) * nslots;
     double s = 0.0;
-    for (int k = 0; k < tiles; ++k) s += partial[((long)b * P + p) * tiles + k];   // (tiles: partial sums per pair = strips x chunks)
+    for (int k = lane; k < nslots; k += 64) s += ps[k];
+    s = wave_sum(s);
+    if (lane != 0) return;
+    const double t = prep[((long)b * (Ny + P) + Ny + p) * stride + d * d];
     double v = t * s;
     if (a == bb) v += hyper[(long)a * (d + 2) + d] * hyper[(long)a * (d + 2) + d];
     v -= mean[(long)b * Ny + a] * mean[(long)b * Ny + bb];

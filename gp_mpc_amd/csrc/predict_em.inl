@@ -1,5 +1,16 @@
 // Moment-based methods: 'EM' (a11) and the legacy 'old_ME' / 'old_TA' (a12).  Included by gpmpc_api.hip.
 static int g_em_chunk = 0;          // gpmpc_set_tuning("em_chunk", n): column tiles per workgroup of the pair sums (0 = default)
+static int g_em_diag_segs = -1;     // gpmpc_set_tuning("em_diag_segs", n): ranges per a == b pair (-1 = default, 0 = strips and chunks)
+
+// Ranges per a == b pair of the balanced schedule (em_diag_kernel) when nobody asks for a number: six workgroups per CU over
+// the outputs (four are resident; the a != b launch runs next to them), ranges of at least 24 tiles as long as that still
+// leaves one workgroup per CU.  C3 (N = 8192, Ny = 6, 256 CUs; EM roll-out of 30 steps, profiles/r06_sweep_em_diag_segs.txt):
+// 128 / 170 / 256 / 344 / 512 / 768 / 1032 / 2064 ranges -> 30.7 / 32.4 / 30.6 / 31.4 / 31.7 / 32.2 / 33.3 / 36.1 ms
+// (strips and chunks: 35.3); the rule gives 256 there.
+static int em_diag_default_segs(int cus, int Ny, long tri) {
+    const long fill = std::max(1, 6 * cus / Ny), one_per_cu = std::max(1, cus / Ny);
+    return (int)std::max<long>(1, std::min(fill, std::max(one_per_cu, tri / 24)));
+}
 
 // beta_a = K_a^-1 y_a (gp_functions.py:383; the reference multiplies the explicit inverse)
 static int ensure_beta(gpmpc_gp* h) {
@@ -38,7 +49,15 @@ static int predict_moments_chunk(gpmpc_gp* h, int method, int B, const double* d
         // column tiles per workgroup of the pair sums (em_kernels.hpp; GPMPC_EM_CHUNK, tuning aid; >= tiles: one workgroup per strip)
         // (also gpmpc_set_tuning("em_chunk", n): the tests sweep it at small sizes)
         static const int em_chunk_env = getenv("GPMPC_EM_CHUNK") ? atoi(getenv("GPMPC_EM_CHUNK")) : 64;   // (C3: 64 -> 38.4 ms, 32 -> 39.4, 16 -> 42.5, whole strips 39.9: profiles/r05_em_chunk_ab.txt)
-        const int em_chunk = std::max(1, std::min(g_em_chunk > 0 ? g_em_chunk : em_chunk_env, tiles)), nslots = tiles * ((tiles + em_chunk - 1) / em_chunk);
+        const int em_chunk = std::max(1, std::min(g_em_chunk > 0 ? g_em_chunk : em_chunk_env, tiles)), nstrip = tiles * ((tiles + em_chunk - 1) / em_chunk);
+        // The a == b launch on a balanced schedule (em_diag_kernel): the pair's triangle of tiles in `diag_segs` equal ranges.
+        // GPMPC_EM_DIAG_SEGS / gpmpc_set_tuning("em_diag_segs", n): 0 = strips and chunks as r05 (em_pair2_kernel<true>), n > 0 =
+        // that many ranges per pair.  nslots = partial sums per pair (both launches write all of them).
+        static const int diag_segs_env = getenv("GPMPC_EM_DIAG_SEGS") ? atoi(getenv("GPMPC_EM_DIAG_SEGS")) : -1;
+        const long tri = (long)tiles * (tiles + 1) / 2;
+        const int diag_want = g_em_diag_segs >= 0 ? g_em_diag_segs : diag_segs_env >= 0 ? diag_segs_env : em_diag_default_segs(g_cu_count[h->device], Ny, tri);
+        const int diag_segs = (int)std::min<long>(std::min(diag_want, 4096), tri);
+        const int nslots = std::max(nstrip, diag_segs);
         const long prepN = (long)B * (Ny + P) * (d * d + 1), partN = (long)B * P * nslots;
         const long opsN = (long)B * P * (2 * KD + 2) * Np, mpartN = (long)B * Ny * EM_MEAN_CHUNKS;
         CHK(ensure_em_scratch(h, (prepN + partN + opsN + mpartN) * (long)sizeof(double)));
@@ -48,9 +67,20 @@ static int predict_moments_chunk(gpmpc_gp* h, int method, int B, const double* d
         double* mpart = ops + opsN;
         hipLaunchKernelGGL(em_prep_kernel, dim3((unsigned)(B * (Ny + P))), dim3(DMAX * GJ_LD), 0, cx.stream, h->ws.hyper, dSigma,
                            prep, B, Ny, d);
-        hipLaunchKernelGGL(em_mean_kernel, dim3(Ny, B, EM_MEAN_CHUNKS), dim3(256), 0, cx.stream, h->XT, dZ, h->beta, prep, mpart,
+        // The two pair-sum launches are independent (a != b pairs / a == b pairs, disjoint partial sums): at sizes beyond the
+        // captured-graph range the a == b launch -- the one that streams K^-1 -- goes to the inverse queue NEXT TO the other
+        // (GPMPC_EM_PAIR_OVERLAP=0: one after the other, as r01-r05), and in front of it, next to the operands kernel, the mean
+        // (it needs the prepared matrices only; the covariance's last kernel waits for that queue anyway).
+        static const bool pair_overlap_env = !(getenv("GPMPC_EM_PAIR_OVERLAP") && atoi(getenv("GPMPC_EM_PAIR_OVERLAP")) == 0);
+        const bool pair_overlap = pair_overlap_env && dCov && h->aux_stream && Np > 2048 && Ny > 1;
+        hipStream_t diag_q = pair_overlap ? h->aux_stream : cx.stream;
+        if (pair_overlap) {
+            hipEventRecord(TailState::get(h->tail.ev_tail), cx.stream);
+            hipStreamWaitEvent(diag_q, h->tail.ev_tail, 0);
+        }
+        hipLaunchKernelGGL(em_mean_kernel, dim3(Ny, B, EM_MEAN_CHUNKS), dim3(256), 0, diag_q, h->XT, dZ, h->beta, prep, mpart,
                            N, Np, d, Ny);
-        hipLaunchKernelGGL(em_mean_finish_kernel, dim3((B * Ny + 255) / 256), dim3(256), 0, cx.stream, mpart, dMean, B * Ny);
+        hipLaunchKernelGGL(em_mean_finish_kernel, dim3((B * Ny + 255) / 256), dim3(256), 0, diag_q, mpart, dMean, B * Ny);
         if (!dCov) {     // mean only (gpmpc_predict_em_sens without the covariance value)
             HIPCHK(hipGetLastError());
             return GPMPC_OK;
@@ -59,22 +89,20 @@ static int predict_moments_chunk(gpmpc_gp* h, int method, int B, const double* d
         // 3 the polynomial exp_lean (r05, C3, same box: 40.8 / 43.3 / 46.3 ms per step; r04's kernel 45.7)
         static const int pair_form = getenv("GPMPC_EM_PAIR") ? atoi(getenv("GPMPC_EM_PAIR")) : 1;
         const double* etab = g_exp_tab[h->device];
-        // The two pair-sum launches are independent (a != b pairs / a == b pairs, disjoint partial sums): at sizes beyond the
-        // captured-graph range the a == b launch -- the one that streams K^-1 -- goes to the inverse queue NEXT TO the other
-        // (GPMPC_EM_PAIR_OVERLAP=0: one after the other, as r01-r05)
-        static const bool pair_overlap_env = !(getenv("GPMPC_EM_PAIR_OVERLAP") && atoi(getenv("GPMPC_EM_PAIR_OVERLAP")) == 0);
-        const bool pair_overlap = pair_overlap_env && h->aux_stream && Np > 2048 && Ny > 1;
-        hipStream_t diag_q = pair_overlap ? h->aux_stream : cx.stream;
 #define GPMPC_EM_PAIR2(KDV, TABV)                                                                                                     \
         if (pair_overlap) {                                                                                                           \
             hipEventRecord(TailState::get(h->tail.ev_ks), cx.stream);                                                                 \
             hipStreamWaitEvent(diag_q, h->tail.ev_ks, 0);                                                                             \
         }                                                                                                                             \
-        hipLaunchKernelGGL((em_pair2_kernel<true, KDV, TABV>), dim3(nslots, P, B), dim3(256), 0, diag_q, ops, h->beta, h->ws.InvK,     \
-                           partial, N, Np, Ny, cx.crow_mode, etab, em_chunk);                                                         \
+        if (diag_segs > 0)                                                                                                            \
+            hipLaunchKernelGGL((em_diag_kernel<KDV, TABV>), dim3(nslots, Ny, B), dim3(256), 0, diag_q, ops, h->beta, h->ws.InvK,      \
+                               partial, N, Np, Ny, cx.crow_mode, etab, diag_segs, nslots);                                            \
+        else                                                                                                                          \
+            hipLaunchKernelGGL((em_pair2_kernel<true, KDV, TABV>), dim3(nslots, P, B), dim3(256), 0, diag_q, ops, h->beta, h->ws.InvK, \
+                               partial, N, Np, Ny, cx.crow_mode, etab, em_chunk, nslots);                                             \
         if (pair_overlap) hipEventRecord(TailState::get(h->tail.ev_mean), diag_q);                                                    \
         hipLaunchKernelGGL((em_pair2_kernel<false, KDV, TABV>), dim3(nslots, P, B), dim3(256), 0, cx.stream, ops, h->beta, h->ws.InvK, \
-                           partial, N, Np, Ny, cx.crow_mode, etab, em_chunk);                                                         \
+                           partial, N, Np, Ny, cx.crow_mode, etab, em_chunk, nslots);                                                 \
         if (pair_overlap) hipStreamWaitEvent(cx.stream, h->tail.ev_mean, 0);
 #define GPMPC_EM_PAIR2_ANY(KDV)                                                                                                       \
         if (pair_form == 2) { GPMPC_EM_PAIR2(KDV, 2) } else if (pair_form == 3) { GPMPC_EM_PAIR2(KDV, 0) } else { GPMPC_EM_PAIR2(KDV, 1) }
@@ -89,7 +117,7 @@ static int predict_moments_chunk(gpmpc_gp* h, int method, int B, const double* d
         }
 #undef GPMPC_EM_PAIR2
 #undef GPMPC_EM_PAIR2_ANY
-        hipLaunchKernelGGL(em_finish_kernel, dim3((unsigned)(((long)B * P + 63) / 64)), dim3(64), 0, cx.stream, partial, prep,
+        hipLaunchKernelGGL(em_finish_kernel, dim3((unsigned)((long)B * P)), dim3(64), 0, cx.stream, partial, prep,
                            h->ws.hyper, dMean, dCov, B, Ny, d, nslots);
         HIPCHK(hipGetLastError());
         return GPMPC_OK;

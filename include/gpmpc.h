@@ -315,6 +315,9 @@ int gpmpc_schedule_stats(int mode, int tilesM, int tilesN, int batch, int K, int
  * slot (default, or GPMPC_VARGEMM_PERSIST), 2 = ... at any size (tests), -1 back to the default; same bits either way.
  * "em_chunk": column tiles (64 wide) one workgroup of the exact-moment pair sums sweeps (gp_exact_moment,
  * gp_functions.py:397-414; default 64, or GPMPC_EM_CHUNK); 0 back to the default; results agree to rounding.
+ * "em_diag_segs": the a == b pair sums of the same (the ones that stream K^-1): n > 0 = the lower triangle of tiles in n equal
+ * ranges per pair (default: four workgroups per CU shared by the outputs, at most one per partial-sum slot; or
+ * GPMPC_EM_DIAG_SEGS), 0 = by strips and chunks like the a != b pairs, -1 back to the default; results agree to rounding.
  * Returns GPMPC_EINVAL for an unknown name or value. */
 int gpmpc_set_tuning(const char* name, int value);
 

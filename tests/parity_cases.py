@@ -599,20 +599,25 @@ def check_em_chunks(lib, N=300, d=3, Ny=2, seed=12):
     sf2 = H[:, d] ** 2
     ref = None
     try:
-        for chunk in (1, 2, 3, 1000):
+        # (chunk, ranges per a == b pair: 0 = strips and chunks for those too; 1 / 2 / 4 = one workgroup walks the whole triangle of
+        #  15 tiles / ranges that start and end inside strips; 12 with whole strips: more ranges than strip workgroups, the a != b
+        #  launch zeroes the slots it does not use; -1 = the default, here one tile per range)
+        for chunk, segs in ((1, 0), (2, 0), (3, 0), (1000, 0), (1000, 1), (1000, 2), (2, 4), (1, -1), (3, 7), (1000, 12)):
             lib.set_tuning('em_chunk', chunk)
+            lib.set_tuning('em_diag_segs', segs)
             m, c = h.predict('EM', Z, S)
             for b in range(len(Z)):
                 om, oc = go.exact_moment(f['invK'], X, Y, H, Z[b], S[b])
                 sc = _em_scale(f['invK'], X, Y, H, Z[b], S[b])
-                assert np.max(np.abs(c[b] - oc) / (sc + sf2.max())) <= 1e-9, (chunk, b)
+                assert np.max(np.abs(c[b] - oc) / (sc + sf2.max())) <= 1e-9, (chunk, segs, b)
                 assert np.array_equal(c[b], c[b].T)
             if ref is None:
                 ref = c
             else:
-                assert np.max(np.abs(c - ref)) <= 1e-12 * max(1.0, np.abs(ref).max()) * 1e3, chunk
+                assert np.max(np.abs(c - ref)) <= 1e-12 * max(1.0, np.abs(ref).max()) * 1e3, (chunk, segs)
     finally:
         lib.set_tuning('em_chunk', 0)
+        lib.set_tuning('em_diag_segs', -1)
         h.close()
 
 
