@@ -185,6 +185,7 @@ __global__ void __launch_bounds__(256) em_mean_finish_kernel(const double* __res
 // Cross-term depth of the matrix-pipe path: the value kernels below exist for KD = 8 (d <= 8: two 16x16x4 steps per
 // tile) and KD = 16 (d <= 16 = DMAX: four); the derivative kernels further down for depth EMK = 8 only.
 constexpr int em_depth(int d) { return d <= 8 ? 8 : 16; }
+constexpr double EM_PAD_LOG = -1.0e5;    // row log-weight of padded points (em_operands_kernel)
 
 // Per-(input, pair, point) operands of the pair kernel.  One thread per (b, p, i); arrays are
 // [b][p][...][Np] so that the pair kernel's loads are contiguous in the point index:
@@ -225,7 +226,10 @@ __global__ void __launch_bounds__(256) em_operands_kernel(const double* __restri
         o[(long)(EMK + c) * Np + i] = (c < d) ? ij[c] : 0.0;
         if (c < d) { qa += ua * ii[c]; qb += ub * ij[c]; }
     }
-    o[(long)(2 * EMK) * Np + i] = (2.0 * log(ha[d]) - 0.5 * lka) + qa;
+    // (padded points: a log-weight that makes every Q of their ROW an exact zero through any of the exps -- ldexp underflows,
+    //  the table exps' integer part stays inside 32 bits down to -7e5 --, so that the a == b sums need no row mask on K^-1,
+    //  whose padded rows are identity rows)
+    o[(long)(2 * EMK) * Np + i] = i < N ? (2.0 * log(ha[d]) - 0.5 * lka) + qa : EM_PAD_LOG;
     o[(long)(2 * EMK + 1) * Np + i] = (2.0 * log(hb[d]) - 0.5 * lkb) + qb;
 }
 
@@ -402,8 +406,11 @@ em_pair2_kernel(const double* __restrict__ ops, const double* __restrict__ beta,
 // range crosses a strip's diagonal tile it closes that strip (weights: tiles left of the diagonal count twice) and loads
 // the next strip's row operands.  Same tile body as em_pair2_kernel<true> (K^-1 one sub-tile ahead of its use).
 // grid (slot_stride, Ny, B): partial[(b*P + p(a,a)) * slot_stride + blockIdx.x], workgroups >= segs write 0.
+// (register budget: at depth 8 the kernel is held to 80 registers = six waves per SIMD, the a != b launch's figure, at the price
+//  of 22 spilled registers outside the tile loop -- next to that launch what limits the pair is wave slots: C3 EM roll-out
+//  108 registers / four waves 29.5 ms, 96 / five 29.4, 80 / six 29.1; profiles/r06_em_diag_maskless_ab.txt)
 template <int KD, int TAB>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3)))
+__global__ void __launch_bounds__(256, KD == 8 ? 6 : 3)
 em_diag_kernel(const double* __restrict__ ops, const double* __restrict__ beta, const double* __restrict__ invK,
                double* __restrict__ partial, int N, int Np, int Ny, int crow_mode, const double* __restrict__ etab, int segs,
                int slot_stride) {
@@ -427,7 +434,13 @@ em_diag_kernel(const double* __restrict__ ops, const double* __restrict__ beta, 
     const double* __restrict__ La = o + (long)(2 * EMK) * Np;
     const double* __restrict__ Lb = o + (long)(2 * EMK + 1) * Np;
     const double* __restrict__ ba = beta + (long)a * Np;
-    const double* __restrict__ iK = invK + (long)a * Np * Np;
+    // K^-1: accumulator register r of a lane sits crow-step rows below register 0 -- four wave-uniform row bases and ONE
+    // 32-bit element offset per lane (host: Np^2 < 2^29), which the compiler turns into scalar-base loads
+    const long cstep = (long)(crow(0, 1, crow_mode) - crow(0, 0, crow_mode)) * Np;
+    const double* __restrict__ iK0 = invK + (long)a * Np * Np;
+    const double* __restrict__ iK1 = iK0 + cstep;
+    const double* __restrict__ iK2 = iK1 + cstep;
+    const double* __restrict__ iK3 = iK2 + cstep;
     __shared__ double red[4];
     __shared__ double Cs[2][EMK + 2][64];
     __shared__ double Et[TAB == 1 ? EXPT_N : (TAB == 2 ? EXPT32_N : 1)];
@@ -435,19 +448,18 @@ em_diag_kernel(const double* __restrict__ ops, const double* __restrict__ beta, 
     if (TAB == 2) exp_tab32_fill(Et, tid);
     const int fr = lane & 15, fk = lane >> 4;
     double af[KD / 4], la[4], bai[4], racc[4];
-    int irow[4];
-    bool rok[4];
-    auto load_rows = [&](int tis) {
+    unsigned ko = 0;                                             // element offset of (row of register 0, current sub-tile's column)
+    auto load_rows = [&](int tis, int jts) {
         const int i0 = tis * 64 + 16 * wave;
 #pragma unroll
         for (int s4 = 0; s4 < KD / 4; ++s4) af[s4] = o[(long)(4 * s4 + fk) * Np + i0 + fr];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            irow[r] = i0 + crow(lane, r, crow_mode);
-            rok[r] = irow[r] < N;
-            la[r] = La[irow[r]];
-            bai[r] = rok[r] ? ba[irow[r]] : 0.0;
+            const int irow = i0 + crow(lane, r, crow_mode);
+            la[r] = La[irow];                                    // (padded rows: EM_PAD_LOG, their Q is an exact zero)
+            bai[r] = irow < N ? ba[irow] : 0.0;
         }
+        ko = (unsigned)(i0 + crow(lane, 0, crow_mode)) * (unsigned)Np + (unsigned)(jts * 64 + fr);
     };
     double st[NQ];
     auto fetch = [&](int jtf) {
@@ -468,20 +480,13 @@ em_diag_kernel(const double* __restrict__ ops, const double* __restrict__ beta, 
             if (rw < EMK + 2) Cs[buf][rw][cl] = st[q];
         }
     };
-    load_rows(ti);
+    load_rows(ti, jt);
     fetch(jt);
     stage(0);
     __syncthreads();
     int cur = 0;
-    double ikc[4], ikn[4];
-    long kofs[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        racc[r] = 0.0;
-        kofs[r] = (long)irow[r] * Np + jt * 64 + fr;
-        ikn[r] = iK[kofs[r]];
-        kofs[r] += 16;
-    }
+    for (int r = 0; r < 4; ++r) racc[r] = 0.0;
     double kacc = 0.0, tot = 0.0;
     for (long n = lo; n < hi; ++n) {
         const bool last = n + 1 == hi, diag = jt == ti;
@@ -493,20 +498,11 @@ em_diag_kernel(const double* __restrict__ ops, const double* __restrict__ beta, 
         }
 #pragma unroll 1
         for (int t = 0; t < 4; ++t) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) ikc[r] = rok[r] ? ikn[r] : 0.0;
+            // K^-1 of this sub-tile: requested here, used by the last instruction of the sub-tile (behind the matrix products
+            // and the exps), no second set of registers, no mask (Q is an exact zero in padded rows, K^-1 in padded columns)
+            const double ik0 = iK0[ko], ik1 = iK1[ko], ik2 = iK2[ko], ik3 = iK3[ko];
+            ko += 16;
             if (t == 0 && !last) fetch(jn);
-            if (t < 3 || !last) {
-                if (t == 3 && diag) {                              // the next sub-tile is the first of the next strip
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) kofs[r] = (long)(irow[r] + 64) * Np + fr;
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    ikn[r] = iK[kofs[r]];
-                    kofs[r] += 16;
-                }
-            }
             const int cl = 16 * t + fr;
             const double lbj = Cs[cur][EMK][cl];
             const double bj = Cs[cur][EMK + 1][cl];
@@ -515,19 +511,23 @@ em_diag_kernel(const double* __restrict__ ops, const double* __restrict__ beta, 
             for (int r = 0; r < 4; ++r) c[r] = la[r] + lbj;
 #pragma unroll
             for (int s4 = 0; s4 < KD / 4; ++s4) c = mfma16(af[s4], Cs[cur][4 * s4 + fk][cl], c);
+            double q[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const double q = TAB == 2 ? exp_tab32(c[r], Et) : TAB == 1 ? exp_tab(c[r], Et) : exp_lean(c[r]);
-                racc[r] = fma(bj, q, racc[r]);
-                kacc = fma(ikc[r], q, kacc);
+                q[r] = TAB == 2 ? exp_tab32(c[r], Et) : TAB == 1 ? exp_tab(c[r], Et) : exp_lean(c[r]);
+                racc[r] = fma(bj, q[r], racc[r]);
             }
+            kacc = fma(ik0, q[0], kacc);
+            kacc = fma(ik1, q[1], kacc);
+            kacc = fma(ik2, q[2], kacc);
+            kacc = fma(ik3, q[3], kacc);
         }
         if (diag) {                                                // the strip is complete
             tot += ((bai[0] * racc[0] + bai[1] * racc[1]) + (bai[2] * racc[2] + bai[3] * racc[3])) - kacc;
 #pragma unroll
             for (int r = 0; r < 4; ++r) racc[r] = 0.0;
             kacc = 0.0;
-            if (!last) load_rows(++ti);
+            if (!last) load_rows(++ti, 0);
         }
         jt = jn;
         if (!last) stage(cur ^ 1);
@@ -546,9 +546,13 @@ em_diag_kernel(const double* __restrict__ ops, const double* __restrict__ beta, 
 // grid (B * P), 64 threads: one wave per (input, pair) -- lane l adds the slots l, l + 64, ..., the lanes meet in wave_sum's
 // fixed butterfly.  (r01-r05: one THREAD per (input, pair) walked its 256 partial sums, a chain of dependent loads: 50-100 us
 // per input at C3, 1.5-3 % of that step.)
+// mpart (optional): the mean's chunk sums (em_mean_kernel) -- the pair's two means are added here in em_mean_finish_kernel's
+// order and the a == b workgroup writes mean_a, so that no one-workgroup launch sits between the mean and the pair sums
+// (on the a == b launch's queue such a launch waited 110 us for a place while the other launch's workgroups poured in).
 __global__ void __launch_bounds__(64) em_finish_kernel(const double* __restrict__ partial, const double* __restrict__ prep,
-                                                       const double* __restrict__ hyper, const double* __restrict__ mean,
-                                                       double* __restrict__ cov, int B, int Ny, int d, int nslots) {
+                                                       const double* __restrict__ hyper, double* __restrict__ mean,
+                                                       double* __restrict__ cov, int B, int Ny, int d, int nslots,
+                                                       const double* __restrict__ mpart) {
     const int P = Ny * (Ny + 1) / 2, stride = d * d + 1;
     const long gid = blockIdx.x;
     const int b = (int)(gid / P), p = (int)(gid % P), lane = threadIdx.x;
@@ -563,7 +567,19 @@ __global__ void __launch_bounds__(64) em_finish_kernel(const double* __restrict_
     const double t = prep[((long)b * (Ny + P) + Ny + p) * stride + d * d];
     double v = t * s;
     if (a == bb) v += hyper[(long)a * (d + 2) + d] * hyper[(long)a * (d + 2) + d];
-    v -= mean[(long)b * Ny + a] * mean[(long)b * Ny + bb];
+    double ma, mb;
+    if (mpart) {
+        ma = mb = 0.0;
+        for (int ch = 0; ch < EM_MEAN_CHUNKS; ++ch) {
+            ma += mpart[((long)b * Ny + a) * EM_MEAN_CHUNKS + ch];
+            mb += mpart[((long)b * Ny + bb) * EM_MEAN_CHUNKS + ch];
+        }
+        if (a == bb) mean[(long)b * Ny + a] = ma;
+    } else {
+        ma = mean[(long)b * Ny + a];
+        mb = mean[(long)b * Ny + bb];
+    }
+    v -= ma * mb;
     cov[((long)b * Ny + a) * Ny + bb] = v;
     cov[((long)b * Ny + bb) * Ny + a] = v;
 }

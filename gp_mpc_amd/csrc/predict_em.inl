@@ -80,11 +80,12 @@ static int predict_moments_chunk(gpmpc_gp* h, int method, int B, const double* d
         }
         hipLaunchKernelGGL(em_mean_kernel, dim3(Ny, B, EM_MEAN_CHUNKS), dim3(256), 0, diag_q, h->XT, dZ, h->beta, prep, mpart,
                            N, Np, d, Ny);
-        hipLaunchKernelGGL(em_mean_finish_kernel, dim3((B * Ny + 255) / 256), dim3(256), 0, diag_q, mpart, dMean, B * Ny);
         if (!dCov) {     // mean only (gpmpc_predict_em_sens without the covariance value)
+            hipLaunchKernelGGL(em_mean_finish_kernel, dim3((B * Ny + 255) / 256), dim3(256), 0, diag_q, mpart, dMean, B * Ny);
             HIPCHK(hipGetLastError());
             return GPMPC_OK;
         }
+        // (with the covariance the chunk sums of the mean are added up by em_finish_kernel)
         // exp of the pair sums: GPMPC_EM_PAIR (tuning aid) 1 (default) the 2^(j / 2048) table, 2 the conflict-free 32-entry table,
         // 3 the polynomial exp_lean (r05, C3, same box: 40.8 / 43.3 / 46.3 ms per step; r04's kernel 45.7)
         static const int pair_form = getenv("GPMPC_EM_PAIR") ? atoi(getenv("GPMPC_EM_PAIR")) : 1;
@@ -118,7 +119,7 @@ static int predict_moments_chunk(gpmpc_gp* h, int method, int B, const double* d
 #undef GPMPC_EM_PAIR2
 #undef GPMPC_EM_PAIR2_ANY
         hipLaunchKernelGGL(em_finish_kernel, dim3((unsigned)((long)B * P)), dim3(64), 0, cx.stream, partial, prep,
-                           h->ws.hyper, dMean, dCov, B, Ny, d, nslots);
+                           h->ws.hyper, dMean, dCov, B, Ny, d, nslots, mpart);
         HIPCHK(hipGetLastError());
         return GPMPC_OK;
     }
