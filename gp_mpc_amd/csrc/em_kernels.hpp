@@ -94,7 +94,8 @@ __device__ inline double gauss_jordan_lds(double* M, int d, int nc, int* piv) {
 // (A first version gave each item ONE thread with its matrices in scratch memory: 0.28 ms per input at C3, an
 //  eighth of the whole exact-moment step, all of it latency.)
 __global__ void __launch_bounds__(DMAX * GJ_LD) em_prep_kernel(const double* __restrict__ hyper, const double* __restrict__ Sigma,
-                                                               double* __restrict__ prep, int B, int Ny, int d) {
+                                                               double* __restrict__ prep, int B, int Ny, int d,
+                                                               unsigned long long* __restrict__ bnd = nullptr) {
     const int P = Ny * (Ny + 1) / 2, items = Ny + P;
     const int b = blockIdx.x / items, it = blockIdx.x % items;
     const double* Sg = Sigma + (long)b * d * d;
@@ -129,6 +130,7 @@ __global__ void __launch_bounds__(DMAX * GJ_LD) em_prep_kernel(const double* __r
         const int bb = p - a * (a + 1) / 2;
         const double* ha = hyper + (long)a * (d + 2);
         const double* hb = hyper + (long)bb * (d + 2);
+        if (bnd && tid < 4) bnd[((long)b * P + p) * 4 + tid] = 0ull;       // (operand magnitudes of this pair: em_operands_kernel)
         if (r < d && c < 2 * d) {
             const int cc = c < d ? c : c - d;
             M[r * GJ_LD + c] = c < d ? Sg[r * d + cc] * (1.0 / (ha[cc] * ha[cc]) + 1.0 / (hb[cc] * hb[cc])) + (r == cc ? 1.0 : 0.0)
@@ -187,6 +189,27 @@ __global__ void __launch_bounds__(256) em_mean_finish_kernel(const double* __res
 constexpr int em_depth(int d) { return d <= 8 ? 8 : 16; }
 constexpr double EM_PAD_LOG = -1.0e5;    // row log-weight of padded points (em_operands_kernel)
 
+// Magnitudes of a pair's operands, four words per (input, pair): bit patterns of max |La|, max |Lb|, max |U|, max |Wt| over the
+// points (em_operands_kernel: atomicMax on the patterns, which order like the non-negative doubles they are; NaN sorts above
+// inf).  An exponent of the pair sums is La_i + Lb_j + sum_k U_ik Wt_jk, so |c| <= max|La| + max|Lb| + KD max|U| max|Wt|: when
+// that stays below 1e9 the table exp needs no clamp (exp_tab, gp_kernels.hpp).  em_prep_kernel zeroes the words.  The pair-sum
+// kernels exist with and without the clamp (+1.8 % on the C3 step when always on); both are launched and the workgroups of the
+// one that is not needed leave at once -- a test point 1e5 length scales away, or sf = 0, gives exact zeros instead of NaN.
+__device__ __forceinline__ bool em_needs_clamp(const unsigned long long* __restrict__ w, int KD) {
+    const double mLa = __longlong_as_double((long long)w[0]), mLb = __longlong_as_double((long long)w[1]);
+    const double mU = __longlong_as_double((long long)w[2]), mW = __longlong_as_double((long long)w[3]);
+    const double bound = mLa + mLb + (double)KD * mU * mW;
+    return !(bound < 1.0e9);                                     // (NaN or inf anywhere: clamp)
+}
+__device__ __forceinline__ double em_wave_max_pattern(double v) {   // v >= 0 or NaN; the lane with the largest bit pattern wins
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const double o = __shfl_xor(v, m);
+        if ((unsigned long long)__double_as_longlong(o) > (unsigned long long)__double_as_longlong(v)) v = o;
+    }
+    return v;
+}
+
 // Per-(input, pair, point) operands of the pair kernel.  One thread per (b, p, i); arrays are
 // [b][p][...][Np] so that the pair kernel's loads are contiguous in the point index:
 //   U[k][i]  = (ii_i S)_k * 2        (A operand of the cross-term product, k < EMK, zero padded)
@@ -196,11 +219,12 @@ constexpr double EM_PAD_LOG = -1.0e5;    // row log-weight of padded points (em_
 template <int KD>
 __global__ void __launch_bounds__(256) em_operands_kernel(const double* __restrict__ XT, const double* __restrict__ Z,
                                                           const double* __restrict__ hyper, const double* __restrict__ prep,
-                                                          double* __restrict__ ops, int N, int Np, int d, int Ny) {
+                                                          double* __restrict__ ops, int N, int Np, int d, int Ny,
+                                                          unsigned long long* __restrict__ bnd) {
     constexpr int EMK = KD;
     const int P = Ny * (Ny + 1) / 2, stride = d * d + 1;
     const int i = blockIdx.x * 256 + threadIdx.x, p = blockIdx.y, b = blockIdx.z;
-    if (i >= Np) return;
+    if (i >= Np) return;                                         // (whole waves: Np is a multiple of 64)
     int a = 0;
     while ((a + 1) * (a + 2) / 2 <= p) ++a;
     const int bb = p - a * (a + 1) / 2;
@@ -217,20 +241,36 @@ __global__ void __launch_bounds__(256) em_operands_kernel(const double* __restri
         lka += v[k] * v[k] / (ha[k] * ha[k]);
         lkb += v[k] * v[k] / (hb[k] * hb[k]);
     }
-    double qa = 0.0, qb = 0.0;
+    double qa = 0.0, qb = 0.0, mU = 0.0, mW = 0.0;
     for (int c = 0; c < EMK; ++c) {
         double ua = 0.0, ub = 0.0;
         if (c < d)
             for (int k = 0; k < d; ++k) { ua += ii[k] * S[k * d + c]; ub += ij[k] * S[k * d + c]; }
         o[(long)c * Np + i] = 2.0 * ua;
         o[(long)(EMK + c) * Np + i] = (c < d) ? ij[c] : 0.0;
-        if (c < d) { qa += ua * ii[c]; qb += ub * ij[c]; }
+        if (c < d) {
+            qa += ua * ii[c]; qb += ub * ij[c];
+            const double au = fabs(2.0 * ua), aw = fabs(ij[c]);
+            if (!(au <= mU)) mU = au;                            // (keeps a NaN)
+            if (!(aw <= mW)) mW = aw;
+        }
     }
     // (padded points: a log-weight that makes every Q of their ROW an exact zero through any of the exps -- ldexp underflows,
     //  the table exps' integer part stays inside 32 bits down to -7e5 --, so that the a == b sums need no row mask on K^-1,
     //  whose padded rows are identity rows)
-    o[(long)(2 * EMK) * Np + i] = i < N ? (2.0 * log(ha[d]) - 0.5 * lka) + qa : EM_PAD_LOG;
-    o[(long)(2 * EMK + 1) * Np + i] = (2.0 * log(hb[d]) - 0.5 * lkb) + qb;
+    const double lai = i < N ? (2.0 * log(ha[d]) - 0.5 * lka) + qa : EM_PAD_LOG, lbi = (2.0 * log(hb[d]) - 0.5 * lkb) + qb;
+    o[(long)(2 * EMK) * Np + i] = lai;
+    o[(long)(2 * EMK + 1) * Np + i] = lbi;
+    // the pair's operand magnitudes (em_needs_clamp): one atomic per wave and word
+    const double wLa = em_wave_max_pattern(fabs(lai)), wLb = em_wave_max_pattern(fabs(lbi));
+    const double wU = em_wave_max_pattern(mU), wW = em_wave_max_pattern(mW);
+    if ((threadIdx.x & 63) == 0) {
+        unsigned long long* w = bnd + ((long)b * P + p) * 4;
+        atomicMax(w + 0, (unsigned long long)__double_as_longlong(wLa));
+        atomicMax(w + 1, (unsigned long long)__double_as_longlong(wLb));
+        atomicMax(w + 2, (unsigned long long)__double_as_longlong(wU));
+        atomicMax(w + 3, (unsigned long long)__double_as_longlong(wW));
+    }
 }
 
 // Pair sums on a 64-row strip.  256 threads = 4 waves; wave w owns rows 16w..16w+15 of the strip and sweeps column tiles
@@ -253,11 +293,11 @@ __global__ void __launch_bounds__(256) em_operands_kernel(const double* __restri
 //    (everything accumulated before the diagonal tile is doubled) instead of per entry;
 //  * TAB = 2: exp through the 32-entry table that meets every LDS bank once (exp_tab32, gp_kernels.hpp), TAB = 1: the
 //    2048-entry table of r04, TAB = 0: the polynomial exp_lean.
-template <bool DIAG, int KD, int TAB>
+template <bool DIAG, int KD, int TAB, bool CLAMP>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3)))
 em_pair2_kernel(const double* __restrict__ ops, const double* __restrict__ beta, const double* __restrict__ invK,
                 double* __restrict__ partial, int N, int Np, int Ny, int crow_mode, const double* __restrict__ etab, int chunk,
-                int slot_stride) {
+                int slot_stride, const unsigned long long* __restrict__ bnd) {
     constexpr int EMK = KD;
     constexpr int NQ = ((KD + 2) * 64 + 255) / 256;
     const int P = Ny * (Ny + 1) / 2, tiles = Np / 64, nch = (tiles + chunk - 1) / chunk;
@@ -266,6 +306,7 @@ em_pair2_kernel(const double* __restrict__ ops, const double* __restrict__ beta,
     while ((a + 1) * (a + 2) / 2 <= p) ++a;
     const int bb = p - a * (a + 1) / 2;
     if ((a == bb) != DIAG) return;
+    if (em_needs_clamp(bnd + ((long)b * P + p) * 4, KD) != CLAMP) return;      // (the other instantiation serves this pair)
     // (slot_stride >= tiles * nch partial sums per pair: the a == b launch may use more of them, em_diag_kernel)
     const int jt_beg = (blockIdx.x % nch) * chunk, jt_end = ti < tiles ? min(DIAG ? ti + 1 : tiles, jt_beg + chunk) : 0;
     double* __restrict__ pout = partial + ((long)b * P + p) * slot_stride + blockIdx.x;
@@ -378,7 +419,7 @@ em_pair2_kernel(const double* __restrict__ ops, const double* __restrict__ beta,
             for (int r = 0; r < 4; ++r) {
                 // no per-entry masks: beta is zero in padded rows / columns, K^-1's padded rows are masked at the load
                 // above and its padded columns are exact zeros in live rows (identity padding), Q is finite everywhere
-                const double q = TAB == 2 ? exp_tab32(c[r], Et) : TAB == 1 ? exp_tab(c[r], Et) : exp_lean(c[r]);
+                const double q = TAB == 2 ? exp_tab32(c[r], Et) : TAB == 1 ? exp_tab<CLAMP>(c[r], Et) : exp_lean(c[r]);
                 racc[r] = fma(bj, q, racc[r]);
                 if (DIAG) kacc = fma(ikc[r], q, kacc);
             }
@@ -409,16 +450,17 @@ em_pair2_kernel(const double* __restrict__ ops, const double* __restrict__ beta,
 // (register budget: at depth 8 the kernel is held to 80 registers = six waves per SIMD, the a != b launch's figure, at the price
 //  of 22 spilled registers outside the tile loop -- next to that launch what limits the pair is wave slots: C3 EM roll-out
 //  108 registers / four waves 29.5 ms, 96 / five 29.4, 80 / six 29.1; profiles/r06_em_diag_maskless_ab.txt)
-template <int KD, int TAB>
+template <int KD, int TAB, bool CLAMP>
 __global__ void __launch_bounds__(256, KD == 8 ? 6 : 3)
 em_diag_kernel(const double* __restrict__ ops, const double* __restrict__ beta, const double* __restrict__ invK,
                double* __restrict__ partial, int N, int Np, int Ny, int crow_mode, const double* __restrict__ etab, int segs,
-               int slot_stride) {
+               int slot_stride, const unsigned long long* __restrict__ bnd) {
     constexpr int EMK = KD;
     constexpr int NQ = ((KD + 2) * 64 + 255) / 256;
     const int P = Ny * (Ny + 1) / 2, tiles = Np / 64;
     const int a = blockIdx.y, p = a * (a + 1) / 2 + a, b = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double* __restrict__ pout = partial + ((long)b * P + p) * slot_stride + blockIdx.x;
+    if (em_needs_clamp(bnd + ((long)b * P + p) * 4, KD) != CLAMP) return;      // (the other instantiation serves this pair)
     const long T = (long)tiles * (tiles + 1) / 2;
     const long lo = (int)blockIdx.x < segs ? T * blockIdx.x / segs : 0, hi = (int)blockIdx.x < segs ? T * (blockIdx.x + 1) / segs : 0;
     if (lo >= hi) {
@@ -514,7 +556,7 @@ em_diag_kernel(const double* __restrict__ ops, const double* __restrict__ beta, 
             double q[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                q[r] = TAB == 2 ? exp_tab32(c[r], Et) : TAB == 1 ? exp_tab(c[r], Et) : exp_lean(c[r]);
+                q[r] = TAB == 2 ? exp_tab32(c[r], Et) : TAB == 1 ? exp_tab<CLAMP>(c[r], Et) : exp_lean(c[r]);
                 racc[r] = fma(bj, q[r], racc[r]);
             }
             kacc = fma(ik0, q[0], kacc);

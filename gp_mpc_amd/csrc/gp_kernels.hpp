@@ -51,8 +51,17 @@ constexpr int EXPT_LOG2 = 11, EXPT_N = 1 << EXPT_LOG2;
 __device__ __forceinline__ void exp_tab_fill(double* __restrict__ T_lds, const double* __restrict__ T_glob, int tid, int nthreads) {
     for (int i = tid; i < EXPT_N; i += nthreads) T_lds[i] = T_glob[i];
 }
+// Domain (r06): the integer n = rint(x 2048 / ln 2) sits in the mantissa of t; its part above the table index -- the power of
+// two -- is taken from BOTH words of t (one funnel shift, v_alignbit_b32, where r01-r05 shifted the low word alone and n
+// wrapped beyond |x| = 7.3e5, a test point 1 200 length scales away: ldexp then returned inf or garbage instead of 0 and the
+// exact-moment covariance came out NaN), so it is exact for |n| < 2^42, |x| < 1.5e9 (5e4 length scales).  CLAMP adds one
+// v_max_f64 that makes every x <= -1e9, -inf included (sf = 0 through gpmpc_set_factors), an exact zero: +1.8 % on the C3 step
+// when always on (profiles/r06_em_exp_clamp_ab.txt), so the pair-sum kernels instantiate their sweep twice and take the
+// clamped one only when the operands' magnitudes (em_operands_kernel) do not rule such arguments out.
+template <bool CLAMP = true>
 __device__ __forceinline__ double exp_tab(double x, const double* __restrict__ T_lds) {
     const double magic = 6755399441055744.0;                    // 1.5 * 2^52
+    if (CLAMP) x = fmax(x, -1.0e9);
     const double t = fma(x, 2954.6394437405970050, magic);      // 2048 / ln 2
     const double nf = t - magic;
     // ONE reduction constant (r05: one VALU instruction of twelve less): RN(ln2) / 2048 is off by < 2^-54 relative, so
@@ -64,7 +73,8 @@ __device__ __forceinline__ double exp_tab(double x, const double* __restrict__ T
     double p = fma(r, 1.0 / 6.0, 0.5);
     p = fma(p, r, 1.0);
     p = fma(p, r, 1.0);
-    return ldexp(tj * p, ki >> EXPT_LOG2);
+    const int e2 = (int)(((unsigned)__double2hiint(t) << (32 - EXPT_LOG2)) | ((unsigned)ki >> EXPT_LOG2));   // bits 11 .. 42 of n
+    return ldexp(tj * p, e2);
 }
 
 // exp(x) with a table that occupies the 64 LDS banks exactly once: 32 doubles 2^(j / 32) = 256 bytes (every 64th entry of the
@@ -92,6 +102,7 @@ __device__ __forceinline__ void exp_tab32_fill(double* __restrict__ T_lds, int t
 }
 __device__ __forceinline__ double exp_tab32(double x, const double* __restrict__ T_lds) {
     const double magic = 6755399441055744.0;                    // 1.5 * 2^52
+    x = fmax(x, -1.0e6);                                         // (n = rint(x 32 / ln 2) must stay inside 32 bits; exp(-1e6) = 0)
     const double t = fma(x, 46.166241308446829036, magic);      // 32 / ln 2
     const double nf = t - magic;
     const double r = fma(-nf, 6.93147180559945309417e-01 / 32.0, x);     // (one constant: see exp_tab)

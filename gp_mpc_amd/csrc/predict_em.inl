@@ -59,14 +59,15 @@ static int predict_moments_chunk(gpmpc_gp* h, int method, int B, const double* d
         const int diag_segs = (int)std::min<long>(std::min(diag_want, 4096), tri);
         const int nslots = std::max(nstrip, diag_segs);
         const long prepN = (long)B * (Ny + P) * (d * d + 1), partN = (long)B * P * nslots;
-        const long opsN = (long)B * P * (2 * KD + 2) * Np, mpartN = (long)B * Ny * EM_MEAN_CHUNKS;
-        CHK(ensure_em_scratch(h, (prepN + partN + opsN + mpartN) * (long)sizeof(double)));
+        const long opsN = (long)B * P * (2 * KD + 2) * Np, mpartN = (long)B * Ny * EM_MEAN_CHUNKS, bndN = (long)B * P * 4;
+        CHK(ensure_em_scratch(h, (prepN + partN + opsN + mpartN + bndN) * (long)sizeof(double)));
         double* prep = h->em;
         double* partial = h->em + prepN;
         double* ops = partial + partN;
         double* mpart = ops + opsN;
+        unsigned long long* bnd = reinterpret_cast<unsigned long long*>(mpart + mpartN);   // operand magnitudes per (input, pair)
         hipLaunchKernelGGL(em_prep_kernel, dim3((unsigned)(B * (Ny + P))), dim3(DMAX * GJ_LD), 0, cx.stream, h->ws.hyper, dSigma,
-                           prep, B, Ny, d);
+                           prep, B, Ny, d, bnd);
         // The two pair-sum launches are independent (a != b pairs / a == b pairs, disjoint partial sums): at sizes beyond the
         // captured-graph range the a == b launch -- the one that streams K^-1 -- goes to the inverse queue NEXT TO the other
         // (GPMPC_EM_PAIR_OVERLAP=0: one after the other, as r01-r05), and in front of it, next to the operands kernel, the mean
@@ -95,25 +96,33 @@ static int predict_moments_chunk(gpmpc_gp* h, int method, int B, const double* d
             hipEventRecord(TailState::get(h->tail.ev_ks), cx.stream);                                                                 \
             hipStreamWaitEvent(diag_q, h->tail.ev_ks, 0);                                                                             \
         }                                                                                                                             \
-        if (diag_segs > 0)                                                                                                            \
-            hipLaunchKernelGGL((em_diag_kernel<KDV, TABV>), dim3(nslots, Ny, B), dim3(256), 0, diag_q, ops, h->beta, h->ws.InvK,      \
-                               partial, N, Np, Ny, cx.crow_mode, etab, diag_segs, nslots);                                            \
-        else                                                                                                                          \
-            hipLaunchKernelGGL((em_pair2_kernel<true, KDV, TABV>), dim3(nslots, P, B), dim3(256), 0, diag_q, ops, h->beta, h->ws.InvK, \
-                               partial, N, Np, Ny, cx.crow_mode, etab, em_chunk, nslots);                                             \
+        /* each launch twice: without / with the table exp's clamp; the workgroups of the one a pair does not need leave at once */  \
+        if (diag_segs > 0) {                                                                                                          \
+            hipLaunchKernelGGL((em_diag_kernel<KDV, TABV, false>), dim3(nslots, Ny, B), dim3(256), 0, diag_q, ops, h->beta,           \
+                               h->ws.InvK, partial, N, Np, Ny, cx.crow_mode, etab, diag_segs, nslots, bnd);                           \
+            hipLaunchKernelGGL((em_diag_kernel<KDV, TABV, true>), dim3(nslots, Ny, B), dim3(256), 0, diag_q, ops, h->beta,            \
+                               h->ws.InvK, partial, N, Np, Ny, cx.crow_mode, etab, diag_segs, nslots, bnd);                           \
+        } else {                                                                                                                      \
+            hipLaunchKernelGGL((em_pair2_kernel<true, KDV, TABV, false>), dim3(nslots, P, B), dim3(256), 0, diag_q, ops, h->beta,     \
+                               h->ws.InvK, partial, N, Np, Ny, cx.crow_mode, etab, em_chunk, nslots, bnd);                            \
+            hipLaunchKernelGGL((em_pair2_kernel<true, KDV, TABV, true>), dim3(nslots, P, B), dim3(256), 0, diag_q, ops, h->beta,      \
+                               h->ws.InvK, partial, N, Np, Ny, cx.crow_mode, etab, em_chunk, nslots, bnd);                            \
+        }                                                                                                                             \
         if (pair_overlap) hipEventRecord(TailState::get(h->tail.ev_mean), diag_q);                                                    \
-        hipLaunchKernelGGL((em_pair2_kernel<false, KDV, TABV>), dim3(nslots, P, B), dim3(256), 0, cx.stream, ops, h->beta, h->ws.InvK, \
-                           partial, N, Np, Ny, cx.crow_mode, etab, em_chunk, nslots);                                                 \
+        hipLaunchKernelGGL((em_pair2_kernel<false, KDV, TABV, false>), dim3(nslots, P, B), dim3(256), 0, cx.stream, ops, h->beta,     \
+                           h->ws.InvK, partial, N, Np, Ny, cx.crow_mode, etab, em_chunk, nslots, bnd);                                \
+        hipLaunchKernelGGL((em_pair2_kernel<false, KDV, TABV, true>), dim3(nslots, P, B), dim3(256), 0, cx.stream, ops, h->beta,      \
+                           h->ws.InvK, partial, N, Np, Ny, cx.crow_mode, etab, em_chunk, nslots, bnd);                                \
         if (pair_overlap) hipStreamWaitEvent(cx.stream, h->tail.ev_mean, 0);
 #define GPMPC_EM_PAIR2_ANY(KDV)                                                                                                       \
         if (pair_form == 2) { GPMPC_EM_PAIR2(KDV, 2) } else if (pair_form == 3) { GPMPC_EM_PAIR2(KDV, 0) } else { GPMPC_EM_PAIR2(KDV, 1) }
         if (KD == 8) {
             hipLaunchKernelGGL((em_operands_kernel<8>), dim3((Np + 255) / 256, P, B), dim3(256), 0, cx.stream, h->XT, dZ, h->ws.hyper,
-                               prep, ops, N, Np, d, Ny);
+                               prep, ops, N, Np, d, Ny, bnd);
             GPMPC_EM_PAIR2_ANY(8)
         } else {      // d = 9 .. 16: the same kernels with a 16-deep cross term (gp_exact_moment is dimension-generic)
             hipLaunchKernelGGL((em_operands_kernel<16>), dim3((Np + 255) / 256, P, B), dim3(256), 0, cx.stream, h->XT, dZ, h->ws.hyper,
-                               prep, ops, N, Np, d, Ny);
+                               prep, ops, N, Np, d, Ny, bnd);
             GPMPC_EM_PAIR2_ANY(16)
         }
 #undef GPMPC_EM_PAIR2

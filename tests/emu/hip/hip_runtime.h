@@ -41,6 +41,8 @@ struct alignas(16) double2 { double x, y; };
 struct alignas(32) double4 { double x, y, z, w; };
 using std::max;
 using std::min;
+inline long long __double_as_longlong(double v) { long long b; std::memcpy(&b, &v, 8); return b; }
+inline double __longlong_as_double(long long b) { double v; std::memcpy(&v, &b, 8); return v; }
 inline int __double2loint(double v) { int64_t b; std::memcpy(&b, &v, 8); return (int)(uint32_t)(b & 0xffffffff); }
 inline int __double2hiint(double v) { int64_t b; std::memcpy(&b, &v, 8); return (int)(uint32_t)((uint64_t)b >> 32); }
 inline double __hiloint2double(int hi, int lo) {
@@ -184,6 +186,7 @@ inline unsigned atomicAdd(unsigned* p, unsigned v) { unsigned o = *p; *p = o + v
 inline int atomicCAS(int* p, int cmp, int val) { int o = *p; if (o == cmp) *p = val; return o; }
 inline int atomicMin(int* p, int v) { int o = *p; if (v < o) *p = v; return o; }
 inline int atomicMax(int* p, int v) { int o = *p; if (v > o) *p = v; return o; }
+inline unsigned long long atomicMax(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; if (v > o) *p = v; return o; }
 inline double rsqrt(double x) { return 1.0 / std::sqrt(x); }
 using std::isnan;
 using std::isfinite;

@@ -1285,7 +1285,7 @@ def check_far_points(lib, N=150, d=3, Ny=2, seed=9):
     """Test points 1e5 length scales away from every training point (the table exp of the cross-covariance
     kernel took its integer from the low word of a magic-number sum, which wraps beyond |x - z| / ell ~ 1e4 -- ldexp then
     returned inf or garbage instead of 0): k(X, z) = 0, so mean = 0 and var = sf^2 exactly, in the large-batch and the
-    small-batch route; and sf = 0 handed in through gpmpc_set_factors gives zeros, not NaN."""
+    small-batch route; and sf = 0 handed in through gpmpc_set_factors gives zeros, not NaN.  The same for the exact moments."""
     p = go.synthetic_problem(N, d, Ny, 80, seed=seed, sn=0.1)
     X, Y, H = p['X'], p['Y'], p['hyper']
     h = Handle(lib, X, Y)
@@ -1301,6 +1301,17 @@ def check_far_points(lib, N=150, d=3, Ny=2, seed=9):
         assert np.all(m[far[:len(Zq)]] == 0.0) and np.all(v[far[:len(Zq)]] == H[:, d] ** 2)
     m, c, J = h.predict_jac('TA', Z[:4], p['Sigma'][:4])
     assert np.all(np.isfinite(c)) and np.all(J[0] == 0.0)
+    # exact moments (r06: the pair sums' table exp took the power of two from the low word of its magic-number sum alone and
+    # the covariance came out NaN from ~1 200 length scales on; now from both words, and arguments <= -1e9 are clamped):
+    # every Q is an exact zero, so mean = 0 and cov = diag(sf^2) exactly, at 1e3, 1e5 length scales and at 3e8
+    for scale in (1e3, 1e5):
+        Ze = p['Z'][:4].copy()
+        Ze[0] = Ze[0] + scale * H[0, :d].max() * np.array([1.0, -1.0, 1.0][:d])
+        Ze[2] = 3e8
+        me, ce = h.predict('EM', Ze, p['Sigma'][:4] * 1e-3)
+        assert np.all(np.isfinite(me)) and np.all(np.isfinite(ce)), scale
+        for b in (0, 2):
+            assert np.all(me[b] == 0.0) and np.array_equal(ce[b], np.diag(H[:, d] ** 2)), (scale, b)
     f = h.get_factors()
     H0 = H.copy()
     H0[0, d] = 0.0                                                  # sf = 0 for the first output
