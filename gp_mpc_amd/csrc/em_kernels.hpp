@@ -443,9 +443,10 @@ em_pair2_kernel(const double* __restrict__ ops, const double* __restrict__ beta,
 // chunks: workgroups of 1 .. 64 tiles, 1 152 of them at C3 for the chip's 1 024 places -- list scheduling of those lengths
 // ends 1.56 x later than the balanced time, and the launch (461 us per input, 1.6 GB of K^-1 = 3.5 TB/s on average) spends its
 // tail on a few long strips.  Here the T = tiles (tiles + 1) / 2 tiles of a pair are numbered row by row and cut in `segs`
-// equal ranges (host: places / Ny, so that the whole launch is resident at once); a workgroup walks its range, and when the
-// range crosses a strip's diagonal tile it closes that strip (weights: tiles left of the diagonal count twice) and loads
-// the next strip's row operands.  Same tile body as em_pair2_kernel<true> (K^-1 one sub-tile ahead of its use).
+// equal ranges (host: em_diag_default_segs, 256 per pair at C3); a workgroup walks its range, and when the range crosses a
+// strip's diagonal tile it closes that strip (weights: tiles left of the diagonal count twice) and loads the next strip's row
+// operands.  Tile body: as em_pair2_kernel, with K^-1 of a 16 x 16 sub-tile requested at the sub-tile's top and consumed by its
+// last four instructions, unmasked (padded rows have Q = 0: EM_PAD_LOG).
 // grid (slot_stride, Ny, B): partial[(b*P + p(a,a)) * slot_stride + blockIdx.x], workgroups >= segs write 0.
 // (register budget: at depth 8 the kernel is held to 80 registers = six waves per SIMD, the a != b launch's figure, at the price
 //  of 22 spilled registers outside the tile loop -- next to that launch what limits the pair is wave slots: C3 EM roll-out
