@@ -65,7 +65,7 @@ PY
     N=$(echo $C | tr ' ' '_' | cut -c1-24)
     timeout 600 rocprofv3 --kernel-trace --pmc $C -d "$O/pmc_em_$N" -o p -- python /tmp/emv.py > "$O/pmc_em_$N.log" 2>&1
     echo "== EM $C rc=$?"
-    python "$R/tools/pmc_summary.py" "$O/pmc_em_$N/p_results.db" > "$O/${TAG}_pmc_em_$N.txt" 2>&1; grep -E -A5 "em_pair" "$O/${TAG}_pmc_em_$N.txt" | head -14; rm -rf "$O/pmc_em_$N"
+    python "$R/tools/pmc_summary.py" "$O/pmc_em_$N/p_results.db" > "$O/${TAG}_pmc_em_$N.txt" 2>&1; grep -E -A5 "em_pair|em_diag" "$O/${TAG}_pmc_em_$N.txt" | head -14; rm -rf "$O/pmc_em_$N"
   done
   cd "$R"
 fi
